@@ -1,0 +1,195 @@
+/*
+ * tgx.h — the drop-in boundary of the MI355X decode path (C ABI, no C++/torch types).
+ *
+ * TinyGPT has no FFI of its own: the device is a tinytorch::Device value threaded through
+ * GPTConfig -> ModelLoader::load -> every nn::Module (reference: src/engine/GPTEngine.h:25-32,
+ * src/huggingface/ModelLoader.cpp:25-89) and CPU-vs-CUDA dispatch happens inside TinyTorch.
+ * This header defines the boundary at the seams the reference does expose — the virtual
+ * GPTModel interface (src/model/GPTModel.h:80-106), KVCacheManager (src/engine/CacheManager.h:18-55),
+ * Sampler::sample (src/engine/Sampler.h:30, Sampler.cpp:23-79) and the AsyncTokenPipeline hook
+ * (src/engine/GPTEngine.cpp:17-35).  Each entry point names the reference interface it replaces.
+ *
+ * Conventions (mirroring the reference's: bool returns + LOGE, exceptions disabled,
+ * src/CMakeLists.txt:63-67; single engine thread, server/HttpServer.cpp:118-163):
+ *   - every function returns a tgx_status (0 = ok) and never throws across the ABI;
+ *   - one opaque context per GPU; all calls on a context come from one host thread;
+ *   - the caller owns host buffers; the library owns device memory and one HIP stream;
+ *   - host buffers may be pageable; ids are int64 like the reference's token tensors.
+ */
+#ifndef TGX_H
+#define TGX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGX_ABI_VERSION 1
+
+typedef struct tgx_ctx tgx_ctx;
+
+typedef enum tgx_status {
+  TGX_OK = 0,
+  TGX_ERR_INVALID = 1,     /* bad argument (null pointer, batch/seq out of range, ...)        */
+  TGX_ERR_UNSUPPORTED = 2, /* family / dtype / head_dim this backend does not implement       */
+  TGX_ERR_DEVICE = 3,      /* a HIP call failed; tgx_last_error() has the HIP error string     */
+  TGX_ERR_STATE = 4,       /* call order violated (forward before finalize, missing tensors)  */
+  TGX_ERR_NOMEM = 5,       /* host or device allocation failed                                */
+  TGX_ERR_NAME = 6,        /* tensor name not part of this model ("Unexpected key")           */
+  TGX_ERR_SHAPE = 7,       /* "shape not equal for tensor" (SafeTensors.cpp:187-193)          */
+  TGX_ERR_CONTEXT = 8      /* pastLength + seq would exceed contextSize()                     */
+} tgx_status;
+
+/* GPTModelType (src/model/GPTModel.h:71-78) */
+typedef enum tgx_family {
+  TGX_FAMILY_GPT2 = 1,
+  TGX_FAMILY_LLAMA = 2,
+  TGX_FAMILY_QWEN2 = 3,
+  TGX_FAMILY_QWEN3 = 4,
+  TGX_FAMILY_MISTRAL = 5
+} tgx_family;
+
+/* tinytorch::DType values the CLI accepts (examples/inference/main.cpp:82-88) */
+typedef enum tgx_dtype { TGX_F32 = 0, TGX_BF16 = 1, TGX_F16 = 2 } tgx_dtype;
+
+/*
+ * What the family factories derive from config.json (src/huggingface/ModelConfig.cpp:63-122,
+ * src/model/ModelLlama.h:21-53, ModelQwen2.h:23-45, ModelMistral.h:23-40, ModelGPT2.h:226-230).
+ */
+typedef struct tgx_model_desc {
+  int32_t family;         /* tgx_family                                                          */
+  int32_t hidden;         /* hidden_size / n_embd                                                */
+  int32_t layers;         /* num_hidden_layers / n_layer                                         */
+  int32_t heads;          /* num_attention_heads / n_head                                        */
+  int32_t kv_heads;       /* num_key_value_heads (must divide heads, Attention.h:38)             */
+  int32_t head_dim;       /* hidden/heads for llama/qwen2/mistral (ModelLlama.h:37)              */
+  int32_t inter;          /* intermediate_size (4*n_embd for GPT-2, ModelGPT2.h:96)              */
+  int32_t vocab;          /* vocab_size                                                          */
+  int32_t max_ctx;        /* GPTModel::contextSize(): KV capacity and RoPE table length          */
+  int32_t qkv_bias;       /* 1 for Qwen2 (ModelQwen2.h:26-31) and GPT-2                          */
+  int32_t tied;           /* tie_word_embeddings: lm_head aliases embed_tokens (GPTModel.h:39-41)*/
+  int32_t compute_dtype;  /* tgx_dtype the model is cast to after load (ModelLoader.cpp:84)      */
+  float norm_eps;         /* rms_norm_eps / layer_norm_epsilon                                   */
+  float rope_theta;       /* rope_theta                                                          */
+  float rope_factor;      /* llama3 RopeScalingConfig.factor; 0 = std::nullopt (no scaling)      */
+  float rope_low_freq;    /* .lowFreqFactor                                                      */
+  float rope_high_freq;   /* .highFreqFactor                                                     */
+  int32_t rope_orig_ctx;  /* .originalMaxPositionEmbeddings                                      */
+  int32_t n_positions;    /* GPT-2 wpe rows; 0 otherwise                                         */
+  int32_t max_batch;      /* rows of independent KV state to allocate (>= 1)                     */
+} tgx_model_desc;
+
+/* SamplerConfig (src/engine/Sampler.h:13-22).  Greedy iff temperature<=0 && top_k<=0 &&
+ * top_p>=1 && min_p<=0 (Sampler.cpp:15-21). */
+typedef struct tgx_sampler_cfg {
+  float temperature;
+  int64_t top_k;
+  float top_p;
+  float min_p;
+} tgx_sampler_cfg;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+
+/* Number of visible MI355X devices (the `--device mi355x` probe; reference branch:
+ * examples/inference/main.cpp:76-80). */
+int tgx_device_count(int* out_count);
+
+/* == Model{Llama,Qwen2,Mistral}::Model*(config, device) (e.g. src/model/ModelLlama.h:57-65):
+ * validates the description, binds the GPU, allocates parameter storage in compute_dtype. */
+int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx);
+
+/* == SafeTensors::loadInternal -> Storage::copyOnDevice for ONE named tensor
+ * (src/util/SafeTensors.cpp:157-215).  `hf_name` is the checkpoint key; q/k/v and gate/up land in
+ * the row slices of the merged weights exactly like MergedLinear's LinearRef views
+ * (src/layer/Linear.h:64-79).  Shape must match (TGX_ERR_SHAPE); an unknown key is TGX_ERR_NAME
+ * (the reference warns "Unexpected key" and continues — callers may ignore that status).
+ * `src_dtype` is the dtype of `host`; conversion to compute_dtype happens on upload
+ * (bf16->fp32 exact, fp32->bf16 round-to-nearest-even), == model().to(dtype), ModelLoader.cpp:84. */
+int tgx_upload(tgx_ctx* ctx, const char* hf_name, const void* host, const int64_t* shape, int ndim,
+               int src_dtype);
+
+/* == model().eval() + GPTModel::init(): checks every tensor arrived (TGX_ERR_STATE names the
+ * first missing key in tgx_last_error), builds the RoPE tables (nn::RoPE ctor, ModelLlama.h:41-42),
+ * allocates the KV cache for max_batch x max_ctx tokens and instantiates the decode graph. */
+int tgx_finalize(tgx_ctx* ctx);
+
+void tgx_destroy(tgx_ctx* ctx);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+
+/* == GPTModel::forward(inputIds[B,S]) + narrow-to-last-position (src/model/GPTModel.h:86,
+ * src/engine/GPTEngine.cpp:96-97).  `ids` is a row-major host array [batch][seq] (left-padded by
+ * the caller, no mask — GPTEngine.cpp:95).  Appends seq positions to every row's KV cache
+ * (KVCacheManager::append, CacheManager.h:24-42) and leaves the last-position logits [batch][vocab]
+ * on the device for tgx_sample / tgx_read_logits.  seq>1 with pastLength>0 is rejected with
+ * TGX_ERR_INVALID (the reference would run it non-causally, Attention.h:108; its engine never does). */
+int tgx_forward(tgx_ctx* ctx, const int64_t* ids, int batch, int seq);
+
+/* Copies the logits of the last tgx_forward / decode step to `out` [batch*vocab] as fp32.
+ * rounded=1: values as the reference's logits tensor holds them (rounded to compute_dtype);
+ * rounded=0: the fp32 accumulators before that rounding (for tolerance checks). */
+int tgx_read_logits(tgx_ctx* ctx, float* out, int rounded);
+
+/* == Sampler::sample(logits[B,V]) (src/engine/Sampler.cpp:23-79) on the current logits.
+ * The sampled ids become the device-resident "next token" of every row; if out_ids != NULL they
+ * are also copied to the host ([batch], int64).  `seed` drives the multinomial draw (the
+ * reference's RNG stream is not reproducible; greedy ignores it). */
+int tgx_sample(tgx_ctx* ctx, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* out_ids);
+
+/* == the decode loop body of GPTEngine::generateSync (src/engine/GPTEngine.cpp:165-168), n_steps
+ * times: nextToken = sample(forward(nextToken)).  Token ids and positions stay on the GPU between
+ * steps; out_ids (may be NULL) receives [n_steps][batch] int64. */
+int tgx_decode(tgx_ctx* ctx, const tgx_sampler_cfg* cfg, uint64_t seed, int n_steps, int64_t* out_ids);
+
+/* == AsyncTokenPipeline (src/engine/GPTEngine.cpp:17-35) for generateAsync's one-step lookahead
+ * (GPTEngine.cpp:196-217), batch row 0.  tgx_step_async enqueues one decode step and returns
+ * immediately with a ticket; tgx_fetch_token blocks until the step with that ticket has sampled
+ * and returns its id.  Ticket 0 refers to the token produced by the last tgx_sample. */
+int tgx_step_async(tgx_ctx* ctx, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* out_ticket);
+int tgx_fetch_token(tgx_ctx* ctx, int64_t ticket, int32_t* out_id);
+
+/* == GPTModel::resetCache() (src/model/GPTModel.h:91-94): pastLength back to 0 for all rows. */
+int tgx_reset_cache(tgx_ctx* ctx);
+
+/* == KVCacheManager::pastLength (src/engine/CacheManager.h:44-51). */
+int64_t tgx_past_length(const tgx_ctx* ctx);
+
+/* == GPTModel::contextSize() / numLayers() (src/model/GPTModel.h:97-98). */
+int64_t tgx_context_size(const tgx_ctx* ctx);
+int32_t tgx_num_layers(const tgx_ctx* ctx);
+
+/* ---- diagnostics ------------------------------------------------------------------------- */
+
+/* Last error text for this context (or for tgx_create when ctx == NULL). */
+const char* tgx_last_error(const tgx_ctx* ctx);
+
+/* Blocks until all work enqueued on the context's stream has finished. */
+int tgx_synchronize(tgx_ctx* ctx);
+
+/* Reads back the KV cache of (row, layer) as fp32 into k_out/v_out, each [pastLength][kv_heads][head_dim]
+ * (the BSHD view KVCacheManager::append returns, Attention.h:106).  Test/diagnostic use. */
+int tgx_read_kv(tgx_ctx* ctx, int row, int layer, float* k_out, float* v_out);
+
+/* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg): runs
+ * n_steps eager (un-graphed) decode steps and returns, for kernel class `which`
+ * (see TGX_KERNEL_*), the number of launches and their summed duration in milliseconds. */
+#define TGX_KERNEL_QKV 0
+#define TGX_KERNEL_ATTN 1
+#define TGX_KERNEL_OPROJ 2
+#define TGX_KERNEL_GATEUP 3
+#define TGX_KERNEL_DOWN 4
+#define TGX_KERNEL_LMHEAD 5
+#define TGX_KERNEL_COUNT 6
+int tgx_profile_decode(tgx_ctx* ctx, int n_steps, int64_t* launches /*[TGX_KERNEL_COUNT]*/,
+                       double* total_ms /*[TGX_KERNEL_COUNT]*/);
+
+/* Algorithmic HBM bytes one decoded token streams at context length T (SURVEY.md §8d formula). */
+int64_t tgx_bytes_per_token(const tgx_ctx* ctx, int64_t T);
+
+int tgx_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGX_H */

@@ -1,0 +1,686 @@
+/*
+ * tgx_oracle.c — CPU restatement of TinyGPT's decode path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (tinygpt_amd/) never links, imports or falls back to it.
+ *
+ * What it restates (structure and order of operations; reference = /root/reference):
+ *   CausalLM::forward            src/model/GPTModel.h:51-58
+ *   DecoderLayer::forward        src/layer/DecoderLayer.h:38-43
+ *   Attention::forward           src/layer/Attention.h:71-112   (qkv -> split BSHD -> RoPE@pastLength
+ *                                                               -> cache append -> attention -> o_proj)
+ *   MergedLinear row order       src/layer/Linear.h:64-79       (q,k,v / gate,up)
+ *   GatedMLP::forward, SiLUMul   src/layer/GatedMLP.h:37-41, src/layer/Activation.h:14-17
+ *   KVCacheManager               src/engine/CacheManager.h:24-51
+ *   Sampler::sample              src/engine/Sampler.cpp:15-79
+ *   family flags                 src/model/ModelLlama.h:21-53, ModelQwen2.h:26-34, ModelMistral.h:25-29
+ *   GPT-2 stack                  src/model/ModelGPT2.h:23-208
+ *   engine loop                  src/engine/GPTEngine.cpp:94-99,154-174
+ *
+ * The arithmetic itself lives in the reference's un-vendored submodule keith2018/TinyTorch
+ * (.gitmodules:1-3; pinned SHA unrecoverable, directory empty), so it cannot be compiled here.
+ * Per-op numerics therefore follow HF `transformers` (the source of the checkpoints the reference
+ * loads by name) and are PINNED by tests/golden/ — vectors generated in the build container from
+ * transformers 5.15 / torch 2.10 CPU by tools/gen_fixtures.py.  The reference itself holds no test
+ * for this path, so relative to TinyTorch's own kernels parity is unpinned; relative to
+ * HF it is pinned.
+ *
+ * Numerics contract (R = round-to-nearest-even to compute dtype; identity for fp32):
+ *   Linear      y = R(sum_k x_k w_k [+ b])          fp32 accumulate
+ *   RMSNorm     y = R(w * R(x * (1/sqrt(mean(x^2)+eps))))      (HF LlamaRMSNorm order)
+ *   RoPE        cos/sin tables rounded with R; y = R(R(x*cos) + R(rot_half(x)*sin))   (HF apply_rotary_pos_emb)
+ *   attention   fp32 scores (q.k)*hd^-1/2, fp32 softmax, fp32 P.V, one R on the output
+ *   MLP         h = R(R(silu(g)) * u);  residual x = R(x + y)
+ *   logits      fp32 accumulators kept; the sampler sees R(logits)
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define TGXO_EXPORT __attribute__((visibility("default")))
+
+enum { F_GPT2 = 1, F_LLAMA = 2, F_QWEN2 = 3, F_QWEN3 = 4, F_MISTRAL = 5 };
+enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
+
+typedef struct {
+  int32_t family, hidden, layers, heads, kv_heads, head_dim, inter, vocab, max_ctx, qkv_bias, tied, compute_dtype;
+  float norm_eps, rope_theta, rope_factor, rope_low_freq, rope_high_freq;
+  int32_t rope_orig_ctx, n_positions, max_batch;
+} desc_t;
+
+typedef struct { float temperature; int64_t top_k; float top_p; float min_p; } sampler_cfg_t;
+
+/* A parameter matrix [rows][cols] held either as bf16 bits or fp32, plus an optional fp32 bias. */
+typedef struct {
+  int64_t rows, cols;
+  uint16_t* wb;
+  float* wf;
+  float* bias;
+  int64_t filled_rows; /* upload bookkeeping */
+  int bias_filled;
+  int transposed_src;  /* GPT-2 Conv1D stores [in][out]; we transpose on upload */
+} mat_t;
+
+typedef struct { float* w; float* b; int filled_w, filled_b; } vec_t;
+
+typedef struct {
+  vec_t in_norm, post_norm;      /* input_layernorm / post_attention_layernorm, or ln_1 / ln_2 (with bias) */
+  mat_t qkv, o, gate_up, down;   /* GPT-2: c_attn, c_proj, c_fc, mlp.c_proj */
+} layer_t;
+
+typedef struct tgxo_ctx {
+  desc_t d;
+  int bf16;
+  mat_t embed, wpe, lm_head;
+  vec_t final_norm;
+  layer_t* L;
+  float *rope_cos, *rope_sin;    /* [max_ctx][head_dim/2], already R()-rounded */
+  float* kcache;                 /* [max_batch][layers][max_ctx][kv_dim] */
+  float* vcache;
+  int64_t past;
+  int finalized;
+  int last_batch;
+  float* logits;                 /* [max_batch][vocab] fp32 accumulators */
+  int64_t* next_tok;             /* [max_batch] */
+  char err[256];
+} tgxo_ctx;
+
+static char g_err[256];
+
+/* ---------------------------------------------------------------- rounding helpers */
+static inline float bf16_to_f32(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f;
+}
+static inline uint16_t f32_to_bf16(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float rbf(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+#define R(c, x) ((c)->bf16 ? rbf(x) : (x))
+
+static float half_to_f32(uint16_t h) {
+  uint32_t s = (h >> 15) & 1, e = (h >> 10) & 0x1f, m = h & 0x3ff, u;
+  if (e == 0) {
+    if (m == 0) u = s << 31;
+    else { e = 127 - 15 + 1; while (!(m & 0x400)) { m <<= 1; e--; } m &= 0x3ff; u = (s << 31) | (e << 23) | (m << 13); }
+  } else if (e == 31) u = (s << 31) | 0x7f800000u | (m << 13);
+  else u = (s << 31) | ((e + 127 - 15) << 23) | (m << 13);
+  float f; memcpy(&f, &u, 4); return f;
+}
+
+/* ---------------------------------------------------------------- allocation */
+static int mat_alloc(tgxo_ctx* c, mat_t* m, int64_t rows, int64_t cols, int bias) {
+  memset(m, 0, sizeof(*m));
+  m->rows = rows; m->cols = cols;
+  if (c->bf16) m->wb = (uint16_t*)calloc((size_t)(rows * cols), 2);
+  else m->wf = (float*)calloc((size_t)(rows * cols), 4);
+  if (bias) m->bias = (float*)calloc((size_t)rows, 4);
+  return (m->wb || m->wf) && (!bias || m->bias);
+}
+static void mat_free(mat_t* m) { free(m->wb); free(m->wf); free(m->bias); memset(m, 0, sizeof(*m)); }
+static int vec_alloc(vec_t* v, int64_t n, int bias) {
+  memset(v, 0, sizeof(*v));
+  v->w = (float*)calloc((size_t)n, 4);
+  if (bias) v->b = (float*)calloc((size_t)n, 4);
+  return v->w && (!bias || v->b);
+}
+
+static inline float src_elem(const void* host, int dt, int64_t i) {
+  if (dt == DT_F32) return ((const float*)host)[i];
+  if (dt == DT_BF16) return bf16_to_f32(((const uint16_t*)host)[i]);
+  return half_to_f32(((const uint16_t*)host)[i]);
+}
+
+/* == model().to(dtype): store in compute dtype (bf16->fp32 exact, fp32->bf16 RNE) */
+static void mat_store_rows(tgxo_ctx* c, mat_t* m, int64_t row0, int64_t nrows, const void* host, int dt, int src_is_in_out) {
+  for (int64_t r = 0; r < nrows; r++)
+    for (int64_t k = 0; k < m->cols; k++) {
+      float v = src_is_in_out ? src_elem(host, dt, k * nrows + r) : src_elem(host, dt, r * m->cols + k);
+      if (c->bf16) m->wb[(row0 + r) * m->cols + k] = f32_to_bf16(v);
+      else m->wf[(row0 + r) * m->cols + k] = v;
+    }
+  m->filled_rows += nrows;
+}
+static void vec_store(tgxo_ctx* c, float* dst, int64_t n, const void* host, int dt) {
+  for (int64_t i = 0; i < n; i++) dst[i] = R(c, src_elem(host, dt, i));
+}
+
+/* ---------------------------------------------------------------- API: lifetime */
+TGXO_EXPORT const char* tgxo_last_error(const tgxo_ctx* c) { return c ? c->err : g_err; }
+
+static int fail(tgxo_ctx* c, int code, const char* fmt, const char* a) {
+  snprintf(c ? c->err : g_err, 256, fmt, a);
+  return code;
+}
+
+TGXO_EXPORT int tgxo_create(const desc_t* d, int device_ordinal, tgxo_ctx** out) {
+  (void)device_ordinal;
+  if (!d || !out) return fail(NULL, 1, "%s", "null argument");
+  if (d->compute_dtype != DT_F32 && d->compute_dtype != DT_BF16) return fail(NULL, 2, "%s", "oracle computes in fp32 or bf16");
+  if (d->heads <= 0 || d->kv_heads <= 0 || d->heads % d->kv_heads) return fail(NULL, 1, "%s", "heads % kv_heads != 0");
+  if (d->head_dim % 2) return fail(NULL, 1, "%s", "odd head_dim");
+  tgxo_ctx* c = (tgxo_ctx*)calloc(1, sizeof(tgxo_ctx));
+  if (!c) return 5;
+  c->d = *d;
+  if (c->d.max_batch < 1) c->d.max_batch = 1;
+  c->bf16 = d->compute_dtype == DT_BF16;
+  int H = d->hidden, I = d->inter, V = d->vocab;
+  int qd = d->heads * d->head_dim, kvd = d->kv_heads * d->head_dim;
+  int gpt2 = d->family == F_GPT2;
+  int ok = mat_alloc(c, &c->embed, V, H, 0);
+  if (gpt2) ok &= mat_alloc(c, &c->wpe, d->n_positions, H, 0);
+  if (!d->tied && !gpt2) ok &= mat_alloc(c, &c->lm_head, V, H, 0);
+  ok &= vec_alloc(&c->final_norm, H, gpt2);
+  c->L = (layer_t*)calloc((size_t)d->layers, sizeof(layer_t));
+  for (int l = 0; l < d->layers && ok; l++) {
+    layer_t* y = &c->L[l];
+    ok &= vec_alloc(&y->in_norm, H, gpt2) && vec_alloc(&y->post_norm, H, gpt2);
+    ok &= mat_alloc(c, &y->qkv, qd + 2 * kvd, H, d->qkv_bias || gpt2);
+    ok &= mat_alloc(c, &y->o, H, qd, gpt2);
+    ok &= mat_alloc(c, &y->gate_up, gpt2 ? I : 2 * I, H, gpt2);
+    ok &= mat_alloc(c, &y->down, H, I, gpt2);
+  }
+  size_t kvn = (size_t)c->d.max_batch * d->layers * d->max_ctx * kvd;
+  c->kcache = (float*)calloc(kvn, 4);
+  c->vcache = (float*)calloc(kvn, 4);
+  c->logits = (float*)calloc((size_t)c->d.max_batch * V, 4);
+  c->next_tok = (int64_t*)calloc((size_t)c->d.max_batch, 8);
+  if (!ok || !c->kcache || !c->vcache || !c->logits || !c->next_tok) { *out = c; return fail(c, 5, "%s", "allocation failed"); }
+  *out = c;
+  return 0;
+}
+
+TGXO_EXPORT void tgxo_destroy(tgxo_ctx* c) {
+  if (!c) return;
+  mat_free(&c->embed); mat_free(&c->wpe); mat_free(&c->lm_head);
+  free(c->final_norm.w); free(c->final_norm.b);
+  if (c->L) for (int l = 0; l < c->d.layers; l++) {
+    layer_t* y = &c->L[l];
+    free(y->in_norm.w); free(y->in_norm.b); free(y->post_norm.w); free(y->post_norm.b);
+    mat_free(&y->qkv); mat_free(&y->o); mat_free(&y->gate_up); mat_free(&y->down);
+  }
+  free(c->L); free(c->rope_cos); free(c->rope_sin); free(c->kcache); free(c->vcache); free(c->logits); free(c->next_tok);
+  free(c);
+}
+
+/* ---------------------------------------------------------------- API: upload by HF name */
+static int64_t numel(const int64_t* s, int nd) { int64_t n = 1; for (int i = 0; i < nd; i++) n *= s[i]; return n; }
+
+static int shape_is(const int64_t* s, int nd, int64_t a, int64_t b) {
+  if (b < 0) return nd == 1 && s[0] == a;
+  return nd == 2 && s[0] == a && s[1] == b;
+}
+
+TGXO_EXPORT int tgxo_upload(tgxo_ctx* c, const char* name, const void* host, const int64_t* shape, int nd, int dt) {
+  if (!c || !name || !host || !shape) return 1;
+  const desc_t* d = &c->d;
+  int H = d->hidden, I = d->inter, V = d->vocab, qd = d->heads * d->head_dim, kvd = d->kv_heads * d->head_dim;
+  int l = -1; char rest[128] = {0};
+  (void)numel;
+  if (d->family == F_GPT2) {
+    /* hub layout without "transformer." (ModelGPT2.h:226); accept the prefixed form too */
+    if (!strncmp(name, "transformer.", 12)) name += 12;
+    if (!strcmp(name, "wte.weight")) { if (!shape_is(shape, nd, V, H)) goto bad_shape; mat_store_rows(c, &c->embed, 0, V, host, dt, 0); return 0; }
+    if (!strcmp(name, "wpe.weight")) { if (!shape_is(shape, nd, d->n_positions, H)) goto bad_shape; mat_store_rows(c, &c->wpe, 0, d->n_positions, host, dt, 0); return 0; }
+    if (!strcmp(name, "ln_f.weight")) { if (!shape_is(shape, nd, H, -1)) goto bad_shape; vec_store(c, c->final_norm.w, H, host, dt); c->final_norm.filled_w = 1; return 0; }
+    if (!strcmp(name, "ln_f.bias")) { if (!shape_is(shape, nd, H, -1)) goto bad_shape; vec_store(c, c->final_norm.b, H, host, dt); c->final_norm.filled_b = 1; return 0; }
+    if (sscanf(name, "h.%d.%127s", &l, rest) == 2 && l >= 0 && l < d->layers) {
+      layer_t* y = &c->L[l];
+      struct { const char* n; vec_t* v; int isb; } vs[] = {
+        {"ln_1.weight", &y->in_norm, 0}, {"ln_1.bias", &y->in_norm, 1}, {"ln_2.weight", &y->post_norm, 0}, {"ln_2.bias", &y->post_norm, 1}};
+      for (int i = 0; i < 4; i++) if (!strcmp(rest, vs[i].n)) {
+        if (!shape_is(shape, nd, H, -1)) goto bad_shape;
+        vec_store(c, vs[i].isb ? vs[i].v->b : vs[i].v->w, H, host, dt);
+        if (vs[i].isb) vs[i].v->filled_b = 1; else vs[i].v->filled_w = 1;
+        return 0;
+      }
+      struct { const char* n; mat_t* m; } ms[] = {
+        {"attn.c_attn", &y->qkv}, {"attn.c_proj", &y->o}, {"mlp.c_fc", &y->gate_up}, {"mlp.c_proj", &y->down}};
+      for (int i = 0; i < 4; i++) {
+        size_t ln = strlen(ms[i].n);
+        if (!strncmp(rest, ms[i].n, ln) && rest[ln] == '.') {
+          mat_t* m = ms[i].m;
+          if (!strcmp(rest + ln + 1, "weight")) {   /* Conv1D weight is [in][out] (ModelGPT2.h:26) */
+            if (!shape_is(shape, nd, m->cols, m->rows)) goto bad_shape;
+            mat_store_rows(c, m, 0, m->rows, host, dt, 1); return 0;
+          }
+          if (!strcmp(rest + ln + 1, "bias")) {
+            if (!shape_is(shape, nd, m->rows, -1)) goto bad_shape;
+            vec_store(c, m->bias, m->rows, host, dt); m->bias_filled = 1; return 0;
+          }
+        }
+      }
+    }
+    return fail(c, 6, "Unexpected key: %s", name);
+  }
+  if (!strcmp(name, "model.embed_tokens.weight")) { if (!shape_is(shape, nd, V, H)) goto bad_shape; mat_store_rows(c, &c->embed, 0, V, host, dt, 0); return 0; }
+  if (!strcmp(name, "lm_head.weight")) {
+    if (!shape_is(shape, nd, V, H)) goto bad_shape;
+    if (d->tied) return 0;   /* aliased storage (GPTModel.h:39-41): the embed copy wins, like the reference's shared tensor */
+    mat_store_rows(c, &c->lm_head, 0, V, host, dt, 0); return 0;
+  }
+  if (!strcmp(name, "model.norm.weight")) { if (!shape_is(shape, nd, H, -1)) goto bad_shape; vec_store(c, c->final_norm.w, H, host, dt); c->final_norm.filled_w = 1; return 0; }
+  if (sscanf(name, "model.layers.%d.%127s", &l, rest) == 2 && l >= 0 && l < d->layers) {
+    layer_t* y = &c->L[l];
+    if (!strcmp(rest, "input_layernorm.weight")) { if (!shape_is(shape, nd, H, -1)) goto bad_shape; vec_store(c, y->in_norm.w, H, host, dt); y->in_norm.filled_w = 1; return 0; }
+    if (!strcmp(rest, "post_attention_layernorm.weight")) { if (!shape_is(shape, nd, H, -1)) goto bad_shape; vec_store(c, y->post_norm.w, H, host, dt); y->post_norm.filled_w = 1; return 0; }
+    /* MergedLinear slices (Linear.h:64-79): q rows [0,qd), k [qd,qd+kvd), v [qd+kvd, qd+2kvd) */
+    struct { const char* n; mat_t* m; int64_t row0, rows, cols; } ws[] = {
+      {"self_attn.q_proj", &y->qkv, 0, qd, H}, {"self_attn.k_proj", &y->qkv, qd, kvd, H}, {"self_attn.v_proj", &y->qkv, qd + kvd, kvd, H},
+      {"self_attn.o_proj", &y->o, 0, H, qd}, {"mlp.gate_proj", &y->gate_up, 0, I, H}, {"mlp.up_proj", &y->gate_up, I, I, H},
+      {"mlp.down_proj", &y->down, 0, H, I}};
+    for (int i = 0; i < 7; i++) {
+      size_t ln = strlen(ws[i].n);
+      if (!strncmp(rest, ws[i].n, ln) && rest[ln] == '.') {
+        if (!strcmp(rest + ln + 1, "weight")) {
+          if (!shape_is(shape, nd, ws[i].rows, ws[i].cols)) goto bad_shape;
+          mat_store_rows(c, ws[i].m, ws[i].row0, ws[i].rows, host, dt, 0); return 0;
+        }
+        if (!strcmp(rest + ln + 1, "bias") && ws[i].m->bias) {
+          if (!shape_is(shape, nd, ws[i].rows, -1)) goto bad_shape;
+          vec_store(c, ws[i].m->bias + ws[i].row0, ws[i].rows, host, dt); ws[i].m->bias_filled += (int)ws[i].rows; return 0;
+        }
+      }
+    }
+  }
+  return fail(c, 6, "Unexpected key: %s", name);
+bad_shape:
+  return fail(c, 7, "shape not equal for tensor: %s", name);
+}
+
+/* ---------------------------------------------------------------- RoPE tables (HF LlamaRotaryEmbedding + llama3 scaling) */
+static void build_rope(tgxo_ctx* c) {
+  const desc_t* d = &c->d;
+  int half = d->head_dim / 2;
+  float* inv = (float*)malloc((size_t)half * 4);
+  for (int i = 0; i < half; i++) {
+    float e = (float)(2 * i) / (float)d->head_dim;                 /* arange(0,dim,2).float()/dim */
+    float p = (float)pow((double)d->rope_theta, (double)e);        /* base ** e in fp32 */
+    inv[i] = 1.0f / p;
+  }
+  if (d->family == F_LLAMA && d->rope_factor > 0.f) {              /* RopeScalingConfig (ModelLlama.h:21-24) */
+    float factor = d->rope_factor, lo = d->rope_low_freq, hi = d->rope_high_freq, old = (float)d->rope_orig_ctx;
+    float low_wl = old / lo, high_wl = old / hi;
+    for (int i = 0; i < half; i++) {
+      float wl = 2.0f * (float)M_PI / inv[i];
+      float v = wl > low_wl ? inv[i] / factor : inv[i];
+      float smooth = (old / wl - lo) / (hi - lo);
+      float sm = (1.0f - smooth) * v / factor + smooth * v;
+      int medium = !(wl < high_wl) && !(wl > low_wl);
+      inv[i] = medium ? sm : v;
+    }
+  }
+  c->rope_cos = (float*)malloc((size_t)d->max_ctx * half * 4);
+  c->rope_sin = (float*)malloc((size_t)d->max_ctx * half * 4);
+  for (int p = 0; p < d->max_ctx; p++)
+    for (int i = 0; i < half; i++) {
+      float a = inv[i] * (float)p;
+      c->rope_cos[(size_t)p * half + i] = R(c, cosf(a));
+      c->rope_sin[(size_t)p * half + i] = R(c, sinf(a));
+    }
+  free(inv);
+}
+
+TGXO_EXPORT int tgxo_finalize(tgxo_ctx* c) {
+  if (!c) return 1;
+  const desc_t* d = &c->d;
+  int gpt2 = d->family == F_GPT2;
+  char nm[96];
+  if (c->embed.filled_rows != d->vocab) return fail(c, 4, "Missing key: %s", gpt2 ? "wte.weight" : "model.embed_tokens.weight");
+  if (!gpt2 && !d->tied && c->lm_head.filled_rows != d->vocab) return fail(c, 4, "Missing key: %s", "lm_head.weight");
+  if (!c->final_norm.filled_w) return fail(c, 4, "Missing key: %s", gpt2 ? "ln_f.weight" : "model.norm.weight");
+  for (int l = 0; l < d->layers; l++) {
+    layer_t* y = &c->L[l];
+    snprintf(nm, sizeof nm, "layer %d", l);
+    if (!y->in_norm.filled_w || !y->post_norm.filled_w || y->qkv.filled_rows != y->qkv.rows || y->o.filled_rows != y->o.rows ||
+        y->gate_up.filled_rows != y->gate_up.rows || y->down.filled_rows != y->down.rows)
+      return fail(c, 4, "Missing key in %s", nm);
+    if (d->qkv_bias && !gpt2 && y->qkv.bias_filled != y->qkv.rows) return fail(c, 4, "Missing qkv bias in %s", nm);
+  }
+  if (!gpt2) build_rope(c);
+  c->finalized = 1;
+  c->past = 0;
+  return 0;
+}
+
+/* ---------------------------------------------------------------- math kernels */
+static inline float dot_row(const tgxo_ctx* c, const mat_t* m, int64_t row, const float* x) {
+  int64_t K = m->cols;
+  float acc = 0.f;
+  if (c->bf16) {
+    const uint16_t* w = m->wb + row * K;
+#pragma omp simd reduction(+ : acc)
+    for (int64_t k = 0; k < K; k++) {
+      uint32_t u = (uint32_t)w[k] << 16; float f; memcpy(&f, &u, 4);
+      acc += f * x[k];
+    }
+  } else {
+    const float* w = m->wf + row * K;
+#pragma omp simd reduction(+ : acc)
+    for (int64_t k = 0; k < K; k++) acc += w[k] * x[k];
+  }
+  return acc;
+}
+
+/* y[s][n] = R(x[s] . W[n] + b[n]) for S rows of x; raw != 0 keeps the fp32 accumulator */
+static void linear(const tgxo_ctx* c, const mat_t* m, const float* x, int S, float* y, int raw) {
+  int64_t N = m->rows, K = m->cols;
+#pragma omp parallel for schedule(static)
+  for (int64_t n = 0; n < N; n++) {
+    float b = m->bias ? m->bias[n] : 0.f;
+    for (int s = 0; s < S; s++) {
+      float a = dot_row(c, m, n, x + (int64_t)s * K) + b;
+      y[(int64_t)s * N + n] = raw ? a : R(c, a);
+    }
+  }
+}
+
+static void rmsnorm(const tgxo_ctx* c, const float* x, const float* w, int n, float* y) {
+  float ss = 0.f;
+  for (int i = 0; i < n; i++) ss += x[i] * x[i];
+  float inv = 1.0f / sqrtf(ss / (float)n + c->d.norm_eps);
+  for (int i = 0; i < n; i++) y[i] = R(c, w[i] * R(c, x[i] * inv));
+}
+
+static void layernorm(const tgxo_ctx* c, const float* x, const float* w, const float* b, int n, float* y) {
+  float mean = 0.f;
+  for (int i = 0; i < n; i++) mean += x[i];
+  mean /= (float)n;
+  float var = 0.f;
+  for (int i = 0; i < n; i++) { float t = x[i] - mean; var += t * t; }
+  var /= (float)n;
+  float inv = 1.0f / sqrtf(var + c->d.norm_eps);
+  for (int i = 0; i < n; i++) y[i] = R(c, (x[i] - mean) * inv * w[i] + b[i]);
+}
+
+static inline float silu(float x) { return x / (1.0f + expf(-x)); }
+static inline float gelu_new(float x) {
+  return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+
+/* rotate-half RoPE on one head vector at absolute position pos (Attention.h:81-83) */
+static void rope_head(const tgxo_ctx* c, float* v, int pos) {
+  int hd = c->d.head_dim, half = hd / 2;
+  const float* cs = c->rope_cos + (size_t)pos * half;
+  const float* sn = c->rope_sin + (size_t)pos * half;
+  for (int i = 0; i < half; i++) {
+    float a = v[i], b = v[i + half];
+    v[i] = R(c, R(c, a * cs[i]) + R(c, -b * sn[i]));
+    v[i + half] = R(c, R(c, b * cs[i]) + R(c, a * sn[i]));
+  }
+}
+
+/* softmax(q.K^T * scale) . V for one query head over keys [0, nkeys) */
+static void attend(const tgxo_ctx* c, const float* q, const float* K, const float* V, int nkeys, int kvd, float* out, float* sc) {
+  int hd = c->d.head_dim;
+  float scale = 1.0f / sqrtf((float)hd), mx = -INFINITY;
+  for (int j = 0; j < nkeys; j++) {
+    const float* k = K + (size_t)j * kvd;
+    float a = 0.f;
+    for (int t = 0; t < hd; t++) a += q[t] * k[t];
+    sc[j] = a * scale;
+    if (sc[j] > mx) mx = sc[j];
+  }
+  float sum = 0.f;
+  for (int j = 0; j < nkeys; j++) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+  float inv = 1.0f / sum;
+  for (int t = 0; t < hd; t++) out[t] = 0.f;
+  for (int j = 0; j < nkeys; j++) {
+    const float* v = V + (size_t)j * kvd;
+    float p = sc[j] * inv;
+    for (int t = 0; t < hd; t++) out[t] += p * v[t];
+  }
+  for (int t = 0; t < hd; t++) out[t] = R(c, out[t]);
+}
+
+static inline float embed_elem(const tgxo_ctx* c, const mat_t* m, int64_t row, int64_t k) {
+  return c->bf16 ? bf16_to_f32(m->wb[row * m->cols + k]) : m->wf[row * m->cols + k];
+}
+
+/* ---------------------------------------------------------------- forward for one batch row */
+static int forward_row(tgxo_ctx* c, int b, const int64_t* ids, int S) {
+  const desc_t* d = &c->d;
+  int H = d->hidden, I = d->inter, V = d->vocab, hd = d->head_dim, nh = d->heads, nkv = d->kv_heads;
+  int qd = nh * hd, kvd = nkv * hd, G = nh / nkv, gpt2 = d->family == F_GPT2;
+  int64_t past = c->past;
+  size_t SH = (size_t)S * H;
+  float* x = (float*)malloc(SH * 4);
+  float* xn = (float*)malloc(SH * 4);
+  float* qkv = (float*)malloc((size_t)S * (qd + 2 * kvd) * 4);
+  float* att = (float*)malloc((size_t)S * qd * 4);
+  float* proj = (float*)malloc(SH * 4);
+  float* gu = (float*)malloc((size_t)S * 2 * I * 4);
+  float* hmid = (float*)malloc((size_t)S * I * 4);
+  if (!x || !xn || !qkv || !att || !proj || !gu || !hmid) return 5;
+
+  for (int s = 0; s < S; s++) {
+    int64_t id = ids[s];
+    if (id < 0 || id >= V) { free(x); free(xn); free(qkv); free(att); free(proj); free(gu); free(hmid); return fail(c, 1, "%s", "token id out of range"); }
+    for (int k = 0; k < H; k++) {
+      float e = embed_elem(c, &c->embed, id, k);
+      if (gpt2) e = R(c, e + embed_elem(c, &c->wpe, past + s, k));   /* wte(ids) + wpe(arange(past,past+S)) (ModelGPT2.h:165-169) */
+      x[(size_t)s * H + k] = e;
+    }
+  }
+
+  for (int l = 0; l < d->layers; l++) {
+    const layer_t* y = &c->L[l];
+    float* Kc = c->kcache + (((size_t)b * d->layers + l) * d->max_ctx) * kvd;
+    float* Vc = c->vcache + (((size_t)b * d->layers + l) * d->max_ctx) * kvd;
+    for (int s = 0; s < S; s++) {
+      if (gpt2) layernorm(c, x + (size_t)s * H, y->in_norm.w, y->in_norm.b, H, xn + (size_t)s * H);
+      else rmsnorm(c, x + (size_t)s * H, y->in_norm.w, H, xn + (size_t)s * H);
+    }
+    linear(c, &y->qkv, xn, S, qkv, 0);
+    /* split -> heads -> RoPE(q), RoPE(k) at pastLength -> cache append (Attention.h:94-106) */
+    for (int s = 0; s < S; s++) {
+      float* row = qkv + (size_t)s * (qd + 2 * kvd);
+      if (!gpt2) {
+        for (int h = 0; h < nh; h++) rope_head(c, row + h * hd, (int)(past + s));
+        for (int h = 0; h < nkv; h++) rope_head(c, row + qd + h * hd, (int)(past + s));
+      }
+      memcpy(Kc + (size_t)(past + s) * kvd, row + qd, (size_t)kvd * 4);
+      memcpy(Vc + (size_t)(past + s) * kvd, row + qd + kvd, (size_t)kvd * 4);
+    }
+    /* isCausal = (pastLength == 0) (Attention.h:108): query s sees keys [0, past+s]; with past>0 S must be 1 */
+#pragma omp parallel
+    {
+      float* sc = (float*)malloc((size_t)(past + S) * 4);
+#pragma omp for collapse(2) schedule(static)
+      for (int s = 0; s < S; s++)
+        for (int h = 0; h < nh; h++) {
+          int nkeys = (int)(past + s + 1);
+          attend(c, qkv + (size_t)s * (qd + 2 * kvd) + h * hd, Kc + (h / G) * hd, Vc + (h / G) * hd, nkeys, kvd,
+                 att + (size_t)s * qd + h * hd, sc);
+        }
+      free(sc);
+    }
+    linear(c, &y->o, att, S, proj, 0);
+    for (size_t i = 0; i < SH; i++) x[i] = R(c, x[i] + proj[i]);           /* x = x + attn(norm(x)) (DecoderLayer.h:40) */
+    for (int s = 0; s < S; s++) {
+      if (gpt2) layernorm(c, x + (size_t)s * H, y->post_norm.w, y->post_norm.b, H, xn + (size_t)s * H);
+      else rmsnorm(c, x + (size_t)s * H, y->post_norm.w, H, xn + (size_t)s * H);
+    }
+    linear(c, &y->gate_up, xn, S, gu, 0);
+    if (gpt2) {
+      for (size_t i = 0; i < (size_t)S * I; i++) hmid[i] = R(c, gelu_new(gu[i]));
+    } else {
+      /* siluMul: silu(x[..., :I]) * x[..., I:] (Activation.h:16; gate rows first, GatedMLP.h:46-47) */
+      for (int s = 0; s < S; s++)
+        for (int i = 0; i < I; i++) {
+          float g = gu[(size_t)s * 2 * I + i], u = gu[(size_t)s * 2 * I + I + i];
+          hmid[(size_t)s * I + i] = R(c, R(c, silu(g)) * u);
+        }
+    }
+    linear(c, &y->down, hmid, S, proj, 0);
+    for (size_t i = 0; i < SH; i++) x[i] = R(c, x[i] + proj[i]);           /* x = x + mlp(norm(x)) (DecoderLayer.h:41) */
+  }
+  /* final norm + lm_head on the last position only (== forward over all S then narrow, GPTEngine.cpp:96-97) */
+  const float* xl = x + (size_t)(S - 1) * H;
+  if (gpt2) layernorm(c, xl, c->final_norm.w, c->final_norm.b, H, xn);
+  else rmsnorm(c, xl, c->final_norm.w, H, xn);
+  const mat_t* head = (d->tied || gpt2) ? &c->embed : &c->lm_head;
+  linear(c, head, xn, 1, c->logits + (size_t)b * V, 1);
+  free(x); free(xn); free(qkv); free(att); free(proj); free(gu); free(hmid);
+  return 0;
+}
+
+TGXO_EXPORT int tgxo_forward(tgxo_ctx* c, const int64_t* ids, int batch, int seq) {
+  if (!c || !ids) return 1;
+  if (!c->finalized) return fail(c, 4, "%s", "forward before finalize");
+  if (batch < 1 || batch > c->d.max_batch || seq < 1) return fail(c, 1, "%s", "batch/seq out of range");
+  if (seq > 1 && c->past > 0) return fail(c, 1, "%s", "seq>1 with pastLength>0");
+  if (c->past + seq > c->d.max_ctx) return fail(c, 8, "%s", "context size exceeded");
+  for (int b = 0; b < batch; b++) {
+    int rc = forward_row(c, b, ids + (size_t)b * seq, seq);
+    if (rc) return rc;
+  }
+  c->past += seq;
+  c->last_batch = batch;
+  return 0;
+}
+
+TGXO_EXPORT int tgxo_read_logits(tgxo_ctx* c, float* out, int rounded) {
+  if (!c || !out || c->last_batch < 1) return 1;
+  size_t n = (size_t)c->last_batch * c->d.vocab;
+  for (size_t i = 0; i < n; i++) out[i] = rounded ? R(c, c->logits[i]) : c->logits[i];
+  return 0;
+}
+
+/* ---------------------------------------------------------------- sampler (Sampler.cpp:23-79) */
+static uint64_t splitmix(uint64_t* s) {
+  uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+typedef struct { float v; int32_t i; } kv_t;
+static int cmp_desc(const void* a, const void* b) {   /* value descending, index ascending: stable sort order */
+  const kv_t *x = (const kv_t*)a, *y = (const kv_t*)b;
+  if (x->v > y->v) return -1;
+  if (x->v < y->v) return 1;
+  return (x->i > y->i) - (x->i < y->i);
+}
+
+static void softmax_inplace(float* p, const float* l, int V) {
+  float mx = -INFINITY;
+  for (int i = 0; i < V; i++) if (l[i] > mx) mx = l[i];
+  float sum = 0.f;
+  for (int i = 0; i < V; i++) { p[i] = expf(l[i] - mx); sum += p[i]; }
+  float inv = 1.0f / sum;
+  for (int i = 0; i < V; i++) p[i] *= inv;
+}
+
+/* Applies temperature / top-k / top-p / min-p to l[V] in place (masked entries become -inf) and
+ * writes the final probabilities to probs[V].  Exposed for kept-set parity tests. */
+TGXO_EXPORT int tgxo_filter_logits(const sampler_cfg_t* cfg, float* l, float* probs, int V) {
+  int setT = cfg->temperature > 0.f, setK = cfg->top_k > 0, setP = cfg->top_p < 1.f, setM = cfg->min_p > 0.f;
+  kv_t* srt = (kv_t*)malloc((size_t)V * sizeof(kv_t));
+  float* tmp = (float*)malloc((size_t)V * 4);
+  if (!srt || !tmp) { free(srt); free(tmp); return 5; }
+  if (setT) for (int i = 0; i < V; i++) l[i] = l[i] / cfg->temperature;
+  if (setK) {
+    int k = cfg->top_k < V ? (int)cfg->top_k : V;
+    for (int i = 0; i < V; i++) { srt[i].v = l[i]; srt[i].i = i; }
+    qsort(srt, (size_t)V, sizeof(kv_t), cmp_desc);
+    for (int i = 0; i < V; i++) l[i] = -INFINITY;
+    for (int i = 0; i < k; i++) l[srt[i].i] = srt[i].v;
+  }
+  if (setP) {
+    for (int i = 0; i < V; i++) { srt[i].v = l[i]; srt[i].i = i; }
+    qsort(srt, (size_t)V, sizeof(kv_t), cmp_desc);
+    for (int i = 0; i < V; i++) tmp[i] = srt[i].v;
+    softmax_inplace(tmp, tmp, V);
+    float cum = 0.f;
+    for (int i = 0; i < V; i++) {
+      cum += tmp[i];
+      int keep = (cum <= cfg->top_p) || i == 0;     /* cumulativeProbs <= topP, first always kept (Sampler.cpp:52-57) */
+      l[srt[i].i] = keep ? srt[i].v : -INFINITY;
+    }
+  }
+  if (setM) {
+    softmax_inplace(tmp, l, V);
+    float mx = 0.f;
+    for (int i = 0; i < V; i++) if (tmp[i] > mx) mx = tmp[i];
+    float thr = mx * cfg->min_p;
+    for (int i = 0; i < V; i++) if (tmp[i] < thr) l[i] = -INFINITY;
+  }
+  softmax_inplace(probs, l, V);
+  free(srt); free(tmp);
+  return 0;
+}
+
+TGXO_EXPORT int tgxo_sample(tgxo_ctx* c, const sampler_cfg_t* cfg, uint64_t seed, int64_t* out_ids) {
+  if (!c || !cfg || c->last_batch < 1) return 1;
+  int V = c->d.vocab;
+  int greedy = !(cfg->temperature > 0.f || cfg->top_k > 0 || cfg->top_p < 1.f || cfg->min_p > 0.f);
+  float* l = (float*)malloc((size_t)V * 4);
+  float* p = (float*)malloc((size_t)V * 4);
+  for (int b = 0; b < c->last_batch; b++) {
+    for (int i = 0; i < V; i++) l[i] = R(c, c->logits[(size_t)b * V + i]);   /* the sampler sees compute-dtype logits */
+    int64_t pick = 0;
+    if (greedy) {
+      float mx = l[0];
+      for (int i = 1; i < V; i++) if (l[i] > mx) { mx = l[i]; pick = i; }     /* first maximal index */
+    } else {
+      tgxo_filter_logits(cfg, l, p, V);
+      uint64_t s = seed * 0x9E3779B97F4A7C15ull + (uint64_t)c->past * 0xD1342543DE82EF95ull + (uint64_t)b;
+      double u = (double)(splitmix(&s) >> 11) * (1.0 / 9007199254740992.0);
+      double cum = 0.0;
+      pick = -1;
+      for (int i = 0; i < V; i++) { if (p[i] > 0.f) { cum += p[i]; pick = i; if (u < cum) break; } }
+    }
+    c->next_tok[b] = pick;
+    if (out_ids) out_ids[b] = pick;
+  }
+  free(l); free(p);
+  return 0;
+}
+
+/* == decode loop of generateSync (GPTEngine.cpp:165-168) */
+TGXO_EXPORT int tgxo_decode(tgxo_ctx* c, const sampler_cfg_t* cfg, uint64_t seed, int n_steps, int64_t* out_ids) {
+  if (!c || !cfg || c->last_batch < 1) return 1;
+  int B = c->last_batch;
+  for (int i = 0; i < n_steps; i++) {
+    int rc = tgxo_forward(c, c->next_tok, B, 1);
+    if (rc) return rc;
+    rc = tgxo_sample(c, cfg, seed, out_ids ? out_ids + (size_t)i * B : NULL);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+TGXO_EXPORT int tgxo_set_next_token(tgxo_ctx* c, const int64_t* ids, int batch) {
+  if (!c || !ids || batch < 1 || batch > c->d.max_batch) return 1;
+  for (int b = 0; b < batch; b++) c->next_tok[b] = ids[b];
+  c->last_batch = batch;
+  return 0;
+}
+
+TGXO_EXPORT int tgxo_reset_cache(tgxo_ctx* c) { if (!c) return 1; c->past = 0; return 0; }
+TGXO_EXPORT int64_t tgxo_past_length(const tgxo_ctx* c) { return c ? c->past : -1; }
+TGXO_EXPORT int64_t tgxo_context_size(const tgxo_ctx* c) { return c ? c->d.max_ctx : -1; }
+
+TGXO_EXPORT int tgxo_read_kv(tgxo_ctx* c, int row, int layer, float* k_out, float* v_out) {
+  if (!c || row < 0 || row >= c->d.max_batch || layer < 0 || layer >= c->d.layers) return 1;
+  size_t kvd = (size_t)c->d.kv_heads * c->d.head_dim;
+  size_t off = (((size_t)row * c->d.layers + layer) * c->d.max_ctx) * kvd;
+  if (k_out) memcpy(k_out, c->kcache + off, (size_t)c->past * kvd * 4);
+  if (v_out) memcpy(v_out, c->vcache + off, (size_t)c->past * kvd * 4);
+  return 0;
+}
+
+/* RoPE table read-back for the golden-table test: out[2][n_pos][head_dim/2] */
+TGXO_EXPORT int tgxo_read_rope(tgxo_ctx* c, int n_pos, float* out) {
+  if (!c || !c->rope_cos || n_pos > c->d.max_ctx) return 1;
+  size_t n = (size_t)n_pos * (c->d.head_dim / 2);
+  memcpy(out, c->rope_cos, n * 4);
+  memcpy(out + n, c->rope_sin, n * 4);
+  return 0;
+}

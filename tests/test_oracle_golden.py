@@ -1,0 +1,86 @@
+"""The CPU oracle against the golden vectors from HF transformers (tools/gen_fixtures.py).
+
+fp32 mode pins structure (RoPE pairing and llama3 scaling, GQA mapping, merge order, norms, GPT-2's
+Conv1D/LayerNorm/gelu_new/left-pad-no-mask) at 1e-4 relative; bf16 mode pins the rounding contract to
+within the bf16 noise floor (HF-bf16 vs HF-fp32 on the same vectors is 0.7-4.4e-2) with greedy ids equal.
+"""
+import numpy as np
+import pytest
+
+from conftest import FAMILIES, load_golden, rel_err
+from tinygpt_amd.desc import desc_from_hf_config
+from tinygpt_amd.ffi import GREEDY
+
+TOL = {"fp32": 1e-4, "bf16": 5e-2}
+
+
+def make_oracle(fam, mode, oracle_lib):
+    from oracle.oracle_ffi import OracleModel
+    cfg, g = load_golden(fam)
+    d = desc_from_hf_config(cfg, mode, max_batch=g["prompt"].shape[0])
+    m = OracleModel(d).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
+    return m, g
+
+
+@pytest.mark.parametrize("fam", FAMILIES)
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_free_running_greedy_matches_hf(fam, mode, oracle_lib):
+    """prefill + 15 decode steps == generateSync; ids identical, logits within tolerance."""
+    m, g = make_oracle(fam, mode, oracle_lib)
+    L, ids = g[f"logits_{mode}"], g[f"ids_{mode}"]
+    m.forward(g["prompt"])
+    assert m.past_length == g["prompt"].shape[1]
+    assert rel_err(m.logits(rounded=(mode == "bf16")), L[:, 0]) < TOL[mode]
+    first = m.sample(GREEDY)
+    np.testing.assert_array_equal(first, ids[:, 0])
+    rest = m.decode(L.shape[1] - 1, GREEDY)                  # [n-1, B]
+    np.testing.assert_array_equal(rest.T, ids[:, 1:])
+    assert rel_err(m.logits(rounded=(mode == "bf16")), L[:, -1]) < TOL[mode]
+    assert m.past_length == g["prompt"].shape[1] + L.shape[1] - 1
+
+
+@pytest.mark.parametrize("fam", FAMILIES)
+def test_teacher_forced_logits_every_step(fam, oracle_lib):
+    m, g = make_oracle(fam, "fp32", oracle_lib)
+    L, ids = g["logits_fp32"], g["ids_fp32"]
+    m.forward(g["prompt"])
+    for i in range(1, L.shape[1]):
+        m.forward(ids[:, i - 1:i])
+        assert rel_err(m.logits(rounded=False), L[:, i]) < 1e-4, f"step {i}"
+
+
+@pytest.mark.parametrize("fam", [f for f in FAMILIES if f != "gpt2_tiny"])
+def test_rope_tables(fam, oracle_lib):
+    m, g = make_oracle(fam, "fp32", oracle_lib)
+    cos, sin = m.rope_tables(g["rope_cos"].shape[0])
+    assert np.abs(cos - g["rope_cos"]).max() < 1e-6
+    assert np.abs(sin - g["rope_sin"]).max() < 1e-6
+
+
+def test_kv_cache_grows_by_append(oracle_lib):
+    """KVCacheManager semantics (CacheManager.h:24-51): rows already cached never change; reset empties."""
+    m, g = make_oracle("llama_tiny", "bf16", oracle_lib)
+    m.forward(g["prompt"])
+    k0, v0 = m.read_kv(0, 1)
+    assert k0.shape[0] == g["prompt"].shape[1]
+    m.sample(GREEDY)
+    m.decode(3, GREEDY)
+    k1, v1 = m.read_kv(0, 1)
+    assert k1.shape[0] == k0.shape[0] + 3
+    np.testing.assert_array_equal(k1[:k0.shape[0]], k0)
+    np.testing.assert_array_equal(v1[:v0.shape[0]], v0)
+    m.reset_cache()
+    assert m.past_length == 0
+
+
+def test_context_limit_and_bad_calls(oracle_lib):
+    from tinygpt_amd.ffi import TgxError
+    m, g = make_oracle("llama_tiny", "fp32", oracle_lib)
+    assert m.context_size == 64                                # original_max_position_embeddings (ModelLlama.h:26-31)
+    with pytest.raises(TgxError):
+        m.forward(np.zeros((1, 65), np.int64))
+    m.forward(g["prompt"])
+    with pytest.raises(TgxError):
+        m.forward(g["prompt"])                                 # seq>1 with pastLength>0
+    with pytest.raises(TgxError):
+        m.forward(np.array([[10_000]]))                        # id out of range

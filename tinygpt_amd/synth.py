@@ -1,0 +1,81 @@
+"""Deterministic synthetic checkpoints, keyed by HF tensor name.
+
+No real checkpoint is available offline, so every benchmark and parity model is
+filled from a counter-based integer hash: the same (seed, tensor name, element index) gives the
+same bf16 bit pattern on every machine, with no dependence on libm or on numpy's distribution
+code.  Values are uniform in (-a, a) with a = std*sqrt(3); norm weights are 1 + U(-0.1, 0.1) so a
+wrong norm weight is visible in parity tests.  All tensors are produced as bf16 bit patterns
+(uint16) — the storage dtype of the BASELINE configs — and widened exactly when fp32 is wanted.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .desc import ModelDesc
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+def _fnv1a64(name: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in name.encode():
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def f32_to_bf16_bits(f: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16 bit pattern (uint16); NaN kept quiet."""
+    u = np.ascontiguousarray(f, dtype=np.float32).view(np.uint32)
+    rounded = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)
+    nan = (u & np.uint32(0x7FFFFFFF)) > np.uint32(0x7F800000)
+    return np.where(nan, (u >> np.uint32(16)) | np.uint32(0x40), rounded).astype(np.uint16)
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def synth_tensor_bf16(seed: int, name: str, shape, std: float) -> np.ndarray:
+    """uint16 (bf16 bits) tensor of `shape` for checkpoint entry `name`."""
+    n = int(np.prod(shape))
+    base = np.uint64(_fnv1a64(name) ^ ((seed * 0xD1342543DE82EF95) & 0xFFFFFFFFFFFFFFFF))
+    out = np.empty(n, dtype=np.uint16)
+    leaf = name.rsplit(".", 2)[-2:]
+    is_norm = leaf[-1] == "weight" and (leaf[0].endswith("norm") or leaf[0].endswith("layernorm")
+                                        or leaf[0] in ("ln_1", "ln_2", "ln_f"))
+    if is_norm:
+        lo, a = np.float32(1.0), np.float32(0.1)
+    else:
+        lo, a = np.float32(0.0), np.float32(std * 1.7320508)
+    CH = 1 << 22
+    with np.errstate(over="ignore"):
+        for s in range(0, n, CH):
+            e = min(n, s + CH)
+            idx = np.arange(s, e, dtype=np.uint64)
+            z = _splitmix64((base + idx * np.uint64(0x9E3779B97F4A7C15)) & _M64)
+            u24 = (z >> np.uint64(40)).astype(np.float32)                  # 24 random bits, exact in fp32
+            f = (u24 * np.float32(2.0 ** -24) - np.float32(0.5)) * (np.float32(2.0) * a) + lo
+            out[s:e] = f32_to_bf16_bits(f)
+    return out.reshape(shape)
+
+
+def synth_checkpoint(desc: ModelDesc, seed: int = 1234, std: float = 0.02):
+    """Yield (hf_name, uint16 bf16-bits ndarray) for every tensor of `desc`, in checkpoint order."""
+    for name, shape in desc.tensor_shapes().items():
+        yield name, synth_tensor_bf16(seed, name, shape, std)
+
+
+def synth_prompt(vocab: int, length: int, seed: int = 1234) -> np.ndarray:
+    """Prompt ids uniform in [0, vocab), int64."""
+    base = np.uint64((seed * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        z = _splitmix64((base + np.arange(length, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) & _M64)
+    return ((z >> np.uint64(33)) % np.uint64(vocab)).astype(np.int64)
