@@ -27,6 +27,12 @@ extern "C" {
 
 #define TGX_ABI_VERSION 1
 
+#if defined(__GNUC__)
+#define TGX_API __attribute__((visibility("default")))
+#else
+#define TGX_API
+#endif
+
 typedef struct tgx_ctx tgx_ctx;
 
 typedef enum tgx_status {
@@ -93,11 +99,11 @@ typedef struct tgx_sampler_cfg {
 
 /* Number of visible MI355X devices (the `--device mi355x` probe; reference branch:
  * examples/inference/main.cpp:76-80). */
-int tgx_device_count(int* out_count);
+TGX_API int tgx_device_count(int* out_count);
 
 /* == Model{Llama,Qwen2,Mistral}::Model*(config, device) (e.g. src/model/ModelLlama.h:57-65):
  * validates the description, binds the GPU, allocates parameter storage in compute_dtype. */
-int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx);
+TGX_API int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx);
 
 /* == SafeTensors::loadInternal -> Storage::copyOnDevice for ONE named tensor
  * (src/util/SafeTensors.cpp:157-215).  `hf_name` is the checkpoint key; q/k/v and gate/up land in
@@ -106,15 +112,15 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
  * (the reference warns "Unexpected key" and continues — callers may ignore that status).
  * `src_dtype` is the dtype of `host`; conversion to compute_dtype happens on upload
  * (bf16->fp32 exact, fp32->bf16 round-to-nearest-even), == model().to(dtype), ModelLoader.cpp:84. */
-int tgx_upload(tgx_ctx* ctx, const char* hf_name, const void* host, const int64_t* shape, int ndim,
+TGX_API int tgx_upload(tgx_ctx* ctx, const char* hf_name, const void* host, const int64_t* shape, int ndim,
                int src_dtype);
 
 /* == model().eval() + GPTModel::init(): checks every tensor arrived (TGX_ERR_STATE names the
  * first missing key in tgx_last_error), builds the RoPE tables (nn::RoPE ctor, ModelLlama.h:41-42),
  * allocates the KV cache for max_batch x max_ctx tokens and instantiates the decode graph. */
-int tgx_finalize(tgx_ctx* ctx);
+TGX_API int tgx_finalize(tgx_ctx* ctx);
 
-void tgx_destroy(tgx_ctx* ctx);
+TGX_API void tgx_destroy(tgx_ctx* ctx);
 
 /* ---- the hot path ------------------------------------------------------------------------ */
 
@@ -124,52 +130,52 @@ void tgx_destroy(tgx_ctx* ctx);
  * (KVCacheManager::append, CacheManager.h:24-42) and leaves the last-position logits [batch][vocab]
  * on the device for tgx_sample / tgx_read_logits.  seq>1 with pastLength>0 is rejected with
  * TGX_ERR_INVALID (the reference would run it non-causally, Attention.h:108; its engine never does). */
-int tgx_forward(tgx_ctx* ctx, const int64_t* ids, int batch, int seq);
+TGX_API int tgx_forward(tgx_ctx* ctx, const int64_t* ids, int batch, int seq);
 
 /* Copies the logits of the last tgx_forward / decode step to `out` [batch*vocab] as fp32.
  * rounded=1: values as the reference's logits tensor holds them (rounded to compute_dtype);
  * rounded=0: the fp32 accumulators before that rounding (for tolerance checks). */
-int tgx_read_logits(tgx_ctx* ctx, float* out, int rounded);
+TGX_API int tgx_read_logits(tgx_ctx* ctx, float* out, int rounded);
 
 /* == Sampler::sample(logits[B,V]) (src/engine/Sampler.cpp:23-79) on the current logits.
  * The sampled ids become the device-resident "next token" of every row; if out_ids != NULL they
  * are also copied to the host ([batch], int64).  `seed` drives the multinomial draw (the
  * reference's RNG stream is not reproducible; greedy ignores it). */
-int tgx_sample(tgx_ctx* ctx, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* out_ids);
+TGX_API int tgx_sample(tgx_ctx* ctx, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* out_ids);
 
 /* == the decode loop body of GPTEngine::generateSync (src/engine/GPTEngine.cpp:165-168), n_steps
  * times: nextToken = sample(forward(nextToken)).  Token ids and positions stay on the GPU between
  * steps; out_ids (may be NULL) receives [n_steps][batch] int64. */
-int tgx_decode(tgx_ctx* ctx, const tgx_sampler_cfg* cfg, uint64_t seed, int n_steps, int64_t* out_ids);
+TGX_API int tgx_decode(tgx_ctx* ctx, const tgx_sampler_cfg* cfg, uint64_t seed, int n_steps, int64_t* out_ids);
 
 /* == AsyncTokenPipeline (src/engine/GPTEngine.cpp:17-35) for generateAsync's one-step lookahead
  * (GPTEngine.cpp:196-217), batch row 0.  tgx_step_async enqueues one decode step and returns
  * immediately with a ticket; tgx_fetch_token blocks until the step with that ticket has sampled
  * and returns its id.  Ticket 0 refers to the token produced by the last tgx_sample. */
-int tgx_step_async(tgx_ctx* ctx, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* out_ticket);
-int tgx_fetch_token(tgx_ctx* ctx, int64_t ticket, int32_t* out_id);
+TGX_API int tgx_step_async(tgx_ctx* ctx, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* out_ticket);
+TGX_API int tgx_fetch_token(tgx_ctx* ctx, int64_t ticket, int32_t* out_id);
 
 /* == GPTModel::resetCache() (src/model/GPTModel.h:91-94): pastLength back to 0 for all rows. */
-int tgx_reset_cache(tgx_ctx* ctx);
+TGX_API int tgx_reset_cache(tgx_ctx* ctx);
 
 /* == KVCacheManager::pastLength (src/engine/CacheManager.h:44-51). */
-int64_t tgx_past_length(const tgx_ctx* ctx);
+TGX_API int64_t tgx_past_length(const tgx_ctx* ctx);
 
 /* == GPTModel::contextSize() / numLayers() (src/model/GPTModel.h:97-98). */
-int64_t tgx_context_size(const tgx_ctx* ctx);
-int32_t tgx_num_layers(const tgx_ctx* ctx);
+TGX_API int64_t tgx_context_size(const tgx_ctx* ctx);
+TGX_API int32_t tgx_num_layers(const tgx_ctx* ctx);
 
 /* ---- diagnostics ------------------------------------------------------------------------- */
 
 /* Last error text for this context (or for tgx_create when ctx == NULL). */
-const char* tgx_last_error(const tgx_ctx* ctx);
+TGX_API const char* tgx_last_error(const tgx_ctx* ctx);
 
 /* Blocks until all work enqueued on the context's stream has finished. */
-int tgx_synchronize(tgx_ctx* ctx);
+TGX_API int tgx_synchronize(tgx_ctx* ctx);
 
 /* Reads back the KV cache of (row, layer) as fp32 into k_out/v_out, each [pastLength][kv_heads][head_dim]
  * (the BSHD view KVCacheManager::append returns, Attention.h:106).  Test/diagnostic use. */
-int tgx_read_kv(tgx_ctx* ctx, int row, int layer, float* k_out, float* v_out);
+TGX_API int tgx_read_kv(tgx_ctx* ctx, int row, int layer, float* k_out, float* v_out);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg): runs
  * n_steps eager (un-graphed) decode steps and returns, for kernel class `which`
@@ -181,13 +187,13 @@ int tgx_read_kv(tgx_ctx* ctx, int row, int layer, float* k_out, float* v_out);
 #define TGX_KERNEL_DOWN 4
 #define TGX_KERNEL_LMHEAD 5
 #define TGX_KERNEL_COUNT 6
-int tgx_profile_decode(tgx_ctx* ctx, int n_steps, int64_t* launches /*[TGX_KERNEL_COUNT]*/,
+TGX_API int tgx_profile_decode(tgx_ctx* ctx, int n_steps, int64_t* launches /*[TGX_KERNEL_COUNT]*/,
                        double* total_ms /*[TGX_KERNEL_COUNT]*/);
 
 /* Algorithmic HBM bytes one decoded token streams at context length T (SURVEY.md §8d formula). */
-int64_t tgx_bytes_per_token(const tgx_ctx* ctx, int64_t T);
+TGX_API int64_t tgx_bytes_per_token(const tgx_ctx* ctx, int64_t T);
 
-int tgx_abi_version(void);
+TGX_API int tgx_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,43 @@
+"""Builds tinygpt_amd/lib/libtgx_mi355x.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU build container; the .so travels to the
+GPU box with the gpurun snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libtgx_mi355x.so")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+         "-Wall", "-Wno-unused-function", "-DNDEBUG"]
+
+
+def sources():
+    out = [os.path.join(CSRC, "tgx_mi355x.hip")]
+    deps = list(out) + [os.path.join(HERE, "..", "include", "tgx.h")]
+    kd = os.path.join(CSRC, "kernels")
+    deps += [os.path.join(kd, f) for f in sorted(os.listdir(kd))]
+    return out, deps
+
+
+def build_lib(force: bool = False, verbose: bool = False, extra_flags=()):
+    srcs, deps = sources()
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + srcs + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="-f" in sys.argv, verbose=True))

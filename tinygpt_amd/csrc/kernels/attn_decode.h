@@ -1,0 +1,158 @@
+// attn_decode.h — single-query GQA attention over the pre-allocated KV cache (decode step).
+//
+// Replaces, for seq == 1:  KVCacheManager::append's concat (CacheManager.h:24-42 — the O(T) realloc+copy
+// is gone: the QKV epilogue already stored this step's K/V row in place) and
+// function::flashAttention(q, Kall, Vall, isCausal=false) (Attention.h:108-109).
+//
+// Numerics contract: scores = (q.k) * hd^-1/2 in fp32, fp32 softmax, fp32 P.V, one rounding of the output.
+//
+// Roofline: HBM — 2 * kv_heads * (T+1) * hd * 2 bytes per launch (K and V rows read once; all G = heads/kv_heads
+// query heads of a group share one pass over their kv head).
+//
+// Decomposition (split-K flash-decode): grid = kv_heads * nsplit workgroups of 4 waves.  Workgroup (kvh, sp)
+// owns the token range [sp*chunk, (sp+1)*chunk) with chunk derived on the device from the device-resident
+// position (so one captured hipGraph serves every step).  Inside a wave, HD/8 adjacent lanes hold one
+// token's row as 16-byte slices (a wave-load covers 64/(HD/8) consecutive tokens = 1 KiB contiguous);
+// every lane group keeps its own online-softmax stream, merged once at the end (lanes -> waves via LDS ->
+// one (m, l, o[HD]) partial per query head per split).  attn_combine_kernel merges the splits.
+#pragma once
+#include "common.h"
+
+namespace tgx {
+
+struct AttnArgs {
+  const bf16_t* q;        // [heads][hd] (RoPE applied, bf16)
+  const bf16_t* k_cache;  // this layer/row: [kv_heads][max_ctx][hd]
+  const bf16_t* v_cache;
+  const int* pos;         // pastLength BEFORE this step; keys [0, pos] are attended
+  float* part;            // [heads][nsplit][hd + 2]  (m, l, o[hd])
+  bf16_t* out;            // [heads*hd] (combine kernel)
+  int heads, kv_heads, max_ctx, nsplit;
+  float scale;
+};
+
+template <int HD, int G>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
+  constexpr int LPT = HD / 8;         // lanes per token row
+  constexpr int TPW = 64 / LPT;       // tokens per wave-load
+  __shared__ float red[4][G][HD + 2];
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int kvh = blockIdx.x / a.nsplit, sp = blockIdx.x - kvh * a.nsplit;
+  const int part_i = lane % LPT, slot = lane / LPT;
+  const int n_keys = *a.pos + 1;
+  // token range of this split: multiples of 4*TPW so that waves stay aligned to whole wave-loads
+  constexpr int STEP = 4 * TPW;
+  int chunk = (n_keys + a.nsplit - 1) / a.nsplit;
+  chunk = ((chunk + STEP - 1) / STEP) * STEP;
+  const int t_begin = sp * chunk;
+  const int t_end = min(n_keys, t_begin + chunk);
+
+  // query slices: q[g][part_i*8 .. +8) as fp32
+  float qf[G][8];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(a.q + (size_t)(kvh * G + g) * HD + part_i * 8);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { qf[g][2 * j] = bf16_lo(v[j]); qf[g][2 * j + 1] = bf16_hi(v[j]); }
+  }
+  float m[G], l[G], o[G][8];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    m[g] = -INFINITY; l[g] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[g][j] = 0.f;
+  }
+
+  const bf16_t* kbase = a.k_cache + (size_t)kvh * a.max_ctx * HD;
+  const bf16_t* vbase = a.v_cache + (size_t)kvh * a.max_ctx * HD;
+  for (int t0 = t_begin + wv * TPW; t0 < t_end; t0 += STEP) {
+    const int t = t0 + slot;
+    const bool valid = t < t_end;
+    const int tc = valid ? t : t_end - 1;
+    const u32x4 kv = *reinterpret_cast<const u32x4*>(kbase + (size_t)tc * HD + part_i * 8);
+    const u32x4 vv = *reinterpret_cast<const u32x4*>(vbase + (size_t)tc * HD + part_i * 8);
+    float kf[8], vf[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      kf[2 * j] = bf16_lo(kv[j]); kf[2 * j + 1] = bf16_hi(kv[j]);
+      vf[2 * j] = bf16_lo(vv[j]); vf[2 * j + 1] = bf16_hi(vv[j]);
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) s = fmaf(qf[g][j], kf[j], s);
+      s = group_sum<LPT>(s) * a.scale;
+      if (valid) {
+        const float mn = fmaxf(m[g], s);
+        const float alpha = expf(m[g] - mn);     // exp(-inf) = 0 on the first key
+        const float p = expf(s - mn);
+        l[g] = l[g] * alpha + p;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[g][j] = o[g][j] * alpha + p * vf[j];
+        m[g] = mn;
+      }
+    }
+  }
+
+  // merge the TPW token-slot streams of this wave (lanes with equal part_i), then the 4 waves via LDS
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    float M = m[g];
+#pragma unroll
+    for (int off = LPT; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+    const float sc = (m[g] == -INFINITY) ? 0.f : expf(m[g] - M);
+    float L = l[g] * sc;
+#pragma unroll
+    for (int off = LPT; off < 64; off <<= 1) L += __shfl_xor(L, off, 64);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      float v = o[g][j] * sc;
+#pragma unroll
+      for (int off = LPT; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+      o[g][j] = v;
+    }
+    if (slot == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) red[wv][g][part_i * 8 + j] = o[g][j];
+      if (part_i == 0) { red[wv][g][HD] = M; red[wv][g][HD + 1] = L; }
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < G * HD; idx += 256) {
+    const int g = idx / HD, d = idx - g * HD;
+    float M = fmaxf(fmaxf(red[0][g][HD], red[1][g][HD]), fmaxf(red[2][g][HD], red[3][g][HD]));
+    float L = 0.f, acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const float mw = red[w][g][HD];
+      const float sc = (mw == -INFINITY) ? 0.f : expf(mw - M);
+      L += red[w][g][HD + 1] * sc;
+      acc += red[w][g][d] * sc;
+    }
+    float* dst = a.part + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 2);
+    dst[d] = acc;
+    if (d == 0) { dst[HD] = M; dst[HD + 1] = L; }
+  }
+}
+
+// Merges the nsplit partials of every query head and writes the attention output in bf16
+// (== the reshape to [B,S,qDim] that feeds o_proj, Attention.h:111).
+template <int HD>
+__global__ void attn_combine_kernel(const AttnArgs a) {
+  const int h = blockIdx.x, d = threadIdx.x;
+  const float* p = a.part + (size_t)h * a.nsplit * (HD + 2);
+  float M = -INFINITY;
+  for (int s = 0; s < a.nsplit; s++) M = fmaxf(M, p[s * (HD + 2) + HD]);
+  float L = 0.f, acc = 0.f;
+  for (int s = 0; s < a.nsplit; s++) {
+    const float ms = p[s * (HD + 2) + HD];
+    const float sc = (ms == -INFINITY) ? 0.f : expf(ms - M);
+    L += p[s * (HD + 2) + HD + 1] * sc;
+    acc += p[s * (HD + 2) + d] * sc;
+  }
+  a.out[h * HD + d] = f32_to_bf16(acc / L);
+}
+
+}  // namespace tgx

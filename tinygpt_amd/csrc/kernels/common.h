@@ -1,0 +1,72 @@
+// common.h — device helpers shared by the gfx950 kernels of the decode path.
+// Wavefront = 64 lanes everywhere (CDNA4); all reductions run in a fixed order (deterministic output).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tgx {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;   // bf16 bit pattern
+
+constexpr int WAVE = 64;
+
+// ---- bf16 <-> fp32 (round-to-nearest-even; the R() of the numerics contract) ----
+__device__ __forceinline__ float bf16_lo(unsigned int u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned int u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((unsigned int)b) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float rbf(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
+  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+}
+
+// ---- streaming (read-once) 16-byte load: global_load_dwordx4 ... nt -------------------------------
+__device__ __forceinline__ u32x4 load_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
+
+// acc += dot(8 bf16 weights in w, 8 fp32 activations in xa/xb) — exact products, fp32 FMA chain
+__device__ __forceinline__ float dot8(float acc, const u32x4 w, const f32x4 xa, const f32x4 xb) {
+  acc = fmaf(bf16_lo(w[0]), xa[0], acc);
+  acc = fmaf(bf16_hi(w[0]), xa[1], acc);
+  acc = fmaf(bf16_lo(w[1]), xa[2], acc);
+  acc = fmaf(bf16_hi(w[1]), xa[3], acc);
+  acc = fmaf(bf16_lo(w[2]), xb[0], acc);
+  acc = fmaf(bf16_hi(w[2]), xb[1], acc);
+  acc = fmaf(bf16_lo(w[3]), xb[2], acc);
+  acc = fmaf(bf16_hi(w[3]), xb[3], acc);
+  return acc;
+}
+
+// ---- cross-lane reductions ----------------------------------------------------------------------
+template <int WIDTH = 64>
+__device__ __forceinline__ float group_sum(float v) {   // butterfly: every lane of the group ends with the sum
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int WIDTH = 64>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum over 256 threads (4 waves) through a 4-float LDS scratch; every thread gets the result.
+__device__ __forceinline__ float block_sum_256(float v, float* scratch4) {
+  v = group_sum<64>(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) scratch4[wv] = v;
+  __syncthreads();
+  float r = scratch4[0] + scratch4[1] + scratch4[2] + scratch4[3];
+  __syncthreads();
+  return r;
+}
+
+}  // namespace tgx

@@ -1,0 +1,766 @@
+// tgx_mi355x.hip — the extern "C" shim of include/tgx.h for MI355X (gfx950): context, weight upload by HF
+// name, KV cache, decode-step hipGraph, and the launch sequence of the hand-written kernels in kernels/*.h.
+//
+// One context = one GPU = one HIP stream; every call comes from one host thread (the reference's engine is
+// entered by one thread only: examples/inference/main.cpp, server/HttpServer.cpp:118-163).
+// There is NO CPU path in this library: every entry point either runs on the GPU or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tgx.h"
+#include "kernels/attn_decode.h"
+#include "kernels/common.h"
+#include "kernels/gemv.h"
+
+using tgx::bf16_t;
+
+namespace {
+
+constexpr int MAX_TICKET_EVENTS = 64;
+constexpr int HOST_RING = 256;
+
+struct LayerW {
+  bf16_t *in_norm = nullptr, *post_norm = nullptr;
+  bf16_t *wqkv = nullptr, *bqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wdown = nullptr;
+  int64_t qkv_rows = 0, gu_rows = 0;
+  bool in_norm_ok = false, post_norm_ok = false, wo_ok = false, wdown_ok = false;
+  int64_t bias_rows = 0;
+};
+
+struct RowState {       // independent KV/sequence state of one batch row
+  bf16_t *x = nullptr, *q = nullptr, *attn = nullptr, *h = nullptr;
+  float* logits = nullptr;
+  float* part_val = nullptr;
+  int* part_idx = nullptr;
+  float* attn_part = nullptr;
+  int *tok = nullptr, *pos = nullptr;
+  long long* prompt = nullptr;
+  bf16_t *kcache = nullptr, *vcache = nullptr;   // [layers][kv_heads][max_ctx][hd]
+};
+
+struct Profiler {
+  bool on = false;
+  hipEvent_t ev[2 * 8] = {};
+  int64_t launches[TGX_KERNEL_COUNT] = {};
+  double ms[TGX_KERNEL_COUNT] = {};
+};
+
+}  // namespace
+
+struct tgx_ctx {
+  tgx_model_desc d{};
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool finalized = false;
+
+  bf16_t *embed = nullptr, *lm_head = nullptr, *final_norm = nullptr;
+  bool embed_ok = false, lm_head_ok = false, final_norm_ok = false;
+  std::vector<LayerW> L;
+  float *rope_cos = nullptr, *rope_sin = nullptr;
+  std::vector<RowState> rows;
+
+  int64_t past = 0;       // host mirror of every row's device-resident pos
+  int batch = 0;          // rows used by the last forward
+  bool have_logits = false, have_token = false;
+
+  int* step = nullptr;    // device: number of decode steps finalized (monotonic)
+  int* tok_log = nullptr; // device ring [log_cap][rows]
+  int log_cap = 0;
+  int* host_ring = nullptr;  // pinned host ring [HOST_RING][rows]
+  int* host_ring_dev = nullptr;
+  int64_t steps_issued = 0;
+  hipEvent_t ticket_ev[MAX_TICKET_EVENTS] = {};
+  int32_t last_sampled0 = -1;
+
+  hipGraphExec_t step_graph = nullptr;
+  int step_graph_batch = 0;
+  bool use_graph = true;
+
+  int gemv_bpc = 4;       // GEMV workgroups per CU
+  int lm_grid = 0, attn_nsplit = 1;
+  Profiler prof;
+};
+
+namespace {
+
+std::string g_create_err;
+
+int set_err(tgx_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_err = buf;
+  return code;
+}
+
+#define HIP_OK(c, call)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return set_err((c), TGX_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+inline uint16_t host_f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline float host_bf16_to_f32(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline float host_half_to_f32(uint16_t h) {
+  uint32_t s = (h >> 15) & 1, e = (h >> 10) & 0x1f, m = h & 0x3ff, u;
+  if (e == 0) {
+    if (m == 0) u = s << 31;
+    else { e = 127 - 15 + 1; while (!(m & 0x400)) { m <<= 1; e--; } m &= 0x3ff; u = (s << 31) | (e << 23) | (m << 13); }
+  } else if (e == 31) u = (s << 31) | 0x7f800000u | (m << 13);
+  else u = (s << 31) | ((e + 127 - 15) << 23) | (m << 13);
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// host -> device copy with conversion to the compute dtype (== model().to(dtype), ModelLoader.cpp:84)
+int upload_bf16(tgx_ctx* c, bf16_t* dst, const void* host, int64_t n, int src_dtype) {
+  if (src_dtype == TGX_BF16) {
+    HIP_OK(c, hipMemcpy(dst, host, (size_t)n * 2, hipMemcpyHostToDevice));
+    return TGX_OK;
+  }
+  std::vector<uint16_t> tmp((size_t)n);
+  if (src_dtype == TGX_F32) {
+    const float* s = (const float*)host;
+    for (int64_t i = 0; i < n; i++) tmp[(size_t)i] = host_f32_to_bf16(s[i]);
+  } else if (src_dtype == TGX_F16) {
+    const uint16_t* s = (const uint16_t*)host;
+    for (int64_t i = 0; i < n; i++) tmp[(size_t)i] = host_f32_to_bf16(host_half_to_f32(s[i]));
+  } else {
+    return set_err(c, TGX_ERR_INVALID, "unknown source dtype %d", src_dtype);
+  }
+  HIP_OK(c, hipMemcpy(dst, tmp.data(), (size_t)n * 2, hipMemcpyHostToDevice));
+  return TGX_OK;
+}
+
+bool shape_is(const int64_t* s, int nd, int64_t a, int64_t b) {
+  if (b < 0) return nd == 1 && s[0] == a;
+  return nd == 2 && s[0] == a && s[1] == b;
+}
+
+// nn::RoPE tables (ctor at ModelLlama.h:41-42): HF LlamaRotaryEmbedding incl. llama3 scaling; values are
+// rounded to bf16 (cos/sin are cast to the activation dtype before use) and kept as fp32 words.
+void build_rope_host(const tgx_model_desc& d, std::vector<float>& cs, std::vector<float>& sn) {
+  const int half = d.head_dim / 2;
+  std::vector<float> inv((size_t)half);
+  for (int i = 0; i < half; i++) {
+    const float e = (float)(2 * i) / (float)d.head_dim;
+    const float p = (float)std::pow((double)d.rope_theta, (double)e);
+    inv[(size_t)i] = 1.0f / p;
+  }
+  if (d.family == TGX_FAMILY_LLAMA && d.rope_factor > 0.f) {
+    const float factor = d.rope_factor, lo = d.rope_low_freq, hi = d.rope_high_freq, old = (float)d.rope_orig_ctx;
+    const float low_wl = old / lo, high_wl = old / hi;
+    for (int i = 0; i < half; i++) {
+      const float wl = 2.0f * (float)M_PI / inv[(size_t)i];
+      const float v = wl > low_wl ? inv[(size_t)i] / factor : inv[(size_t)i];
+      const float smooth = (old / wl - lo) / (hi - lo);
+      const float sm = (1.0f - smooth) * v / factor + smooth * v;
+      const bool medium = !(wl < high_wl) && !(wl > low_wl);
+      inv[(size_t)i] = medium ? sm : v;
+    }
+  }
+  cs.resize((size_t)d.max_ctx * half);
+  sn.resize((size_t)d.max_ctx * half);
+  for (int p = 0; p < d.max_ctx; p++)
+    for (int i = 0; i < half; i++) {
+      const float a = inv[(size_t)i] * (float)p;
+      cs[(size_t)p * half + i] = host_bf16_to_f32(host_f32_to_bf16(cosf(a)));
+      sn[(size_t)p * half + i] = host_bf16_to_f32(host_f32_to_bf16(sinf(a)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel launch helpers
+// ------------------------------------------------------------------------------------------------
+struct Timed {   // brackets one launch with events when profiling
+  tgx_ctx* c; int cls; bool on;
+  Timed(tgx_ctx* c_, int cls_) : c(c_), cls(cls_), on(c_->prof.on && cls_ >= 0) {
+    if (on) (void)hipEventRecord(c->prof.ev[0], c->stream);
+  }
+  ~Timed() {
+    if (!on) return;
+    (void)hipEventRecord(c->prof.ev[1], c->stream);
+    (void)hipEventSynchronize(c->prof.ev[1]);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->prof.ev[0], c->prof.ev[1]);
+    c->prof.launches[cls]++;
+    c->prof.ms[cls] += ms;
+  }
+};
+
+int gemv_grid(const tgx_ctx* c, int units) {
+  const int want = (units + 3) / 4;
+  const int cap = c->num_cus * c->gemv_bpc;
+  return want < cap ? want : cap;
+}
+
+template <int PRO, int EPI>
+void launch_gemv(tgx_ctx* c, const tgx::GemvArgs& a, int grid, int cls) {
+  Timed t(c, cls);
+  const size_t lds = (size_t)a.K * 4 + 64;
+  hipLaunchKernelGGL((tgx::gemv_kernel<PRO, EPI>), dim3(grid), dim3(256), lds, c->stream, a);
+}
+
+template <int HD>
+void launch_attn_g(tgx_ctx* c, const tgx::AttnArgs& a, int G) {
+  const dim3 grid(a.kv_heads * a.nsplit), blk(256);
+  switch (G) {
+    case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 1>), grid, blk, 0, c->stream, a); break;
+    case 2: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 2>), grid, blk, 0, c->stream, a); break;
+    case 3: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 3>), grid, blk, 0, c->stream, a); break;
+    case 4: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 4>), grid, blk, 0, c->stream, a); break;
+    case 5: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 5>), grid, blk, 0, c->stream, a); break;
+    case 6: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 6>), grid, blk, 0, c->stream, a); break;
+    case 7: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 7>), grid, blk, 0, c->stream, a); break;
+    default: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 8>), grid, blk, 0, c->stream, a); break;
+  }
+  hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads), dim3(HD), 0, c->stream, a);
+}
+
+void launch_attn(tgx_ctx* c, const tgx::AttnArgs& a) {
+  Timed t(c, TGX_KERNEL_ATTN);
+  const int G = a.heads / a.kv_heads;
+  if (c->d.head_dim == 64) launch_attn_g<64>(c, a, G);
+  else launch_attn_g<128>(c, a, G);
+}
+
+// All decoder layers for the token whose embedding sits in row.x, at position *row.pos.
+// == for (auto& layer : layers_) x = layer->forward(x)  (GPTModel.h:53-55)
+void launch_layers(tgx_ctx* c, RowState& r) {
+  const tgx_model_desc& d = c->d;
+  const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
+  const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd;
+  for (int l = 0; l < d.layers; l++) {
+    const LayerW& w = c->L[(size_t)l];
+    {   // input_layernorm -> qkv_proj -> RoPE -> cache append      (DecoderLayer.h:40, Attention.h:94-106)
+      tgx::GemvArgs a{};
+      a.W = w.wqkv; a.bias = w.bqkv; a.x = r.x; a.norm_w = w.in_norm; a.eps = d.norm_eps;
+      a.N = qd + 2 * kvd; a.K = H; a.units = a.N / 2;
+      a.q_out = r.q; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
+      a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos = r.pos;
+      a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx;
+      launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_QKV_ROPE>(c, a, gemv_grid(c, a.units), TGX_KERNEL_QKV);
+    }
+    {   // flashAttention(q, Kall, Vall) over keys [0, pos]          (Attention.h:108-111)
+      tgx::AttnArgs a{};
+      a.q = r.q; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
+      a.pos = r.pos; a.part = r.attn_part; a.out = r.attn;
+      a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
+      a.scale = 1.0f / sqrtf((float)hd);
+      launch_attn(c, a);
+    }
+    {   // o_proj + residual                                        (Attention.h:90, DecoderLayer.h:40)
+      tgx::GemvArgs a{};
+      a.W = w.wo; a.x = r.attn; a.N = H; a.K = qd; a.units = (H + 1) / 2; a.out = r.x; a.hd = 2;
+      launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, gemv_grid(c, a.units), TGX_KERNEL_OPROJ);
+    }
+    {   // post_attention_layernorm -> gate_up_proj -> siluMul       (DecoderLayer.h:41, GatedMLP.h:37-39)
+      tgx::GemvArgs a{};
+      a.W = w.wgu; a.x = r.x; a.norm_w = w.post_norm; a.eps = d.norm_eps;
+      a.N = 2 * I; a.K = H; a.units = I; a.out = r.h; a.hd = 2;
+      launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_SILU_MUL>(c, a, gemv_grid(c, a.units), TGX_KERNEL_GATEUP);
+    }
+    {   // down_proj + residual                                     (GatedMLP.h:40, DecoderLayer.h:41)
+      tgx::GemvArgs a{};
+      a.W = w.wdown; a.x = r.h; a.N = H; a.K = I; a.units = (H + 1) / 2; a.out = r.x; a.hd = 2;
+      launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, gemv_grid(c, a.units), TGX_KERNEL_DOWN);
+    }
+  }
+}
+
+// model.norm -> lm_head on the current position + per-workgroup argmax partials   (GPTModel.h:56-57)
+void launch_lm_head(tgx_ctx* c, RowState& r) {
+  const tgx_model_desc& d = c->d;
+  tgx::GemvArgs a{};
+  a.W = d.tied ? c->embed : c->lm_head; a.x = r.x; a.norm_w = c->final_norm; a.eps = d.norm_eps;
+  a.N = d.vocab; a.K = d.hidden; a.units = (d.vocab + 1) / 2; a.hd = 2;
+  a.logits = r.logits; a.part_val = r.part_val; a.part_idx = r.part_idx;
+  launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_LOGITS>(c, a, c->lm_grid, TGX_KERNEL_LMHEAD);
+}
+
+void launch_finalize_greedy(tgx_ctx* c, int row, bool advance_pos, bool log_step) {
+  RowState& r = c->rows[(size_t)row];
+  tgx::FinalizeArgs a{};
+  a.part_val = r.part_val; a.part_idx = r.part_idx; a.n_part = c->lm_grid;
+  a.tok = r.tok; a.pos = r.pos; a.step = c->step; a.tok_log = c->tok_log; a.host_ring = c->host_ring_dev;
+  a.log_cap = c->log_cap; a.ring_cap = HOST_RING;
+  a.row = row; a.rows = c->batch;
+  a.log = log_step ? 1 : 0; a.bump_step = (row == c->batch - 1) ? 1 : 0;
+  a.embed = c->embed; a.x = r.x; a.H = c->d.hidden; a.advance_pos = advance_pos ? 1 : 0;
+  hipLaunchKernelGGL(tgx::finalize_greedy_kernel, dim3(1), dim3(256), 0, c->stream, a);
+}
+
+// One greedy decode step for all active rows: layers at pos, lm_head, then {argmax, pos+=1, next embedding}.
+// == nextToken = genNextToken(nextToken)  (GPTEngine.cpp:94-99,165-168)
+void launch_decode_step(tgx_ctx* c) {
+  for (int b = 0; b < c->batch; b++) {
+    RowState& r = c->rows[(size_t)b];
+    launch_layers(c, r);
+    launch_lm_head(c, r);
+    launch_finalize_greedy(c, b, /*advance_pos=*/true, /*log_step=*/true);
+  }
+}
+
+int ensure_step_graph(tgx_ctx* c) {
+  if (!c->use_graph) return TGX_OK;
+  if (c->step_graph && c->step_graph_batch == c->batch) return TGX_OK;
+  if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
+  hipGraph_t g = nullptr;
+  HIP_OK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  launch_decode_step(c);
+  HIP_OK(c, hipStreamEndCapture(c->stream, &g));
+  HIP_OK(c, hipGraphInstantiate(&c->step_graph, g, nullptr, nullptr, 0));
+  (void)hipGraphDestroy(g);
+  c->step_graph_batch = c->batch;
+  return TGX_OK;
+}
+
+int run_decode_steps(tgx_ctx* c, int n) {
+  if (c->use_graph && !c->prof.on) {
+    int rc = ensure_step_graph(c);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) HIP_OK(c, hipGraphLaunch(c->step_graph, c->stream));
+  } else {
+    for (int i = 0; i < n; i++) launch_decode_step(c);
+    HIP_OK(c, hipGetLastError());
+  }
+  c->past += n;
+  c->steps_issued += n;
+  return TGX_OK;
+}
+
+template <typename T>
+int dev_alloc(tgx_ctx* c, T** p, size_t n) {
+  HIP_OK(c, hipMalloc((void**)p, n * sizeof(T)));
+  return TGX_OK;
+}
+
+bool is_greedy(const tgx_sampler_cfg* s) {   // Sampler.cpp:15-21
+  return !(s->temperature > 0.f || s->top_k > 0 || s->top_p < 1.f || s->min_p > 0.f);
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int tgx_abi_version(void) { return TGX_ABI_VERSION; }
+
+int tgx_device_count(int* out_count) {
+  if (!out_count) return TGX_ERR_INVALID;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *out_count = 0; return set_err(nullptr, TGX_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+  *out_count = n;
+  return TGX_OK;
+}
+
+const char* tgx_last_error(const tgx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx) {
+  if (!desc || !out_ctx) return set_err(nullptr, TGX_ERR_INVALID, "null argument");
+  *out_ctx = nullptr;
+  const tgx_model_desc& d = *desc;
+  if (d.family != TGX_FAMILY_LLAMA && d.family != TGX_FAMILY_QWEN2 && d.family != TGX_FAMILY_MISTRAL)
+    return set_err(nullptr, TGX_ERR_UNSUPPORTED, "family %d is not implemented on mi355x (llama/qwen2/mistral are)", d.family);
+  if (d.compute_dtype != TGX_BF16) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "mi355x backend computes in bf16 only");
+  if (d.head_dim != 64 && d.head_dim != 128) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "head_dim %d (64 and 128 are built)", d.head_dim);
+  if (d.heads <= 0 || d.kv_heads <= 0 || d.heads % d.kv_heads) return set_err(nullptr, TGX_ERR_INVALID, "heads %% kv_heads != 0");
+  if (d.heads / d.kv_heads > 8) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "GQA group size %d > 8", d.heads / d.kv_heads);
+  if (d.hidden % 8 || d.inter % 8 || (d.heads * d.head_dim) % 8) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "hidden/intermediate sizes must be multiples of 8");
+  if (d.hidden <= 0 || d.layers <= 0 || d.inter <= 0 || d.vocab <= 0 || d.max_ctx <= 0) return set_err(nullptr, TGX_ERR_INVALID, "non-positive model dimension");
+  if ((size_t)d.inter * 4 + 64 > 64 * 1024 || (size_t)d.hidden * 4 + 64 > 64 * 1024)
+    return set_err(nullptr, TGX_ERR_UNSUPPORTED, "activation vector does not fit the 64 KiB LDS stage");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(nullptr, TGX_ERR_DEVICE, "no HIP device visible (--device mi355x needs a GPU; there is no CPU fallback)");
+  if (device_ordinal < 0 || device_ordinal >= ndev) return set_err(nullptr, TGX_ERR_INVALID, "device ordinal %d out of range [0,%d)", device_ordinal, ndev);
+
+  tgx_ctx* c = new (std::nothrow) tgx_ctx();
+  if (!c) return set_err(nullptr, TGX_ERR_NOMEM, "host allocation failed");
+  *out_ctx = c;
+  c->d = d;
+  if (c->d.max_batch < 1) c->d.max_batch = 1;
+  c->device = device_ordinal;
+  HIP_OK(c, hipSetDevice(device_ordinal));
+  hipDeviceProp_t prop;
+  HIP_OK(c, hipGetDeviceProperties(&prop, device_ordinal));
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_OK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (const char* e = getenv("TGX_NO_GRAPH")) c->use_graph = !(e[0] == '1');
+  if (const char* e = getenv("TGX_GEMV_BPC")) { int v = atoi(e); if (v >= 1 && v <= 16) c->gemv_bpc = v; }
+
+  const int H = d.hidden, I = d.inter, V = d.vocab, qd = d.heads * d.head_dim, kvd = d.kv_heads * d.head_dim;
+  int rc;
+  if ((rc = dev_alloc(c, &c->embed, (size_t)V * H))) return rc;
+  if (!d.tied && (rc = dev_alloc(c, &c->lm_head, (size_t)V * H))) return rc;
+  if ((rc = dev_alloc(c, &c->final_norm, (size_t)H))) return rc;
+  c->L.resize((size_t)d.layers);
+  for (auto& w : c->L) {
+    if ((rc = dev_alloc(c, &w.in_norm, (size_t)H))) return rc;
+    if ((rc = dev_alloc(c, &w.post_norm, (size_t)H))) return rc;
+    if ((rc = dev_alloc(c, &w.wqkv, (size_t)(qd + 2 * kvd) * H))) return rc;
+    if (d.qkv_bias && (rc = dev_alloc(c, &w.bqkv, (size_t)(qd + 2 * kvd)))) return rc;
+    if ((rc = dev_alloc(c, &w.wo, (size_t)H * qd))) return rc;
+    if ((rc = dev_alloc(c, &w.wgu, (size_t)2 * I * H))) return rc;
+    if ((rc = dev_alloc(c, &w.wdown, (size_t)H * I))) return rc;
+  }
+  return TGX_OK;
+}
+
+int tgx_upload(tgx_ctx* c, const char* name, const void* host, const int64_t* shape, int nd, int src_dtype) {
+  if (!c || !name || !host || !shape) return c ? set_err(c, TGX_ERR_INVALID, "null argument") : TGX_ERR_INVALID;
+  HIP_OK(c, hipSetDevice(c->device));
+  const tgx_model_desc& d = c->d;
+  const int64_t H = d.hidden, I = d.inter, V = d.vocab, qd = (int64_t)d.heads * d.head_dim, kvd = (int64_t)d.kv_heads * d.head_dim;
+  auto bad_shape = [&]() { return set_err(c, TGX_ERR_SHAPE, "shape not equal for tensor: %s", name); };
+  if (!strcmp(name, "model.embed_tokens.weight")) {
+    if (!shape_is(shape, nd, V, H)) return bad_shape();
+    c->embed_ok = true;
+    return upload_bf16(c, c->embed, host, V * H, src_dtype);
+  }
+  if (!strcmp(name, "lm_head.weight")) {
+    if (!shape_is(shape, nd, V, H)) return bad_shape();
+    if (d.tied) return TGX_OK;   // aliased to embed_tokens (GPTModel.h:39-41)
+    c->lm_head_ok = true;
+    return upload_bf16(c, c->lm_head, host, V * H, src_dtype);
+  }
+  if (!strcmp(name, "model.norm.weight")) {
+    if (!shape_is(shape, nd, H, -1)) return bad_shape();
+    c->final_norm_ok = true;
+    return upload_bf16(c, c->final_norm, host, H, src_dtype);
+  }
+  int l = -1;
+  char rest[128] = {0};
+  if (sscanf(name, "model.layers.%d.%127s", &l, rest) == 2 && l >= 0 && l < d.layers) {
+    LayerW& w = c->L[(size_t)l];
+    if (!strcmp(rest, "input_layernorm.weight")) {
+      if (!shape_is(shape, nd, H, -1)) return bad_shape();
+      w.in_norm_ok = true;
+      return upload_bf16(c, w.in_norm, host, H, src_dtype);
+    }
+    if (!strcmp(rest, "post_attention_layernorm.weight")) {
+      if (!shape_is(shape, nd, H, -1)) return bad_shape();
+      w.post_norm_ok = true;
+      return upload_bf16(c, w.post_norm, host, H, src_dtype);
+    }
+    // MergedLinear row slices (Linear.h:64-79): [q | k | v] and [gate | up]
+    struct Slot { const char* n; bf16_t* base; bf16_t* bias; int64_t row0, rows, cols; int kind; };
+    const Slot slots[] = {
+        {"self_attn.q_proj", w.wqkv, w.bqkv, 0, qd, H, 0},        {"self_attn.k_proj", w.wqkv, w.bqkv, qd, kvd, H, 0},
+        {"self_attn.v_proj", w.wqkv, w.bqkv, qd + kvd, kvd, H, 0}, {"self_attn.o_proj", w.wo, nullptr, 0, H, qd, 1},
+        {"mlp.gate_proj", w.wgu, nullptr, 0, I, H, 2},             {"mlp.up_proj", w.wgu, nullptr, I, I, H, 2},
+        {"mlp.down_proj", w.wdown, nullptr, 0, H, I, 3}};
+    for (const Slot& s : slots) {
+      const size_t ln = strlen(s.n);
+      if (strncmp(rest, s.n, ln) || rest[ln] != '.') continue;
+      if (!strcmp(rest + ln + 1, "weight")) {
+        if (!shape_is(shape, nd, s.rows, s.cols)) return bad_shape();
+        int rc = upload_bf16(c, s.base + s.row0 * s.cols, host, s.rows * s.cols, src_dtype);
+        if (rc) return rc;
+        if (s.kind == 0) w.qkv_rows += s.rows;
+        else if (s.kind == 1) w.wo_ok = true;
+        else if (s.kind == 2) w.gu_rows += s.rows;
+        else w.wdown_ok = true;
+        return TGX_OK;
+      }
+      if (!strcmp(rest + ln + 1, "bias") && s.bias) {
+        if (!shape_is(shape, nd, s.rows, -1)) return bad_shape();
+        w.bias_rows += s.rows;
+        return upload_bf16(c, s.bias + s.row0, host, s.rows, src_dtype);
+      }
+    }
+  }
+  return set_err(c, TGX_ERR_NAME, "Unexpected key: %s", name);
+}
+
+int tgx_finalize(tgx_ctx* c) {
+  if (!c) return TGX_ERR_INVALID;
+  HIP_OK(c, hipSetDevice(c->device));
+  const tgx_model_desc& d = c->d;
+  const int H = d.hidden, I = d.inter, V = d.vocab, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
+  if (!c->embed_ok) return set_err(c, TGX_ERR_STATE, "Missing key: model.embed_tokens.weight");
+  if (!d.tied && !c->lm_head_ok) return set_err(c, TGX_ERR_STATE, "Missing key: lm_head.weight");
+  if (!c->final_norm_ok) return set_err(c, TGX_ERR_STATE, "Missing key: model.norm.weight");
+  for (int l = 0; l < d.layers; l++) {
+    const LayerW& w = c->L[(size_t)l];
+    if (!w.in_norm_ok || !w.post_norm_ok || w.qkv_rows != qd + 2 * kvd || !w.wo_ok || w.gu_rows != 2 * (int64_t)I || !w.wdown_ok)
+      return set_err(c, TGX_ERR_STATE, "Missing key in model.layers.%d", l);
+    if (d.qkv_bias && w.bias_rows != qd + 2 * kvd) return set_err(c, TGX_ERR_STATE, "Missing qkv bias in model.layers.%d", l);
+  }
+  if (c->finalized) return TGX_OK;
+
+  std::vector<float> cs, sn;
+  build_rope_host(d, cs, sn);
+  int rc;
+  if ((rc = dev_alloc(c, &c->rope_cos, cs.size()))) return rc;
+  if ((rc = dev_alloc(c, &c->rope_sin, sn.size()))) return rc;
+  HIP_OK(c, hipMemcpy(c->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(c, hipMemcpy(c->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+
+  c->lm_grid = gemv_grid(c, (V + 1) / 2);
+  int ns = c->num_cus / d.kv_heads;
+  c->attn_nsplit = ns < 1 ? 1 : (ns > 32 ? 32 : ns);
+
+  c->rows.resize((size_t)d.max_batch);
+  const size_t kv_elems = (size_t)d.layers * d.kv_heads * d.max_ctx * hd;
+  for (auto& r : c->rows) {
+    if ((rc = dev_alloc(c, &r.x, (size_t)H))) return rc;
+    if ((rc = dev_alloc(c, &r.q, (size_t)qd))) return rc;
+    if ((rc = dev_alloc(c, &r.attn, (size_t)qd))) return rc;
+    if ((rc = dev_alloc(c, &r.h, (size_t)I))) return rc;
+    if ((rc = dev_alloc(c, &r.logits, (size_t)V))) return rc;
+    if ((rc = dev_alloc(c, &r.part_val, (size_t)c->lm_grid))) return rc;
+    if ((rc = dev_alloc(c, &r.part_idx, (size_t)c->lm_grid))) return rc;
+    if ((rc = dev_alloc(c, &r.attn_part, (size_t)d.heads * c->attn_nsplit * (hd + 2)))) return rc;
+    if ((rc = dev_alloc(c, &r.tok, 1))) return rc;
+    if ((rc = dev_alloc(c, &r.pos, 1))) return rc;
+    if ((rc = dev_alloc(c, &r.prompt, (size_t)d.max_ctx))) return rc;
+    if ((rc = dev_alloc(c, &r.kcache, kv_elems))) return rc;
+    if ((rc = dev_alloc(c, &r.vcache, kv_elems))) return rc;
+    HIP_OK(c, hipMemset(r.tok, 0, 4));
+    HIP_OK(c, hipMemset(r.pos, 0, 4));
+    HIP_OK(c, hipMemset(r.kcache, 0, kv_elems * 2));
+    HIP_OK(c, hipMemset(r.vcache, 0, kv_elems * 2));
+  }
+  c->log_cap = d.max_ctx > 1024 ? d.max_ctx : 1024;
+  if ((rc = dev_alloc(c, &c->step, 1))) return rc;
+  if ((rc = dev_alloc(c, &c->tok_log, (size_t)c->log_cap * d.max_batch))) return rc;
+  HIP_OK(c, hipMemset(c->step, 0, 4));
+  HIP_OK(c, hipHostMalloc((void**)&c->host_ring, (size_t)HOST_RING * d.max_batch * 4, hipHostMallocMapped));
+  HIP_OK(c, hipHostGetDevicePointer((void**)&c->host_ring_dev, c->host_ring, 0));
+  for (int i = 0; i < MAX_TICKET_EVENTS; i++) HIP_OK(c, hipEventCreateWithFlags(&c->ticket_ev[i], hipEventDisableTiming));
+  for (int i = 0; i < 2; i++) HIP_OK(c, hipEventCreate(&c->prof.ev[i]));
+  c->past = 0;
+  c->finalized = true;
+  return TGX_OK;
+}
+
+void tgx_destroy(tgx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
+  auto fr = [](void* p) { if (p) (void)hipFree(p); };
+  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log);
+  for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.wgu); fr(w.wdown); }
+  for (auto& r : c->rows) {
+    fr(r.x); fr(r.q); fr(r.attn); fr(r.h); fr(r.logits); fr(r.part_val); fr(r.part_idx); fr(r.attn_part);
+    fr(r.tok); fr(r.pos); fr(r.prompt); fr(r.kcache); fr(r.vcache);
+  }
+  if (c->host_ring) (void)hipHostFree(c->host_ring);
+  for (auto& e : c->ticket_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->prof.ev) if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
+  if (!c || !ids) return c ? set_err(c, TGX_ERR_INVALID, "null argument") : TGX_ERR_INVALID;
+  if (!c->finalized) return set_err(c, TGX_ERR_STATE, "forward before finalize");
+  if (batch < 1 || batch > c->d.max_batch || seq < 1) return set_err(c, TGX_ERR_INVALID, "batch/seq out of range");
+  if (seq > 1 && c->past > 0) return set_err(c, TGX_ERR_INVALID, "seq>1 with pastLength>0");
+  if (c->past + seq > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded: %lld + %d > %d", (long long)c->past, seq, c->d.max_ctx);
+  for (int64_t i = 0; i < (int64_t)batch * seq; i++)
+    if (ids[i] < 0 || ids[i] >= c->d.vocab) return set_err(c, TGX_ERR_INVALID, "token id out of range");
+  HIP_OK(c, hipSetDevice(c->device));
+  c->batch = batch;
+  for (int b = 0; b < batch; b++) {
+    RowState& r = c->rows[(size_t)b];
+    HIP_OK(c, hipMemcpyAsync(r.prompt, ids + (size_t)b * seq, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream));
+    // Prefill as `seq` single-position passes (results identical to a batched causal pass; the MFMA
+    // batched-prefill path replaces this loop).  The last position also produces logits.
+    tgx::EmbedArgs e{};
+    e.ids = r.prompt; e.pos = r.pos; e.pos0 = (int)c->past; e.embed = c->embed; e.x = r.x; e.H = c->d.hidden; e.V = c->d.vocab; e.tok = r.tok;
+    for (int s = 0; s < seq; s++) {
+      hipLaunchKernelGGL(tgx::embed_prompt_kernel, dim3(1), dim3(256), 0, c->stream, e);
+      launch_layers(c, r);
+      if (s == seq - 1) launch_lm_head(c, r);
+      hipLaunchKernelGGL(tgx::advance_pos_kernel, dim3(1), dim3(64), 0, c->stream, r.pos);
+    }
+  }
+  HIP_OK(c, hipGetLastError());
+  HIP_OK(c, hipStreamSynchronize(c->stream));   // host `ids` may be pageable and reused by the caller
+  c->past += seq;
+  c->have_logits = true;
+  c->have_token = false;
+  return TGX_OK;
+}
+
+int tgx_read_logits(tgx_ctx* c, float* out, int rounded) {
+  if (!c || !out) return TGX_ERR_INVALID;
+  if (!c->have_logits) return set_err(c, TGX_ERR_STATE, "no logits: call tgx_forward/tgx_decode first");
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  const size_t V = (size_t)c->d.vocab;
+  for (int b = 0; b < c->batch; b++) HIP_OK(c, hipMemcpy(out + b * V, c->rows[(size_t)b].logits, V * 4, hipMemcpyDeviceToHost));
+  if (rounded)
+    for (size_t i = 0; i < V * (size_t)c->batch; i++) out[i] = host_bf16_to_f32(host_f32_to_bf16(out[i]));
+  return TGX_OK;
+}
+
+int tgx_sample(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* out_ids) {
+  (void)seed;
+  if (!c || !cfg) return TGX_ERR_INVALID;
+  if (!c->have_logits) return set_err(c, TGX_ERR_STATE, "no logits to sample from");
+  if (!is_greedy(cfg)) return set_err(c, TGX_ERR_UNSUPPORTED, "temperature/top-k/top-p/min-p sampling is not built yet on mi355x");
+  HIP_OK(c, hipSetDevice(c->device));
+  for (int b = 0; b < c->batch; b++) launch_finalize_greedy(c, b, /*advance_pos=*/false, /*log_step=*/false);
+  HIP_OK(c, hipGetLastError());
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  for (int b = 0; b < c->batch; b++) {
+    int t = 0;
+    HIP_OK(c, hipMemcpy(&t, c->rows[(size_t)b].tok, 4, hipMemcpyDeviceToHost));
+    if (out_ids) out_ids[b] = t;
+    if (b == 0) c->last_sampled0 = t;
+  }
+  c->have_token = true;
+  return TGX_OK;
+}
+
+int tgx_decode(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int n_steps, int64_t* out_ids) {
+  (void)seed;
+  if (!c || !cfg || n_steps < 0) return TGX_ERR_INVALID;
+  if (!c->have_token) return set_err(c, TGX_ERR_STATE, "decode needs a current token: call tgx_sample after tgx_forward");
+  if (!is_greedy(cfg)) return set_err(c, TGX_ERR_UNSUPPORTED, "temperature/top-k/top-p/min-p sampling is not built yet on mi355x");
+  if (c->past + n_steps > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded: %lld + %d > %d", (long long)c->past, n_steps, c->d.max_ctx);
+  if (n_steps > c->log_cap) return set_err(c, TGX_ERR_INVALID, "n_steps exceeds the token log capacity %d", c->log_cap);
+  HIP_OK(c, hipSetDevice(c->device));
+  const int64_t start = c->steps_issued;
+  int rc = run_decode_steps(c, n_steps);
+  if (rc) return rc;
+  c->have_logits = true;
+  if (out_ids && n_steps > 0) {
+    const size_t B = (size_t)c->batch;
+    std::vector<int> tmp((size_t)n_steps * B);
+    const int64_t s0 = start % c->log_cap;
+    const int64_t first = (s0 + n_steps <= c->log_cap) ? n_steps : c->log_cap - s0;
+    HIP_OK(c, hipMemcpyAsync(tmp.data(), c->tok_log + (size_t)s0 * B, (size_t)first * B * 4, hipMemcpyDeviceToHost, c->stream));
+    if (first < n_steps)
+      HIP_OK(c, hipMemcpyAsync(tmp.data() + (size_t)first * B, c->tok_log, (size_t)(n_steps - first) * B * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < tmp.size(); i++) out_ids[i] = tmp[i];
+    c->last_sampled0 = tmp[(size_t)(n_steps - 1) * B];
+  }
+  return TGX_OK;
+}
+
+int tgx_step_async(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* out_ticket) {
+  (void)seed;
+  if (!c || !cfg || !out_ticket) return TGX_ERR_INVALID;
+  if (!c->have_token) return set_err(c, TGX_ERR_STATE, "step needs a current token: call tgx_sample after tgx_forward");
+  if (!is_greedy(cfg)) return set_err(c, TGX_ERR_UNSUPPORTED, "temperature/top-k/top-p/min-p sampling is not built yet on mi355x");
+  if (c->past + 1 > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded");
+  HIP_OK(c, hipSetDevice(c->device));
+  int rc = run_decode_steps(c, 1);
+  if (rc) return rc;
+  const int64_t ticket = c->steps_issued;
+  HIP_OK(c, hipEventRecord(c->ticket_ev[ticket % MAX_TICKET_EVENTS], c->stream));
+  c->have_logits = true;
+  *out_ticket = ticket;
+  return TGX_OK;
+}
+
+int tgx_fetch_token(tgx_ctx* c, int64_t ticket, int32_t* out_id) {
+  if (!c || !out_id) return TGX_ERR_INVALID;
+  if (ticket == 0) { *out_id = c->last_sampled0; return TGX_OK; }
+  if (ticket < 0 || ticket > c->steps_issued || c->steps_issued - ticket >= MAX_TICKET_EVENTS)
+    return set_err(c, TGX_ERR_INVALID, "ticket %lld is not outstanding", (long long)ticket);
+  HIP_OK(c, hipEventSynchronize(c->ticket_ev[ticket % MAX_TICKET_EVENTS]));
+  *out_id = c->host_ring[((ticket - 1) % HOST_RING) * c->batch];   // row 0 of the step that ticket names
+  return TGX_OK;
+}
+
+int tgx_reset_cache(tgx_ctx* c) {
+  if (!c) return TGX_ERR_INVALID;
+  if (!c->finalized) return set_err(c, TGX_ERR_STATE, "reset before finalize");
+  HIP_OK(c, hipSetDevice(c->device));
+  for (auto& r : c->rows) HIP_OK(c, hipMemsetAsync(r.pos, 0, 4, c->stream));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  c->past = 0;
+  c->have_logits = c->have_token = false;
+  return TGX_OK;
+}
+
+int64_t tgx_past_length(const tgx_ctx* c) { return c ? c->past : -1; }
+int64_t tgx_context_size(const tgx_ctx* c) { return c ? c->d.max_ctx : -1; }
+int32_t tgx_num_layers(const tgx_ctx* c) { return c ? c->d.layers : -1; }
+
+int tgx_synchronize(tgx_ctx* c) {
+  if (!c) return TGX_ERR_INVALID;
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  return TGX_OK;
+}
+
+int tgx_read_kv(tgx_ctx* c, int row, int layer, float* k_out, float* v_out) {
+  if (!c || !c->finalized || row < 0 || row >= c->d.max_batch || layer < 0 || layer >= c->d.layers) return TGX_ERR_INVALID;
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  const tgx_model_desc& d = c->d;
+  const size_t hd = (size_t)d.head_dim, per_head = (size_t)d.max_ctx * hd, T = (size_t)c->past;
+  std::vector<uint16_t> tmp(per_head);
+  for (int which = 0; which < 2; which++) {
+    float* out = which ? v_out : k_out;
+    if (!out) continue;
+    const bf16_t* base = (which ? c->rows[(size_t)row].vcache : c->rows[(size_t)row].kcache) + (size_t)layer * d.kv_heads * per_head;
+    for (int h = 0; h < d.kv_heads; h++) {
+      HIP_OK(c, hipMemcpy(tmp.data(), base + (size_t)h * per_head, T * hd * 2, hipMemcpyDeviceToHost));
+      for (size_t t = 0; t < T; t++)
+        for (size_t k = 0; k < hd; k++) out[(t * d.kv_heads + h) * hd + k] = host_bf16_to_f32(tmp[t * hd + k]);   // BSHD view
+    }
+  }
+  return TGX_OK;
+}
+
+int tgx_profile_decode(tgx_ctx* c, int n_steps, int64_t* launches, double* total_ms) {
+  if (!c || !launches || !total_ms || n_steps < 0) return TGX_ERR_INVALID;
+  if (!c->have_token) return set_err(c, TGX_ERR_STATE, "profile needs a current token: call tgx_sample after tgx_forward");
+  if (c->past + n_steps > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded");
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  c->prof.on = true;
+  memset(c->prof.launches, 0, sizeof c->prof.launches);
+  memset(c->prof.ms, 0, sizeof c->prof.ms);
+  int rc = run_decode_steps(c, n_steps);
+  c->prof.on = false;
+  if (rc) return rc;
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < TGX_KERNEL_COUNT; i++) { launches[i] = c->prof.launches[i]; total_ms[i] = c->prof.ms[i]; }
+  return TGX_OK;
+}
+
+int64_t tgx_bytes_per_token(const tgx_ctx* c, int64_t T) {
+  if (!c) return -1;
+  const tgx_model_desc& d = c->d;
+  const int64_t H = d.hidden, I = d.inter, V = d.vocab, L = d.layers, q = (int64_t)d.heads * d.head_dim, kv = (int64_t)d.kv_heads * d.head_dim;
+  const int64_t per_layer = (q + 2 * kv) * H + (d.qkv_bias ? (q + 2 * kv) : 0) + H * q + 2 * I * H + H * I + 2 * H;
+  return 2 * (L * per_layer + H + V * H) + 2 * 2 * L * kv * T;
+}
+
+}  // extern "C"

@@ -6,8 +6,8 @@ bench.py and the parity tests.
 Sampler::sample (src/engine/Sampler.cpp:23-79) on top of one opaque `tgx_ctx`.
 
 The product library is tinygpt_amd/lib/libtgx_mi355x.so (built by tinygpt_amd.build); loading
-fails loudly if it is missing — there is no CPU fallback in this package.  The same binder class
-is reused by oracle/oracle_ffi.py for the test oracle (symbol prefix ``tgxo_``).
+fails loudly if it is missing — there is no CPU fallback in this package.  `Backend` binds any
+library exporting the same entry points under a symbol prefix (the test infrastructure reuses it).
 """
 from __future__ import annotations
 

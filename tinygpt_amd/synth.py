@@ -9,11 +9,15 @@ wrong norm weight is visible in parity tests.  All tensors are produced as bf16 
 """
 from __future__ import annotations
 
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 from .desc import ModelDesc
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_WORKERS = max(1, min(32, (os.cpu_count() or 1)))
 
 
 def _splitmix64(x: np.ndarray) -> np.ndarray:
@@ -55,15 +59,23 @@ def synth_tensor_bf16(seed: int, name: str, shape, std: float) -> np.ndarray:
         lo, a = np.float32(1.0), np.float32(0.1)
     else:
         lo, a = np.float32(0.0), np.float32(std * 1.7320508)
-    CH = 1 << 22
-    with np.errstate(over="ignore"):
-        for s in range(0, n, CH):
-            e = min(n, s + CH)
+    CH = 1 << 21
+
+    def fill(s):
+        e = min(n, s + CH)
+        with np.errstate(over="ignore"):
             idx = np.arange(s, e, dtype=np.uint64)
             z = _splitmix64((base + idx * np.uint64(0x9E3779B97F4A7C15)) & _M64)
-            u24 = (z >> np.uint64(40)).astype(np.float32)                  # 24 random bits, exact in fp32
-            f = (u24 * np.float32(2.0 ** -24) - np.float32(0.5)) * (np.float32(2.0) * a) + lo
-            out[s:e] = f32_to_bf16_bits(f)
+        u24 = (z >> np.uint64(40)).astype(np.float32)                  # 24 random bits, exact in fp32
+        f = (u24 * np.float32(2.0 ** -24) - np.float32(0.5)) * (np.float32(2.0) * a) + lo
+        out[s:e] = f32_to_bf16_bits(f)
+
+    starts = range(0, n, CH)
+    if n <= CH:
+        fill(0)
+    else:   # numpy releases the GIL inside ufuncs: chunks scale across host cores
+        with ThreadPoolExecutor(max_workers=_WORKERS) as ex:
+            list(ex.map(fill, starts))
     return out.reshape(shape)
 
 
