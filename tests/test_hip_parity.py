@@ -1,8 +1,9 @@
 """GPU parity: the HIP decode path (through the C ABI) against the CPU oracle on the same seeded inputs,
-and against the committed HF golden vectors.  bf16 compute; tolerances per the numerics contract:
-  * fp32 logit accumulators vs the oracle's: max|d|/max|ref| <= 1e-3 (north_star's "1e-3 relative fp32");
-  * greedy token ids identical;
-  * vs HF-bf16 golden logits: within the bf16 noise floor (5e-2, same bound the oracle is held to).
+and against the committed HF golden vectors.  bf16 parameters + bf16 KV cache, fp32 activations
+(DESIGN.md §3); tolerances:
+  * fp32 logits vs the oracle's: max|d|/max|ref| <= 1e-3 (north_star's "1e-3 relative fp32"; measured ~1e-6);
+  * greedy token ids identical to the oracle's and to HF's;
+  * vs HF golden logits: fp32 goldens within 2e-2, bf16 goldens within 8e-2 (the bounds the oracle is held to).
 """
 import numpy as np
 import pytest
@@ -13,7 +14,7 @@ from tinygpt_amd.ffi import GREEDY
 
 pytestmark = pytest.mark.gpu
 TOL_ORACLE = 1e-3
-TOL_HF = 5e-2
+TOL_HF32, TOL_HF16 = 2e-2, 8e-2
 
 
 @pytest.fixture(scope="module")
@@ -41,7 +42,8 @@ def test_prefill_logits_and_greedy_ids(fam, hip, oracle_lib):
     assert gpu.past_length == ref.past_length == prompt.shape[1]
     lg, lr = gpu.logits(rounded=False), ref.logits(rounded=False)
     assert rel_err(lg, lr) < TOL_ORACLE
-    assert rel_err(gpu.logits(rounded=True), g["logits_bf16"][:, 0]) < TOL_HF
+    assert rel_err(lg, g["logits_fp32"][:, 0]) < TOL_HF32
+    assert rel_err(lg, g["logits_bf16"][:, 0]) < TOL_HF16
     t_gpu, t_ref = gpu.sample(GREEDY), ref.sample(GREEDY)
     np.testing.assert_array_equal(t_gpu, t_ref)
     np.testing.assert_array_equal(t_gpu, g["ids_bf16"][:, 0])
@@ -61,7 +63,7 @@ def test_teacher_forced_every_step(fam, hip, oracle_lib):
     for i in range(1, ids.shape[1]):
         gpu.forward(ids[:, i - 1:i]); ref.forward(ids[:, i - 1:i])
         assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_ORACLE, f"step {i}"
-        assert rel_err(gpu.logits(rounded=True), g["logits_bf16"][:, i]) < TOL_HF, f"step {i}"
+        assert rel_err(gpu.logits(rounded=False), g["logits_fp32"][:, i]) < TOL_HF32, f"step {i}"
 
 
 @pytest.mark.parametrize("fam", GPU_FAMILIES)
@@ -75,9 +77,9 @@ def test_kv_cache_matches_oracle(fam, hip, oracle_lib):
         kg, vg = gpu.read_kv(0, layer)
         kr, vr = ref.read_kv(0, layer)
         assert kg.shape == kr.shape
-        # identical up to rare 1-ulp bf16 flips from fp32 accumulation order
-        assert np.mean(kg != kr) < 0.02 and rel_err(kg, kr) < 1e-2
-        assert np.mean(vg != vr) < 0.02 and rel_err(vg, vr) < 1e-2
+        # bf16 cache entries: identical except where the fp32 value sits on a rounding boundary (1 ulp = 2^-8)
+        assert np.mean(kg != kr) < 5e-3 and rel_err(kg, kr) < 1e-2
+        assert np.mean(vg != vr) < 5e-3 and rel_err(vg, vr) < 1e-2
 
 
 def test_reset_and_rerun_is_bit_identical(hip, oracle_lib):

@@ -1,8 +1,10 @@
 """The CPU oracle against the golden vectors from HF transformers (tools/gen_fixtures.py).
 
 fp32 mode pins structure (RoPE pairing and llama3 scaling, GQA mapping, merge order, norms, GPT-2's
-Conv1D/LayerNorm/gelu_new/left-pad-no-mask) at 1e-4 relative; bf16 mode pins the rounding contract to
-within the bf16 noise floor (HF-bf16 vs HF-fp32 on the same vectors is 0.7-4.4e-2) with greedy ids equal.
+Conv1D/LayerNorm/gelu_new/left-pad-no-mask) at 1e-4 relative.  bf16 mode (bf16 parameters + bf16 KV cache,
+fp32 activations — DESIGN.md §3) is held to HF-fp32 within 2e-2 (the only difference is the KV rounding;
+measured 1.6e-3..1.4e-2 on these vectors) and to HF-bf16 within 8e-2 (HF-bf16 itself sits 0.7-4.4e-2 from
+HF-fp32), with greedy ids equal to HF's in both dtypes.
 """
 import numpy as np
 import pytest
@@ -11,7 +13,8 @@ from conftest import FAMILIES, load_golden, rel_err
 from tinygpt_amd.desc import desc_from_hf_config
 from tinygpt_amd.ffi import GREEDY
 
-TOL = {"fp32": 1e-4, "bf16": 5e-2}
+TOL = {"fp32": 1e-4, "bf16": 2e-2}      # vs HF fp32 logits
+TOL_BF16_VS_HF_BF16 = 8e-2
 
 
 def make_oracle(fam, mode, oracle_lib):
@@ -27,15 +30,17 @@ def make_oracle(fam, mode, oracle_lib):
 def test_free_running_greedy_matches_hf(fam, mode, oracle_lib):
     """prefill + 15 decode steps == generateSync; ids identical, logits within tolerance."""
     m, g = make_oracle(fam, mode, oracle_lib)
-    L, ids = g[f"logits_{mode}"], g[f"ids_{mode}"]
+    L, ids = g["logits_fp32"], g[f"ids_{mode}"]
     m.forward(g["prompt"])
     assert m.past_length == g["prompt"].shape[1]
-    assert rel_err(m.logits(rounded=(mode == "bf16")), L[:, 0]) < TOL[mode]
+    assert rel_err(m.logits(rounded=False), L[:, 0]) < TOL[mode]
+    if mode == "bf16":
+        assert rel_err(m.logits(rounded=False), g["logits_bf16"][:, 0]) < TOL_BF16_VS_HF_BF16
     first = m.sample(GREEDY)
     np.testing.assert_array_equal(first, ids[:, 0])
     rest = m.decode(L.shape[1] - 1, GREEDY)                  # [n-1, B]
     np.testing.assert_array_equal(rest.T, ids[:, 1:])
-    assert rel_err(m.logits(rounded=(mode == "bf16")), L[:, -1]) < TOL[mode]
+    assert rel_err(m.logits(rounded=False), L[:, -1]) < TOL[mode]
     assert m.past_length == g["prompt"].shape[1] + L.shape[1] - 1
 
 

@@ -4,7 +4,7 @@
 // is gone: the QKV epilogue already stored this step's K/V row in place) and
 // function::flashAttention(q, Kall, Vall, isCausal=false) (Attention.h:108-109).
 //
-// Numerics contract: scores = (q.k) * hd^-1/2 in fp32, fp32 softmax, fp32 P.V, one rounding of the output.
+// Numerics contract: K/V are bf16 in the cache; scores = (q.k) * hd^-1/2, softmax and P.V are fp32; fp32 output.
 //
 // Roofline: HBM — 2 * kv_heads * (T+1) * hd * 2 bytes per launch (K and V rows read once; all G = heads/kv_heads
 // query heads of a group share one pass over their kv head).
@@ -21,12 +21,12 @@
 namespace tgx {
 
 struct AttnArgs {
-  const bf16_t* q;        // [heads][hd] (RoPE applied, bf16)
+  const float* q;         // [heads][hd] fp32 (RoPE applied)
   const bf16_t* k_cache;  // this layer/row: [kv_heads][max_ctx][hd]
   const bf16_t* v_cache;
   const int* pos;         // pastLength BEFORE this step; keys [0, pos] are attended
   float* part;            // [heads][nsplit][hd + 2]  (m, l, o[hd])
-  bf16_t* out;            // [heads*hd] (combine kernel)
+  float* out;             // [heads*hd] fp32 (combine kernel)
   int heads, kv_heads, max_ctx, nsplit;
   float scale;
 };
@@ -52,9 +52,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   float qf[G][8];
 #pragma unroll
   for (int g = 0; g < G; g++) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(a.q + (size_t)(kvh * G + g) * HD + part_i * 8);
+    const f32x4* qp = reinterpret_cast<const f32x4*>(a.q + (size_t)(kvh * G + g) * HD + part_i * 8);
+    const f32x4 q0 = qp[0], q1 = qp[1];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { qf[g][2 * j] = bf16_lo(v[j]); qf[g][2 * j + 1] = bf16_hi(v[j]); }
+    for (int j = 0; j < 4; j++) { qf[g][j] = q0[j]; qf[g][4 + j] = q1[j]; }
   }
   float m[G], l[G], o[G][8];
 #pragma unroll
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   }
 }
 
-// Merges the nsplit partials of every query head and writes the attention output in bf16
+// Merges the nsplit partials of every query head and writes the attention output (fp32)
 // (== the reshape to [B,S,qDim] that feeds o_proj, Attention.h:111).
 template <int HD>
 __global__ void attn_combine_kernel(const AttnArgs a) {
@@ -152,7 +153,7 @@ __global__ void attn_combine_kernel(const AttnArgs a) {
     L += p[s * (HD + 2) + HD + 1] * sc;
     acc += p[s * (HD + 2) + d] * sc;
   }
-  a.out[h * HD + d] = f32_to_bf16(acc / L);
+  a.out[h * HD + d] = acc / L;
 }
 
 }  // namespace tgx

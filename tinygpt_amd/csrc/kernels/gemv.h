@@ -29,64 +29,58 @@ enum { EPI_QKV_ROPE = 0, EPI_RESIDUAL = 1, EPI_SILU_MUL = 2, EPI_LOGITS = 3 };
 struct GemvArgs {
   const bf16_t* W;        // [N][K] row-major (torch Linear layout)
   const bf16_t* bias;     // [N] or nullptr
-  const bf16_t* x;        // [K] input activations
+  const float* x;         // [K] input activations (fp32 between ops)
   const bf16_t* norm_w;   // [K] RMSNorm weight (PRO_RMSNORM)
   float eps;
   int N, K;
   int units;              // number of row pairs
   // EPI_QKV_ROPE
-  bf16_t* q_out;          // [heads*hd]
+  float* q_out;           // [heads*hd] fp32
   bf16_t* k_cache;        // this layer, this row: [kv_heads][max_ctx][hd]
   bf16_t* v_cache;
-  const float* rope_cos;  // [max_ctx][hd/2], values already rounded to bf16
+  const float* rope_cos;  // [max_ctx][hd/2] fp32
   const float* rope_sin;
   const int* pos;         // device-resident pastLength of this row
   int heads, kv_heads, hd, max_ctx;
-  // EPI_RESIDUAL: xres[n] = R(xres[n] + R(acc));  EPI_SILU_MUL: out[i] = R(R(silu(g)) * u)
-  bf16_t* out;
+  // EPI_RESIDUAL: out[n] += acc;  EPI_SILU_MUL: out[i] = silu(g) * u      (fp32)
+  float* out;
   // EPI_LOGITS
   float* logits;          // [N] fp32 accumulators
-  float* part_val;        // [gridDim.x] best R(logit) of this workgroup
+  float* part_val;        // [gridDim.x] best logit of this workgroup
   int* part_idx;
 };
 
 template <int PRO>
 __device__ __forceinline__ void stage_x(const GemvArgs& a, float* xs, float* scratch4) {
   const int nchunk = a.K >> 3;
-  const u32x4* xg = reinterpret_cast<const u32x4*>(a.x);
+  const f32x4* xg = reinterpret_cast<const f32x4*>(a.x);
   float inv = 1.f;
   if (PRO == PRO_RMSNORM) {
     float ss = 0.f;
     for (int c = threadIdx.x; c < nchunk; c += blockDim.x) {
-      u32x4 v = xg[c];
+      const f32x4 v0 = xg[2 * c], v1 = xg[2 * c + 1];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        float lo = bf16_lo(v[j]), hi = bf16_hi(v[j]);
-        ss = fmaf(lo, lo, ss);
-        ss = fmaf(hi, hi, ss);
-      }
+      for (int j = 0; j < 4; j++) { ss = fmaf(v0[j], v0[j], ss); }
+#pragma unroll
+      for (int j = 0; j < 4; j++) { ss = fmaf(v1[j], v1[j], ss); }
     }
     ss = block_sum_256(ss, scratch4);
     inv = 1.0f / sqrtf(ss / (float)a.K + a.eps);
   }
   const u32x4* wg = reinterpret_cast<const u32x4*>(a.norm_w);
   for (int c = threadIdx.x; c < nchunk; c += blockDim.x) {
-    u32x4 v = xg[c];
-    float f[8];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { f[2 * j] = bf16_lo(v[j]); f[2 * j + 1] = bf16_hi(v[j]); }
+    f32x4 v0 = xg[2 * c], v1 = xg[2 * c + 1];
     if (PRO == PRO_RMSNORM) {
-      u32x4 w = wg[c];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        // HF LlamaRMSNorm order: weight * (x * rsqrt(var+eps)).to(bf16)
-        f[2 * j] = rbf(bf16_lo(w[j]) * rbf(f[2 * j] * inv));
-        f[2 * j + 1] = rbf(bf16_hi(w[j]) * rbf(f[2 * j + 1] * inv));
-      }
+      const u32x4 w = wg[c];
+      // HF LlamaRMSNorm order: weight * (x * rsqrt(var+eps)), all fp32
+      v0[0] = bf16_lo(w[0]) * (v0[0] * inv); v0[1] = bf16_hi(w[0]) * (v0[1] * inv);
+      v0[2] = bf16_lo(w[1]) * (v0[2] * inv); v0[3] = bf16_hi(w[1]) * (v0[3] * inv);
+      v1[0] = bf16_lo(w[2]) * (v1[0] * inv); v1[1] = bf16_hi(w[2]) * (v1[1] * inv);
+      v1[2] = bf16_lo(w[3]) * (v1[2] * inv); v1[3] = bf16_hi(w[3]) * (v1[3] * inv);
     }
     f32x4* dst = reinterpret_cast<f32x4*>(xs + (c << 3));
-    dst[0] = f32x4{f[0], f[1], f[2], f[3]};
-    dst[1] = f32x4{f[4], f[5], f[6], f[7]};
+    dst[0] = v0;
+    dst[1] = v1;
   }
   __syncthreads();
 }
@@ -162,47 +156,45 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     if (EPI == EPI_LOGITS) {
       if (lane == 0) {
         a.logits[ra] = sa;
-        const float va = rbf(sa);
-        if (va > best_val) { best_val = va; best_idx = ra; }     // rows ascend within a wave: '>' keeps the first
+        if (sa > best_val) { best_val = sa; best_idx = ra; }     // rows ascend within a wave: '>' keeps the first
         if (rb_valid) {
           a.logits[rb] = sb;
-          const float vb = rbf(sb);
-          if (vb > best_val) { best_val = vb; best_idx = rb; }
+          if (sb > best_val) { best_val = sb; best_idx = rb; }
         }
       }
       continue;
     }
     if (lane != 0) continue;
     if (a.bias) { sa += bf16_to_f32(a.bias[ra]); sb += bf16_to_f32(a.bias[rb]); }
-    sa = rbf(sa);
-    sb = rbf(sb);
     if (EPI == EPI_QKV_ROPE) {
       const int hh = u / half, p = u - hh * half;
       const int pos = *a.pos;
       if (hh < a.heads + a.kv_heads) {   // q or k head: rotate-half RoPE at absolute position pos
         const float cs = a.rope_cos[(size_t)pos * half + p], sn = a.rope_sin[(size_t)pos * half + p];
-        const float na = rbf(rbf(sa * cs) + rbf(-sb * sn));
-        const float nb = rbf(rbf(sb * cs) + rbf(sa * sn));
+        const float na = sa * cs - sb * sn;
+        const float nb = sb * cs + sa * sn;
         sa = na; sb = nb;
       }
-      bf16_t* dst;
-      if (hh < a.heads) dst = a.q_out + hh * a.hd;
-      else if (hh < a.heads + a.kv_heads) dst = a.k_cache + ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd;
-      else dst = a.v_cache + ((size_t)(hh - a.heads - a.kv_heads) * a.max_ctx + pos) * a.hd;
-      dst[p] = f32_to_bf16(sa);
-      dst[p + half] = f32_to_bf16(sb);
+      if (hh < a.heads) {
+        a.q_out[hh * a.hd + p] = sa;
+        a.q_out[hh * a.hd + p + half] = sb;
+      } else {   // KVCacheManager::append: this position's K / V row, stored in bf16
+        bf16_t* dst = (hh < a.heads + a.kv_heads)
+                          ? a.k_cache + ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd
+                          : a.v_cache + ((size_t)(hh - a.heads - a.kv_heads) * a.max_ctx + pos) * a.hd;
+        dst[p] = f32_to_bf16(sa);
+        dst[p + half] = f32_to_bf16(sb);
+      }
     } else if (EPI == EPI_RESIDUAL) {
-      const float xa = bf16_to_f32(a.out[ra]);
-      a.out[ra] = f32_to_bf16(xa + sa);
-      if (rb_valid) { const float xb = bf16_to_f32(a.out[rb]); a.out[rb] = f32_to_bf16(xb + sb); }
+      a.out[ra] += sa;
+      if (rb_valid) a.out[rb] += sb;
     } else if (EPI == EPI_SILU_MUL) {
-      const float s = rbf(sa / (1.0f + expf(-sa)));
-      a.out[u] = f32_to_bf16(s * sb);
+      a.out[u] = (sa / (1.0f + expf(-sa))) * sb;
     }
   }
 
   if (EPI == EPI_LOGITS) {
-    // workgroup argmax over R(logit), ties -> lowest index (== torch/TinyTorch argmax on the bf16 logits tensor)
+    // workgroup argmax, ties -> lowest index (== argmax(logits, -1), Sampler.cpp:28)
     float* sv = scratch;
     int* si = reinterpret_cast<int*>(scratch + 4);
     __syncthreads();
@@ -222,6 +214,17 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 // == argmax (Sampler.cpp:28) + tokens = concat(tokens, next) + KV pastLength += 1, and it gathers the next
 // step's embedding row (nn::Embedding, GPTModel.h:52) into the residual stream so the decode graph needs
 // no host input between steps.
+// nn::Embedding row gather: bf16 table row -> fp32 residual stream
+__device__ __forceinline__ void gather_embedding(const bf16_t* row, float* x, int H) {
+  const u32x4* src = reinterpret_cast<const u32x4*>(row);
+  f32x4* dst = reinterpret_cast<f32x4*>(x);
+  for (int c = threadIdx.x; c < (H >> 3); c += blockDim.x) {
+    const u32x4 v = src[c];
+    dst[2 * c] = f32x4{bf16_lo(v[0]), bf16_hi(v[0]), bf16_lo(v[1]), bf16_hi(v[1])};
+    dst[2 * c + 1] = f32x4{bf16_lo(v[2]), bf16_hi(v[2]), bf16_lo(v[3]), bf16_hi(v[3])};
+  }
+}
+
 struct FinalizeArgs {
   const float* part_val;
   const int* part_idx;
@@ -236,7 +239,7 @@ struct FinalizeArgs {
   int log;               // 1: record the token in the rings (decode steps); 0: tgx_sample after a prefill
   int bump_step;         // 1 on the last row of a step
   const bf16_t* embed;   // [V][H]
-  bf16_t* x;             // [H] residual stream of this row
+  float* x;              // [H] residual stream of this row (fp32)
   int H;
   int advance_pos;       // 1: pos += 1 (the token just consumed is now in the cache)
 };
@@ -272,9 +275,7 @@ __global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs
     }
   }
   __syncthreads();
-  const u32x4* src = reinterpret_cast<const u32x4*>(a.embed + (size_t)s_tok * a.H);
-  u32x4* dst = reinterpret_cast<u32x4*>(a.x);
-  for (int c = threadIdx.x; c < (a.H >> 3); c += 256) dst[c] = src[c];
+  gather_embedding(a.embed + (size_t)s_tok * a.H, a.x, a.H);
 }
 
 // Prefill-by-steps helper: x <- embed[prompt[pos - pos0]] (nn::Embedding on one prompt position).
@@ -283,7 +284,7 @@ struct EmbedArgs {
   const int* pos;
   int pos0;
   const bf16_t* embed;
-  bf16_t* x;
+  float* x;
   int H, V;
   int* tok;
 };
@@ -291,9 +292,7 @@ __global__ __launch_bounds__(256) void embed_prompt_kernel(const EmbedArgs a) {
   const int i = *a.pos - a.pos0;
   long long t = a.ids[i];
   if (threadIdx.x == 0) *a.tok = (int)t;
-  const u32x4* src = reinterpret_cast<const u32x4*>(a.embed + (size_t)t * a.H);
-  u32x4* dst = reinterpret_cast<u32x4*>(a.x);
-  for (int c = threadIdx.x; c < (a.H >> 3); c += 256) dst[c] = src[c];
+  gather_embedding(a.embed + (size_t)t * a.H, a.x, a.H);
 }
 
 __global__ void advance_pos_kernel(int* pos) { if (threadIdx.x == 0) *pos = *pos + 1; }

@@ -35,7 +35,7 @@ struct LayerW {
 };
 
 struct RowState {       // independent KV/sequence state of one batch row
-  bf16_t *x = nullptr, *q = nullptr, *attn = nullptr, *h = nullptr;
+  float *x = nullptr, *q = nullptr, *attn = nullptr, *h = nullptr;   // fp32 activations
   float* logits = nullptr;
   float* part_val = nullptr;
   int* part_idx = nullptr;
@@ -161,8 +161,7 @@ bool shape_is(const int64_t* s, int nd, int64_t a, int64_t b) {
   return nd == 2 && s[0] == a && s[1] == b;
 }
 
-// nn::RoPE tables (ctor at ModelLlama.h:41-42): HF LlamaRotaryEmbedding incl. llama3 scaling; values are
-// rounded to bf16 (cos/sin are cast to the activation dtype before use) and kept as fp32 words.
+// nn::RoPE tables (ctor at ModelLlama.h:41-42): HF LlamaRotaryEmbedding incl. llama3 scaling, fp32.
 void build_rope_host(const tgx_model_desc& d, std::vector<float>& cs, std::vector<float>& sn) {
   const int half = d.head_dim / 2;
   std::vector<float> inv((size_t)half);
@@ -188,8 +187,8 @@ void build_rope_host(const tgx_model_desc& d, std::vector<float>& cs, std::vecto
   for (int p = 0; p < d.max_ctx; p++)
     for (int i = 0; i < half; i++) {
       const float a = inv[(size_t)i] * (float)p;
-      cs[(size_t)p * half + i] = host_bf16_to_f32(host_f32_to_bf16(cosf(a)));
-      sn[(size_t)p * half + i] = host_bf16_to_f32(host_f32_to_bf16(sinf(a)));
+      cs[(size_t)p * half + i] = cosf(a);
+      sn[(size_t)p * half + i] = sinf(a);
     }
 }
 
