@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — decode tokens/s of the MI355X path on BASELINE.json's headline configuration.
+
+Workload (BASELINE.json configs[2], the one `metric` is quoted on): Llama-3.2-1B, bf16 weights + bf16 KV
+cache, batch 1, 2048-token prefill, then greedy decode.  A *step* is one decoded token: all 16 decoder
+layers + final norm + lm_head over the whole vocabulary + argmax + the next token's embedding gather,
+with token id and position resident on the GPU (one hipGraph replay per step).  Weights are synthetic
+(tinygpt_amd.synth, seed 1234; no checkpoint exists offline) and prompt ids are uniform — timing is
+data-independent; parity is established by tests/.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W
+
+N > 1 runs N independent replicas (one process per GPU, distinct prompt seeds, no data-path collective —
+the streams never exchange data); torch.distributed (gloo) only carries the barrier and the
+MAX-over-ranks of the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     the dominant kernel class (gate_up GEMV: 55 % of a layer's bytes): algorithmic bytes per launch
+               (2*N*K) / its average duration measured with HIP events on the launch stream
+               (tgx_profile_decode: the class launched back-to-back over all layers); HBM peak 8.0 TB/s.
+               Also carries the whole-step figure (`step_*`): bytes_per_token(T) * tokens/s.
+  cpu_baseline the CPU oracle (oracle/liboracle.so, a restatement of the reference path — kind "port"),
+               timed on this box's host cores on a bounded sample of the same model (short context).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--model", default="llama-3.2-1b", help="key of tinygpt_amd.desc.KNOWN_CONFIGS")
+    ap.add_argument("--prompt", type=int, default=2048, help="prefill length before the timed decode")
+    ap.add_argument("--profile-reps", type=int, default=8)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches (needed under rocprofv3 kernel tracing)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(desc, tensors, seconds):
+    """Oracle decode tok/s on the host cores: 16-token prompt, 1 warm-up token, then a bounded sample."""
+    from oracle.oracle_ffi import OracleModel, build_oracle
+    from tinygpt_amd import synth
+    from tinygpt_amd.ffi import GREEDY
+    build_oracle()
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    m = OracleModel(desc)
+    for name, bits in tensors:
+        m.upload(name, bits)
+    m.finalize()
+    ids = synth.synth_prompt(desc.vocab, 16, 1234)[None, :]
+    m.forward(ids)
+    m.sample(GREEDY)
+    t0 = time.perf_counter(); m.decode(1, GREEDY); t1 = time.perf_counter() - t0      # warm-up + rate estimate
+    n = int(max(4, min(64, seconds / max(t1, 1e-3))))
+    t0 = time.perf_counter(); m.decode(n, GREEDY); dt = time.perf_counter() - t0
+    m.close()
+    return {"value": round(n / dt, 3), "unit": "tokens/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
+            "sample": f"oracle/liboracle.so (C+OpenMP restatement), same synthetic {desc.name or 'model'} bf16, "
+                      f"16-token prompt, {n} greedy decode tokens after 1 warm-up token, context 17..{17 + n}"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {args.gpus} "
+                     f"--master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)     # control plane only: barrier + MAX
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    from tinygpt_amd import known_desc, synth
+    from tinygpt_amd.ffi import GREEDY, Model, product_backend
+
+    desc = known_desc(args.model)
+    need_ctx = args.prompt + args.warmup + args.steps + 8
+    if need_ctx > desc.max_ctx:
+        sys.exit(f"prompt+warmup+steps = {need_ctx} exceeds contextSize {desc.max_ctx}")
+    tensors = list(synth.synth_checkpoint(desc, 1234, 0.02))
+    model = Model(desc, product_backend(), device=local_rank)       # raises if the HIP library is missing
+    if args.no_graph:
+        model.set_option("graph", 0)
+    for name, bits in tensors:
+        model.upload(name, bits)
+    model.finalize()
+
+    prompt = synth.synth_prompt(desc.vocab, args.prompt, 1234 + rank)[None, :]
+    t0 = time.perf_counter()
+    model.forward(prompt)
+    model.synchronize()
+    prefill_ms = (time.perf_counter() - t0) * 1e3
+    model.sample(GREEDY)
+
+    def sync():
+        model.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    model.decode(args.warmup, GREEDY, fetch=False)                  # untimed warm-up (instantiates the graph)
+    sync()
+    if dist: dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    model.decode(args.steps, GREEDY, fetch=False)                   # EXACTLY K steps
+    sync()
+    if dist: dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if dist: dist.barrier(); dist.destroy_process_group()
+        return
+
+    T0 = args.prompt + 1 + args.warmup                              # tokens in the cache at the first timed step
+    T_mean = T0 + (args.steps - 1) / 2.0
+    tok_s = world * args.steps / elapsed
+    bytes_tok = model.bytes_per_token(int(round(T_mean)))
+
+    prof = model.profile_decode(args.profile_reps)
+    n_gu, ms_gu = prof["gateup"]
+    gu_bytes = 2 * (2 * desc.inter) * desc.hidden
+    gu_us = ms_gu / n_gu * 1e3
+    achieved = gu_bytes / (gu_us * 1e-6) / 1e9
+    classes = {k: round(ms / n * 1e3, 3) for k, (n, ms) in prof.items() if n}
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    traffic = None
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("gateup_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "gemv_kernel<PRO_RMSNORM,EPI_SILU_MUL> (gate_up)", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "bytes_per_launch": gu_bytes, "avg_launch_us": round(gu_us, 3),
+                "kernel_classes_avg_us": classes,
+                "step_bytes_per_token": bytes_tok, "step_achieved": round(bytes_tok * tok_s / world / 1e9, 1),
+                "step_frac": round(bytes_tok * tok_s / world / 1e9 / HBM_PEAK_GBS, 4)}
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(desc, tensors, args.cpu_seconds)
+        except Exception as e:     # the GPU number stands on its own; say why the baseline is absent
+            cpu = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+    line = {
+        "metric": "decode tokens/sec (and % HBM roofline), Llama-3.2-1B bf16 batch=1, 1 GPU",
+        "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{desc.name} bf16, batch 1 per GPU: {args.prompt}-token prefill then greedy decode "
+                               f"(one step = one token, context {T0}..{T0 + args.steps - 1})",
+                   "replicas": world, "prompt_tokens": args.prompt, "prefill_ms": round(prefill_ms, 1),
+                   "params": desc.param_count(), "graph": not args.no_graph},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(line), flush=True)
+    if dist: dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

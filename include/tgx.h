@@ -177,9 +177,11 @@ TGX_API int tgx_synchronize(tgx_ctx* ctx);
  * (the BSHD view KVCacheManager::append returns, Attention.h:106).  Test/diagnostic use. */
 TGX_API int tgx_read_kv(tgx_ctx* ctx, int row, int layer, float* k_out, float* v_out);
 
-/* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg): runs
- * n_steps eager (un-graphed) decode steps and returns, for kernel class `which`
- * (see TGX_KERNEL_*), the number of launches and their summed duration in milliseconds. */
+/* Per-kernel-class timing with HIP events on the context's stream (bench.py's roofline leg).  For each
+ * class (TGX_KERNEL_*) the kernels of ALL layers are launched back-to-back between two events, n_reps times,
+ * at the current context length; returns launch counts and summed milliseconds.  Every launch streams a
+ * different layer's weights (nothing repeats out of the Infinity Cache); residual outputs go to a scratch
+ * vector so pastLength, the KV cache and the current token are unchanged (the logits buffer is consumed). */
 #define TGX_KERNEL_QKV 0
 #define TGX_KERNEL_ATTN 1
 #define TGX_KERNEL_OPROJ 2
@@ -187,8 +189,13 @@ TGX_API int tgx_read_kv(tgx_ctx* ctx, int row, int layer, float* k_out, float* v
 #define TGX_KERNEL_DOWN 4
 #define TGX_KERNEL_LMHEAD 5
 #define TGX_KERNEL_COUNT 6
-TGX_API int tgx_profile_decode(tgx_ctx* ctx, int n_steps, int64_t* launches /*[TGX_KERNEL_COUNT]*/,
+TGX_API int tgx_profile_decode(tgx_ctx* ctx, int n_reps, int64_t* launches /*[TGX_KERNEL_COUNT]*/,
                        double* total_ms /*[TGX_KERNEL_COUNT]*/);
+
+/* Launch-geometry knobs for tuning sweeps (never change results): "<class>.ks" (waves sharing a row pair's K
+ * range: 1/2/4), "<class>.bpc" (grid cap, workgroups per CU) with class in {qkv,oproj,gateup,down,lmhead};
+ * "attn.nsplit" and "lmhead.bpc" only before tgx_finalize; "graph" 0/1 (hipGraph replay vs eager launches). */
+TGX_API int tgx_set_option(tgx_ctx* ctx, const char* key, int value);
 
 /* Algorithmic HBM bytes one decoded token streams at context length T (SURVEY.md §8d formula). */
 TGX_API int64_t tgx_bytes_per_token(const tgx_ctx* ctx, int64_t T);

@@ -146,6 +146,12 @@ static inline float src_elem(const void* host, int dt, int64_t i) {
 
 /* == model().to(dtype): store in compute dtype (bf16->fp32 exact, fp32->bf16 RNE) */
 static void mat_store_rows(tgxo_ctx* c, mat_t* m, int64_t row0, int64_t nrows, const void* host, int dt, int src_is_in_out) {
+  if (c->bf16 && dt == DT_BF16 && !src_is_in_out) {   /* same storage dtype: plain copy */
+    memcpy(m->wb + row0 * m->cols, host, (size_t)(nrows * m->cols) * 2);
+    m->filled_rows += nrows;
+    return;
+  }
+#pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < nrows; r++)
     for (int64_t k = 0; k < m->cols; k++) {
       float v = src_is_in_out ? src_elem(host, dt, k * nrows + r) : src_elem(host, dt, r * m->cols + k);

@@ -25,7 +25,7 @@ struct AttnArgs {
   const bf16_t* k_cache;  // this layer/row: [kv_heads][max_ctx][hd]
   const bf16_t* v_cache;
   const int* pos;         // pastLength BEFORE this step; keys [0, pos] are attended
-  float* part;            // [heads][nsplit][hd + 2]  (m, l, o[hd])
+  float* part;            // [heads][nsplit][hd + 4]  (o[hd], m, l, pad) — 16-byte aligned records
   float* out;             // [heads*hd] fp32 (combine kernel)
   int heads, kv_heads, max_ctx, nsplit;
   float scale;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
       L += red[w][g][HD + 1] * sc;
       acc += red[w][g][d] * sc;
     }
-    float* dst = a.part + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 2);
+    float* dst = a.part + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
     dst[d] = acc;
     if (d == 0) { dst[HD] = M; dst[HD + 1] = L; }
   }
@@ -140,20 +140,44 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 
 // Merges the nsplit partials of every query head and writes the attention output (fp32)
 // (== the reshape to [B,S,qDim] that feeds o_proj, Attention.h:111).
+// One workgroup per query head; thread (s, dg) owns 8 dims of one split so that all partials are fetched
+// with one round of independent 16-byte loads; splits are then summed through LDS in a fixed order.
 template <int HD>
-__global__ void attn_combine_kernel(const AttnArgs a) {
-  const int h = blockIdx.x, d = threadIdx.x;
-  const float* p = a.part + (size_t)h * a.nsplit * (HD + 2);
+__global__ __launch_bounds__(256) void attn_combine_kernel(const AttnArgs a) {
+  constexpr int DG = HD / 8;            // dim groups of 8
+  constexpr int SPB = 256 / DG;         // splits handled per pass (32 for hd 64, 16 for hd 128)
+  __shared__ float sm_m[32], sm_l[32];
+  __shared__ float sm_o[SPB][HD + 4];
+  const int h = blockIdx.x, tid = threadIdx.x;
+  const float* p = a.part + (size_t)h * a.nsplit * (HD + 4);
+  if (tid < a.nsplit) { sm_m[tid] = p[tid * (HD + 4) + HD]; sm_l[tid] = p[tid * (HD + 4) + HD + 1]; }
+  __syncthreads();
   float M = -INFINITY;
-  for (int s = 0; s < a.nsplit; s++) M = fmaxf(M, p[s * (HD + 2) + HD]);
-  float L = 0.f, acc = 0.f;
-  for (int s = 0; s < a.nsplit; s++) {
-    const float ms = p[s * (HD + 2) + HD];
-    const float sc = (ms == -INFINITY) ? 0.f : expf(ms - M);
-    L += p[s * (HD + 2) + HD + 1] * sc;
-    acc += p[s * (HD + 2) + d] * sc;
+  for (int s = 0; s < a.nsplit; s++) M = fmaxf(M, sm_m[s]);
+  float L = 0.f;
+  for (int s = 0; s < a.nsplit; s++) L += (sm_m[s] == -INFINITY) ? 0.f : sm_l[s] * expf(sm_m[s] - M);
+  const int dg = tid % DG, sl = tid / DG;
+  float acc = 0.f;                       // threads < HD accumulate dim `tid`
+  for (int s0 = 0; s0 < a.nsplit; s0 += SPB) {
+    const int s = s0 + sl;
+    f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (s < a.nsplit && sm_m[s] != -INFINITY) {
+      const float sc = expf(sm_m[s] - M);
+      const f32x4* src = reinterpret_cast<const f32x4*>(p + (size_t)s * (HD + 4) + dg * 8);
+      v0 = src[0] * sc;
+      v1 = src[1] * sc;
+    }
+    float* dst = &sm_o[sl][dg * 8];
+    dst[0] = v0[0]; dst[1] = v0[1]; dst[2] = v0[2]; dst[3] = v0[3];
+    dst[4] = v1[0]; dst[5] = v1[1]; dst[6] = v1[2]; dst[7] = v1[3];
+    __syncthreads();
+    if (tid < HD) {
+#pragma unroll 8
+      for (int k = 0; k < SPB; k++) acc += sm_o[k][tid];
+    }
+    __syncthreads();
   }
-  a.out[h * HD + d] = acc / L;
+  if (tid < HD) a.out[h * HD + tid] = acc / L;
 }
 
 }  // namespace tgx

@@ -45,6 +45,22 @@ __device__ __forceinline__ float dot8(float acc, const u32x4 w, const f32x4 xa, 
 }
 
 // ---- cross-lane reductions ----------------------------------------------------------------------
+// 64-lane sum on the DPP crossbar (no LDS traffic): quad butterflies, half-row / row mirrors, then the two
+// row broadcasts of the GFX9 wave64 reduction; the total lands in lane 63 and is returned wave-uniform.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_mov<0xB1, 0xf>(v);    // quad_perm:[1,0,3,2]
+  v += dpp_mov<0x4E, 0xf>(v);    // quad_perm:[2,3,0,1]
+  v += dpp_mov<0x141, 0xf>(v);   // row_half_mirror
+  v += dpp_mov<0x140, 0xf>(v);   // row_mirror
+  v += dpp_mov<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+  v += dpp_mov<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 template <int WIDTH = 64>
 __device__ __forceinline__ float group_sum(float v) {   // butterfly: every lane of the group ends with the sum
 #pragma unroll

@@ -45,6 +45,11 @@ struct RowState {       // independent KV/sequence state of one batch row
   bf16_t *kcache = nullptr, *vcache = nullptr;   // [layers][kv_heads][max_ctx][hd]
 };
 
+struct Tune {
+  int ks = 1;    // waves sharing one unit's K range (1, 2, 4)
+  int bpc = 4;   // grid cap in workgroups per CU
+};
+
 struct Profiler {
   bool on = false;
   hipEvent_t ev[2 * 8] = {};
@@ -85,8 +90,11 @@ struct tgx_ctx {
   int step_graph_batch = 0;
   bool use_graph = true;
 
-  int gemv_bpc = 4;       // GEMV workgroups per CU
-  int lm_grid = 0, attn_nsplit = 1;
+  Tune tune[TGX_KERNEL_COUNT];   // per kernel class: K-split and workgroups per CU
+  int lm_grid = 0, attn_nsplit = 1, attn_nsplit_opt = 0;
+  int debug_nops = 0;     // extra no-op launches per layer (launch-overhead experiments only)
+  int* nop_word = nullptr;
+  float* scratch_x = nullptr;   // [hidden] residual sink for tgx_profile_decode
   Profiler prof;
 };
 
@@ -195,33 +203,43 @@ void build_rope_host(const tgx_model_desc& d, std::vector<float>& cs, std::vecto
 // ------------------------------------------------------------------------------------------------
 // kernel launch helpers
 // ------------------------------------------------------------------------------------------------
-struct Timed {   // brackets one launch with events when profiling
-  tgx_ctx* c; int cls; bool on;
-  Timed(tgx_ctx* c_, int cls_) : c(c_), cls(cls_), on(c_->prof.on && cls_ >= 0) {
-    if (on) (void)hipEventRecord(c->prof.ev[0], c->stream);
-  }
-  ~Timed() {
-    if (!on) return;
-    (void)hipEventRecord(c->prof.ev[1], c->stream);
-    (void)hipEventSynchronize(c->prof.ev[1]);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, c->prof.ev[0], c->prof.ev[1]);
-    c->prof.launches[cls]++;
-    c->prof.ms[cls] += ms;
-  }
-};
-
-int gemv_grid(const tgx_ctx* c, int units) {
-  const int want = (units + 3) / 4;
-  const int cap = c->num_cus * c->gemv_bpc;
+int gemv_grid(const tgx_ctx* c, int units, int ks, int bpc) {
+  const int upb = 4 / ks;
+  const int want = (units + upb - 1) / upb;
+  const int cap = c->num_cus * bpc;
   return want < cap ? want : cap;
 }
 
+// 16-byte slices per lane per row for a K range split over ks waves (the kernel's NX template parameter)
+int gemv_nx(int K, int ks) { return ((K / 8) + ks * 64 - 1) / (ks * 64); }
+
+// smallest K split that keeps a wave's slice within 8 x 512 elements; norm-fused launches must use 1
+int gemv_auto_ks(int K, int want) {
+  int ks = want;
+  while (ks < 4 && gemv_nx(K, ks) > 8) ks *= 2;
+  return ks;
+}
+
+template <int PRO, int EPI, int NX>
+void launch_gemv_nx(tgx_ctx* c, const tgx::GemvArgs& a, int grid) {
+  hipLaunchKernelGGL((tgx::gemv_kernel<PRO, EPI, NX>), dim3(grid), dim3(256), 0, c->stream, a);
+}
+
 template <int PRO, int EPI>
-void launch_gemv(tgx_ctx* c, const tgx::GemvArgs& a, int grid, int cls) {
-  Timed t(c, cls);
-  const size_t lds = (size_t)a.K * 4 + 64;
-  hipLaunchKernelGGL((tgx::gemv_kernel<PRO, EPI>), dim3(grid), dim3(256), lds, c->stream, a);
+void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls) {
+  const Tune& tn = c->tune[cls];
+  a.ks = (PRO == tgx::PRO_RMSNORM) ? 1 : gemv_auto_ks(a.K, tn.ks);
+  const int grid = (EPI == tgx::EPI_LOGITS) ? c->lm_grid : gemv_grid(c, a.units, a.ks, tn.bpc);
+  switch (gemv_nx(a.K, a.ks)) {
+    case 1: launch_gemv_nx<PRO, EPI, 1>(c, a, grid); break;
+    case 2: launch_gemv_nx<PRO, EPI, 2>(c, a, grid); break;
+    case 3: launch_gemv_nx<PRO, EPI, 3>(c, a, grid); break;
+    case 4: launch_gemv_nx<PRO, EPI, 4>(c, a, grid); break;
+    case 5: launch_gemv_nx<PRO, EPI, 5>(c, a, grid); break;
+    case 6: launch_gemv_nx<PRO, EPI, 6>(c, a, grid); break;
+    case 7: launch_gemv_nx<PRO, EPI, 7>(c, a, grid); break;
+    default: launch_gemv_nx<PRO, EPI, 8>(c, a, grid); break;
+  }
 }
 
 template <int HD>
@@ -237,57 +255,71 @@ void launch_attn_g(tgx_ctx* c, const tgx::AttnArgs& a, int G) {
     case 7: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 7>), grid, blk, 0, c->stream, a); break;
     default: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 8>), grid, blk, 0, c->stream, a); break;
   }
-  hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads), dim3(HD), 0, c->stream, a);
+  hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads), dim3(256), 0, c->stream, a);
 }
 
 void launch_attn(tgx_ctx* c, const tgx::AttnArgs& a) {
-  Timed t(c, TGX_KERNEL_ATTN);
   const int G = a.heads / a.kv_heads;
   if (c->d.head_dim == 64) launch_attn_g<64>(c, a, G);
   else launch_attn_g<128>(c, a, G);
 }
 
-// All decoder layers for the token whose embedding sits in row.x, at position *row.pos.
-// == for (auto& layer : layers_) x = layer->forward(x)  (GPTModel.h:53-55)
-void launch_layers(tgx_ctx* c, RowState& r) {
+// One kernel class of one decoder layer.  `resid` is the residual stream the o_proj/down epilogues update
+// (row.x in the real pass; a scratch vector when tgx_profile_decode replays a class in isolation).
+void launch_layer_kernel(tgx_ctx* c, RowState& r, int l, int cls, float* resid) {
   const tgx_model_desc& d = c->d;
   const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
   const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd;
-  for (int l = 0; l < d.layers; l++) {
-    const LayerW& w = c->L[(size_t)l];
-    {   // input_layernorm -> qkv_proj -> RoPE -> cache append      (DecoderLayer.h:40, Attention.h:94-106)
+  const LayerW& w = c->L[(size_t)l];
+  switch (cls) {
+    case TGX_KERNEL_QKV: {   // input_layernorm -> qkv_proj -> RoPE -> cache append   (DecoderLayer.h:40, Attention.h:94-106)
       tgx::GemvArgs a{};
       a.W = w.wqkv; a.bias = w.bqkv; a.x = r.x; a.norm_w = w.in_norm; a.eps = d.norm_eps;
       a.N = qd + 2 * kvd; a.K = H; a.units = a.N / 2;
       a.q_out = r.q; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos = r.pos;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx;
-      launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_QKV_ROPE>(c, a, gemv_grid(c, a.units), TGX_KERNEL_QKV);
+      launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_QKV_ROPE>(c, a, TGX_KERNEL_QKV);
+      break;
     }
-    {   // flashAttention(q, Kall, Vall) over keys [0, pos]          (Attention.h:108-111)
+    case TGX_KERNEL_ATTN: {  // flashAttention(q, Kall, Vall) over keys [0, pos]       (Attention.h:108-111)
       tgx::AttnArgs a{};
       a.q = r.q; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
       a.pos = r.pos; a.part = r.attn_part; a.out = r.attn;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
       a.scale = 1.0f / sqrtf((float)hd);
       launch_attn(c, a);
+      break;
     }
-    {   // o_proj + residual                                        (Attention.h:90, DecoderLayer.h:40)
+    case TGX_KERNEL_OPROJ: { // o_proj + residual                                     (Attention.h:90, DecoderLayer.h:40)
       tgx::GemvArgs a{};
-      a.W = w.wo; a.x = r.attn; a.N = H; a.K = qd; a.units = (H + 1) / 2; a.out = r.x; a.hd = 2;
-      launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, gemv_grid(c, a.units), TGX_KERNEL_OPROJ);
+      a.W = w.wo; a.x = r.attn; a.N = H; a.K = qd; a.units = (H + 1) / 2; a.out = resid; a.hd = 2;
+      launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_OPROJ);
+      break;
     }
-    {   // post_attention_layernorm -> gate_up_proj -> siluMul       (DecoderLayer.h:41, GatedMLP.h:37-39)
+    case TGX_KERNEL_GATEUP: { // post_attention_layernorm -> gate_up_proj -> siluMul  (DecoderLayer.h:41, GatedMLP.h:37-39)
       tgx::GemvArgs a{};
       a.W = w.wgu; a.x = r.x; a.norm_w = w.post_norm; a.eps = d.norm_eps;
       a.N = 2 * I; a.K = H; a.units = I; a.out = r.h; a.hd = 2;
-      launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_SILU_MUL>(c, a, gemv_grid(c, a.units), TGX_KERNEL_GATEUP);
+      launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_SILU_MUL>(c, a, TGX_KERNEL_GATEUP);
+      break;
     }
-    {   // down_proj + residual                                     (GatedMLP.h:40, DecoderLayer.h:41)
+    case TGX_KERNEL_DOWN: {  // down_proj + residual                                  (GatedMLP.h:40, DecoderLayer.h:41)
       tgx::GemvArgs a{};
-      a.W = w.wdown; a.x = r.h; a.N = H; a.K = I; a.units = (H + 1) / 2; a.out = r.x; a.hd = 2;
-      launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, gemv_grid(c, a.units), TGX_KERNEL_DOWN);
+      a.W = w.wdown; a.x = r.h; a.N = H; a.K = I; a.units = (H + 1) / 2; a.out = resid; a.hd = 2;
+      launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_DOWN);
+      break;
     }
+    default: break;
+  }
+}
+
+// All decoder layers for the token whose embedding sits in row.x, at position *row.pos.
+// == for (auto& layer : layers_) x = layer->forward(x)  (GPTModel.h:53-55)
+void launch_layers(tgx_ctx* c, RowState& r) {
+  for (int l = 0; l < c->d.layers; l++) {
+    for (int cls = TGX_KERNEL_QKV; cls <= TGX_KERNEL_DOWN; cls++) launch_layer_kernel(c, r, l, cls, r.x);
+    for (int i = 0; i < c->debug_nops; i++) hipLaunchKernelGGL(tgx::nop_kernel, dim3(1), dim3(64), 0, c->stream, c->nop_word);
   }
 }
 
@@ -298,7 +330,7 @@ void launch_lm_head(tgx_ctx* c, RowState& r) {
   a.W = d.tied ? c->embed : c->lm_head; a.x = r.x; a.norm_w = c->final_norm; a.eps = d.norm_eps;
   a.N = d.vocab; a.K = d.hidden; a.units = (d.vocab + 1) / 2; a.hd = 2;
   a.logits = r.logits; a.part_val = r.part_val; a.part_idx = r.part_idx;
-  launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_LOGITS>(c, a, c->lm_grid, TGX_KERNEL_LMHEAD);
+  launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_LOGITS>(c, a, TGX_KERNEL_LMHEAD);
 }
 
 void launch_finalize_greedy(tgx_ctx* c, int row, bool advance_pos, bool log_step) {
@@ -339,7 +371,7 @@ int ensure_step_graph(tgx_ctx* c) {
 }
 
 int run_decode_steps(tgx_ctx* c, int n) {
-  if (c->use_graph && !c->prof.on) {
+  if (c->use_graph) {
     int rc = ensure_step_graph(c);
     if (rc) return rc;
     for (int i = 0; i < n; i++) HIP_OK(c, hipGraphLaunch(c->step_graph, c->stream));
@@ -394,8 +426,8 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   if (d.heads / d.kv_heads > 8) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "GQA group size %d > 8", d.heads / d.kv_heads);
   if (d.hidden % 8 || d.inter % 8 || (d.heads * d.head_dim) % 8) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "hidden/intermediate sizes must be multiples of 8");
   if (d.hidden <= 0 || d.layers <= 0 || d.inter <= 0 || d.vocab <= 0 || d.max_ctx <= 0) return set_err(nullptr, TGX_ERR_INVALID, "non-positive model dimension");
-  if ((size_t)d.inter * 4 + 64 > 64 * 1024 || (size_t)d.hidden * 4 + 64 > 64 * 1024)
-    return set_err(nullptr, TGX_ERR_UNSUPPORTED, "activation vector does not fit the 64 KiB LDS stage");
+  if (d.hidden > 4096) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "hidden_size %d > 4096: the norm-fused GEMV keeps x in one wave's registers", d.hidden);
+  if (d.inter > 16384 || d.heads * d.head_dim > 16384) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "projection input wider than 16384");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(nullptr, TGX_ERR_DEVICE, "no HIP device visible (--device mi355x needs a GPU; there is no CPU fallback)");
   if (device_ordinal < 0 || device_ordinal >= ndev) return set_err(nullptr, TGX_ERR_INVALID, "device ordinal %d out of range [0,%d)", device_ordinal, ndev);
@@ -412,7 +444,7 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_OK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   if (const char* e = getenv("TGX_NO_GRAPH")) c->use_graph = !(e[0] == '1');
-  if (const char* e = getenv("TGX_GEMV_BPC")) { int v = atoi(e); if (v >= 1 && v <= 16) c->gemv_bpc = v; }
+  c->tune[TGX_KERNEL_DOWN].ks = 4;   // K = intermediate_size: 4 waves split each row pair
 
   const int H = d.hidden, I = d.inter, V = d.vocab, qd = d.heads * d.head_dim, kvd = d.kv_heads * d.head_dim;
   int rc;
@@ -522,9 +554,10 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipMemcpy(c->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
   HIP_OK(c, hipMemcpy(c->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
 
-  c->lm_grid = gemv_grid(c, (V + 1) / 2);
+  c->lm_grid = gemv_grid(c, (V + 1) / 2, 1, c->tune[TGX_KERNEL_LMHEAD].bpc);
   int ns = c->num_cus / d.kv_heads;
   c->attn_nsplit = ns < 1 ? 1 : (ns > 32 ? 32 : ns);
+  if (c->attn_nsplit_opt > 0) c->attn_nsplit = c->attn_nsplit_opt;
 
   c->rows.resize((size_t)d.max_batch);
   const size_t kv_elems = (size_t)d.layers * d.kv_heads * d.max_ctx * hd;
@@ -536,7 +569,7 @@ int tgx_finalize(tgx_ctx* c) {
     if ((rc = dev_alloc(c, &r.logits, (size_t)V))) return rc;
     if ((rc = dev_alloc(c, &r.part_val, (size_t)c->lm_grid))) return rc;
     if ((rc = dev_alloc(c, &r.part_idx, (size_t)c->lm_grid))) return rc;
-    if ((rc = dev_alloc(c, &r.attn_part, (size_t)d.heads * c->attn_nsplit * (hd + 2)))) return rc;
+    if ((rc = dev_alloc(c, &r.attn_part, (size_t)d.heads * c->attn_nsplit * (hd + 4)))) return rc;
     if ((rc = dev_alloc(c, &r.tok, 1))) return rc;
     if ((rc = dev_alloc(c, &r.pos, 1))) return rc;
     if ((rc = dev_alloc(c, &r.prompt, (size_t)d.max_ctx))) return rc;
@@ -549,6 +582,9 @@ int tgx_finalize(tgx_ctx* c) {
   }
   c->log_cap = d.max_ctx > 1024 ? d.max_ctx : 1024;
   if ((rc = dev_alloc(c, &c->step, 1))) return rc;
+  if ((rc = dev_alloc(c, &c->nop_word, 1))) return rc;
+  if ((rc = dev_alloc(c, &c->scratch_x, (size_t)H))) return rc;
+  HIP_OK(c, hipMemset(c->scratch_x, 0, (size_t)H * 4));
   if ((rc = dev_alloc(c, &c->tok_log, (size_t)c->log_cap * d.max_batch))) return rc;
   HIP_OK(c, hipMemset(c->step, 0, 4));
   HIP_OK(c, hipHostMalloc((void**)&c->host_ring, (size_t)HOST_RING * d.max_batch * 4, hipHostMallocMapped));
@@ -566,7 +602,7 @@ void tgx_destroy(tgx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log);
+  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.wgu); fr(w.wdown); }
   for (auto& r : c->rows) {
     fr(r.x); fr(r.q); fr(r.attn); fr(r.h); fr(r.logits); fr(r.part_val); fr(r.part_idx); fr(r.attn_part);
@@ -737,21 +773,64 @@ int tgx_read_kv(tgx_ctx* c, int row, int layer, float* k_out, float* v_out) {
   return TGX_OK;
 }
 
-int tgx_profile_decode(tgx_ctx* c, int n_steps, int64_t* launches, double* total_ms) {
-  if (!c || !launches || !total_ms || n_steps < 0) return TGX_ERR_INVALID;
+int tgx_profile_decode(tgx_ctx* c, int n_reps, int64_t* launches, double* total_ms) {
+  if (!c || !launches || !total_ms || n_reps < 0) return TGX_ERR_INVALID;
   if (!c->have_token) return set_err(c, TGX_ERR_STATE, "profile needs a current token: call tgx_sample after tgx_forward");
-  if (c->past + n_steps > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded");
+  if (c->past + 1 > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded");
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipStreamSynchronize(c->stream));
-  c->prof.on = true;
-  memset(c->prof.launches, 0, sizeof c->prof.launches);
-  memset(c->prof.ms, 0, sizeof c->prof.ms);
-  int rc = run_decode_steps(c, n_steps);
-  c->prof.on = false;
-  if (rc) return rc;
-  HIP_OK(c, hipStreamSynchronize(c->stream));
-  for (int i = 0; i < TGX_KERNEL_COUNT; i++) { launches[i] = c->prof.launches[i]; total_ms[i] = c->prof.ms[i]; }
+  RowState& r = c->rows[0];
+  for (int i = 0; i < TGX_KERNEL_COUNT; i++) { launches[i] = 0; total_ms[i] = 0.0; }
+  // Each class is launched back-to-back over all layers (every launch streams a different layer's weights, so
+  // nothing is served from the Infinity Cache) between two events on the launch stream.  The residual
+  // epilogues write to a scratch vector: the model state (x, KV cache up to pastLength, token) is untouched.
+  for (int rep = 0; rep < n_reps; rep++) {
+    for (int cls = 0; cls < TGX_KERNEL_COUNT; cls++) {
+      HIP_OK(c, hipEventRecord(c->prof.ev[0], c->stream));
+      int n = 0;
+      if (cls == TGX_KERNEL_LMHEAD) { launch_lm_head(c, r); n = 1; }
+      else for (int l = 0; l < c->d.layers; l++, n++) launch_layer_kernel(c, r, l, cls, c->scratch_x);
+      HIP_OK(c, hipEventRecord(c->prof.ev[1], c->stream));
+      HIP_OK(c, hipEventSynchronize(c->prof.ev[1]));
+      float ms = 0.f;
+      HIP_OK(c, hipEventElapsedTime(&ms, c->prof.ev[0], c->prof.ev[1]));
+      launches[cls] += n;
+      total_ms[cls] += ms;
+    }
+  }
+  HIP_OK(c, hipGetLastError());
+  c->have_logits = false;   // the lm_head replay overwrote the logits buffer
   return TGX_OK;
+}
+
+int tgx_set_option(tgx_ctx* c, const char* key, int value) {
+  if (!c || !key) return TGX_ERR_INVALID;
+  static const char* cls_names[TGX_KERNEL_COUNT] = {"qkv", "attn", "oproj", "gateup", "down", "lmhead"};
+  if (c->step_graph) { (void)hipStreamSynchronize(c->stream); (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
+  if (!strcmp(key, "graph")) { c->use_graph = value != 0; return TGX_OK; }
+  if (!strcmp(key, "debug.nops")) { c->debug_nops = value; return TGX_OK; }
+  if (!strcmp(key, "attn.nsplit")) {
+    if (c->finalized) return set_err(c, TGX_ERR_STATE, "attn.nsplit must be set before tgx_finalize");
+    if (value < 1 || value > 32) return set_err(c, TGX_ERR_INVALID, "attn.nsplit out of range");
+    c->attn_nsplit_opt = value;
+    return TGX_OK;
+  }
+  for (int i = 0; i < TGX_KERNEL_COUNT; i++) {
+    const size_t n = strlen(cls_names[i]);
+    if (strncmp(key, cls_names[i], n) || key[n] != '.') continue;
+    if (!strcmp(key + n + 1, "ks")) {
+      if (value != 1 && value != 2 && value != 4) return set_err(c, TGX_ERR_INVALID, "ks must be 1, 2 or 4");
+      c->tune[i].ks = value;
+      return TGX_OK;
+    }
+    if (!strcmp(key + n + 1, "bpc")) {
+      if (value < 1 || value > 16) return set_err(c, TGX_ERR_INVALID, "bpc out of range");
+      if (i == TGX_KERNEL_LMHEAD && c->finalized) return set_err(c, TGX_ERR_STATE, "lmhead.bpc must be set before tgx_finalize");
+      c->tune[i].bpc = value;
+      return TGX_OK;
+    }
+  }
+  return set_err(c, TGX_ERR_INVALID, "unknown option %s", key);
 }
 
 int64_t tgx_bytes_per_token(const tgx_ctx* c, int64_t T) {

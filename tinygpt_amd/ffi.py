@@ -71,6 +71,7 @@ ABI = {
     "synchronize": (c_int, [c_void_p]),
     "read_kv": (c_int, [c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float)]),
     "profile_decode": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_double)]),
+    "set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "bytes_per_token": (c_int64, [c_void_p, c_int64]),
     "abi_version": (c_int, []),
 }
@@ -242,6 +243,10 @@ class Model:
         ms = (c_double * n)()
         self._check(self.be.profile_decode(self._ctx, n_steps, launches, ms))
         return {k: (launches[i], ms[i]) for i, k in enumerate(KERNEL_CLASSES)}
+
+    def set_option(self, key: str, value: int):
+        self._check(self.be.set_option(self._ctx, key.encode(), int(value)))
+        return self
 
     def bytes_per_token(self, T: int) -> int:
         return self.be.bytes_per_token(self._ctx, T)
