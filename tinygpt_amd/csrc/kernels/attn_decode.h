@@ -35,27 +35,32 @@ template <int HD, int G>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   constexpr int LPT = HD / 8;         // lanes per token row
   constexpr int TPW = 64 / LPT;       // tokens per wave-load
-  __shared__ float red[4][G][HD + 2];
+  constexpr int NSTREAM = 4 * TPW;    // independent online-softmax streams per workgroup (wave x token slot)
+  constexpr int UNR = 4;              // wave-loads of K and of V in flight per iteration
+  constexpr float LOG2E = 1.4426950408889634f;
+  // per stream and query head: o[HD], m, l  (m in the exp2 domain)
+  __shared__ __attribute__((aligned(16))) float red[NSTREAM][G][HD + 4];
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int kvh = blockIdx.x / a.nsplit, sp = blockIdx.x - kvh * a.nsplit;
   const int part_i = lane % LPT, slot = lane / LPT;
   const int n_keys = *a.pos + 1;
-  // token range of this split: multiples of 4*TPW so that waves stay aligned to whole wave-loads
-  constexpr int STEP = 4 * TPW;
+  // token range of this split: a multiple of one full workgroup pass so that waves stay on whole wave-loads
+  constexpr int STEP = 4 * TPW * UNR;
   int chunk = (n_keys + a.nsplit - 1) / a.nsplit;
   chunk = ((chunk + STEP - 1) / STEP) * STEP;
   const int t_begin = sp * chunk;
   const int t_end = min(n_keys, t_begin + chunk);
+  const float qscale = a.scale * LOG2E;     // softmax in base 2: exp(x) = exp2(x * log2 e)
 
-  // query slices: q[g][part_i*8 .. +8) as fp32
+  // query slices: q[g][part_i*8 .. +8) as fp32, pre-scaled
   float qf[G][8];
 #pragma unroll
   for (int g = 0; g < G; g++) {
     const f32x4* qp = reinterpret_cast<const f32x4*>(a.q + (size_t)(kvh * G + g) * HD + part_i * 8);
     const f32x4 q0 = qp[0], q1 = qp[1];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { qf[g][j] = q0[j]; qf[g][4 + j] = q1[j]; }
+    for (int j = 0; j < 4; j++) { qf[g][j] = q0[j] * qscale; qf[g][4 + j] = q1[j] * qscale; }
   }
   float m[G], l[G], o[G][8];
 #pragma unroll
@@ -65,72 +70,68 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     for (int j = 0; j < 8; j++) o[g][j] = 0.f;
   }
 
-  const bf16_t* kbase = a.k_cache + (size_t)kvh * a.max_ctx * HD;
-  const bf16_t* vbase = a.v_cache + (size_t)kvh * a.max_ctx * HD;
-  for (int t0 = t_begin + wv * TPW; t0 < t_end; t0 += STEP) {
-    const int t = t0 + slot;
-    const bool valid = t < t_end;
-    const int tc = valid ? t : t_end - 1;
-    const u32x4 kv = *reinterpret_cast<const u32x4*>(kbase + (size_t)tc * HD + part_i * 8);
-    const u32x4 vv = *reinterpret_cast<const u32x4*>(vbase + (size_t)tc * HD + part_i * 8);
-    float kf[8], vf[8];
+  const bf16_t* kbase = a.k_cache + (size_t)kvh * a.max_ctx * HD + part_i * 8;
+  const bf16_t* vbase = a.v_cache + (size_t)kvh * a.max_ctx * HD + part_i * 8;
+  for (int t0 = t_begin + wv * TPW * UNR; t0 < t_end; t0 += STEP) {
+    u32x4 kv[UNR], vv[UNR];
+    bool valid[UNR];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      kf[2 * j] = bf16_lo(kv[j]); kf[2 * j + 1] = bf16_hi(kv[j]);
-      vf[2 * j] = bf16_lo(vv[j]); vf[2 * j + 1] = bf16_hi(vv[j]);
+    for (int r = 0; r < UNR; r++) {
+      const int t = t0 + r * TPW + slot;
+      valid[r] = t < t_end;
+      const int tc = valid[r] ? t : t_end - 1;
+      kv[r] = *reinterpret_cast<const u32x4*>(kbase + (size_t)tc * HD);
+      vv[r] = *reinterpret_cast<const u32x4*>(vbase + (size_t)tc * HD);
     }
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-      float s = 0.f;
+    for (int r = 0; r < UNR; r++) {
+      float kf[8], vf[8];
 #pragma unroll
-      for (int j = 0; j < 8; j++) s = fmaf(qf[g][j], kf[j], s);
-      s = group_sum<LPT>(s) * a.scale;
-      if (valid) {
-        const float mn = fmaxf(m[g], s);
-        const float alpha = expf(m[g] - mn);     // exp(-inf) = 0 on the first key
-        const float p = expf(s - mn);
-        l[g] = l[g] * alpha + p;
+      for (int j = 0; j < 4; j++) {
+        kf[2 * j] = bf16_lo(kv[r][j]); kf[2 * j + 1] = bf16_hi(kv[r][j]);
+        vf[2 * j] = bf16_lo(vv[r][j]); vf[2 * j + 1] = bf16_hi(vv[r][j]);
+      }
 #pragma unroll
-        for (int j = 0; j < 8; j++) o[g][j] = o[g][j] * alpha + p * vf[j];
-        m[g] = mn;
+      for (int g = 0; g < G; g++) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) s = fmaf(qf[g][j], kf[j], s);
+        s = row_group_sum<LPT>(s);
+        if (valid[r]) {
+          const float mn = fmaxf(m[g], s);
+          const float alpha = exp2f(m[g] - mn);     // exp2(-inf) = 0 on the first key
+          const float p = exp2f(s - mn);
+          l[g] = l[g] * alpha + p;
+#pragma unroll
+          for (int j = 0; j < 8; j++) o[g][j] = o[g][j] * alpha + p * vf[j];
+          m[g] = mn;
+        }
       }
     }
   }
 
-  // merge the TPW token-slot streams of this wave (lanes with equal part_i), then the 4 waves via LDS
+  // every (wave, slot) stream parks its state in LDS; 256 threads then merge the NSTREAM streams
+  const int stream = wv * TPW + slot;
 #pragma unroll
   for (int g = 0; g < G; g++) {
-    float M = m[g];
-#pragma unroll
-    for (int off = LPT; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
-    const float sc = (m[g] == -INFINITY) ? 0.f : expf(m[g] - M);
-    float L = l[g] * sc;
-#pragma unroll
-    for (int off = LPT; off < 64; off <<= 1) L += __shfl_xor(L, off, 64);
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      float v = o[g][j] * sc;
-#pragma unroll
-      for (int off = LPT; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-      o[g][j] = v;
-    }
-    if (slot == 0) {
-#pragma unroll
-      for (int j = 0; j < 8; j++) red[wv][g][part_i * 8 + j] = o[g][j];
-      if (part_i == 0) { red[wv][g][HD] = M; red[wv][g][HD + 1] = L; }
-    }
+    f32x4* dst = reinterpret_cast<f32x4*>(&red[stream][g][part_i * 8]);
+    dst[0] = f32x4{o[g][0], o[g][1], o[g][2], o[g][3]};
+    dst[1] = f32x4{o[g][4], o[g][5], o[g][6], o[g][7]};
+    if (part_i == 0) { red[stream][g][HD] = m[g]; red[stream][g][HD + 1] = l[g]; }
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < G * HD; idx += 256) {
     const int g = idx / HD, d = idx - g * HD;
-    float M = fmaxf(fmaxf(red[0][g][HD], red[1][g][HD]), fmaxf(red[2][g][HD], red[3][g][HD]));
+    float M = -INFINITY;
+#pragma unroll 8
+    for (int s = 0; s < NSTREAM; s++) M = fmaxf(M, red[s][g][HD]);
     float L = 0.f, acc = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      const float mw = red[w][g][HD];
-      const float sc = (mw == -INFINITY) ? 0.f : expf(mw - M);
-      L += red[w][g][HD + 1] * sc;
-      acc += red[w][g][d] * sc;
+#pragma unroll 8
+    for (int s = 0; s < NSTREAM; s++) {
+      const float ms = red[s][g][HD];
+      const float sc = (ms == -INFINITY) ? 0.f : exp2f(ms - M);
+      L += red[s][g][HD + 1] * sc;
+      acc += red[s][g][d] * sc;
     }
     float* dst = a.part + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
     dst[d] = acc;
@@ -155,14 +156,14 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnArgs a) {
   float M = -INFINITY;
   for (int s = 0; s < a.nsplit; s++) M = fmaxf(M, sm_m[s]);
   float L = 0.f;
-  for (int s = 0; s < a.nsplit; s++) L += (sm_m[s] == -INFINITY) ? 0.f : sm_l[s] * expf(sm_m[s] - M);
+  for (int s = 0; s < a.nsplit; s++) L += (sm_m[s] == -INFINITY) ? 0.f : sm_l[s] * exp2f(sm_m[s] - M);   // m is in the exp2 domain
   const int dg = tid % DG, sl = tid / DG;
   float acc = 0.f;                       // threads < HD accumulate dim `tid`
   for (int s0 = 0; s0 < a.nsplit; s0 += SPB) {
     const int s = s0 + sl;
     f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
     if (s < a.nsplit && sm_m[s] != -INFINITY) {
-      const float sc = expf(sm_m[s] - M);
+      const float sc = exp2f(sm_m[s] - M);
       const f32x4* src = reinterpret_cast<const f32x4*>(p + (size_t)s * (HD + 4) + dg * 8);
       v0 = src[0] * sc;
       v1 = src[1] * sc;

@@ -74,6 +74,17 @@ __device__ __forceinline__ float group_max(float v) {
   return v;
 }
 
+// Sum over aligned groups of 8 or 16 adjacent lanes on the DPP crossbar; every lane of the group gets the sum.
+template <int WIDTH>
+__device__ __forceinline__ float row_group_sum(float v) {
+  static_assert(WIDTH == 8 || WIDTH == 16, "row_group_sum: 8 or 16 lanes");
+  v += dpp_mov<0xB1, 0xf>(v);    // quad_perm:[1,0,3,2]
+  v += dpp_mov<0x4E, 0xf>(v);    // quad_perm:[2,3,0,1]
+  v += dpp_mov<0x141, 0xf>(v);   // row_half_mirror
+  if (WIDTH == 16) v += dpp_mov<0x140, 0xf>(v);   // row_mirror
+  return v;
+}
+
 // Block-wide sum over 256 threads (4 waves) through a 4-float LDS scratch; every thread gets the result.
 __device__ __forceinline__ float block_sum_256(float v, float* scratch4) {
   v = group_sum<64>(v);

@@ -124,6 +124,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       for (int t = 0; t < 4; t++) { xr[j][t] = v0[t]; xr[j][4 + t] = v1[t]; }
     }
     if (PRO == PRO_RMSNORM) {   // KS == 1: the wave holds all of x.  HF order: weight * (x * rsqrt(mean(x^2)+eps))
+      const u32x4* wg = reinterpret_cast<const u32x4*>(a.norm_w);
+      u32x4 nw[NX];
+#pragma unroll
+      for (int j = 0; j < NX; j++) nw[j] = wg[cidx[j]];        // in flight together with x
       float ss = 0.f;
 #pragma unroll
       for (int j = 0; j < NX; j++)
@@ -131,10 +135,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         for (int t = 0; t < 8; t++) ss = fmaf(xr[j][t], xr[j][t], ss);
       ss = wave_sum(ss);
       const float inv = 1.0f / sqrtf(ss / (float)a.K + a.eps);
-      const u32x4* wg = reinterpret_cast<const u32x4*>(a.norm_w);
 #pragma unroll
       for (int j = 0; j < NX; j++) {
-        const u32x4 w = wg[cidx[j]];
+        const u32x4 w = nw[j];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
           xr[j][2 * t] = bf16_lo(w[t]) * (xr[j][2 * t] * inv);

@@ -423,7 +423,7 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   if (d.compute_dtype != TGX_BF16) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "mi355x backend computes in bf16 only");
   if (d.head_dim != 64 && d.head_dim != 128) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "head_dim %d (64 and 128 are built)", d.head_dim);
   if (d.heads <= 0 || d.kv_heads <= 0 || d.heads % d.kv_heads) return set_err(nullptr, TGX_ERR_INVALID, "heads %% kv_heads != 0");
-  if (d.heads / d.kv_heads > 8) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "GQA group size %d > 8", d.heads / d.kv_heads);
+  if (d.heads / d.kv_heads > 7) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "GQA group size %d > 7", d.heads / d.kv_heads);
   if (d.hidden % 8 || d.inter % 8 || (d.heads * d.head_dim) % 8) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "hidden/intermediate sizes must be multiples of 8");
   if (d.hidden <= 0 || d.layers <= 0 || d.inter <= 0 || d.vocab <= 0 || d.max_ctx <= 0) return set_err(nullptr, TGX_ERR_INVALID, "non-positive model dimension");
   if (d.hidden > 4096) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "hidden_size %d > 4096: the norm-fused GEMV keeps x in one wave's registers", d.hidden);
