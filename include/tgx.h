@@ -192,6 +192,14 @@ TGX_API int tgx_read_kv(tgx_ctx* ctx, int row, int layer, float* k_out, float* v
 TGX_API int tgx_profile_decode(tgx_ctx* ctx, int n_reps, int64_t* launches /*[TGX_KERNEL_COUNT]*/,
                        double* total_ms /*[TGX_KERNEL_COUNT]*/);
 
+/* Final probability vector(s) [batch*vocab] of the last non-greedy tgx_sample / decode step: what the
+ * reference passes to multinomial (Sampler.cpp:77) — zero where top-k/top-p/min-p removed a token. */
+TGX_API int tgx_read_probs(tgx_ctx* ctx, float* out);
+
+/* Injects logits [batch][vocab] as if a forward had produced them, so that Sampler::sample can be
+ * exercised on its own (the reference's Sampler takes any [B,V] tensor, Sampler.h:30). */
+TGX_API int tgx_set_logits(tgx_ctx* ctx, const float* logits, int batch);
+
 /* Launch-geometry knobs for tuning sweeps (never change results): "<class>.ks" (waves sharing a row pair's K
  * range: 1/2/4), "<class>.bpc" (grid cap, workgroups per CU) with class in {qkv,oproj,gateup,down,lmhead};
  * "attn.nsplit" and "lmhead.bpc" only before tgx_finalize; "graph" 0/1 (hipGraph replay vs eager launches). */

@@ -680,6 +680,13 @@ TGXO_EXPORT int tgxo_set_next_token(tgxo_ctx* c, const int64_t* ids, int batch) 
   return 0;
 }
 
+TGXO_EXPORT int tgxo_set_logits(tgxo_ctx* c, const float* logits, int batch) {
+  if (!c || !logits || batch < 1 || batch > c->d.max_batch) return 1;
+  memcpy(c->logits, logits, (size_t)batch * c->d.vocab * 4);
+  c->last_batch = batch;
+  return 0;
+}
+
 TGXO_EXPORT int tgxo_reset_cache(tgxo_ctx* c) { if (!c) return 1; c->past = 0; return 0; }
 TGXO_EXPORT int64_t tgxo_past_length(const tgxo_ctx* c) { return c ? c->past : -1; }
 TGXO_EXPORT int64_t tgxo_context_size(const tgxo_ctx* c) { return c ? c->d.max_ctx : -1; }

@@ -338,6 +338,27 @@ __global__ __launch_bounds__(256) void embed_prompt_kernel(const EmbedArgs a) {
 }
 
 __global__ void advance_pos_kernel(int* pos) { if (threadIdx.x == 0) *pos = *pos + 1; }
+// Rebuilds the lm_head epilogue's per-workgroup argmax partials from a logits vector (tgx_set_logits: sampler tests).
+__global__ __launch_bounds__(256) void argmax_partials_kernel(const float* logits, int V, float* part_val, int* part_idx) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  float bv = -INFINITY; int bi = 0x7fffffff;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < V; i += gridDim.x * 256) {
+    const float v = logits[i];
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float v = sv[threadIdx.x + s]; const int ix = si[threadIdx.x + s];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && ix < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = ix; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part_val[blockIdx.x] = sv[0]; part_idx[blockIdx.x] = si[0]; }
+}
+
 __global__ void nop_kernel(int* w) { if (threadIdx.x == 999) *w = 0; }
 
 }  // namespace tgx

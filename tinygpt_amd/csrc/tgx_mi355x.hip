@@ -18,6 +18,7 @@
 #include "kernels/attn_decode.h"
 #include "kernels/common.h"
 #include "kernels/gemv.h"
+#include "kernels/sampler.h"
 
 using tgx::bf16_t;
 
@@ -37,6 +38,7 @@ struct LayerW {
 struct RowState {       // independent KV/sequence state of one batch row
   float *x = nullptr, *q = nullptr, *attn = nullptr, *h = nullptr;   // fp32 activations
   float* logits = nullptr;
+  float *work = nullptr, *probs = nullptr;   // sampler scratch / final probabilities [V]
   float* part_val = nullptr;
   int* part_idx = nullptr;
   float* attn_part = nullptr;
@@ -88,6 +90,9 @@ struct tgx_ctx {
 
   hipGraphExec_t step_graph = nullptr;
   int step_graph_batch = 0;
+  tgx_sampler_cfg step_graph_cfg{};
+  unsigned long long* seed_dev = nullptr;
+  bool have_probs = false;
   bool use_graph = true;
 
   Tune tune[TGX_KERNEL_COUNT];   // per kernel class: K-split and workgroups per CU
@@ -333,7 +338,11 @@ void launch_lm_head(tgx_ctx* c, RowState& r) {
   launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_LOGITS>(c, a, TGX_KERNEL_LMHEAD);
 }
 
-void launch_finalize_greedy(tgx_ctx* c, int row, bool advance_pos, bool log_step) {
+bool is_greedy(const tgx_sampler_cfg* s) {   // Sampler.cpp:15-21
+  return !(s->temperature > 0.f || s->top_k > 0 || s->top_p < 1.f || s->min_p > 0.f);
+}
+
+tgx::FinalizeArgs make_finalize_args(tgx_ctx* c, int row, bool advance_pos, bool log_step) {
   RowState& r = c->rows[(size_t)row];
   tgx::FinalizeArgs a{};
   a.part_val = r.part_val; a.part_idx = r.part_idx; a.n_part = c->lm_grid;
@@ -342,41 +351,68 @@ void launch_finalize_greedy(tgx_ctx* c, int row, bool advance_pos, bool log_step
   a.row = row; a.rows = c->batch;
   a.log = log_step ? 1 : 0; a.bump_step = (row == c->batch - 1) ? 1 : 0;
   a.embed = c->embed; a.x = r.x; a.H = c->d.hidden; a.advance_pos = advance_pos ? 1 : 0;
-  hipLaunchKernelGGL(tgx::finalize_greedy_kernel, dim3(1), dim3(256), 0, c->stream, a);
+  return a;
 }
 
-// One greedy decode step for all active rows: layers at pos, lm_head, then {argmax, pos+=1, next embedding}.
+// == Sampler::sample on this row's logits (Sampler.cpp:23-79) + token publish / pastLength / next embedding
+void launch_sample(tgx_ctx* c, int row, const tgx_sampler_cfg& cfg, bool advance_pos, bool log_step) {
+  RowState& r = c->rows[(size_t)row];
+  if (is_greedy(&cfg)) {
+    const tgx::FinalizeArgs a = make_finalize_args(c, row, advance_pos, log_step);
+    hipLaunchKernelGGL(tgx::finalize_greedy_kernel, dim3(1), dim3(256), 0, c->stream, a);
+    return;
+  }
+  tgx::SampleArgs a{};
+  a.logits = r.logits; a.work = r.work; a.probs_out = r.probs; a.V = c->d.vocab;
+  a.temperature = cfg.temperature; a.top_k = cfg.top_k; a.top_p = cfg.top_p; a.min_p = cfg.min_p;
+  a.seed = c->seed_dev;
+  a.fin = make_finalize_args(c, row, advance_pos, log_step);
+  hipLaunchKernelGGL(tgx::sample_kernel, dim3(1), dim3(tgx::SAMPLER_THREADS), 0, c->stream, a);
+}
+
+// One decode step for all active rows: layers at pos, lm_head, then {sample, pos+=1, next embedding}.
 // == nextToken = genNextToken(nextToken)  (GPTEngine.cpp:94-99,165-168)
-void launch_decode_step(tgx_ctx* c) {
+void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
   for (int b = 0; b < c->batch; b++) {
     RowState& r = c->rows[(size_t)b];
     launch_layers(c, r);
     launch_lm_head(c, r);
-    launch_finalize_greedy(c, b, /*advance_pos=*/true, /*log_step=*/true);
+    launch_sample(c, b, cfg, /*advance_pos=*/true, /*log_step=*/true);
   }
 }
 
-int ensure_step_graph(tgx_ctx* c) {
+bool same_cfg(const tgx_sampler_cfg& a, const tgx_sampler_cfg& b) {
+  return a.temperature == b.temperature && a.top_k == b.top_k && a.top_p == b.top_p && a.min_p == b.min_p;
+}
+
+int ensure_step_graph(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
   if (!c->use_graph) return TGX_OK;
-  if (c->step_graph && c->step_graph_batch == c->batch) return TGX_OK;
-  if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
+  if (c->step_graph && c->step_graph_batch == c->batch && same_cfg(c->step_graph_cfg, cfg)) return TGX_OK;
+  if (c->step_graph) { (void)hipStreamSynchronize(c->stream); (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
   hipGraph_t g = nullptr;
   HIP_OK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-  launch_decode_step(c);
+  launch_decode_step(c, cfg);
   HIP_OK(c, hipStreamEndCapture(c->stream, &g));
   HIP_OK(c, hipGraphInstantiate(&c->step_graph, g, nullptr, nullptr, 0));
   (void)hipGraphDestroy(g);
   c->step_graph_batch = c->batch;
+  c->step_graph_cfg = cfg;
   return TGX_OK;
 }
 
-int run_decode_steps(tgx_ctx* c, int n) {
+int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int n) {
+  if (!is_greedy(&cfg)) {
+    const unsigned long long s = seed;
+    HIP_OK(c, hipMemcpyAsync(c->seed_dev, &s, 8, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));     // `s` is a stack variable
+    c->have_probs = true;
+  }
   if (c->use_graph) {
-    int rc = ensure_step_graph(c);
+    int rc = ensure_step_graph(c, cfg);
     if (rc) return rc;
     for (int i = 0; i < n; i++) HIP_OK(c, hipGraphLaunch(c->step_graph, c->stream));
   } else {
-    for (int i = 0; i < n; i++) launch_decode_step(c);
+    for (int i = 0; i < n; i++) launch_decode_step(c, cfg);
     HIP_OK(c, hipGetLastError());
   }
   c->past += n;
@@ -388,10 +424,6 @@ template <typename T>
 int dev_alloc(tgx_ctx* c, T** p, size_t n) {
   HIP_OK(c, hipMalloc((void**)p, n * sizeof(T)));
   return TGX_OK;
-}
-
-bool is_greedy(const tgx_sampler_cfg* s) {   // Sampler.cpp:15-21
-  return !(s->temperature > 0.f || s->top_k > 0 || s->top_p < 1.f || s->min_p > 0.f);
 }
 
 }  // namespace
@@ -567,6 +599,8 @@ int tgx_finalize(tgx_ctx* c) {
     if ((rc = dev_alloc(c, &r.attn, (size_t)qd))) return rc;
     if ((rc = dev_alloc(c, &r.h, (size_t)I))) return rc;
     if ((rc = dev_alloc(c, &r.logits, (size_t)V))) return rc;
+    if ((rc = dev_alloc(c, &r.work, (size_t)V))) return rc;
+    if ((rc = dev_alloc(c, &r.probs, (size_t)V))) return rc;
     if ((rc = dev_alloc(c, &r.part_val, (size_t)c->lm_grid))) return rc;
     if ((rc = dev_alloc(c, &r.part_idx, (size_t)c->lm_grid))) return rc;
     if ((rc = dev_alloc(c, &r.attn_part, (size_t)d.heads * c->attn_nsplit * (hd + 4)))) return rc;
@@ -582,6 +616,7 @@ int tgx_finalize(tgx_ctx* c) {
   }
   c->log_cap = d.max_ctx > 1024 ? d.max_ctx : 1024;
   if ((rc = dev_alloc(c, &c->step, 1))) return rc;
+  if ((rc = dev_alloc(c, &c->seed_dev, 1))) return rc;
   if ((rc = dev_alloc(c, &c->nop_word, 1))) return rc;
   if ((rc = dev_alloc(c, &c->scratch_x, (size_t)H))) return rc;
   HIP_OK(c, hipMemset(c->scratch_x, 0, (size_t)H * 4));
@@ -602,10 +637,10 @@ void tgx_destroy(tgx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x);
+  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x); fr(c->seed_dev);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.wgu); fr(w.wdown); }
   for (auto& r : c->rows) {
-    fr(r.x); fr(r.q); fr(r.attn); fr(r.h); fr(r.logits); fr(r.part_val); fr(r.part_idx); fr(r.attn_part);
+    fr(r.x); fr(r.q); fr(r.attn); fr(r.h); fr(r.logits); fr(r.work); fr(r.probs); fr(r.part_val); fr(r.part_idx); fr(r.attn_part);
     fr(r.tok); fr(r.pos); fr(r.prompt); fr(r.kcache); fr(r.vcache);
   }
   if (c->host_ring) (void)hipHostFree(c->host_ring);
@@ -660,12 +695,15 @@ int tgx_read_logits(tgx_ctx* c, float* out, int rounded) {
 }
 
 int tgx_sample(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* out_ids) {
-  (void)seed;
   if (!c || !cfg) return TGX_ERR_INVALID;
   if (!c->have_logits) return set_err(c, TGX_ERR_STATE, "no logits to sample from");
-  if (!is_greedy(cfg)) return set_err(c, TGX_ERR_UNSUPPORTED, "temperature/top-k/top-p/min-p sampling is not built yet on mi355x");
   HIP_OK(c, hipSetDevice(c->device));
-  for (int b = 0; b < c->batch; b++) launch_finalize_greedy(c, b, /*advance_pos=*/false, /*log_step=*/false);
+  if (!is_greedy(cfg)) {
+    const unsigned long long s = seed;
+    HIP_OK(c, hipMemcpy(c->seed_dev, &s, 8, hipMemcpyHostToDevice));
+    c->have_probs = true;
+  }
+  for (int b = 0; b < c->batch; b++) launch_sample(c, b, *cfg, /*advance_pos=*/false, /*log_step=*/false);
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipStreamSynchronize(c->stream));
   for (int b = 0; b < c->batch; b++) {
@@ -679,15 +717,13 @@ int tgx_sample(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* o
 }
 
 int tgx_decode(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int n_steps, int64_t* out_ids) {
-  (void)seed;
   if (!c || !cfg || n_steps < 0) return TGX_ERR_INVALID;
   if (!c->have_token) return set_err(c, TGX_ERR_STATE, "decode needs a current token: call tgx_sample after tgx_forward");
-  if (!is_greedy(cfg)) return set_err(c, TGX_ERR_UNSUPPORTED, "temperature/top-k/top-p/min-p sampling is not built yet on mi355x");
   if (c->past + n_steps > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded: %lld + %d > %d", (long long)c->past, n_steps, c->d.max_ctx);
   if (n_steps > c->log_cap) return set_err(c, TGX_ERR_INVALID, "n_steps exceeds the token log capacity %d", c->log_cap);
   HIP_OK(c, hipSetDevice(c->device));
   const int64_t start = c->steps_issued;
-  int rc = run_decode_steps(c, n_steps);
+  int rc = run_decode_steps(c, *cfg, seed, n_steps);
   if (rc) return rc;
   c->have_logits = true;
   if (out_ids && n_steps > 0) {
@@ -706,13 +742,11 @@ int tgx_decode(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int n_step
 }
 
 int tgx_step_async(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* out_ticket) {
-  (void)seed;
   if (!c || !cfg || !out_ticket) return TGX_ERR_INVALID;
   if (!c->have_token) return set_err(c, TGX_ERR_STATE, "step needs a current token: call tgx_sample after tgx_forward");
-  if (!is_greedy(cfg)) return set_err(c, TGX_ERR_UNSUPPORTED, "temperature/top-k/top-p/min-p sampling is not built yet on mi355x");
   if (c->past + 1 > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded");
   HIP_OK(c, hipSetDevice(c->device));
-  int rc = run_decode_steps(c, 1);
+  int rc = run_decode_steps(c, *cfg, seed, 1);
   if (rc) return rc;
   const int64_t ticket = c->steps_issued;
   HIP_OK(c, hipEventRecord(c->ticket_ev[ticket % MAX_TICKET_EVENTS], c->stream));
@@ -800,6 +834,36 @@ int tgx_profile_decode(tgx_ctx* c, int n_reps, int64_t* launches, double* total_
   }
   HIP_OK(c, hipGetLastError());
   c->have_logits = false;   // the lm_head replay overwrote the logits buffer
+  return TGX_OK;
+}
+
+int tgx_read_probs(tgx_ctx* c, float* out) {
+  if (!c || !out) return TGX_ERR_INVALID;
+  if (!c->have_probs) return set_err(c, TGX_ERR_STATE, "no probabilities: the last sample was greedy or none was taken");
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  const size_t V = (size_t)c->d.vocab;
+  for (int b = 0; b < c->batch; b++) HIP_OK(c, hipMemcpy(out + b * V, c->rows[(size_t)b].probs, V * 4, hipMemcpyDeviceToHost));
+  return TGX_OK;
+}
+
+int tgx_set_logits(tgx_ctx* c, const float* logits, int batch) {
+  if (!c || !logits) return TGX_ERR_INVALID;
+  if (!c->finalized) return set_err(c, TGX_ERR_STATE, "set_logits before finalize");
+  if (batch < 1 || batch > c->d.max_batch) return set_err(c, TGX_ERR_INVALID, "batch out of range");
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  const size_t V = (size_t)c->d.vocab;
+  for (int b = 0; b < batch; b++) HIP_OK(c, hipMemcpy(c->rows[(size_t)b].logits, logits + b * V, V * 4, hipMemcpyHostToDevice));
+  // the greedy path reads per-workgroup argmax partials: rebuild them from the injected logits
+  for (int b = 0; b < batch; b++) {
+    RowState& r = c->rows[(size_t)b];
+    hipLaunchKernelGGL(tgx::argmax_partials_kernel, dim3(c->lm_grid), dim3(256), 0, c->stream, r.logits, (int)V, r.part_val, r.part_idx);
+  }
+  HIP_OK(c, hipGetLastError());
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  c->batch = batch;
+  c->have_logits = true;
   return TGX_OK;
 }
 

@@ -72,6 +72,8 @@ ABI = {
     "read_kv": (c_int, [c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float)]),
     "profile_decode": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_double)]),
     "set_option": (c_int, [c_void_p, c_char_p, c_int]),
+    "read_probs": (c_int, [c_void_p, POINTER(c_float)]),
+    "set_logits": (c_int, [c_void_p, POINTER(c_float), c_int]),
     "bytes_per_token": (c_int64, [c_void_p, c_int64]),
     "abi_version": (c_int, []),
 }
@@ -243,6 +245,17 @@ class Model:
         ms = (c_double * n)()
         self._check(self.be.profile_decode(self._ctx, n_steps, launches, ms))
         return {k: (launches[i], ms[i]) for i, k in enumerate(KERNEL_CLASSES)}
+
+    def probs(self) -> np.ndarray:
+        out = np.empty((self.batch, self.desc.vocab), dtype=np.float32)
+        self._check(self.be.read_probs(self._ctx, out.ctypes.data_as(POINTER(c_float))))
+        return out
+
+    def set_logits(self, logits):
+        l = np.ascontiguousarray(np.atleast_2d(np.asarray(logits, dtype=np.float32)))
+        self._check(self.be.set_logits(self._ctx, l.ctypes.data_as(POINTER(c_float)), l.shape[0]))
+        self.batch = l.shape[0]
+        return self
 
     def set_option(self, key: str, value: int):
         self._check(self.be.set_option(self._ctx, key.encode(), int(value)))
