@@ -1,0 +1,115 @@
+"""ctypes view of tinygpt_amd/lib/libtgx_host.so (the C++ host engine) + helpers to write HF-style model dirs."""
+import ctypes
+import json
+import os
+from ctypes import CFUNCTYPE, POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint16, c_uint64, c_void_p
+
+import numpy as np
+
+from tinygpt_amd import build, synth
+from tinygpt_amd.desc import desc_from_hf_config
+
+TOKEN_CB = CFUNCTYPE(c_int, c_int32, c_void_p)
+
+
+def host_lib():
+    lib_path, _ = build.build_host()
+    lib = ctypes.CDLL(lib_path)
+    lib.tgxe_create.restype = c_void_p
+    lib.tgxe_create.argtypes = [c_char_p, c_char_p, c_char_p, c_char_p, c_char_p, c_int, c_int, c_int]
+    lib.tgxe_destroy.argtypes = [c_void_p]
+    lib.tgxe_prepare.argtypes = [c_void_p]
+    lib.tgxe_last_error.restype = c_char_p
+    lib.tgxe_last_error.argtypes = [c_void_p]
+    lib.tgxe_context_size.restype = c_int64
+    lib.tgxe_context_size.argtypes = [c_void_p]
+    lib.tgxe_eos_ids.argtypes = [c_void_p, POINTER(c_int32), c_int]
+    lib.tgxe_reconfigure.argtypes = [c_void_p, c_float, c_int64, c_float, c_float, c_int64, POINTER(c_int32), c_int]
+    lib.tgxe_generate_sync.argtypes = [c_void_p, POINTER(c_int32), POINTER(c_int32), c_int, c_int32, POINTER(c_int32), c_int64,
+                                       POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]
+    lib.tgxe_generate_async.argtypes = [c_void_p, POINTER(c_int32), c_int, TOKEN_CB, c_void_p, POINTER(c_int32), c_int64,
+                                        POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]
+    lib.tgxe_synth_tensor.argtypes = [c_uint64, c_char_p, c_int64, c_double, POINTER(c_uint16)]
+    return lib
+
+
+class HostEngine:
+    def __init__(self, lib, model_dir=None, synthetic=None, device="mi355x", backend_lib=None, prefix="tgx_", dtype=1, max_batch=4):
+        self.lib = lib
+        self.h = lib.tgxe_create((model_dir or "").encode(), (synthetic or "").encode(), device.encode(),
+                                 (backend_lib or "").encode(), prefix.encode(), 0, dtype, max_batch)
+
+    def prepare(self):
+        return self.lib.tgxe_prepare(self.h) == 0
+
+    def error(self):
+        return self.lib.tgxe_last_error(self.h).decode()
+
+    def eos_ids(self):
+        buf = (c_int32 * 16)()
+        n = self.lib.tgxe_eos_ids(self.h, buf, 16)
+        return list(buf[:n])
+
+    def reconfigure(self, temperature=0.0, top_k=0, top_p=1.0, min_p=0.0, max_new=16, extra_stop=()):
+        ex = (c_int32 * max(1, len(extra_stop)))(*extra_stop)
+        self.lib.tgxe_reconfigure(self.h, temperature, top_k, top_p, min_p, max_new, ex, len(extra_stop))
+
+    def generate_sync(self, prompts, pad=0, cap=1 << 16):
+        flat = np.concatenate([np.asarray(p, np.int32) for p in prompts])
+        lens = np.asarray([len(p) for p in prompts], np.int32)
+        out = np.zeros(cap, np.int32)
+        n, new, fin = c_int64(), c_int64(), c_int()
+        rc = self.lib.tgxe_generate_sync(self.h, flat.ctypes.data_as(POINTER(c_int32)), lens.ctypes.data_as(POINTER(c_int32)), len(prompts), pad,
+                                         out.ctypes.data_as(POINTER(c_int32)), cap, ctypes.byref(n), ctypes.byref(new), ctypes.byref(fin))
+        assert rc == 0, self.error()
+        return out[:n.value].reshape(len(prompts), -1), new.value, ("stop", "length")[fin.value]
+
+    def generate_async(self, prompt, on_token=None, cap=1 << 16):
+        seen = []
+
+        def cb(tok, _):
+            seen.append(int(tok))
+            return 1 if (on_token is None or on_token(int(tok))) else 0
+
+        p = np.asarray(prompt, np.int32)
+        out = np.zeros(cap, np.int32)
+        n, new, fin = c_int64(), c_int64(), c_int()
+        rc = self.lib.tgxe_generate_async(self.h, p.ctypes.data_as(POINTER(c_int32)), len(p), TOKEN_CB(cb), None,
+                                          out.ctypes.data_as(POINTER(c_int32)), cap, ctypes.byref(n), ctypes.byref(new), ctypes.byref(fin))
+        assert rc == 0, self.error()
+        return out[:n.value], new.value, ("stop", "length")[fin.value], seen
+
+    def close(self):
+        if self.h:
+            self.lib.tgxe_destroy(self.h)
+            self.h = None
+
+
+def write_model_dir(path, cfg, seed, std, shards=1, dtype="bf16", eos=None):
+    """HF-layout directory with deterministic weights: config.json, generation_config.json, model.safetensors
+    (or 2 shards + model.safetensors.index.json).  Written with the `safetensors` package (an independent writer)."""
+    import torch
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    d = desc_from_hf_config(cfg, "bf16")
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    with open(os.path.join(path, "generation_config.json"), "w") as f:
+        json.dump({"bos_token_id": 1, "eos_token_id": eos if eos is not None else cfg.get("eos_token_id", 2)}, f)
+    tensors = {}
+    for name, bits in synth.synth_checkpoint(d, seed, std):
+        t = torch.from_numpy(synth.bf16_bits_to_f32(bits).copy())
+        tensors[name] = t.to(torch.bfloat16) if dtype == "bf16" else t
+    if shards == 1:
+        save_file(tensors, os.path.join(path, "model.safetensors"))
+    else:
+        names = list(tensors)
+        parts = [names[i::shards] for i in range(shards)]
+        wm = {}
+        for i, part in enumerate(parts):
+            fn = f"model-{i + 1:05d}-of-{shards:05d}.safetensors"
+            save_file({n: tensors[n] for n in part}, os.path.join(path, fn))
+            wm.update({n: fn for n in part})
+        with open(os.path.join(path, "model.safetensors.index.json"), "w") as f:
+            json.dump({"metadata": {}, "weight_map": wm}, f)
+    return d

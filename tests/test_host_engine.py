@@ -1,0 +1,132 @@
+"""The C++ host engine (tinygpt_amd/host: GPTEngine mirror, config + safetensors readers) bound to the CPU oracle
+through the same function table that binds the HIP library — host logic is checked without a GPU."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from host_util import HostEngine, host_lib, write_model_dir
+from tinygpt_amd import synth
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return host_lib()
+
+
+@pytest.fixture(scope="module")
+def oracle_path(oracle_lib):
+    return oracle_lib.path
+
+
+def make_engine(lib, oracle_path, tmp_path, fam, dtype, shards=1, max_batch=4, eos=None, file_dtype="bf16"):
+    cfg, g = load_golden(fam)
+    write_model_dir(str(tmp_path), cfg, int(g["seed"]), float(g["std"]), shards=shards, eos=eos, dtype=file_dtype)
+    e = HostEngine(lib, model_dir=str(tmp_path), backend_lib=oracle_path, prefix="tgxo_", dtype=dtype, max_batch=max_batch)
+    assert e.prepare(), e.error()
+    return e, g
+
+
+def test_synth_cpp_equals_python(lib):
+    import ctypes
+    for name, n, std in [("model.layers.3.mlp.up_proj.weight", 70001, 0.02), ("model.norm.weight", 777, 0.02),
+                         ("model.layers.0.input_layernorm.weight", 64, 0.08), ("lm_head.weight", 1 << 21, 0.08)]:
+        out = np.zeros(n, np.uint16)
+        lib.tgxe_synth_tensor(1234, name.encode(), n, std, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)))
+        np.testing.assert_array_equal(out, synth.synth_tensor_bf16(1234, name, (n,), std))
+
+
+@pytest.mark.parametrize("fam,shards", [("llama_tiny", 1), ("qwen2_tiny", 2), ("mistral_tiny", 1)])
+def test_generate_sync_matches_hf_golden(lib, oracle_path, tmp_path, fam, shards):
+    """config.json + (sharded) safetensors -> engine -> greedy ids == HF's, prompt ids echoed, finishReason Length."""
+    e, g = make_engine(lib, oracle_path, tmp_path, fam, dtype=0, shards=shards)
+    n_new = g["ids_fp32"].shape[1]
+    e.reconfigure(max_new=n_new)
+    ids, new, fin = e.generate_sync([g["prompt"][0]])
+    assert new == n_new and fin == "length"                          # generateSync never stops on EOS (GPTEngine.cpp:170-172)
+    np.testing.assert_array_equal(ids[0, :g["prompt"].shape[1]], g["prompt"][0])
+    np.testing.assert_array_equal(ids[0, g["prompt"].shape[1]:], g["ids_fp32"][0])
+    e.close()
+
+
+def test_left_padding_without_mask_gpt2_batch4(lib, oracle_path, tmp_path):
+    """E4: prompts of lengths 5/7/5/5 are left-padded with id 0 to 7 and run WITHOUT a mask (GPTEngine.cpp:95,130-138).
+    The golden ids come from HF run on the padded batch with no attention mask."""
+    e, g = make_engine(lib, oracle_path, tmp_path, "gpt2_tiny", dtype=0, file_dtype="fp32")
+    prompts = [row[np.argmax(row != 0):] for row in g["prompt"]]      # strip the pads the generator added
+    assert [len(p) for p in prompts] == [5, 7, 5, 5]
+    e.reconfigure(max_new=g["ids_fp32"].shape[1])
+    ids, new, fin = e.generate_sync(prompts, pad=0)
+    np.testing.assert_array_equal(ids[:, :7], g["prompt"])
+    np.testing.assert_array_equal(ids[:, 7:], g["ids_fp32"])
+    e.close()
+
+
+def test_truncation_keeps_tail(lib, oracle_path, tmp_path):
+    """Prompts longer than contextSize keep their LAST contextSize tokens (GPTEngine.cpp:127-129); llama3-scaled
+    models use original_max_position_embeddings as contextSize (ModelLlama.h:26-31) = 64 for the fixture."""
+    e, g = make_engine(lib, oracle_path, tmp_path, "llama_tiny", dtype=0)
+    assert e.lib.tgxe_context_size(e.h) == 64
+    long = (np.arange(100) * 7 + 3) % 256
+    e.reconfigure(max_new=1)
+    ids, new, _ = e.generate_sync([long])
+    assert ids.shape[1] == 64 + 1
+    np.testing.assert_array_equal(ids[0, :64], long[-64:])
+    e.close()
+
+
+def test_generate_async_stream_eos_abort(lib, oracle_path, tmp_path):
+    e, g = make_engine(lib, oracle_path, tmp_path, "llama_tiny", dtype=0, eos=[2, 999])
+    gold = g["ids_fp32"][0]
+    prompt = g["prompt"][0]
+    assert e.eos_ids() == [2, 999]                                   # generation_config eos array (ModelConfig.cpp:142-156)
+    n = len(gold)
+    # by length: callback sees T1..T(n-1); the token list also holds the never-reported last one (appendix A.9)
+    e.reconfigure(max_new=n)
+    ids, new, fin, seen = e.generate_async(prompt)
+    assert fin == "length" and seen == list(gold[:n - 1]) and new == n
+    np.testing.assert_array_equal(ids[len(prompt):], gold)
+    # extra stop id -> Stop at that token, which is in the list but not reported
+    stop = int(gold[5])
+    k = list(gold).index(stop)
+    e.reconfigure(max_new=n, extra_stop=[stop])
+    ids, new, fin, seen = e.generate_async(prompt)
+    assert fin == "stop" and seen == list(gold[:k])
+    np.testing.assert_array_equal(ids[len(prompt):], gold[:k + 1])
+    # abort from the callback after 3 tokens
+    e.reconfigure(max_new=n)
+    count = []
+    ids, new, fin, seen = e.generate_async(prompt, on_token=lambda t: (count.append(t), len(count) < 3)[1])
+    assert fin == "stop" and seen == list(gold[:3])                  # the aborting token was delivered, nothing after it
+    np.testing.assert_array_equal(ids[len(prompt):], gold[:3])
+    e.close()
+
+
+def test_sampler_defaults_and_reconfigure_resets_cache(lib, oracle_path, tmp_path):
+    """reconfigure() resets the KV cache (GPTEngine.cpp:83): two identical requests give identical ids."""
+    e, g = make_engine(lib, oracle_path, tmp_path, "qwen2_tiny", dtype=1)
+    outs = []
+    for _ in range(2):
+        e.reconfigure(temperature=0.8, top_p=0.9, max_new=8)          # CLI defaults (main.cpp:36-37)
+        outs.append(e.generate_sync([g["prompt"][0]])[0])
+    np.testing.assert_array_equal(outs[0], outs[1])
+    e.close()
+
+
+def test_bad_inputs_fail_loudly(lib, oracle_path, tmp_path):
+    import json, os
+    cfg, g = load_golden("llama_tiny")
+    write_model_dir(str(tmp_path), cfg, int(g["seed"]), float(g["std"]))
+    os.remove(os.path.join(str(tmp_path), "generation_config.json"))     # required file (ModelLoader.cpp:34-38)
+    e = HostEngine(lib, model_dir=str(tmp_path), backend_lib=oracle_path, prefix="tgxo_", dtype=0)
+    assert not e.prepare() and "generation_config" in e.error()
+    e.close()
+    e = HostEngine(lib, model_dir=str(tmp_path), device="cpu")          # no CPU execution path in the product engine
+    assert not e.prepare() and "mi355x" in e.error()
+    e.close()
+    bad = dict(cfg, model_type="falcon")
+    d2 = tmp_path / "bad"
+    write_model_dir(str(d2), cfg, 1, 0.05)
+    json.dump(bad, open(d2 / "config.json", "w"))
+    e = HostEngine(lib, model_dir=str(d2), backend_lib=oracle_path, prefix="tgxo_", dtype=0)
+    assert not e.prepare() and "Unsupported model_type" in e.error()
+    e.close()

@@ -39,5 +39,28 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=()):
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(LIBDIR, "libtgx_host.so")
+HOST_CLI = os.path.join(LIBDIR, "tgx_cli")
+CXX = shutil.which("g++") or "g++"
+CXXFLAGS = ["-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-exceptions", "-Wall", "-Wextra", "-pthread"]
+
+
+def build_host(force: bool = False, verbose: bool = False):
+    """The C++ host engine (no HIP needed: it dlopen()s the device shim): libtgx_host.so + the tgx_cli binary."""
+    srcs = [os.path.join(HOST, f) for f in ("loader.cpp", "engine.cpp")]
+    deps = [os.path.join(HOST, f) for f in os.listdir(HOST)] + [os.path.join(HERE, "..", "include", "tgx.h")]
+    os.makedirs(LIBDIR, exist_ok=True)
+    for target, extra in ((HOST_LIB, [os.path.join(HOST, "engine_c.cpp"), "-shared"]), (HOST_CLI, [os.path.join(HOST, "main.cpp")])):
+        if not force and os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps):
+            continue
+        cmd = [CXX] + CXXFLAGS + srcs + extra + ["-o", target, "-ldl"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return HOST_LIB, HOST_CLI
+
+
 if __name__ == "__main__":
+    print(build_host(force="-f" in sys.argv, verbose=True))
     print(build_lib(force="-f" in sys.argv, verbose=True))

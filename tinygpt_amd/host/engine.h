@@ -1,0 +1,88 @@
+// engine.h — the host engine above the C ABI: the counterpart of GPTEngine (src/engine/GPTEngine.h:42-73,
+// GPTEngine.cpp:37-232) for token-id inputs.  Tokenisation / detokenisation stay outside;
+// everything else — left-padding without a mask, tail truncation to contextSize, prefill + maxNewTokens-1
+// decode steps, no EOS stop in generateSync, one-step-lookahead streaming with EOS/abort in generateAsync,
+// reconfigure() resetting the KV cache — follows the reference line by line in behaviour.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "backend.h"
+#include "loader.h"
+
+namespace tgxh {
+
+struct SamplerConfig {   // src/engine/Sampler.h:13-22
+  float temperature = 0.f;
+  int64_t topK = 0;
+  float topP = 1.f;
+  float minP = 0.f;
+};
+
+enum class FinishReason { Stop, Length };
+
+struct GPTConfig {       // src/engine/GPTEngine.h:25-32 (+ where to find the device shim)
+  std::string modelDir;              // HF directory; empty with `synthetic` set
+  std::string synthetic;             // "llama-3.2-1b" ...: deterministic synthetic checkpoint of that public config
+  std::string device = "mi355x";     // the reference's CLI knows "cpu" and "cuda" (main.cpp:76-80)
+  int dtype = TGX_BF16;
+  SamplerConfig samplerConfig;
+  int64_t maxNewTokens = 16;
+  int deviceOrdinal = 0;
+  int maxBatch = 4;
+  uint64_t seed = 0;
+  std::string backendLib;            // default: <dir of this binary/library>/libtgx_mi355x.so
+  std::string backendPrefix = "tgx_";
+};
+
+struct GPTOutput {       // src/engine/GPTEngine.h:34-40 (texts omitted: ids only)
+  int64_t batch = 0;
+  int64_t newTokens = 0;
+  std::vector<int32_t> tokenIds;     // [batch][padded prompt + new], row-major — prompt tokens included, like the reference
+  FinishReason finishReason = FinishReason::Stop;
+};
+
+using GenerateCallback = std::function<bool(int32_t tokenId)>;   // return false to abort (GPTEngine.cpp:208-213)
+
+class GPTEngine {
+ public:
+  explicit GPTEngine(GPTConfig config);
+  ~GPTEngine();
+  GPTEngine(const GPTEngine&) = delete;
+  GPTEngine& operator=(const GPTEngine&) = delete;
+
+  bool prepare();                                                            // GPTEngine.cpp:41-65
+  void reconfigure(const SamplerConfig& samplerConfig, int64_t maxNewTokens,
+                   const std::vector<int32_t>& extraStopTokenIds = {});      // GPTEngine.cpp:67-84
+  GPTOutput generateSync(const std::vector<std::vector<int32_t>>& prompts, int32_t padToken);   // :154-174
+  GPTOutput generateAsync(const std::vector<int32_t>& prompt, const GenerateCallback& callback);   // :180-232
+
+  bool isEosToken(int32_t id) const;
+  const std::vector<int32_t>& eosTokenIds() const { return eosTokenIds_; }
+  int64_t contextSize() const;
+  const tgx_model_desc& desc() const { return model_.config.desc; }
+  const std::string& lastError() const { return err_; }
+  tgx_ctx* ctx() { return model_.ctx; }
+  const Backend& backend() const { return be_; }
+
+ private:
+  // == encodeTexts minus the tokenizer (GPTEngine.cpp:101-144): truncate to contextSize keeping the tail, left-pad
+  std::vector<int64_t> alignPrompts(const std::vector<std::vector<int32_t>>& prompts, int32_t padToken, int64_t& maxLen) const;
+  bool fail(const std::string& what);
+
+  GPTConfig config_;
+  Backend be_;
+  LoadedModel model_;
+  std::vector<int32_t> baseEosTokenIds_, eosTokenIds_;
+  std::string err_;
+  bool prepared_ = false;
+};
+
+// Deterministic synthetic checkpoint — bit-identical to tinygpt_amd/synth.py (same integer hash).
+void synth_tensor_bf16(uint64_t seed, const std::string& name, size_t n, double std_dev, uint16_t* out);
+bool known_config(const std::string& key, int compute_dtype, int max_batch, ModelConfig& out);
+bool load_synthetic(const Backend& be, const ModelConfig& cfg, int device_ordinal, uint64_t seed, double std_dev, tgx_ctx** ctx, std::string& err);
+
+}  // namespace tgxh
