@@ -1,0 +1,48 @@
+"""bench.py's N > 1 path is 'replicas only' (DESIGN.md §5): no data-path collective, gloo carries the barrier and the
+MAX-over-ranks of the timed region.  This runs that control plane with world_size 2 on CPU and checks the
+aggregation arithmetic (value = N * K / max_r elapsed_r); the per-rank work is a stand-in since no GPU is present."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+from conftest import ROOT
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    import torch, torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    K = 8
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (rank + 1))            # rank 1 is the slow replica
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    mine = elapsed
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"value": world * K / float(t.item()), "max": float(t.item()), "mine": mine, "n_gpus": world}))
+    dist.barrier(); dist.destroy_process_group()
+""")
+
+
+def test_two_rank_gloo_barrier_and_max(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2
+    assert line["max"] >= 0.1 - 1e-3                 # the barrier makes every rank wait for the slow one
+    assert abs(line["value"] - 2 * 8 / line["max"]) < 1e-9
+
+
+def test_bench_refuses_gpus_without_launcher():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "torch.distributed.run" in (out.stderr + out.stdout)
