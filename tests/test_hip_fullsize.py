@@ -1,0 +1,63 @@
+"""BASELINE.json's headline configuration at FULL size (Llama-3.2-1B geometry, synthetic bf16 weights) against the
+CPU oracle, teacher-forced, plus size-independent properties on the other BASELINE geometries.
+
+Free-running greedy comparison is not meaningful with random weights (the top-2 logits of a 128k vocabulary are
+within 1e-3 of each other at most steps), so every step feeds the ORACLE's token to both sides and compares the fp32
+logits (<= 1e-3 relative) and the argmax unless the oracle's own top-2 gap is inside the comparison tolerance."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from tinygpt_amd import known_desc, synth
+from tinygpt_amd.ffi import GREEDY, Model, product_backend
+
+pytestmark = pytest.mark.gpu
+
+
+def test_llama_3_2_1b_full_size_vs_oracle(oracle_lib):
+    from oracle.oracle_ffi import OracleModel
+    d = known_desc("llama-3.2-1b")
+    d.max_ctx = 256                                   # KV capacity only; weights and layer shapes are the full model
+    tensors = list(synth.synth_checkpoint(d, 1234, 0.02))
+    gpu = Model(d, product_backend())
+    ref = OracleModel(d)
+    for name, bits in tensors:
+        gpu.upload(name, bits); ref.upload(name, bits)
+    del tensors
+    gpu.finalize(); ref.finalize()
+    prompt = synth.synth_prompt(d.vocab, 48, 1234)[None, :]
+    gpu.forward(prompt); ref.forward(prompt)           # MFMA prefill vs the oracle's fp32 loops
+    for step in range(5):
+        lg, lr = gpu.logits(rounded=False), ref.logits(rounded=False)
+        assert rel_err(lg, lr) < 1e-3, (step, rel_err(lg, lr))
+        top2 = np.sort(lr[0])[-2:]
+        tok_ref = ref.sample(GREEDY)
+        if (top2[1] - top2[0]) > 2e-3 * np.abs(lr).max():
+            np.testing.assert_array_equal(gpu.sample(GREEDY), tok_ref)
+        gpu.forward(tok_ref[None, :]); ref.forward(tok_ref[None, :])     # teacher forcing with the oracle's token
+    assert gpu.past_length == ref.past_length == 48 + 5
+
+
+@pytest.mark.parametrize("name", ["qwen2.5-0.5b", "llama-3.2-3b", "mistral-7b-v0.3"])
+def test_other_baseline_geometries_decode_properties(name):
+    """Real layer geometry of the other BASELINE configs (4 layers, 8k vocabulary to bound upload time):
+    (1) decode is deterministic and reset-invariant, (2) a prompt fed as one batched prefill, as single-position
+    passes, or split as prefill(n)+forward(1)... gives the same logits, (3) batch rows do not interact."""
+    d = copy.deepcopy(known_desc(name))
+    d.layers, d.vocab, d.max_ctx, d.max_batch = 4, 8192, 256, 2
+    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    p = synth.synth_prompt(d.vocab, 40, 3)[None, :]
+    m.forward(p); a = m.logits(False).copy(); t0 = m.sample(GREEDY).copy(); r0 = m.decode(6, GREEDY).copy()
+    m.reset_cache(); m.forward(p); np.testing.assert_array_equal(m.logits(False), a)           # (1) bit-identical rerun
+    np.testing.assert_array_equal(m.sample(GREEDY), t0); np.testing.assert_array_equal(m.decode(6, GREEDY), r0)
+    m.reset_cache(); m.forward(p[:, :39]); m.forward(p[:, 39:40])                                   # (2) split prompt
+    assert rel_err(m.logits(False), a) < 1e-3
+    m.reset_cache(); m.set_option("prefill.mfma", 0); m.forward(p); b = m.logits(False).copy(); m.set_option("prefill.mfma", 1)
+    assert rel_err(b, a) < 1e-3
+    q = synth.synth_prompt(d.vocab, 40, 4)[None, :]
+    m.reset_cache(); m.forward(np.concatenate([p, q]))                                              # (3) rows independent
+    assert rel_err(m.logits(False)[0:1], a) < 1e-3
+    np.testing.assert_array_equal(m.sample(GREEDY)[0], t0[0])
+    np.testing.assert_array_equal(m.decode(3, GREEDY)[:, 0], r0[:3, 0])

@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256) void embed_prompt_kernel(const EmbedArgs a) {
 }
 
 __global__ void advance_pos_kernel(int* pos) { if (threadIdx.x == 0) *pos = *pos + 1; }
+__global__ void add_pos_kernel(int* pos, int n) { if (threadIdx.x == 0) *pos = *pos + n; }
 // Rebuilds the lm_head epilogue's per-workgroup argmax partials from a logits vector (tgx_set_logits: sampler tests).
 __global__ __launch_bounds__(256) void argmax_partials_kernel(const float* logits, int V, float* part_val, int* part_idx) {
   __shared__ float sv[256];

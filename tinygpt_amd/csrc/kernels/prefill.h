@@ -1,0 +1,382 @@
+// prefill.h — batched prefill (seq > 1): the S×H·Wᵀ products on the matrix cores, causal GQA flash attention,
+// and the row-wise glue between them.  Same math as S single-position passes, different schedule:
+//
+//   reference op (per layer, [B,S,*] tensors)                 here
+//   nn::Embedding                     GPTModel.h:52            embed_rows_kernel
+//   RMSNorm                           DecoderLayer.h:40-41     rmsnorm_split_kernel      (fp32 -> bf16 hi/lo pair)
+//   MergedLinear qkv / o_proj /       Attention.h:95,90        gemm_bf16x2_kernel        (MFMA 32x32x16 bf16)
+//     gate_up / down_proj             GatedMLP.h:38,40
+//   split + RoPE(q,k) + cache append  Attention.h:96-106       rope_kv_split_kernel
+//   flashAttention(causal)            Attention.h:108-109      attn_prefill_kernel       (MFMA QKᵀ and PV, online softmax)
+//   siluMul                           Activation.h:16          silu_mul_split_kernel
+//
+// Precision: activations are fp32 between ops, the matrix cores take bf16.  Every fp32 MFMA operand x is split as
+// x = hi + lo (hi = bf16(x), lo = bf16(x - hi)) and multiplied in two MFMAs against the exact bf16 weights / K / V,
+// so products carry ~16 mantissa bits and accumulate in fp32: the batched path agrees with the step path to ~1e-5.
+//
+// Roofline: MFMA (bf16 dense peak ~2.5 PFLOP/s); flops per GEMM launch = 2 (hi,lo) * 2*M*N*K.
+#pragma once
+#include "common.h"
+
+namespace tgx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+  hi = f32_to_bf16(x);
+  lo = f32_to_bf16(x - bf16_to_f32(hi));
+}
+
+// ---- X[s][:] = embed[ids[s]] (fp32) ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_rows_kernel(const long long* ids, const bf16_t* embed, float* X, int H) {
+  const long long t = ids[blockIdx.x];
+  const u32x4* src = reinterpret_cast<const u32x4*>(embed + (size_t)t * H);
+  f32x4* dst = reinterpret_cast<f32x4*>(X + (size_t)blockIdx.x * H);
+  for (int c = threadIdx.x; c < (H >> 3); c += 256) {
+    const u32x4 v = src[c];
+    dst[2 * c] = f32x4{bf16_lo(v[0]), bf16_hi(v[0]), bf16_lo(v[1]), bf16_hi(v[1])};
+    dst[2 * c + 1] = f32x4{bf16_lo(v[2]), bf16_hi(v[2]), bf16_lo(v[3]), bf16_hi(v[3])};
+  }
+}
+
+// ---- row-wise RMSNorm, output as bf16 hi/lo ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* X, const bf16_t* w, float eps, int H, bf16_t* hi, bf16_t* lo) {
+  __shared__ float sc[4];
+  const float* x = X + (size_t)blockIdx.x * H;
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < H; i += 256) ss = fmaf(x[i], x[i], ss);
+  ss = block_sum_256(ss, sc);
+  const float inv = 1.0f / sqrtf(ss / (float)H + eps);
+  for (int i = threadIdx.x; i < H; i += 256) {
+    const float y = bf16_to_f32(w[i]) * (x[i] * inv);
+    split_bf16(y, hi[(size_t)blockIdx.x * H + i], lo[(size_t)blockIdx.x * H + i]);
+  }
+}
+
+// ---- siluMul on the merged gate|up output, as bf16 hi/lo ---------------------------------------------------------
+__global__ __launch_bounds__(256) void silu_mul_split_kernel(const float* GU, int I, bf16_t* hi, bf16_t* lo) {
+  const float* g = GU + (size_t)blockIdx.x * 2 * I;
+  for (int i = threadIdx.x; i < I; i += 256) {
+    const float a = g[i], u = g[I + i];
+    split_bf16((a / (1.0f + expf(-a))) * u, hi[(size_t)blockIdx.x * I + i], lo[(size_t)blockIdx.x * I + i]);
+  }
+}
+
+// ---- split -> RoPE(q), RoPE(k) at pastLength+s -> cache append; q as bf16 hi/lo ------------------------------------
+struct RopeKvArgs {
+  const float* QKV;        // [S][qd + 2*kvd] fp32 (bias already added)
+  bf16_t *q_hi, *q_lo;     // [S][qd]
+  bf16_t *k_cache, *v_cache;   // this layer/row: [kv_heads][max_ctx][hd]
+  const float *rope_cos, *rope_sin;
+  int heads, kv_heads, hd, max_ctx, past;
+};
+__global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) {
+  const int s = blockIdx.x, pos = a.past + s, half = a.hd >> 1;
+  const int qd = a.heads * a.hd, kvd = a.kv_heads * a.hd;
+  const float* row = a.QKV + (size_t)s * (qd + 2 * kvd);
+  const int pairs = (a.heads + 2 * a.kv_heads) * half;
+  for (int u = threadIdx.x; u < pairs; u += 256) {
+    const int hh = u / half, p = u - hh * half;
+    float x0 = row[hh * a.hd + p], x1 = row[hh * a.hd + p + half];
+    if (hh < a.heads + a.kv_heads) {
+      const float cs = a.rope_cos[(size_t)pos * half + p], sn = a.rope_sin[(size_t)pos * half + p];
+      const float r0 = x0 * cs - x1 * sn, r1 = x1 * cs + x0 * sn;
+      x0 = r0; x1 = r1;
+    }
+    if (hh < a.heads) {
+      const size_t o = (size_t)s * qd + hh * a.hd + p;
+      split_bf16(x0, a.q_hi[o], a.q_lo[o]);
+      split_bf16(x1, a.q_hi[o + half], a.q_lo[o + half]);
+    } else {
+      bf16_t* dst = (hh < a.heads + a.kv_heads) ? a.k_cache + ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd
+                                                : a.v_cache + ((size_t)(hh - a.heads - a.kv_heads) * a.max_ctx + pos) * a.hd;
+      dst[p] = f32_to_bf16(x0);
+      dst[p + half] = f32_to_bf16(x1);
+    }
+  }
+}
+
+// ---- C[M][N] (+)= (Ahi + Alo)[M][K] · B[N][K]ᵀ on v_mfma_f32_32x32x16_bf16 ------------------------------------------
+// 128x128 workgroup tile, BK = 64, 4 waves as 2x2 (each 64x64 = 2x2 MFMA tiles, 64 accumulator VGPRs).  Tiles are
+// staged global -> registers -> LDS with the next K-step's global loads in flight during the MFMAs; LDS rows are
+// padded to 144 B so the 16-byte fragment reads of a 16-lane group fall on 16 distinct bank quads.
+enum { GEMM_STORE = 0, GEMM_RESIDUAL = 1 };
+struct GemmArgs {
+  const bf16_t *A_hi, *A_lo;   // [M][K]
+  const bf16_t* B;             // [N][K] (torch Linear weight)
+  const bf16_t* bias;          // [N] or nullptr
+  float* C;                    // [M][ldc]
+  int M, N, K, ldc;
+};
+
+constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = GBK + 8;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16x2_kernel(const GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t sAh[GBM * GLD];
+  __shared__ __attribute__((aligned(16))) bf16_t sAl[GBM * GLD];
+  __shared__ __attribute__((aligned(16))) bf16_t sB[GBN * GLD];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+  const int kch = a.K >> 3;                                    // 16-byte chunks per row
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // staging map: chunk c = tid + 256*i -> tile row c/8, 16-byte column c%8
+  u32x4 rah[4], ral[4], rb[4];
+  const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+      const size_t koff = (size_t)(k0 >> 3) + kc;
+      const bool am = m0 + row < a.M, bn = n0 + row < a.N;
+      rah[i] = am ? reinterpret_cast<const u32x4*>(a.A_hi)[(size_t)(m0 + row) * kch + koff] : zero;
+      ral[i] = am ? reinterpret_cast<const u32x4*>(a.A_lo)[(size_t)(m0 + row) * kch + koff] : zero;
+      rb[i] = bn ? reinterpret_cast<const u32x4*>(a.B)[(size_t)(n0 + row) * kch + koff] : zero;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+      *reinterpret_cast<u32x4*>(&sAh[row * GLD + kc * 8]) = rah[i];
+      *reinterpret_cast<u32x4*>(&sAl[row * GLD + kc * 8]) = ral[i];
+      *reinterpret_cast<u32x4*>(&sB[row * GLD + kc * 8]) = rb[i];
+    }
+  };
+
+  load_tiles(0);
+  for (int k0 = 0; k0 < a.K; k0 += GBK) {
+    __syncthreads();                 // everyone is done reading the previous tile
+    store_tiles();
+    __syncthreads();
+    if (k0 + GBK < a.K) load_tiles(k0 + GBK);   // next K-step's global loads fly under the MFMAs
+#pragma unroll
+    for (int kk = 0; kk < GBK / 16; kk++) {
+      const int kcol = kk * 16 + 8 * (lane >> 5);
+      bf16x8 fah[2], fal[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int row = wm * 64 + i * 32 + (lane & 31);
+        fah[i] = *reinterpret_cast<const bf16x8*>(&sAh[row * GLD + kcol]);
+        fal[i] = *reinterpret_cast<const bf16x8*>(&sAl[row * GLD + kcol]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int row = wn * 64 + j * 32 + (lane & 31);
+        fb[j] = *reinterpret_cast<const bf16x8*>(&sB[row * GLD + kcol]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fb[j], acc[i][j], 0, 0, 0);   // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (col >= a.N) continue;
+      const float bv = a.bias ? bf16_to_f32(a.bias[col]) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= a.M) continue;
+        float* dst = a.C + (size_t)row * a.ldc + col;
+        const float v = acc[i][j][r] + bv;
+        *dst = (EPI == GEMM_RESIDUAL) ? (*dst + v) : v;
+      }
+    }
+}
+
+// ---- causal GQA flash attention over the cache, queries past..past+S-1 -------------------------------------------------
+// One workgroup = 64 queries of one query head; key tiles of 64.  S = Q·Kᵀ and O += P·V run on MFMA 32x32x16 with Q and P
+// split hi/lo; softmax is an online fp32 pass through LDS (4 lanes per row).  V is staged transposed so the PV B-fragment
+// (8 consecutive keys of one output dim) is a single 16-byte LDS read.
+struct AttnPrefillArgs {
+  const bf16_t *q_hi, *q_lo;     // [S][heads*hd]
+  const bf16_t *k_cache, *v_cache;   // [kv_heads][max_ctx][hd]
+  bf16_t *o_hi, *o_lo;           // [S][heads*hd]
+  int S, heads, kv_heads, max_ctx, past;
+  float scale;                   // hd^-1/2
+};
+
+template <int HD>
+struct AttnPrefillSmem {
+  static constexpr int LQ = HD + 8;     // bf16 row stride of Q / K tiles
+  static constexpr int LV = 64 + 8;     // bf16 row stride of Vt / P tiles (64 keys)
+  static constexpr int LS = 64 + 4;     // fp32 row stride of the score tile
+  static constexpr size_t bytes = (size_t)(2 * 64 * LQ + 64 * LQ + HD * LV + 2 * 64 * LV) * 2 + (size_t)64 * LS * 4 + 3 * 64 * 4;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs a) {
+  using SM = AttnPrefillSmem<HD>;
+  constexpr int LQ = SM::LQ, LV = SM::LV, LS = SM::LS;
+  constexpr int NJ = HD / 64;                 // 32-wide output-dim tiles per wave
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* sQh = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* sQl = sQh + 64 * LQ;
+  bf16_t* sK = sQl + 64 * LQ;
+  bf16_t* sVt = sK + 64 * LQ;
+  bf16_t* sPh = sVt + HD * LV;
+  bf16_t* sPl = sPh + 64 * LV;
+  float* sS = reinterpret_cast<float*>(sPl + 64 * LV);
+  float* sM = sS + 64 * LS;
+  float* sL = sM + 64;
+  float* sAlpha = sL + 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int h = blockIdx.y, G = a.heads / a.kv_heads, kvh = h / G;
+  const int q0 = blockIdx.x * 64;              // first query (index into this pass) of the tile
+  const int qd = a.heads * HD;
+  constexpr int CH = HD / 8;                   // 16-byte chunks per head row
+
+  // Q tile (hi, lo) -> LDS; rows beyond S are zero
+  for (int c = tid; c < 64 * CH; c += 256) {
+    const int row = c / CH, kc = c - row * CH;
+    u32x4 vh = u32x4{0u, 0u, 0u, 0u}, vl = vh;
+    if (q0 + row < a.S) {
+      const size_t o = (size_t)(q0 + row) * qd + (size_t)h * HD + kc * 8;
+      vh = *reinterpret_cast<const u32x4*>(a.q_hi + o);
+      vl = *reinterpret_cast<const u32x4*>(a.q_lo + o);
+    }
+    *reinterpret_cast<u32x4*>(&sQh[row * LQ + kc * 8]) = vh;
+    *reinterpret_cast<u32x4*>(&sQl[row * LQ + kc * 8]) = vl;
+  }
+  if (tid < 64) { sM[tid] = -INFINITY; sL[tid] = 0.f; }
+
+  f32x16 oacc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) oacc[j][r] = 0.f;
+
+  const bf16_t* kbase = a.k_cache + (size_t)kvh * a.max_ctx * HD;
+  const bf16_t* vbase = a.v_cache + (size_t)kvh * a.max_ctx * HD;
+  const int last_q_pos = a.past + min(q0 + 63, a.S - 1);       // keys beyond this are never attended by the tile
+  const int n_kt = last_q_pos / 64 + 1;
+  const float qs = a.scale * LOG2E;
+
+  for (int kt = 0; kt < n_kt; kt++) {
+    const int key0 = kt * 64;
+    __syncthreads();                           // previous tile fully consumed (and Q / state initialised)
+    for (int c = tid; c < 64 * CH; c += 256) {
+      const int row = c / CH, kc = c - row * CH;
+      const int key = key0 + row;
+      u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = kv;
+      if (key <= last_q_pos) {
+        kv = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * HD + kc * 8);
+        vv = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * HD + kc * 8);
+      }
+      *reinterpret_cast<u32x4*>(&sK[row * LQ + kc * 8]) = kv;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {            // transpose: Vt[d][key]
+        sVt[(kc * 8 + 2 * t) * LV + row] = (bf16_t)(vv[t] & 0xffffu);
+        sVt[(kc * 8 + 2 * t + 1) * LV + row] = (bf16_t)(vv[t] >> 16);
+      }
+    }
+    __syncthreads();
+    // S quadrant: queries wm*32.., keys wn*32..
+    {
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) sacc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < HD / 16; kk++) {
+        const int kcol = kk * 16 + 8 * (lane >> 5);
+        const bf16x8 fqh = *reinterpret_cast<const bf16x8*>(&sQh[(wm * 32 + (lane & 31)) * LQ + kcol]);
+        const bf16x8 fql = *reinterpret_cast<const bf16x8*>(&sQl[(wm * 32 + (lane & 31)) * LQ + kcol]);
+        const bf16x8 fk = *reinterpret_cast<const bf16x8*>(&sK[(wn * 32 + (lane & 31)) * LQ + kcol]);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fql, fk, sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fqh, fk, sacc, 0, 0, 0);
+      }
+      const int kcolg = wn * 32 + (lane & 31);           // key column of this lane inside the tile
+      const int key = key0 + kcolg;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int qrow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int qpos = a.past + q0 + qrow;
+        const bool ok = key <= qpos && q0 + qrow < a.S;  // isCausal (Attention.h:108) with the cache offset
+        sS[qrow * LS + kcolg] = ok ? sacc[r] * qs : -INFINITY;
+      }
+    }
+    __syncthreads();
+    // online softmax (base 2): 4 lanes per query row, 16 keys each
+    {
+      const int row = tid >> 2, part = tid & 3;
+      float sv[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 16; t++) { sv[t] = sS[row * LS + part * 16 + t]; mx = fmaxf(mx, sv[t]); }
+      mx = fmaxf(mx, dpp_mov<0xB1, 0xf>(mx));
+      mx = fmaxf(mx, dpp_mov<0x4E, 0xf>(mx));
+      const float m_old = sM[row];
+      const float m_new = fmaxf(m_old, mx);
+      const bool dead = m_new == -INFINITY;              // padded query row: nothing attended yet
+      const float alpha = dead ? 1.f : exp2f(m_old - m_new);
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; t++) {
+        const float p = dead ? 0.f : exp2f(sv[t] - m_new);
+        sum += p;
+        bf16_t ph, pl;
+        split_bf16(p, ph, pl);
+        sPh[row * LV + part * 16 + t] = ph;
+        sPl[row * LV + part * 16 + t] = pl;
+      }
+      sum += dpp_mov<0xB1, 0xf>(sum);
+      sum += dpp_mov<0x4E, 0xf>(sum);
+      __syncthreads();                                   // every lane has read sM[row] before it is replaced
+      if (part == 0) { sM[row] = m_new; sL[row] = sL[row] * alpha + sum; sAlpha[row] = alpha; }
+    }
+    __syncthreads();
+    // O quadrant: queries wm*32.., dims wn*(HD/2)..
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) oacc[j][r] *= sAlpha[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const int kcol = kk * 16 + 8 * (lane >> 5);
+        const bf16x8 fph = *reinterpret_cast<const bf16x8*>(&sPh[(wm * 32 + (lane & 31)) * LV + kcol]);
+        const bf16x8 fpl = *reinterpret_cast<const bf16x8*>(&sPl[(wm * 32 + (lane & 31)) * LV + kcol]);
+        const bf16x8 fv = *reinterpret_cast<const bf16x8*>(&sVt[(wn * (HD / 2) + j * 32 + (lane & 31)) * LV + kcol]);
+        oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fpl, fv, oacc[j], 0, 0, 0);
+        oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fph, fv, oacc[j], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+  // normalise and emit as bf16 hi/lo (the o_proj GEMM's A operand)
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const int d = wn * (HD / 2) + j * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int qrow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (q0 + qrow >= a.S) continue;
+      const float v = oacc[j][r] / sL[qrow];
+      const size_t o = (size_t)(q0 + qrow) * qd + (size_t)h * HD + d;
+      split_bf16(v, a.o_hi[o], a.o_lo[o]);
+    }
+  }
+}
+
+}  // namespace tgx

@@ -6,6 +6,7 @@
 // There is NO CPU path in this library: every entry point either runs on the GPU or returns an error.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -18,6 +19,7 @@
 #include "kernels/attn_decode.h"
 #include "kernels/common.h"
 #include "kernels/gemv.h"
+#include "kernels/prefill.h"
 #include "kernels/sampler.h"
 
 using tgx::bf16_t;
@@ -97,6 +99,12 @@ struct tgx_ctx {
 
   Tune tune[TGX_KERNEL_COUNT];   // per kernel class: K-split and workgroups per CU
   int lm_grid = 0, attn_nsplit = 1, attn_nsplit_opt = 0;
+  // batched-prefill workspace (grown on demand to the longest prompt seen)
+  int ws_rows = 0;
+  float *ws_x = nullptr, *ws_out = nullptr;           // [S][H] residual stream, [S][max(q+2kv, 2I)] GEMM output
+  bf16_t *ws_ah = nullptr, *ws_al = nullptr;          // [S][max(H, qd, I)] GEMM A operand (hi, lo)
+  bf16_t *ws_qh = nullptr, *ws_ql = nullptr;          // [S][qd] rotated queries (hi, lo)
+  bool prefill_mfma = true;
   int debug_nops = 0;     // extra no-op launches per layer (launch-overhead experiments only)
   int* nop_word = nullptr;
   float* scratch_x = nullptr;   // [hidden] residual sink for tgx_profile_decode
@@ -326,6 +334,76 @@ void launch_layers(tgx_ctx* c, RowState& r) {
     for (int cls = TGX_KERNEL_QKV; cls <= TGX_KERNEL_DOWN; cls++) launch_layer_kernel(c, r, l, cls, r.x);
     for (int i = 0; i < c->debug_nops; i++) hipLaunchKernelGGL(tgx::nop_kernel, dim3(1), dim3(64), 0, c->stream, c->nop_word);
   }
+}
+
+// ---- batched prefill (kernels/prefill.h) -------------------------------------------------------------------------
+bool prefill_shapes_ok(const tgx_model_desc& d) {
+  return d.hidden % 64 == 0 && (d.heads * d.head_dim) % 64 == 0 && d.inter % 64 == 0;
+}
+
+int ensure_prefill_ws(tgx_ctx* c, int S) {
+  if (S <= c->ws_rows) return TGX_OK;
+  const tgx_model_desc& d = c->d;
+  const size_t H = (size_t)d.hidden, qd = (size_t)d.heads * d.head_dim, kvd = (size_t)d.kv_heads * d.head_dim, I = (size_t)d.inter;
+  const size_t wout = std::max(qd + 2 * kvd, 2 * I), wa = std::max(std::max(H, qd), I);
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  auto fr = [](void* p) { if (p) (void)hipFree(p); };
+  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_qh); fr(c->ws_ql);
+  c->ws_x = nullptr; c->ws_out = nullptr; c->ws_ah = c->ws_al = c->ws_qh = c->ws_ql = nullptr; c->ws_rows = 0;
+  const size_t rows = (size_t)S;
+  HIP_OK(c, hipMalloc((void**)&c->ws_x, rows * H * 4));
+  HIP_OK(c, hipMalloc((void**)&c->ws_out, rows * wout * 4));
+  HIP_OK(c, hipMalloc((void**)&c->ws_ah, rows * wa * 2));
+  HIP_OK(c, hipMalloc((void**)&c->ws_al, rows * wa * 2));
+  HIP_OK(c, hipMalloc((void**)&c->ws_qh, rows * qd * 2));
+  HIP_OK(c, hipMalloc((void**)&c->ws_ql, rows * qd * 2));
+  c->ws_rows = S;
+  return TGX_OK;
+}
+
+void launch_gemm(tgx_ctx* c, int epi, const bf16_t* B, const bf16_t* bias, float* C, int M, int N, int K, int ldc) {
+  tgx::GemmArgs g{};
+  g.A_hi = c->ws_ah; g.A_lo = c->ws_al; g.B = B; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
+  const dim3 grid((N + tgx::GBN - 1) / tgx::GBN, (M + tgx::GBM - 1) / tgx::GBM), blk(256);
+  if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_bf16x2_kernel<tgx::GEMM_RESIDUAL>), grid, blk, 0, c->stream, g);
+  else hipLaunchKernelGGL((tgx::gemm_bf16x2_kernel<tgx::GEMM_STORE>), grid, blk, 0, c->stream, g);
+}
+
+// All layers for S prompt positions of one row at once; leaves the last position's hidden state in row.x.
+// == CausalLM::forward on [1,S] ids with an empty cache (GPTModel.h:51-56)
+void launch_prefill(tgx_ctx* c, RowState& r, int S) {
+  const tgx_model_desc& d = c->d;
+  const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
+  const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd;
+  hipLaunchKernelGGL(tgx::embed_rows_kernel, dim3(S), dim3(256), 0, c->stream, (const long long*)r.prompt, (const bf16_t*)c->embed, c->ws_x, H);
+  for (int l = 0; l < d.layers; l++) {
+    const LayerW& w = c->L[(size_t)l];
+    hipLaunchKernelGGL(tgx::rmsnorm_split_kernel, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.in_norm, d.norm_eps, H, c->ws_ah, c->ws_al);
+    launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, S, qd + 2 * kvd, H, qd + 2 * kvd);
+    {
+      tgx::RopeKvArgs a{};
+      a.QKV = c->ws_out; a.q_hi = c->ws_qh; a.q_lo = c->ws_ql;
+      a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
+      a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
+      a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = (int)c->past;
+      hipLaunchKernelGGL(tgx::rope_kv_split_kernel, dim3(S), dim3(256), 0, c->stream, a);
+    }
+    {
+      tgx::AttnPrefillArgs a{};
+      a.q_hi = c->ws_qh; a.q_lo = c->ws_ql; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
+      a.o_hi = c->ws_ah; a.o_lo = c->ws_al; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
+      a.scale = 1.0f / sqrtf((float)hd);
+      const dim3 grid((S + 63) / 64, d.heads), blk(256);
+      if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<64>), grid, blk, tgx::AttnPrefillSmem<64>::bytes, c->stream, a);
+      else hipLaunchKernelGGL((tgx::attn_prefill_kernel<128>), grid, blk, tgx::AttnPrefillSmem<128>::bytes, c->stream, a);
+    }
+    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wo, nullptr, c->ws_x, S, H, qd, H);
+    hipLaunchKernelGGL(tgx::rmsnorm_split_kernel, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al);
+    launch_gemm(c, tgx::GEMM_STORE, w.wgu, nullptr, c->ws_out, S, 2 * I, H, 2 * I);
+    hipLaunchKernelGGL(tgx::silu_mul_split_kernel, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_out, I, c->ws_ah, c->ws_al);
+    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wdown, nullptr, c->ws_x, S, H, I, H);
+  }
+  (void)hipMemcpyAsync(r.x, c->ws_x + (size_t)(S - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, c->stream);
 }
 
 // model.norm -> lm_head on the current position + per-workgroup argmax partials   (GPTModel.h:56-57)
@@ -626,6 +704,9 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipHostGetDevicePointer((void**)&c->host_ring_dev, c->host_ring, 0));
   for (int i = 0; i < MAX_TICKET_EVENTS; i++) HIP_OK(c, hipEventCreateWithFlags(&c->ticket_ev[i], hipEventDisableTiming));
   for (int i = 0; i < 2; i++) HIP_OK(c, hipEventCreate(&c->prof.ev[i]));
+  // the prefill attention tile needs 72-105 KiB of dynamic LDS (opt-in above 64 KiB)
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<64>::bytes));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<128>::bytes));
   c->past = 0;
   c->finalized = true;
   return TGX_OK;
@@ -638,6 +719,7 @@ void tgx_destroy(tgx_ctx* c) {
   if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x); fr(c->seed_dev);
+  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_qh); fr(c->ws_ql);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.wgu); fr(w.wdown); }
   for (auto& r : c->rows) {
     fr(r.x); fr(r.q); fr(r.attn); fr(r.h); fr(r.logits); fr(r.work); fr(r.probs); fr(r.part_val); fr(r.part_idx); fr(r.attn_part);
@@ -663,8 +745,16 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
   for (int b = 0; b < batch; b++) {
     RowState& r = c->rows[(size_t)b];
     HIP_OK(c, hipMemcpyAsync(r.prompt, ids + (size_t)b * seq, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream));
-    // Prefill as `seq` single-position passes (results identical to a batched causal pass; the MFMA
-    // batched-prefill path replaces this loop).  The last position also produces logits.
+    if (seq >= 4 && c->prefill_mfma && prefill_shapes_ok(c->d)) {
+      // batched prefill on the matrix cores; logits for the last position only (== forward + narrow, GPTEngine.cpp:96-97)
+      int rc = ensure_prefill_ws(c, seq);
+      if (rc) return rc;
+      launch_prefill(c, r, seq);
+      launch_lm_head(c, r);
+      hipLaunchKernelGGL(tgx::add_pos_kernel, dim3(1), dim3(64), 0, c->stream, r.pos, seq);
+      continue;
+    }
+    // short prompts (and shapes the GEMM tile does not cover): `seq` single-position passes — identical results
     tgx::EmbedArgs e{};
     e.ids = r.prompt; e.pos = r.pos; e.pos0 = (int)c->past; e.embed = c->embed; e.x = r.x; e.H = c->d.hidden; e.V = c->d.vocab; e.tok = r.tok;
     for (int s = 0; s < seq; s++) {
@@ -873,6 +963,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (c->step_graph) { (void)hipStreamSynchronize(c->stream); (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
   if (!strcmp(key, "graph")) { c->use_graph = value != 0; return TGX_OK; }
   if (!strcmp(key, "debug.nops")) { c->debug_nops = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.mfma")) { c->prefill_mfma = value != 0; return TGX_OK; }
   if (!strcmp(key, "attn.nsplit")) {
     if (c->finalized) return set_err(c, TGX_ERR_STATE, "attn.nsplit must be set before tgx_finalize");
     if (value < 1 || value > 32) return set_err(c, TGX_ERR_INVALID, "attn.nsplit out of range");
