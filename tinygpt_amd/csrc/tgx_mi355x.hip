@@ -105,6 +105,7 @@ struct tgx_ctx {
   bf16_t *ws_ah = nullptr, *ws_al = nullptr;          // [S][max(H, qd, I)] GEMM A operand (hi, lo)
   bf16_t *ws_qh = nullptr, *ws_ql = nullptr;          // [S][qd] rotated queries (hi, lo)
   bool prefill_mfma = true;
+  int prof_same_layer = 0;   // experiment: tgx_profile_decode replays ONE layer's weights (Infinity-Cache resident)
   int debug_nops = 0;     // extra no-op launches per layer (launch-overhead experiments only)
   int* nop_word = nullptr;
   float* scratch_x = nullptr;   // [hidden] residual sink for tgx_profile_decode
@@ -913,7 +914,7 @@ int tgx_profile_decode(tgx_ctx* c, int n_reps, int64_t* launches, double* total_
       HIP_OK(c, hipEventRecord(c->prof.ev[0], c->stream));
       int n = 0;
       if (cls == TGX_KERNEL_LMHEAD) { launch_lm_head(c, r); n = 1; }
-      else for (int l = 0; l < c->d.layers; l++, n++) launch_layer_kernel(c, r, l, cls, c->scratch_x);
+      else for (int l = 0; l < c->d.layers; l++, n++) launch_layer_kernel(c, r, c->prof_same_layer ? 0 : l, cls, c->scratch_x);
       HIP_OK(c, hipEventRecord(c->prof.ev[1], c->stream));
       HIP_OK(c, hipEventSynchronize(c->prof.ev[1]));
       float ms = 0.f;
@@ -964,6 +965,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "graph")) { c->use_graph = value != 0; return TGX_OK; }
   if (!strcmp(key, "debug.nops")) { c->debug_nops = value; return TGX_OK; }
   if (!strcmp(key, "prefill.mfma")) { c->prefill_mfma = value != 0; return TGX_OK; }
+  if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
   if (!strcmp(key, "attn.nsplit")) {
     if (c->finalized) return set_err(c, TGX_ERR_STATE, "attn.nsplit must be set before tgx_finalize");
     if (value < 1 || value > 32) return set_err(c, TGX_ERR_INVALID, "attn.nsplit out of range");
