@@ -174,6 +174,12 @@ def main():
         except Exception as e:     # the GPU number stands on its own; say why the baseline is absent
             cpu = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
+    # batched prefill (MFMA): algorithmic flops of the S x H·W^T products (one bf16 pass; the kernel issues two, hi and lo)
+    L, H, I = desc.layers, desc.hidden, desc.inter
+    gemm_flops = 2.0 * args.prompt * L * ((desc.q_dim + 2 * desc.kv_dim) * H + H * desc.q_dim + 3 * I * H)
+    attn_flops = 4.0 * L * desc.heads * desc.head_dim * args.prompt * (args.prompt + 1) / 2.0
+    prefill_tflops = (gemm_flops + attn_flops) / (prefill_ms * 1e-3) / 1e12
+
     line = {
         "metric": "decode tokens/sec (and % HBM roofline), Llama-3.2-1B bf16 batch=1, 1 GPU",
         "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -182,6 +188,7 @@ def main():
         "config": {"workload": f"{desc.name} bf16, batch 1 per GPU: {args.prompt}-token prefill then greedy decode "
                                f"(one step = one token, context {T0}..{T0 + args.steps - 1})",
                    "replicas": world, "prompt_tokens": args.prompt, "prefill_ms": round(prefill_ms, 1),
+                   "prefill_tflops": round(prefill_tflops, 1), "prefill_mfma_frac_of_2500": round(2 * prefill_tflops / 2500.0, 4),
                    "params": desc.param_count(), "graph": not args.no_graph},
         "roofline": roofline,
         "cpu_baseline": cpu,

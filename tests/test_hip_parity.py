@@ -77,9 +77,11 @@ def test_kv_cache_matches_oracle(fam, hip, oracle_lib):
         kg, vg = gpu.read_kv(0, layer)
         kr, vr = ref.read_kv(0, layer)
         assert kg.shape == kr.shape
-        # bf16 cache entries: identical except where the fp32 value sits on a rounding boundary (1 ulp = 2^-8)
-        assert np.mean(kg != kr) < 5e-3 and rel_err(kg, kr) < 1e-2
-        assert np.mean(vg != vr) < 5e-3 and rel_err(vg, vr) < 1e-2
+        # bf16 cache entries: identical except where the fp32 value sits on a rounding boundary; a differing entry is
+        # off by one bf16 ulp of ITS OWN magnitude (2^-8 relative), never more
+        for g_, r_ in ((kg, kr), (vg, vr)):
+            assert np.mean(g_ != r_) < 1e-2
+            assert np.all(np.abs(g_ - r_) <= 2.0 ** -7 * (np.abs(r_) + 1e-3 * np.abs(r_).max()))   # floor for entries near zero
 
 
 def test_reset_and_rerun_is_bit_identical(hip, oracle_lib):

@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const long long* ids, c
 }
 
 // ---- row-wise RMSNorm, output as bf16 hi/lo ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* X, const bf16_t* w, float eps, int H, bf16_t* hi, bf16_t* lo) {
+// `lo2` (optional) receives a third term: x = hi + lo + lo2 carries ~24 mantissa bits.  The QKV projection uses it,
+// because its output is the only one that is rounded to bf16 again (the KV cache): with two terms (2^-18) a few
+// per cent of the cache entries round differently from the single-position path, with three the schedules agree.
+__global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* X, const bf16_t* w, float eps, int H, bf16_t* hi, bf16_t* lo, bf16_t* lo2) {
   __shared__ float sc[4];
   const float* x = X + (size_t)blockIdx.x * H;
   float ss = 0.f;
@@ -50,7 +53,9 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* X, cons
   const float inv = 1.0f / sqrtf(ss / (float)H + eps);
   for (int i = threadIdx.x; i < H; i += 256) {
     const float y = bf16_to_f32(w[i]) * (x[i] * inv);
-    split_bf16(y, hi[(size_t)blockIdx.x * H + i], lo[(size_t)blockIdx.x * H + i]);
+    const size_t o = (size_t)blockIdx.x * H + i;
+    split_bf16(y, hi[o], lo[o]);
+    if (lo2) lo2[o] = f32_to_bf16(y - bf16_to_f32(hi[o]) - bf16_to_f32(lo[o]));
   }
 }
 
@@ -104,6 +109,7 @@ __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) 
 enum { GEMM_STORE = 0, GEMM_RESIDUAL = 1 };
 struct GemmArgs {
   const bf16_t *A_hi, *A_lo;   // [M][K]
+  const bf16_t* A_lo2;         // optional third term (nullptr: two-term product)
   const bf16_t* B;             // [N][K] (torch Linear weight)
   const bf16_t* bias;          // [N] or nullptr
   float* C;                    // [M][ldc]
@@ -117,6 +123,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(const GemmArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t sAh[GBM * GLD];
   __shared__ __attribute__((aligned(16))) bf16_t sAl[GBM * GLD];
   __shared__ __attribute__((aligned(16))) bf16_t sB[GBN * GLD];
+  extern __shared__ __attribute__((aligned(16))) bf16_t sAl2[];   // [GBM*GLD] only when the launch asks for it
+  const bool three = a.A_lo2 != nullptr;      // wave-uniform
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
   const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(const GemmArgs a) {
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   // staging map: chunk c = tid + 256*i -> tile row c/8, 16-byte column c%8
-  u32x4 rah[4], ral[4], rb[4];
+  u32x4 rah[4], ral[4], ral2[4], rb[4];
   const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
   auto load_tiles = [&](int k0) {
 #pragma unroll
@@ -141,6 +149,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(const GemmArgs a) {
       const bool am = m0 + row < a.M, bn = n0 + row < a.N;
       rah[i] = am ? reinterpret_cast<const u32x4*>(a.A_hi)[(size_t)(m0 + row) * kch + koff] : zero;
       ral[i] = am ? reinterpret_cast<const u32x4*>(a.A_lo)[(size_t)(m0 + row) * kch + koff] : zero;
+      ral2[i] = (three && am) ? reinterpret_cast<const u32x4*>(a.A_lo2)[(size_t)(m0 + row) * kch + koff] : zero;
       rb[i] = bn ? reinterpret_cast<const u32x4*>(a.B)[(size_t)(n0 + row) * kch + koff] : zero;
     }
   };
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(const GemmArgs a) {
       const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
       *reinterpret_cast<u32x4*>(&sAh[row * GLD + kc * 8]) = rah[i];
       *reinterpret_cast<u32x4*>(&sAl[row * GLD + kc * 8]) = ral[i];
+      if (three) *reinterpret_cast<u32x4*>(&sAl2[row * GLD + kc * 8]) = ral2[i];
       *reinterpret_cast<u32x4*>(&sB[row * GLD + kc * 8]) = rb[i];
     }
   };
@@ -163,12 +173,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(const GemmArgs a) {
 #pragma unroll
     for (int kk = 0; kk < GBK / 16; kk++) {
       const int kcol = kk * 16 + 8 * (lane >> 5);
-      bf16x8 fah[2], fal[2], fb[2];
+      bf16x8 fah[2], fal[2], fal2[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         const int row = wm * 64 + i * 32 + (lane & 31);
         fah[i] = *reinterpret_cast<const bf16x8*>(&sAh[row * GLD + kcol]);
         fal[i] = *reinterpret_cast<const bf16x8*>(&sAl[row * GLD + kcol]);
+        if (three) fal2[i] = *reinterpret_cast<const bf16x8*>(&sAl2[row * GLD + kcol]);
       }
 #pragma unroll
       for (int j = 0; j < 2; j++) {
@@ -179,6 +190,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(const GemmArgs a) {
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
+          if (three) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal2[i], fb[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fb[j], acc[i][j], 0, 0, 0);   // small terms first
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fb[j], acc[i][j], 0, 0, 0);
         }

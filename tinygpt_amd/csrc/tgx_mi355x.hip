@@ -103,6 +103,7 @@ struct tgx_ctx {
   int ws_rows = 0;
   float *ws_x = nullptr, *ws_out = nullptr;           // [S][H] residual stream, [S][max(q+2kv, 2I)] GEMM output
   bf16_t *ws_ah = nullptr, *ws_al = nullptr;          // [S][max(H, qd, I)] GEMM A operand (hi, lo)
+  bf16_t* ws_al2 = nullptr;                           // [S][H] third term for the QKV projection
   bf16_t *ws_qh = nullptr, *ws_ql = nullptr;          // [S][qd] rotated queries (hi, lo)
   bool prefill_mfma = true;
   int prof_same_layer = 0;   // experiment: tgx_profile_decode replays ONE layer's weights (Infinity-Cache resident)
@@ -349,25 +350,29 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
   const size_t wout = std::max(qd + 2 * kvd, 2 * I), wa = std::max(std::max(H, qd), I);
   HIP_OK(c, hipStreamSynchronize(c->stream));
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_qh); fr(c->ws_ql);
+  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql);
+  c->ws_al2 = nullptr;
   c->ws_x = nullptr; c->ws_out = nullptr; c->ws_ah = c->ws_al = c->ws_qh = c->ws_ql = nullptr; c->ws_rows = 0;
   const size_t rows = (size_t)S;
   HIP_OK(c, hipMalloc((void**)&c->ws_x, rows * H * 4));
   HIP_OK(c, hipMalloc((void**)&c->ws_out, rows * wout * 4));
   HIP_OK(c, hipMalloc((void**)&c->ws_ah, rows * wa * 2));
   HIP_OK(c, hipMalloc((void**)&c->ws_al, rows * wa * 2));
+  HIP_OK(c, hipMalloc((void**)&c->ws_al2, rows * H * 2));
   HIP_OK(c, hipMalloc((void**)&c->ws_qh, rows * qd * 2));
   HIP_OK(c, hipMalloc((void**)&c->ws_ql, rows * qd * 2));
   c->ws_rows = S;
   return TGX_OK;
 }
 
-void launch_gemm(tgx_ctx* c, int epi, const bf16_t* B, const bf16_t* bias, float* C, int M, int N, int K, int ldc) {
+void launch_gemm(tgx_ctx* c, int epi, const bf16_t* B, const bf16_t* bias, float* C, int M, int N, int K, int ldc, bool three_terms = false) {
   tgx::GemmArgs g{};
-  g.A_hi = c->ws_ah; g.A_lo = c->ws_al; g.B = B; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
+  g.A_hi = c->ws_ah; g.A_lo = c->ws_al; g.A_lo2 = three_terms ? c->ws_al2 : nullptr;
+  g.B = B; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
   const dim3 grid((N + tgx::GBN - 1) / tgx::GBN, (M + tgx::GBM - 1) / tgx::GBM), blk(256);
-  if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_bf16x2_kernel<tgx::GEMM_RESIDUAL>), grid, blk, 0, c->stream, g);
-  else hipLaunchKernelGGL((tgx::gemm_bf16x2_kernel<tgx::GEMM_STORE>), grid, blk, 0, c->stream, g);
+  const size_t dyn = three_terms ? (size_t)tgx::GBM * tgx::GLD * 2 : 0;      // LDS tile of the third term
+  if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_bf16x2_kernel<tgx::GEMM_RESIDUAL>), grid, blk, dyn, c->stream, g);
+  else hipLaunchKernelGGL((tgx::gemm_bf16x2_kernel<tgx::GEMM_STORE>), grid, blk, dyn, c->stream, g);
 }
 
 // All layers for S prompt positions of one row at once; leaves the last position's hidden state in row.x.
@@ -379,8 +384,8 @@ void launch_prefill(tgx_ctx* c, RowState& r, int S) {
   hipLaunchKernelGGL(tgx::embed_rows_kernel, dim3(S), dim3(256), 0, c->stream, (const long long*)r.prompt, (const bf16_t*)c->embed, c->ws_x, H);
   for (int l = 0; l < d.layers; l++) {
     const LayerW& w = c->L[(size_t)l];
-    hipLaunchKernelGGL(tgx::rmsnorm_split_kernel, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.in_norm, d.norm_eps, H, c->ws_ah, c->ws_al);
-    launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, S, qd + 2 * kvd, H, qd + 2 * kvd);
+    hipLaunchKernelGGL(tgx::rmsnorm_split_kernel, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.in_norm, d.norm_eps, H, c->ws_ah, c->ws_al, c->ws_al2);
+    launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, S, qd + 2 * kvd, H, qd + 2 * kvd, /*three_terms=*/true);
     {
       tgx::RopeKvArgs a{};
       a.QKV = c->ws_out; a.q_hi = c->ws_qh; a.q_lo = c->ws_ql;
@@ -399,7 +404,7 @@ void launch_prefill(tgx_ctx* c, RowState& r, int S) {
       else hipLaunchKernelGGL((tgx::attn_prefill_kernel<128>), grid, blk, tgx::AttnPrefillSmem<128>::bytes, c->stream, a);
     }
     launch_gemm(c, tgx::GEMM_RESIDUAL, w.wo, nullptr, c->ws_x, S, H, qd, H);
-    hipLaunchKernelGGL(tgx::rmsnorm_split_kernel, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al);
+    hipLaunchKernelGGL(tgx::rmsnorm_split_kernel, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al, (bf16_t*)nullptr);
     launch_gemm(c, tgx::GEMM_STORE, w.wgu, nullptr, c->ws_out, S, 2 * I, H, 2 * I);
     hipLaunchKernelGGL(tgx::silu_mul_split_kernel, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_out, I, c->ws_ah, c->ws_al);
     launch_gemm(c, tgx::GEMM_RESIDUAL, w.wdown, nullptr, c->ws_x, S, H, I, H);
@@ -705,6 +710,8 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipHostGetDevicePointer((void**)&c->host_ring_dev, c->host_ring, 0));
   for (int i = 0; i < MAX_TICKET_EVENTS; i++) HIP_OK(c, hipEventCreateWithFlags(&c->ticket_ev[i], hipEventDisableTiming));
   for (int i = 0; i < 2; i++) HIP_OK(c, hipEventCreate(&c->prof.ev[i]));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_bf16x2_kernel<tgx::GEMM_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_bf16x2_kernel<tgx::GEMM_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   // the prefill attention tile needs 72-105 KiB of dynamic LDS (opt-in above 64 KiB)
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<64>::bytes));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<128>::bytes));
@@ -720,7 +727,7 @@ void tgx_destroy(tgx_ctx* c) {
   if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x); fr(c->seed_dev);
-  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_qh); fr(c->ws_ql);
+  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.wgu); fr(w.wdown); }
   for (auto& r : c->rows) {
     fr(r.x); fr(r.q); fr(r.attn); fr(r.h); fr(r.logits); fr(r.work); fr(r.probs); fr(r.part_val); fr(r.part_idx); fr(r.attn_part);
