@@ -55,12 +55,14 @@ def parse():
 
 def cpu_baseline(desc, tensors, seconds):
     """Oracle decode tok/s on the host cores: 16-token prompt, 1 warm-up token, then a bounded sample."""
-    from oracle.oracle_ffi import OracleModel, build_oracle
+    from oracle.oracle_ffi import OracleModel, build_oracle, oracle_backend
     from tinygpt_amd import synth
     from tinygpt_amd.ffi import GREEDY
     build_oracle()
     cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    be = oracle_backend()
+    be.set_threads(min(16, cores))          # before the first parallel region: wide teams are pathologically slow
     m = OracleModel(desc)
     for name, bits in tensors:
         m.upload(name, bits)
@@ -68,13 +70,23 @@ def cpu_baseline(desc, tensors, seconds):
     ids = synth.synth_prompt(desc.vocab, 16, 1234)[None, :]
     m.forward(ids)
     m.sample(GREEDY)
-    t0 = time.perf_counter(); m.decode(1, GREEDY); t1 = time.perf_counter() - t0      # warm-up + rate estimate
-    n = int(max(4, min(64, seconds / max(t1, 1e-3))))
+    # The port is memory-bound and libgomp's barriers degrade with wide teams (measured on the 2x64-core host:
+    # 16 threads 40 tok/s, 64 threads 16, 256 threads 0.1): pick the best team size from a 2-token probe each.
+    best_n, best_rate = 1, 0.0
+    for n_thr in sorted({t for t in (8, 16, 24, 32, 48) if t <= cores} or {cores}):
+        be.set_threads(n_thr)
+        m.decode(1, GREEDY)
+        t0 = time.perf_counter(); m.decode(2, GREEDY); r = 2 / (time.perf_counter() - t0)
+        if r > best_rate:
+            best_n, best_rate = n_thr, r
+    be.set_threads(best_n)
+    n = int(max(4, min(256, seconds * best_rate)))
     t0 = time.perf_counter(); m.decode(n, GREEDY); dt = time.perf_counter() - t0
+    cores_used = best_n
     m.close()
-    return {"value": round(n / dt, 3), "unit": "tokens/s", "cores": int(os.environ["OMP_NUM_THREADS"]), "kind": "port",
+    return {"value": round(n / dt, 3), "unit": "tokens/s", "cores": cores_used, "host_cores": cores, "kind": "port",
             "sample": f"oracle/liboracle.so (C+OpenMP restatement), same synthetic {desc.name or 'model'} bf16, "
-                      f"16-token prompt, {n} greedy decode tokens after 1 warm-up token, context 17..{17 + n}"}
+                      f"16-token prompt, {n} greedy decode tokens at the best OpenMP team size ({cores_used} of {cores} host threads), context ~30..{30 + n}"}
 
 
 def main():

@@ -21,6 +21,7 @@ ORACLE_EXTRA = {
     "set_next_token": (c_int, [c_void_p, POINTER(c_int64), c_int]),
     "read_rope": (c_int, [c_void_p, c_int, POINTER(c_float)]),
     "set_logits": (c_int, [c_void_p, POINTER(c_float), c_int]),
+    "set_threads": (c_int, [c_int]),
 }
 
 

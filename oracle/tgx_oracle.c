@@ -41,6 +41,7 @@
  */
 #define _GNU_SOURCE
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -686,6 +687,8 @@ TGXO_EXPORT int tgxo_set_logits(tgxo_ctx* c, const float* logits, int batch) {
   c->last_batch = batch;
   return 0;
 }
+
+TGXO_EXPORT int tgxo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
 
 TGXO_EXPORT int tgxo_reset_cache(tgxo_ctx* c) { if (!c) return 1; c->past = 0; return 0; }
 TGXO_EXPORT int64_t tgxo_past_length(const tgxo_ctx* c) { return c ? c->past : -1; }
