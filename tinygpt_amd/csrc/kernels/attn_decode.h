@@ -44,6 +44,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int kvh = blockIdx.x / a.nsplit, sp = blockIdx.x - kvh * a.nsplit;
   const int part_i = lane % LPT, slot = lane / LPT;
+  // the query slices (q[g][part_i*8 .. +8)) are requested together with the position: one memory round trip, not two
+  float qf[G][8];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const f32x4* qp = reinterpret_cast<const f32x4*>(a.q + (size_t)(kvh * G + g) * HD + part_i * 8);
+    const f32x4 q0 = qp[0], q1 = qp[1];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { qf[g][j] = q0[j]; qf[g][4 + j] = q1[j]; }
+  }
   const int n_keys = *a.pos + 1;
   // token range of this split: a multiple of one full workgroup pass so that waves stay on whole wave-loads
   constexpr int STEP = 4 * TPW * UNR;
@@ -53,15 +62,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   const int t_end = min(n_keys, t_begin + chunk);
   const float qscale = a.scale * LOG2E;     // softmax in base 2: exp(x) = exp2(x * log2 e)
 
-  // query slices: q[g][part_i*8 .. +8) as fp32, pre-scaled
-  float qf[G][8];
-#pragma unroll
-  for (int g = 0; g < G; g++) {
-    const f32x4* qp = reinterpret_cast<const f32x4*>(a.q + (size_t)(kvh * G + g) * HD + part_i * 8);
-    const f32x4 q0 = qp[0], q1 = qp[1];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { qf[g][j] = q0[j] * qscale; qf[g][4 + j] = q1[j] * qscale; }
+  if (t_begin >= n_keys) {   // this split has no keys at the current context length (wave-uniform): publish "empty"
+    for (int g = threadIdx.x; g < G; g += 256) {
+      float* dst = a.part + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
+      dst[HD] = -INFINITY; dst[HD + 1] = 0.f;
+    }
+    return;
   }
+
+#pragma unroll
+  for (int g = 0; g < G; g++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) qf[g][j] *= qscale;
   float m[G], l[G], o[G][8];
 #pragma unroll
   for (int g = 0; g < G; g++) {
@@ -110,7 +122,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     }
   }
 
-  // every (wave, slot) stream parks its state in LDS; 256 threads then merge the NSTREAM streams
+  // every (wave, slot) stream parks its state in LDS; the per-stream rescale factors are computed once
+  // (NSTREAM*G threads, one exp2 each) and the 256 threads then only multiply-add
+  __shared__ float sm_scale[NSTREAM][G];
+  __shared__ float sm_M[G];
   const int stream = wv * TPW + slot;
 #pragma unroll
   for (int g = 0; g < G; g++) {
@@ -120,22 +135,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     if (part_i == 0) { red[stream][g][HD] = m[g]; red[stream][g][HD + 1] = l[g]; }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < G * HD; idx += 256) {
-    const int g = idx / HD, d = idx - g * HD;
+  for (int idx = threadIdx.x; idx < NSTREAM * G; idx += 256) {
+    const int g = idx / NSTREAM, st = idx - g * NSTREAM;
     float M = -INFINITY;
 #pragma unroll 8
-    for (int s = 0; s < NSTREAM; s++) M = fmaxf(M, red[s][g][HD]);
+    for (int s2 = 0; s2 < NSTREAM; s2++) M = fmaxf(M, red[s2][g][HD]);
+    const float ms = red[st][g][HD];
+    sm_scale[st][g] = (ms == -INFINITY) ? 0.f : exp2f(ms - M);
+    if (st == 0) sm_M[g] = M;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < G * HD; idx += 256) {
+    const int g = idx / HD, d = idx - g * HD;
     float L = 0.f, acc = 0.f;
 #pragma unroll 8
-    for (int s = 0; s < NSTREAM; s++) {
-      const float ms = red[s][g][HD];
-      const float sc = (ms == -INFINITY) ? 0.f : exp2f(ms - M);
-      L += red[s][g][HD + 1] * sc;
-      acc += red[s][g][d] * sc;
+    for (int s2 = 0; s2 < NSTREAM; s2++) {
+      const float sc = sm_scale[s2][g];
+      acc = fmaf(red[s2][g][d], sc, acc);
+      if (d == 0) L = fmaf(red[s2][g][HD + 1], sc, L);
     }
     float* dst = a.part + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
     dst[d] = acc;
-    if (d == 0) { dst[HD] = M; dst[HD + 1] = L; }
+    if (d == 0) { dst[HD] = sm_M[g]; dst[HD + 1] = L; }
   }
 }
 
@@ -151,23 +172,39 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnArgs a) {
   __shared__ float sm_o[SPB][HD + 4];
   const int h = blockIdx.x, tid = threadIdx.x;
   const float* p = a.part + (size_t)h * a.nsplit * (HD + 4);
+  __shared__ float sm_e[32];
+  const int dg = tid % DG, sl = tid / DG;
+  constexpr int NPASS = 32 / SPB;        // 1 (hd 64) or 2 (hd 128) passes cover the 32 possible splits
+  // all loads of the kernel are issued up front: the (m, l) scalars and this thread's data slices of every split
+  f32x4 d0[NPASS], d1[NPASS];
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ps++) {
+    const int s = ps * SPB + sl;
+    d0[ps] = f32x4{0.f, 0.f, 0.f, 0.f}; d1[ps] = d0[ps];
+    if (s < a.nsplit) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(p + (size_t)s * (HD + 4) + dg * 8);
+      d0[ps] = src[0]; d1[ps] = src[1];
+    }
+  }
   if (tid < a.nsplit) { sm_m[tid] = p[tid * (HD + 4) + HD]; sm_l[tid] = p[tid * (HD + 4) + HD + 1]; }
   __syncthreads();
-  float M = -INFINITY;
-  for (int s = 0; s < a.nsplit; s++) M = fmaxf(M, sm_m[s]);
+  if (tid < a.nsplit) {   // one exp2 per split; empty splits (m = -inf) get weight 0 (their stale data is multiplied away)
+    float M0 = -INFINITY;
+    for (int s = 0; s < a.nsplit; s++) M0 = fmaxf(M0, sm_m[s]);
+    sm_e[tid] = (sm_m[tid] == -INFINITY) ? 0.f : exp2f(sm_m[tid] - M0);   // m is in the exp2 domain
+  }
+  __syncthreads();
   float L = 0.f;
-  for (int s = 0; s < a.nsplit; s++) L += (sm_m[s] == -INFINITY) ? 0.f : sm_l[s] * exp2f(sm_m[s] - M);   // m is in the exp2 domain
-  const int dg = tid % DG, sl = tid / DG;
+  for (int s = 0; s < a.nsplit; s++) L = fmaf(sm_l[s], sm_e[s], L);
   float acc = 0.f;                       // threads < HD accumulate dim `tid`
-  for (int s0 = 0; s0 < a.nsplit; s0 += SPB) {
-    const int s = s0 + sl;
-    f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
-    if (s < a.nsplit && sm_m[s] != -INFINITY) {
-      const float sc = exp2f(sm_m[s] - M);
-      const f32x4* src = reinterpret_cast<const f32x4*>(p + (size_t)s * (HD + 4) + dg * 8);
-      v0 = src[0] * sc;
-      v1 = src[1] * sc;
-    }
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ps++) {
+    const int s = ps * SPB + sl;
+    const bool live = s < a.nsplit && sm_e[s] != 0.f;
+    const float sc = live ? sm_e[s] : 0.f;
+    // empty splits hold stale (possibly non-finite) data: select, do not multiply
+    const f32x4 v0 = live ? d0[ps] * sc : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 v1 = live ? d1[ps] * sc : f32x4{0.f, 0.f, 0.f, 0.f};
     float* dst = &sm_o[sl][dg * 8];
     dst[0] = v0[0]; dst[1] = v0[1]; dst[2] = v0[2]; dst[3] = v0[3];
     dst[4] = v1[0]; dst[5] = v1[1]; dst[6] = v1[2]; dst[7] = v1[3];

@@ -106,6 +106,7 @@ struct tgx_ctx {
   bf16_t* ws_al2 = nullptr;                           // [S][H] third term for the QKV projection
   bf16_t *ws_qh = nullptr, *ws_ql = nullptr;          // [S][qd] rotated queries (hi, lo)
   bool prefill_mfma = true;
+  int debug_skip = 0;        // experiment: bit0 skip attn decode kernel, bit1 skip combine (results invalid)
   int prof_same_layer = 0;   // experiment: tgx_profile_decode replays ONE layer's weights (Infinity-Cache resident)
   int debug_nops = 0;     // extra no-op launches per layer (launch-overhead experiments only)
   int* nop_word = nullptr;
@@ -260,7 +261,7 @@ void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls) {
 template <int HD>
 void launch_attn_g(tgx_ctx* c, const tgx::AttnArgs& a, int G) {
   const dim3 grid(a.kv_heads * a.nsplit), blk(256);
-  switch (G) {
+  if (!(c->debug_skip & 1)) switch (G) {
     case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 1>), grid, blk, 0, c->stream, a); break;
     case 2: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 2>), grid, blk, 0, c->stream, a); break;
     case 3: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 3>), grid, blk, 0, c->stream, a); break;
@@ -270,7 +271,7 @@ void launch_attn_g(tgx_ctx* c, const tgx::AttnArgs& a, int G) {
     case 7: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 7>), grid, blk, 0, c->stream, a); break;
     default: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 8>), grid, blk, 0, c->stream, a); break;
   }
-  hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads), dim3(256), 0, c->stream, a);
+  if (!(c->debug_skip & 2)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads), dim3(256), 0, c->stream, a);
 }
 
 void launch_attn(tgx_ctx* c, const tgx::AttnArgs& a) {
@@ -971,6 +972,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (c->step_graph) { (void)hipStreamSynchronize(c->stream); (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
   if (!strcmp(key, "graph")) { c->use_graph = value != 0; return TGX_OK; }
   if (!strcmp(key, "debug.nops")) { c->debug_nops = value; return TGX_OK; }
+  if (!strcmp(key, "debug.skip")) { c->debug_skip = value; return TGX_OK; }
   if (!strcmp(key, "prefill.mfma")) { c->prefill_mfma = value != 0; return TGX_OK; }
   if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
   if (!strcmp(key, "attn.nsplit")) {
