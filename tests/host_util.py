@@ -98,8 +98,10 @@ def write_model_dir(path, cfg, seed, std, shards=1, dtype="bf16", eos=None):
         json.dump({"bos_token_id": 1, "eos_token_id": eos if eos is not None else cfg.get("eos_token_id", 2)}, f)
     tensors = {}
     for name, bits in synth.synth_checkpoint(d, seed, std):
-        t = torch.from_numpy(synth.bf16_bits_to_f32(bits).copy())
-        tensors[name] = t.to(torch.bfloat16) if dtype == "bf16" else t
+        if dtype == "bf16":      # reinterpret the bit patterns: no float round trip (matters at full model size)
+            tensors[name] = torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(torch.bfloat16)
+        else:
+            tensors[name] = torch.from_numpy(synth.bf16_bits_to_f32(bits).copy())
     if shards == 1:
         save_file(tensors, os.path.join(path, "model.safetensors"))
     else:

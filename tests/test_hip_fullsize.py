@@ -61,3 +61,27 @@ def test_other_baseline_geometries_decode_properties(name):
     assert rel_err(m.logits(False)[0:1], a) < 1e-3
     np.testing.assert_array_equal(m.sample(GREEDY)[0], t0[0])
     np.testing.assert_array_equal(m.decode(3, GREEDY)[:, 0], r0[:3, 0])
+
+
+def test_full_size_sharded_checkpoint_through_cpp_engine(tmp_path):
+    """a full-size (Llama-3.2-1B geometry, 2.5 GB) checkpoint written as 3 safetensors shards +
+    index by the `safetensors` package, read by the C++ loader (mmap -> tgx_upload by HF name) and run by the C++ engine
+    on the GPU; greedy ids must equal the ctypes path that uploads the same tensors directly."""
+    import json
+    from host_util import HostEngine, host_lib, write_model_dir
+    from tinygpt_amd.desc import KNOWN_CONFIGS
+    cfg = dict(KNOWN_CONFIGS["llama-3.2-1b"])
+    write_model_dir(str(tmp_path), cfg, 1234, 0.02, shards=3, eos=[128001, 128009])
+    assert len([f for f in __import__("os").listdir(tmp_path) if f.endswith(".safetensors")]) == 3
+    e = HostEngine(host_lib(), model_dir=str(tmp_path), device="mi355x", dtype=1, max_batch=1)
+    assert e.prepare(), e.error()
+    assert e.eos_ids() == [128001, 128009] and e.lib.tgxe_context_size(e.h) == 8192
+    prompt = synth.synth_prompt(cfg["vocab_size"], 40, 1234)
+    e.reconfigure(max_new=12)
+    ids, new, fin = e.generate_sync([prompt])
+    e.close()
+    d = known_desc("llama-3.2-1b"); d.max_ctx = 256
+    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    m.forward(prompt[None, :])
+    want = np.concatenate([m.sample(GREEDY), m.decode(11, GREEDY)[:, 0]])
+    np.testing.assert_array_equal(ids[0, 40:], want)
