@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TGX_ABI_VERSION 1
+#define TGX_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define TGX_API __attribute__((visibility("default")))
@@ -84,6 +84,8 @@ typedef struct tgx_model_desc {
   int32_t rope_orig_ctx;  /* .originalMaxPositionEmbeddings                                      */
   int32_t n_positions;    /* GPT-2 wpe rows; 0 otherwise                                         */
   int32_t max_batch;      /* rows of independent KV state to allocate (>= 1)                     */
+  int32_t qk_norm;        /* 1: per-head RMSNorm on q and k before RoPE (AttentionWithQKNorm,    */
+                          /*    src/layer/Attention.h:128-167; Qwen3, ModelQwen3.h:23-40)        */
 } tgx_model_desc;
 
 /* SamplerConfig (src/engine/Sampler.h:13-22).  Greedy iff temperature<=0 && top_k<=0 &&

@@ -55,7 +55,7 @@ enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 typedef struct {
   int32_t family, hidden, layers, heads, kv_heads, head_dim, inter, vocab, max_ctx, qkv_bias, tied, compute_dtype;
   float norm_eps, rope_theta, rope_factor, rope_low_freq, rope_high_freq;
-  int32_t rope_orig_ctx, n_positions, max_batch;
+  int32_t rope_orig_ctx, n_positions, max_batch, qk_norm;
 } desc_t;
 
 typedef struct { float temperature; int64_t top_k; float top_p; float min_p; } sampler_cfg_t;
@@ -75,6 +75,7 @@ typedef struct { float* w; float* b; int filled_w, filled_b; } vec_t;
 
 typedef struct {
   vec_t in_norm, post_norm;      /* input_layernorm / post_attention_layernorm, or ln_1 / ln_2 (with bias) */
+  vec_t q_norm, k_norm;          /* Qwen3 per-head RMSNorm weights [head_dim] (Attention.h:128-167) */
   mat_t qkv, o, gate_up, down;   /* GPT-2: c_attn, c_proj, c_fc, mlp.c_proj */
 } layer_t;
 
@@ -196,6 +197,7 @@ TGXO_EXPORT int tgxo_create(const desc_t* d, int device_ordinal, tgxo_ctx** out)
   for (int l = 0; l < d->layers && ok; l++) {
     layer_t* y = &c->L[l];
     ok &= vec_alloc(&y->in_norm, H, gpt2) && vec_alloc(&y->post_norm, H, gpt2);
+    if (d->qk_norm) ok &= vec_alloc(&y->q_norm, d->head_dim, 0) && vec_alloc(&y->k_norm, d->head_dim, 0);
     ok &= mat_alloc(c, &y->qkv, qd + 2 * kvd, H, d->qkv_bias || gpt2);
     ok &= mat_alloc(c, &y->o, H, qd, gpt2);
     ok &= mat_alloc(c, &y->gate_up, gpt2 ? I : 2 * I, H, gpt2);
@@ -217,7 +219,7 @@ TGXO_EXPORT void tgxo_destroy(tgxo_ctx* c) {
   free(c->final_norm.w); free(c->final_norm.b);
   if (c->L) for (int l = 0; l < c->d.layers; l++) {
     layer_t* y = &c->L[l];
-    free(y->in_norm.w); free(y->in_norm.b); free(y->post_norm.w); free(y->post_norm.b);
+    free(y->in_norm.w); free(y->in_norm.b); free(y->post_norm.w); free(y->post_norm.b); free(y->q_norm.w); free(y->k_norm.w);
     mat_free(&y->qkv); mat_free(&y->o); mat_free(&y->gate_up); mat_free(&y->down);
   }
   free(c->L); free(c->rope_cos); free(c->rope_sin); free(c->kcache); free(c->vcache); free(c->logits); free(c->next_tok);
@@ -284,6 +286,8 @@ TGXO_EXPORT int tgxo_upload(tgxo_ctx* c, const char* name, const void* host, con
   if (sscanf(name, "model.layers.%d.%127s", &l, rest) == 2 && l >= 0 && l < d->layers) {
     layer_t* y = &c->L[l];
     if (!strcmp(rest, "input_layernorm.weight")) { if (!shape_is(shape, nd, H, -1)) goto bad_shape; vec_store(c, y->in_norm.w, H, host, dt); y->in_norm.filled_w = 1; return 0; }
+    if (d->qk_norm && !strcmp(rest, "self_attn.q_norm.weight")) { if (!shape_is(shape, nd, d->head_dim, -1)) goto bad_shape; vec_store(c, y->q_norm.w, d->head_dim, host, dt); y->q_norm.filled_w = 1; return 0; }
+    if (d->qk_norm && !strcmp(rest, "self_attn.k_norm.weight")) { if (!shape_is(shape, nd, d->head_dim, -1)) goto bad_shape; vec_store(c, y->k_norm.w, d->head_dim, host, dt); y->k_norm.filled_w = 1; return 0; }
     if (!strcmp(rest, "post_attention_layernorm.weight")) { if (!shape_is(shape, nd, H, -1)) goto bad_shape; vec_store(c, y->post_norm.w, H, host, dt); y->post_norm.filled_w = 1; return 0; }
     /* MergedLinear slices (Linear.h:64-79): q rows [0,qd), k [qd,qd+kvd), v [qd+kvd, qd+2kvd) */
     struct { const char* n; mat_t* m; int64_t row0, rows, cols; } ws[] = {
@@ -357,6 +361,7 @@ TGXO_EXPORT int tgxo_finalize(tgxo_ctx* c) {
         y->gate_up.filled_rows != y->gate_up.rows || y->down.filled_rows != y->down.rows)
       return fail(c, 4, "Missing key in %s", nm);
     if (d->qkv_bias && !gpt2 && y->qkv.bias_filled != y->qkv.rows) return fail(c, 4, "Missing qkv bias in %s", nm);
+    if (d->qk_norm && (!y->q_norm.filled_w || !y->k_norm.filled_w)) return fail(c, 4, "Missing q_norm/k_norm in %s", nm);
   }
   if (!gpt2) build_rope(c);
   c->finalized = 1;
@@ -496,6 +501,11 @@ static int forward_row(tgxo_ctx* c, int b, const int64_t* ids, int S) {
     /* split -> heads -> RoPE(q), RoPE(k) at pastLength -> cache append (Attention.h:94-106) */
     for (int s = 0; s < S; s++) {
       float* row = qkv + (size_t)s * (qd + 2 * kvd);
+      if (d->qk_norm) {   /* AttentionWithQKNorm::projectQKV (Attention.h:156-163): RMSNorm over head_dim, per head, before RoPE */
+        float tmp[512];
+        for (int h = 0; h < nh; h++) { rmsnorm(c, row + h * hd, y->q_norm.w, hd, tmp); memcpy(row + h * hd, tmp, (size_t)hd * 4); }
+        for (int h = 0; h < nkv; h++) { rmsnorm(c, row + qd + h * hd, y->k_norm.w, hd, tmp); memcpy(row + qd + h * hd, tmp, (size_t)hd * 4); }
+      }
       if (!gpt2) {
         for (int h = 0; h < nh; h++) rope_head(c, row + h * hd, (int)(past + s));
         for (int h = 0; h < nkv; h++) rope_head(c, row + qd + h * hd, (int)(past + s));

@@ -10,8 +10,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-FAMILIES = ["llama_tiny", "qwen2_tiny", "mistral_tiny", "gpt2_tiny"]
-GPU_FAMILIES = ["llama_tiny", "qwen2_tiny", "mistral_tiny"]     # GPT-2 is the CPU-only plumbing config
+FAMILIES = ["llama_tiny", "qwen2_tiny", "mistral_tiny", "qwen3_tiny", "gpt2_tiny"]
+GPU_FAMILIES = ["llama_tiny", "qwen2_tiny", "mistral_tiny", "qwen3_tiny"]     # GPT-2 is the CPU-only plumbing config
 
 
 def pytest_configure(config):

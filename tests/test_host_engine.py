@@ -35,7 +35,7 @@ def test_synth_cpp_equals_python(lib):
         np.testing.assert_array_equal(out, synth.synth_tensor_bf16(1234, name, (n,), std))
 
 
-@pytest.mark.parametrize("fam,shards", [("llama_tiny", 1), ("qwen2_tiny", 2), ("mistral_tiny", 1)])
+@pytest.mark.parametrize("fam,shards", [("llama_tiny", 1), ("qwen2_tiny", 2), ("mistral_tiny", 1), ("qwen3_tiny", 1)])
 def test_generate_sync_matches_hf_golden(lib, oracle_path, tmp_path, fam, shards):
     """config.json + (sharded) safetensors -> engine -> greedy ids == HF's, prompt ids echoed, finishReason Length."""
     e, g = make_engine(lib, oracle_path, tmp_path, fam, dtype=0, shards=shards)

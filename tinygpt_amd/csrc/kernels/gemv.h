@@ -46,6 +46,8 @@ struct GemvArgs {
   const float* rope_sin;
   const int* pos;         // device-resident pastLength of this row
   int heads, kv_heads, hd, max_ctx;
+  int raw_qk;             // Qwen3 (q/k RMSNorm before RoPE): emit un-rotated q and k, qk_norm_rope_kernel finishes them
+  float* k_raw;           // [kv_heads*hd] fp32 staging for k when raw_qk
   // EPI_RESIDUAL: out[n] += acc;  EPI_SILU_MUL: out[i] = silu(g) * u      (fp32)
   float* out;
   // EPI_LOGITS
@@ -205,7 +207,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         if (EPI == EPI_QKV_ROPE) {
           const int half = a.hd >> 1;
           const int hh = u / half, p = u - hh * half;
-          if (hh < a.heads + a.kv_heads) {   // q or k head: rotate-half RoPE at absolute position pos
+          if (a.raw_qk && hh >= a.heads && hh < a.heads + a.kv_heads) {
+            a.k_raw[(hh - a.heads) * a.hd + p] = sa;
+            a.k_raw[(hh - a.heads) * a.hd + p + half] = sb;
+          } else
+          if (!a.raw_qk && hh < a.heads + a.kv_heads) {   // q or k head: rotate-half RoPE at absolute position pos
             const float cs = e0, sn = e1;
             const float ra_ = sa * cs - sb * sn;
             const float rb_ = sb * cs + sa * sn;
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
           if (hh < a.heads) {
             a.q_out[hh * a.hd + p] = sa;
             a.q_out[hh * a.hd + p + half] = sb;
-          } else {   // KVCacheManager::append: this position's K / V row, stored in bf16
+          } else if (!(a.raw_qk && hh < a.heads + a.kv_heads)) {   // KVCacheManager::append: this position's K / V row, stored in bf16
             bf16_t* dst = (hh < a.heads + a.kv_heads)
                               ? a.k_cache + ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd
                               : a.v_cache + ((size_t)(hh - a.heads - a.kv_heads) * a.max_ctx + pos) * a.hd;
@@ -249,6 +255,40 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       a.part_val[blockIdx.x] = bv;
       a.part_idx[blockIdx.x] = bi;
     }
+  }
+}
+
+// ---- Qwen3: per-head RMSNorm on q and k, then RoPE, then the cache append (AttentionWithQKNorm::projectQKV,
+// Attention.h:156-163 + Attention::forward :81-83,:106).  One wave per head; lane p owns the RoPE pair (p, p+hd/2).
+struct QkNormArgs {
+  float* q;               // [heads][hd] in/out
+  const float* k_raw;     // [kv_heads][hd]
+  bf16_t* k_cache;        // this layer/row: [kv_heads][max_ctx][hd]
+  const bf16_t *q_norm_w, *k_norm_w;   // [hd]
+  const float *rope_cos, *rope_sin;
+  const int* pos;
+  int heads, kv_heads, hd, max_ctx;
+  float eps;
+};
+__global__ __launch_bounds__(64) void qk_norm_rope_kernel(const QkNormArgs a) {
+  const int hh = blockIdx.x, p = threadIdx.x, half = a.hd >> 1;
+  const bool is_q = hh < a.heads;
+  const float* src = is_q ? a.q + hh * a.hd : a.k_raw + (hh - a.heads) * a.hd;
+  const bf16_t* w = is_q ? a.q_norm_w : a.k_norm_w;
+  const bool act = p < half;
+  float x0 = act ? src[p] : 0.f, x1 = act ? src[p + half] : 0.f;
+  const float ss = wave_sum(x0 * x0 + x1 * x1);
+  const float inv = 1.0f / sqrtf(ss / (float)a.hd + a.eps);
+  if (!act) return;
+  x0 = bf16_to_f32(w[p]) * (x0 * inv);
+  x1 = bf16_to_f32(w[p + half]) * (x1 * inv);
+  const int pos = *a.pos;
+  const float cs = a.rope_cos[(size_t)pos * half + p], sn = a.rope_sin[(size_t)pos * half + p];
+  const float r0 = x0 * cs - x1 * sn, r1 = x1 * cs + x0 * sn;
+  if (is_q) { a.q[hh * a.hd + p] = r0; a.q[hh * a.hd + p + half] = r1; }
+  else {
+    bf16_t* dst = a.k_cache + ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd;
+    dst[p] = f32_to_bf16(r0); dst[p + half] = f32_to_bf16(r1);
   }
 }
 

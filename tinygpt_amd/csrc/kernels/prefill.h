@@ -75,6 +75,8 @@ struct RopeKvArgs {
   bf16_t *k_cache, *v_cache;   // this layer/row: [kv_heads][max_ctx][hd]
   const float *rope_cos, *rope_sin;
   int heads, kv_heads, hd, max_ctx, past;
+  const bf16_t *q_norm_w, *k_norm_w;   // Qwen3 per-head RMSNorm weights [hd] (nullptr: no QK-norm)
+  float eps;
 };
 __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) {
   const int s = blockIdx.x, pos = a.past + s, half = a.hd >> 1;
@@ -84,6 +86,16 @@ __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) 
   for (int u = threadIdx.x; u < pairs; u += 256) {
     const int hh = u / half, p = u - hh * half;
     float x0 = row[hh * a.hd + p], x1 = row[hh * a.hd + p + half];
+    if (a.q_norm_w != nullptr && hh < a.heads + a.kv_heads) {
+      // AttentionWithQKNorm (Attention.h:156-163): RMSNorm over head_dim; the hd/2 lanes of one head are adjacent and
+      // aligned (hd/2 = 32 or 64), so the mean of squares is a sub-wave butterfly
+      float ss = x0 * x0 + x1 * x1;
+      for (int o = half >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      const float inv = 1.0f / sqrtf(ss / (float)a.hd + a.eps);
+      const bf16_t* w = hh < a.heads ? a.q_norm_w : a.k_norm_w;
+      x0 = bf16_to_f32(w[p]) * (x0 * inv);
+      x1 = bf16_to_f32(w[p + half]) * (x1 * inv);
+    }
     if (hh < a.heads + a.kv_heads) {
       const float cs = a.rope_cos[(size_t)pos * half + p], sn = a.rope_sin[(size_t)pos * half + p];
       const float r0 = x0 * cs - x1 * sn, r1 = x1 * cs + x0 * sn;

@@ -32,6 +32,8 @@ constexpr int HOST_RING = 256;
 struct LayerW {
   bf16_t *in_norm = nullptr, *post_norm = nullptr;
   bf16_t *wqkv = nullptr, *bqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wdown = nullptr;
+  bf16_t *q_norm = nullptr, *k_norm = nullptr;   // Qwen3 [head_dim]
+  bool q_norm_ok = false, k_norm_ok = false;
   int64_t qkv_rows = 0, gu_rows = 0;
   bool in_norm_ok = false, post_norm_ok = false, wo_ok = false, wdown_ok = false;
   int64_t bias_rows = 0;
@@ -39,6 +41,7 @@ struct LayerW {
 
 struct RowState {       // independent KV/sequence state of one batch row
   float *x = nullptr, *q = nullptr, *attn = nullptr, *h = nullptr;   // fp32 activations
+  float* k_raw = nullptr;   // Qwen3: un-normalised k of the current position
   float* logits = nullptr;
   float *work = nullptr, *probs = nullptr;   // sampler scratch / final probabilities [V]
   float* part_val = nullptr;
@@ -295,7 +298,15 @@ void launch_layer_kernel(tgx_ctx* c, RowState& r, int l, int cls, float* resid) 
       a.q_out = r.q; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos = r.pos;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx;
+      a.raw_qk = d.qk_norm ? 1 : 0; a.k_raw = r.k_raw;
       launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_QKV_ROPE>(c, a, TGX_KERNEL_QKV);
+      if (d.qk_norm) {   // q_norm / k_norm -> RoPE -> cache append (Attention.h:156-163)
+        tgx::QkNormArgs n{};
+        n.q = r.q; n.k_raw = r.k_raw; n.k_cache = a.k_cache; n.q_norm_w = w.q_norm; n.k_norm_w = w.k_norm;
+        n.rope_cos = c->rope_cos; n.rope_sin = c->rope_sin; n.pos = r.pos;
+        n.heads = d.heads; n.kv_heads = d.kv_heads; n.hd = hd; n.max_ctx = d.max_ctx; n.eps = d.norm_eps;
+        hipLaunchKernelGGL(tgx::qk_norm_rope_kernel, dim3(d.heads + d.kv_heads), dim3(64), 0, c->stream, n);
+      }
       break;
     }
     case TGX_KERNEL_ATTN: {  // flashAttention(q, Kall, Vall) over keys [0, pos]       (Attention.h:108-111)
@@ -393,6 +404,7 @@ void launch_prefill(tgx_ctx* c, RowState& r, int S) {
       a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = (int)c->past;
+      a.q_norm_w = d.qk_norm ? w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? w.k_norm : nullptr; a.eps = d.norm_eps;
       hipLaunchKernelGGL(tgx::rope_kv_split_kernel, dim3(S), dim3(256), 0, c->stream, a);
     }
     {
@@ -535,8 +547,8 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   if (!desc || !out_ctx) return set_err(nullptr, TGX_ERR_INVALID, "null argument");
   *out_ctx = nullptr;
   const tgx_model_desc& d = *desc;
-  if (d.family != TGX_FAMILY_LLAMA && d.family != TGX_FAMILY_QWEN2 && d.family != TGX_FAMILY_MISTRAL)
-    return set_err(nullptr, TGX_ERR_UNSUPPORTED, "family %d is not implemented on mi355x (llama/qwen2/mistral are)", d.family);
+  if (d.family != TGX_FAMILY_LLAMA && d.family != TGX_FAMILY_QWEN2 && d.family != TGX_FAMILY_MISTRAL && d.family != TGX_FAMILY_QWEN3)
+    return set_err(nullptr, TGX_ERR_UNSUPPORTED, "family %d is not implemented on mi355x (llama/qwen2/qwen3/mistral are)", d.family);
   if (d.compute_dtype != TGX_BF16) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "mi355x backend computes in bf16 only");
   if (d.head_dim != 64 && d.head_dim != 128) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "head_dim %d (64 and 128 are built)", d.head_dim);
   if (d.heads <= 0 || d.kv_heads <= 0 || d.heads % d.kv_heads) return set_err(nullptr, TGX_ERR_INVALID, "heads %% kv_heads != 0");
@@ -575,6 +587,7 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
     if ((rc = dev_alloc(c, &w.wqkv, (size_t)(qd + 2 * kvd) * H))) return rc;
     if (d.qkv_bias && (rc = dev_alloc(c, &w.bqkv, (size_t)(qd + 2 * kvd)))) return rc;
     if ((rc = dev_alloc(c, &w.wo, (size_t)H * qd))) return rc;
+    if (d.qk_norm && ((rc = dev_alloc(c, &w.q_norm, (size_t)d.head_dim)) || (rc = dev_alloc(c, &w.k_norm, (size_t)d.head_dim)))) return rc;
     if ((rc = dev_alloc(c, &w.wgu, (size_t)2 * I * H))) return rc;
     if ((rc = dev_alloc(c, &w.wdown, (size_t)H * I))) return rc;
   }
@@ -611,6 +624,12 @@ int tgx_upload(tgx_ctx* c, const char* name, const void* host, const int64_t* sh
       if (!shape_is(shape, nd, H, -1)) return bad_shape();
       w.in_norm_ok = true;
       return upload_bf16(c, w.in_norm, host, H, src_dtype);
+    }
+    if (d.qk_norm && (!strcmp(rest, "self_attn.q_norm.weight") || !strcmp(rest, "self_attn.k_norm.weight"))) {
+      if (!shape_is(shape, nd, d.head_dim, -1)) return bad_shape();
+      const bool isq = rest[10] == 'q';
+      (isq ? w.q_norm_ok : w.k_norm_ok) = true;
+      return upload_bf16(c, isq ? w.q_norm : w.k_norm, host, d.head_dim, src_dtype);
     }
     if (!strcmp(rest, "post_attention_layernorm.weight")) {
       if (!shape_is(shape, nd, H, -1)) return bad_shape();
@@ -660,6 +679,7 @@ int tgx_finalize(tgx_ctx* c) {
     if (!w.in_norm_ok || !w.post_norm_ok || w.qkv_rows != qd + 2 * kvd || !w.wo_ok || w.gu_rows != 2 * (int64_t)I || !w.wdown_ok)
       return set_err(c, TGX_ERR_STATE, "Missing key in model.layers.%d", l);
     if (d.qkv_bias && w.bias_rows != qd + 2 * kvd) return set_err(c, TGX_ERR_STATE, "Missing qkv bias in model.layers.%d", l);
+    if (d.qk_norm && (!w.q_norm_ok || !w.k_norm_ok)) return set_err(c, TGX_ERR_STATE, "Missing key: model.layers.%d.self_attn.{q,k}_norm.weight", l);
   }
   if (c->finalized) return TGX_OK;
 
@@ -681,6 +701,7 @@ int tgx_finalize(tgx_ctx* c) {
   for (auto& r : c->rows) {
     if ((rc = dev_alloc(c, &r.x, (size_t)H))) return rc;
     if ((rc = dev_alloc(c, &r.q, (size_t)qd))) return rc;
+    if ((rc = dev_alloc(c, &r.k_raw, (size_t)kvd))) return rc;
     if ((rc = dev_alloc(c, &r.attn, (size_t)qd))) return rc;
     if ((rc = dev_alloc(c, &r.h, (size_t)I))) return rc;
     if ((rc = dev_alloc(c, &r.logits, (size_t)V))) return rc;
@@ -729,9 +750,9 @@ void tgx_destroy(tgx_ctx* c) {
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x); fr(c->seed_dev);
   fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql);
-  for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.wgu); fr(w.wdown); }
+  for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); }
   for (auto& r : c->rows) {
-    fr(r.x); fr(r.q); fr(r.attn); fr(r.h); fr(r.logits); fr(r.work); fr(r.probs); fr(r.part_val); fr(r.part_idx); fr(r.attn_part);
+    fr(r.x); fr(r.q); fr(r.k_raw); fr(r.attn); fr(r.h); fr(r.logits); fr(r.work); fr(r.probs); fr(r.part_val); fr(r.part_idx); fr(r.attn_part);
     fr(r.tok); fr(r.pos); fr(r.prompt); fr(r.kcache); fr(r.vcache);
   }
   if (c->host_ring) (void)hipHostFree(c->host_ring);

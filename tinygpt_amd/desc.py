@@ -47,6 +47,7 @@ class CDesc(ctypes.Structure):
         ("rope_orig_ctx", ctypes.c_int32),
         ("n_positions", ctypes.c_int32),
         ("max_batch", ctypes.c_int32),
+        ("qk_norm", ctypes.c_int32),
     ]
 
 
@@ -72,6 +73,7 @@ class ModelDesc:
     rope_orig_ctx: int = 0
     n_positions: int = 0         # GPT-2 learned position table rows
     max_batch: int = 1
+    qk_norm: bool = False        # Qwen3: per-head RMSNorm on q, k before RoPE (Attention.h:128-167)
     name: str = ""               # label only (bench/config reporting)
 
     # ---- derived sizes -------------------------------------------------------------------
@@ -86,7 +88,7 @@ class ModelDesc:
                      self.head_dim, self.inter, self.vocab, self.max_ctx, int(self.qkv_bias), int(self.tied),
                      DTYPE_BY_NAME[self.compute_dtype], self.norm_eps, self.rope_theta, self.rope_factor,
                      self.rope_low_freq, self.rope_high_freq, self.rope_orig_ctx, self.n_positions,
-                     self.max_batch)
+                     self.max_batch, int(self.qk_norm))
 
     def to_dict(self):
         return asdict(self)
@@ -120,6 +122,9 @@ class ModelDesc:
                 out[p + "self_attn.q_proj.bias"] = (self.q_dim,)
                 out[p + "self_attn.k_proj.bias"] = (self.kv_dim,)
                 out[p + "self_attn.v_proj.bias"] = (self.kv_dim,)
+            if self.qk_norm:
+                out[p + "self_attn.q_norm.weight"] = (self.head_dim,)
+                out[p + "self_attn.k_norm.weight"] = (self.head_dim,)
             out[p + "self_attn.o_proj.weight"] = (H, self.q_dim)
             out[p + "post_attention_layernorm.weight"] = (H,)
             out[p + "mlp.gate_proj.weight"] = (I, H)
@@ -179,7 +184,7 @@ def desc_from_hf_config(cfg: dict, compute_dtype: str = "bf16", max_batch: int =
                   qkv_bias=(mt == "qwen2"),                            # ModelQwen2.h:26-31
                   tied=bool(cfg.get("tie_word_embeddings", False)),
                   compute_dtype=compute_dtype, norm_eps=float(cfg.get("rms_norm_eps", 1e-5)),
-                  rope_theta=theta, max_batch=max_batch, name=cfg.get("_name_or_path", ""))
+                  rope_theta=theta, max_batch=max_batch, qk_norm=(mt == "qwen3"), name=cfg.get("_name_or_path", ""))
     if mt == "llama" and rs:
         d.rope_factor = float(rs.get("factor", 1.0))
         d.rope_high_freq = float(rs.get("high_freq_factor", 1.0))

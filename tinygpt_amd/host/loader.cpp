@@ -84,6 +84,7 @@ bool load_model_config(const std::string& path, int compute_dtype, int max_batch
   d.head_dim = d.heads > 0 ? d.hidden / d.heads : 0;               // ModelLlama.h:37 ignores "head_dim"
   if (fam == TGX_FAMILY_QWEN3) d.head_dim = (int32_t)doc.get_int("head_dim", d.head_dim);   // ModelQwen3.h:25
   d.qkv_bias = fam == TGX_FAMILY_QWEN2 ? 1 : 0;                    // ModelQwen2.h:26-31
+  d.qk_norm = fam == TGX_FAMILY_QWEN3 ? 1 : 0;                     // AttentionWithQKNorm (ModelQwen3.h:29-33)
   // rope: hub-era flat keys (what the reference parses) or the nested rope_parameters newer transformers write
   const Json* rp = doc.get("rope_parameters");
   const Json* rs = doc.get("rope_scaling");

@@ -31,7 +31,7 @@ from tinygpt_amd.desc import desc_from_hf_config  # noqa: E402
 
 import transformers  # noqa: E402
 from transformers import (GPT2Config, GPT2LMHeadModel, LlamaConfig, LlamaForCausalLM, MistralConfig,  # noqa: E402
-                          MistralForCausalLM, Qwen2Config, Qwen2ForCausalLM)
+                          MistralForCausalLM, Qwen2Config, Qwen2ForCausalLM, Qwen3Config, Qwen3ForCausalLM)
 
 OUT = os.path.join(ROOT, "tests", "golden")
 N_PROMPT, N_STEPS, STD = 9, 16, 0.08
@@ -55,13 +55,20 @@ FAMILIES = {
         "num_key_value_heads": 2, "intermediate_size": 640, "vocab_size": 256, "tie_word_embeddings": False,
         "rms_norm_eps": 1e-5, "rope_theta": 1000000.0, "max_position_embeddings": 128, "torch_dtype": "bfloat16",
         "hidden_act": "silu", "bos_token_id": 1, "eos_token_id": 2, "sliding_window": None},
+    "qwen3_tiny": {   # per-head q/k RMSNorm, explicit head_dim with q_dim (256) != hidden_size (192)
+        "model_type": "qwen3", "hidden_size": 192, "num_hidden_layers": 2, "num_attention_heads": 4,
+        "num_key_value_heads": 2, "head_dim": 64, "intermediate_size": 320, "vocab_size": 320,
+        "tie_word_embeddings": True, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0, "max_position_embeddings": 128,
+        "torch_dtype": "bfloat16", "hidden_act": "silu", "bos_token_id": 1, "eos_token_id": 2,
+        "use_sliding_window": False, "attention_bias": False},
     "gpt2_tiny": {
         "model_type": "gpt2", "n_embd": 64, "n_layer": 2, "n_head": 2, "n_ctx": 64, "n_positions": 64,
         "vocab_size": 256, "layer_norm_epsilon": 1e-5, "activation_function": "gelu_new", "torch_dtype": "float32",
         "bos_token_id": 1, "eos_token_id": 2},
 }
 HF_CLASSES = {"llama": (LlamaConfig, LlamaForCausalLM), "qwen2": (Qwen2Config, Qwen2ForCausalLM),
-              "mistral": (MistralConfig, MistralForCausalLM), "gpt2": (GPT2Config, GPT2LMHeadModel)}
+              "mistral": (MistralConfig, MistralForCausalLM), "gpt2": (GPT2Config, GPT2LMHeadModel),
+              "qwen3": (Qwen3Config, Qwen3ForCausalLM)}
 
 
 def build_hf(cfg: dict, seed: int, dtype):
