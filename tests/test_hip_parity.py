@@ -131,6 +131,23 @@ def test_batch_rows_are_independent(hip, oracle_lib):
     assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_ORACLE
 
 
+@pytest.mark.parametrize("family", ["llama_tiny", "qwen2_tiny", "qwen3_tiny"])
+def test_batched_decode_shares_weight_passes(family, hip, oracle_lib):
+    """7 rows decode as row groups of 4 + 2 + 1 (kernels/gemv.h's R template; attention takes the row on blockIdx.y):
+    every row must still equal the oracle's row — ids exactly, logits within the fp32-ordering tolerance."""
+    gpu, ref, g = make_pair(family, hip, oracle_lib, max_batch=7)
+    p = g["prompt"]
+    ids = np.concatenate([(p + 3 * b) % gpu.desc.vocab for b in range(7)])
+    gpu.forward(ids); ref.forward(ids)
+    np.testing.assert_array_equal(gpu.sample(GREEDY), ref.sample(GREEDY))
+    np.testing.assert_array_equal(gpu.decode(6, GREEDY), ref.decode(6, GREEDY))
+    assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_ORACLE
+    for row in (3, 5, 6):                                  # last row of each group: its own cache slab, its own length
+        (kg, vg), (kr, vr) = gpu.read_kv(row, 0), ref.read_kv(row, 0)
+        for g_, r_ in ((kg, kr), (vg, vr)):
+            assert np.all(np.abs(g_ - r_) <= 2.0 ** -7 * (np.abs(r_) + 1e-3 * np.abs(r_).max()))
+
+
 def test_errors_are_loud(hip):
     from tinygpt_amd.ffi import Model, TgxError, SamplerCfg
     cfg, g = load_golden("llama_tiny")

@@ -29,6 +29,8 @@ struct AttnArgs {
   float* out;             // [heads*hd] fp32 (combine kernel)
   int heads, kv_heads, max_ctx, nsplit;
   float scale;
+  // batch rows: blockIdx.y = row; row r uses q + r*q_stride, caches + r*kv_stride, pos[r], part + r*part_stride, out + r*q_stride
+  long long q_stride, kv_stride, part_stride;
 };
 
 template <int HD, int G>
@@ -42,18 +44,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float red[NSTREAM][G][HD + 4];
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float* q_row = a.q + blockIdx.y * a.q_stride;
+  const bf16_t* k_row = a.k_cache + blockIdx.y * a.kv_stride;
+  const bf16_t* v_row = a.v_cache + blockIdx.y * a.kv_stride;
+  float* part_row = a.part + blockIdx.y * a.part_stride;
   const int kvh = blockIdx.x / a.nsplit, sp = blockIdx.x - kvh * a.nsplit;
   const int part_i = lane % LPT, slot = lane / LPT;
   // the query slices (q[g][part_i*8 .. +8)) are requested together with the position: one memory round trip, not two
   float qf[G][8];
 #pragma unroll
   for (int g = 0; g < G; g++) {
-    const f32x4* qp = reinterpret_cast<const f32x4*>(a.q + (size_t)(kvh * G + g) * HD + part_i * 8);
+    const f32x4* qp = reinterpret_cast<const f32x4*>(q_row + (size_t)(kvh * G + g) * HD + part_i * 8);
     const f32x4 q0 = qp[0], q1 = qp[1];
 #pragma unroll
     for (int j = 0; j < 4; j++) { qf[g][j] = q0[j]; qf[g][4 + j] = q1[j]; }
   }
-  const int n_keys = *a.pos + 1;
+  const int n_keys = a.pos[blockIdx.y] + 1;
   // token range of this split: a multiple of one full workgroup pass so that waves stay on whole wave-loads
   constexpr int STEP = 4 * TPW * UNR;
   int chunk = (n_keys + a.nsplit - 1) / a.nsplit;
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 
   if (t_begin >= n_keys) {   // this split has no keys at the current context length (wave-uniform): publish "empty"
     for (int g = threadIdx.x; g < G; g += 256) {
-      float* dst = a.part + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
+      float* dst = part_row + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
       dst[HD] = -INFINITY; dst[HD + 1] = 0.f;
     }
     return;
@@ -82,8 +88,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     for (int j = 0; j < 8; j++) o[g][j] = 0.f;
   }
 
-  const bf16_t* kbase = a.k_cache + (size_t)kvh * a.max_ctx * HD + part_i * 8;
-  const bf16_t* vbase = a.v_cache + (size_t)kvh * a.max_ctx * HD + part_i * 8;
+  const bf16_t* kbase = k_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
+  const bf16_t* vbase = v_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
   for (int t0 = t_begin + wv * TPW * UNR; t0 < t_end; t0 += STEP) {
     u32x4 kv[UNR], vv[UNR];
     bool valid[UNR];
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
       acc = fmaf(red[s2][g][d], sc, acc);
       if (d == 0) L = fmaf(red[s2][g][HD + 1], sc, L);
     }
-    float* dst = a.part + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
+    float* dst = part_row + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
     dst[d] = acc;
     if (d == 0) { dst[HD] = sm_M[g]; dst[HD + 1] = L; }
   }
@@ -171,7 +177,9 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnArgs a) {
   __shared__ float sm_m[32], sm_l[32];
   __shared__ float sm_o[SPB][HD + 4];
   const int h = blockIdx.x, tid = threadIdx.x;
-  const float* p = a.part + (size_t)h * a.nsplit * (HD + 4);
+  const float* part_row = a.part + blockIdx.y * a.part_stride;
+  float* out_row = a.out + blockIdx.y * a.q_stride;
+  const float* p = part_row + (size_t)h * a.nsplit * (HD + 4);
   __shared__ float sm_e[32];
   const int dg = tid % DG, sl = tid / DG;
   constexpr int NPASS = 32 / SPB;        // 1 (hd 64) or 2 (hd 128) passes cover the 32 possible splits
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnArgs a) {
     }
     __syncthreads();
   }
-  if (tid < HD) a.out[h * HD + tid] = acc / L;
+  if (tid < HD) out_row[h * HD + tid] = acc / L;
 }
 
 }  // namespace tgx

@@ -29,30 +29,34 @@ namespace tgx {
 enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
 enum { EPI_QKV_ROPE = 0, EPI_RESIDUAL = 1, EPI_SILU_MUL = 2, EPI_LOGITS = 3 };
 
+// Batch rows: R rows (1, 2 or 4) of independent sequences share ONE pass over the weights — every weight slice that
+// lands in a register is multiplied into R activation vectors (the reference runs the whole batch through each
+// nn::Linear as a [B,1,K] x [K,N] product).  Per-row buffers are slabs with a constant row stride.
 struct GemvArgs {
   const bf16_t* W;        // [N][K] row-major (torch Linear layout)
   const bf16_t* bias;     // [N] or nullptr
-  const float* x;         // [K] input activations (fp32 between ops)
+  const float* x;         // [R][x_stride] input activations (fp32 between ops)
   const bf16_t* norm_w;   // [K] RMSNorm weight (PRO_RMSNORM)
   float eps;
   int N, K;
   int units;              // number of row pairs
   int ks;                 // waves per unit (1, 2, 4)
+  long long x_stride, out_stride, q_stride, kv_stride, logits_stride, part_stride, kraw_stride;   // elements between batch rows
   // EPI_QKV_ROPE
-  float* q_out;           // [heads*hd] fp32
-  bf16_t* k_cache;        // this layer, this row: [kv_heads][max_ctx][hd]
+  float* q_out;           // [R][heads*hd] fp32
+  bf16_t* k_cache;        // this layer: [R][...kv_stride...]: [kv_heads][max_ctx][hd]
   bf16_t* v_cache;
   const float* rope_cos;  // [max_ctx][hd/2] fp32
   const float* rope_sin;
-  const int* pos;         // device-resident pastLength of this row
+  const int* pos;         // [R] device-resident pastLength of each row
   int heads, kv_heads, hd, max_ctx;
   int raw_qk;             // Qwen3 (q/k RMSNorm before RoPE): emit un-rotated q and k, qk_norm_rope_kernel finishes them
-  float* k_raw;           // [kv_heads*hd] fp32 staging for k when raw_qk
+  float* k_raw;           // [R][kv_heads*hd] fp32 staging for k when raw_qk
   // EPI_RESIDUAL: out[n] += acc;  EPI_SILU_MUL: out[i] = silu(g) * u      (fp32)
   float* out;
   // EPI_LOGITS
-  float* logits;          // [N] fp32
-  float* part_val;        // [gridDim.x] best logit of this workgroup
+  float* logits;          // [R][N] fp32
+  float* part_val;        // [R][gridDim.x] best logit of this workgroup
   int* part_idx;
 };
 
@@ -74,12 +78,12 @@ __device__ __forceinline__ void unit_rows(const GemvArgs& a, int u, int& ra, int
   }
 }
 
-template <int PRO, int EPI, int NX>
+template <int PRO, int EPI, int NX, int R>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
-  constexpr bool PIPE = NX <= 4;           // double-buffer the weight registers when they fit
-  __shared__ float ps[4][2];
-  __shared__ float sv[4];
-  __shared__ int si[4];
+  constexpr bool PIPE = NX * R <= 4;       // double-buffer the weight registers when the activations leave room
+  __shared__ float ps[4][2 * R];
+  __shared__ float sv[R][4];
+  __shared__ int si[R][4];
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int KS = a.ks, UPB = 4 / KS;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     cidx[j] = cok[j] ? c : max(c_end - 1, 0);    // clamped: always a legal slice of the row
   }
 
-  u32x4 wa[NX], wb[NX], na[NX], nb[NX];
+  u32x4 wa[NX], wb[NX], na[PIPE ? NX : 1], nb[PIPE ? NX : 1];
   auto load_unit = [&](int ub, u32x4* ta, u32x4* tb) {
     const int u = min(ub + slot, a.units - 1);
     int ra, rb; bool v;
@@ -114,27 +118,31 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   int ub = blockIdx.x * UPB;
   if (ub < a.units) load_unit(ub, wa, wb);
 
-  // 2. this wave's slice of the activation vector -> registers (zero outside the range)
-  float xr[NX][8];
-  {
-    const f32x4* xg = reinterpret_cast<const f32x4*>(a.x);
+  // 2. this wave's slice of every row's activation vector -> registers (zero outside the range)
+  float xr[R][NX][8];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const f32x4* xg = reinterpret_cast<const f32x4*>(a.x + (size_t)r * a.x_stride);
 #pragma unroll
     for (int j = 0; j < NX; j++) {
       f32x4 v0 = xg[2 * cidx[j]], v1 = xg[2 * cidx[j] + 1];
       if (!cok[j]) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
 #pragma unroll
-      for (int t = 0; t < 4; t++) { xr[j][t] = v0[t]; xr[j][4 + t] = v1[t]; }
+      for (int t = 0; t < 4; t++) { xr[r][j][t] = v0[t]; xr[r][j][4 + t] = v1[t]; }
     }
-    if (PRO == PRO_RMSNORM) {   // KS == 1: the wave holds all of x.  HF order: weight * (x * rsqrt(mean(x^2)+eps))
-      const u32x4* wg = reinterpret_cast<const u32x4*>(a.norm_w);
-      u32x4 nw[NX];
+  }
+  if (PRO == PRO_RMSNORM) {   // KS == 1: the wave holds all of x.  HF order: weight * (x * rsqrt(mean(x^2)+eps))
+    const u32x4* wg = reinterpret_cast<const u32x4*>(a.norm_w);
+    u32x4 nw[NX];
 #pragma unroll
-      for (int j = 0; j < NX; j++) nw[j] = wg[cidx[j]];        // in flight together with x
+    for (int j = 0; j < NX; j++) nw[j] = wg[cidx[j]];        // in flight together with x
+#pragma unroll
+    for (int r = 0; r < R; r++) {
       float ss = 0.f;
 #pragma unroll
       for (int j = 0; j < NX; j++)
 #pragma unroll
-        for (int t = 0; t < 8; t++) ss = fmaf(xr[j][t], xr[j][t], ss);
+        for (int t = 0; t < 8; t++) ss = fmaf(xr[r][j][t], xr[r][j][t], ss);
       ss = wave_sum(ss);
       const float inv = 1.0f / sqrtf(ss / (float)a.K + a.eps);
 #pragma unroll
@@ -142,17 +150,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         const u32x4 w = nw[j];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-          xr[j][2 * t] = bf16_lo(w[t]) * (xr[j][2 * t] * inv);
-          xr[j][2 * t + 1] = bf16_hi(w[t]) * (xr[j][2 * t + 1] * inv);
+          xr[r][j][2 * t] = bf16_lo(w[t]) * (xr[r][j][2 * t] * inv);
+          xr[r][j][2 * t + 1] = bf16_hi(w[t]) * (xr[r][j][2 * t + 1] * inv);
         }
       }
     }
   }
 
-  float best_val = -INFINITY;
-  int best_idx = 0x7fffffff;
-
-  const int pos = (EPI == EPI_QKV_ROPE) ? *a.pos : 0;
+  float best_val[R];
+  int best_idx[R];
+  int pos[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) { best_val[r] = -INFINITY; best_idx[r] = 0x7fffffff; pos[r] = (EPI == EPI_QKV_ROPE) ? a.pos[r] : 0; }
 
   for (; ub < a.units; ub += stride) {   // trip count uniform per workgroup
     const bool has_next = ub + stride < a.units;
@@ -162,76 +171,98 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     const int u = ub + slot;
     const bool writer = u < a.units && kpart == 0 && lane == 0;
     int ra = 0, rb = 0; bool rb_valid = false;
-    float e0 = 0.f, e1 = 0.f;          // RESIDUAL: x[ra], x[rb];  QKV_ROPE: cos, sin
+    float e0[R], e1[R];                // RESIDUAL: x[ra], x[rb];  QKV_ROPE: cos, sin
+#pragma unroll
+    for (int r = 0; r < R; r++) { e0[r] = 0.f; e1[r] = 0.f; }
     if (writer) {
       unit_rows<EPI>(a, u, ra, rb, rb_valid);
-      if (EPI == EPI_RESIDUAL) { e0 = a.out[ra]; e1 = a.out[rb]; }
-      if (EPI == EPI_QKV_ROPE) {
-        const int half = a.hd >> 1;
-        const int p = u % half;
-        e0 = a.rope_cos[(size_t)pos * half + p]; e1 = a.rope_sin[(size_t)pos * half + p];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (EPI == EPI_RESIDUAL) { const float* o = a.out + (size_t)r * a.out_stride; e0[r] = o[ra]; e1[r] = o[rb]; }
+        if (EPI == EPI_QKV_ROPE) {
+          const int half = a.hd >> 1;
+          const int p = u % half;
+          e0[r] = a.rope_cos[(size_t)pos[r] * half + p]; e1[r] = a.rope_sin[(size_t)pos[r] * half + p];
+        }
       }
     }
 
-    float acc_a0 = 0.f, acc_b0 = 0.f, acc_a1 = 0.f, acc_b1 = 0.f;
+    float sa[R], sb[R];
 #pragma unroll
-    for (int j = 0; j < NX; j++) {
-      const f32x4 xa = f32x4{xr[j][0], xr[j][1], xr[j][2], xr[j][3]};
-      const f32x4 xb = f32x4{xr[j][4], xr[j][5], xr[j][6], xr[j][7]};
-      if (j & 1) { acc_a1 = dot8(acc_a1, wa[j], xa, xb); acc_b1 = dot8(acc_b1, wb[j], xa, xb); }
-      else       { acc_a0 = dot8(acc_a0, wa[j], xa, xb); acc_b0 = dot8(acc_b0, wb[j], xa, xb); }
+    for (int r = 0; r < R; r++) {
+      float acc_a0 = 0.f, acc_b0 = 0.f, acc_a1 = 0.f, acc_b1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NX; j++) {
+        const f32x4 xa = f32x4{xr[r][j][0], xr[r][j][1], xr[r][j][2], xr[r][j][3]};
+        const f32x4 xb = f32x4{xr[r][j][4], xr[r][j][5], xr[r][j][6], xr[r][j][7]};
+        if (j & 1) { acc_a1 = dot8(acc_a1, wa[j], xa, xb); acc_b1 = dot8(acc_b1, wb[j], xa, xb); }
+        else       { acc_a0 = dot8(acc_a0, wa[j], xa, xb); acc_b0 = dot8(acc_b0, wb[j], xa, xb); }
+      }
+      sa[r] = wave_sum(acc_a0 + acc_a1);
+      sb[r] = wave_sum(acc_b0 + acc_b1);
     }
-    float sa = wave_sum(acc_a0 + acc_a1);
-    float sb = wave_sum(acc_b0 + acc_b1);
 
     if (KS > 1) {   // fixed-order sum of the KS k-part partials through LDS
       __syncthreads();             // previous iteration's readers are done
-      if (lane == 0) { ps[wv][0] = sa; ps[wv][1] = sb; }
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) { ps[wv][2 * r] = sa[r]; ps[wv][2 * r + 1] = sb[r]; }
+      }
       __syncthreads();
       if (kpart == 0) {
-        sa = ps[slot * KS][0]; sb = ps[slot * KS][1];
-        for (int k = 1; k < KS; k++) { sa += ps[slot * KS + k][0]; sb += ps[slot * KS + k][1]; }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          sa[r] = ps[slot * KS][2 * r]; sb[r] = ps[slot * KS][2 * r + 1];
+          for (int k = 1; k < KS; k++) { sa[r] += ps[slot * KS + k][2 * r]; sb[r] += ps[slot * KS + k][2 * r + 1]; }
+        }
       }
     }
 
     if (writer) {
-      if (EPI == EPI_LOGITS) {
-        a.logits[ra] = sa;
-        if (sa > best_val) { best_val = sa; best_idx = ra; }     // rows ascend within a wave: '>' keeps the first
-        if (rb_valid) {
-          a.logits[rb] = sb;
-          if (sb > best_val) { best_val = sb; best_idx = rb; }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        float va = sa[r], vb = sb[r];
+        if (EPI == EPI_LOGITS) {
+          float* lg = a.logits + (size_t)r * a.logits_stride;
+          lg[ra] = va;
+          if (va > best_val[r]) { best_val[r] = va; best_idx[r] = ra; }     // rows ascend within a wave: '>' keeps the first
+          if (rb_valid) {
+            lg[rb] = vb;
+            if (vb > best_val[r]) { best_val[r] = vb; best_idx[r] = rb; }
+          }
+          continue;
         }
-      } else {
-        if (a.bias) { sa += bf16_to_f32(a.bias[ra]); sb += bf16_to_f32(a.bias[rb]); }
+        if (a.bias) { va += bf16_to_f32(a.bias[ra]); vb += bf16_to_f32(a.bias[rb]); }
         if (EPI == EPI_QKV_ROPE) {
           const int half = a.hd >> 1;
           const int hh = u / half, p = u - hh * half;
-          if (a.raw_qk && hh >= a.heads && hh < a.heads + a.kv_heads) {
-            a.k_raw[(hh - a.heads) * a.hd + p] = sa;
-            a.k_raw[(hh - a.heads) * a.hd + p + half] = sb;
-          } else
-          if (!a.raw_qk && hh < a.heads + a.kv_heads) {   // q or k head: rotate-half RoPE at absolute position pos
-            const float cs = e0, sn = e1;
-            const float ra_ = sa * cs - sb * sn;
-            const float rb_ = sb * cs + sa * sn;
-            sa = ra_; sb = rb_;
+          const bool is_q = hh < a.heads, is_k = !is_q && hh < a.heads + a.kv_heads;
+          if (a.raw_qk && is_k) {   // Qwen3: qk_norm_rope_kernel normalises, rotates and appends k
+            float* kr = a.k_raw + (size_t)r * a.kraw_stride + (hh - a.heads) * a.hd;
+            kr[p] = va; kr[p + half] = vb;
+            continue;
           }
-          if (hh < a.heads) {
-            a.q_out[hh * a.hd + p] = sa;
-            a.q_out[hh * a.hd + p + half] = sb;
-          } else if (!(a.raw_qk && hh < a.heads + a.kv_heads)) {   // KVCacheManager::append: this position's K / V row, stored in bf16
-            bf16_t* dst = (hh < a.heads + a.kv_heads)
-                              ? a.k_cache + ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd
-                              : a.v_cache + ((size_t)(hh - a.heads - a.kv_heads) * a.max_ctx + pos) * a.hd;
-            dst[p] = f32_to_bf16(sa);
-            dst[p + half] = f32_to_bf16(sb);
+          if (!a.raw_qk && (is_q || is_k)) {   // rotate-half RoPE at absolute position pos
+            const float cs = e0[r], sn = e1[r];
+            const float ra_ = va * cs - vb * sn;
+            const float rb_ = vb * cs + va * sn;
+            va = ra_; vb = rb_;
+          }
+          if (is_q) {
+            float* q = a.q_out + (size_t)r * a.q_stride + hh * a.hd;
+            q[p] = va; q[p + half] = vb;
+          } else {   // KVCacheManager::append: this position's K / V row, stored in bf16
+            bf16_t* dst = (is_k ? a.k_cache + ((size_t)(hh - a.heads) * a.max_ctx + pos[r]) * a.hd
+                                : a.v_cache + ((size_t)(hh - a.heads - a.kv_heads) * a.max_ctx + pos[r]) * a.hd) + (size_t)r * a.kv_stride;
+            dst[p] = f32_to_bf16(va);
+            dst[p + half] = f32_to_bf16(vb);
           }
         } else if (EPI == EPI_RESIDUAL) {
-          a.out[ra] = e0 + sa;
-          if (rb_valid) a.out[rb] = e1 + sb;
+          float* o = a.out + (size_t)r * a.out_stride;
+          o[ra] = e0[r] + va;
+          if (rb_valid) o[rb] = e1[r] + vb;
         } else if (EPI == EPI_SILU_MUL) {
-          a.out[u] = (sa / (1.0f + expf(-sa))) * sb;
+          a.out[(size_t)r * a.out_stride + u] = (va / (1.0f + expf(-va))) * vb;
         }
       }
     }
@@ -245,15 +276,19 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   }
 
   if (EPI == EPI_LOGITS) {
-    // workgroup argmax, ties -> lowest index (== argmax(logits, -1), Sampler.cpp:28)
-    if (lane == 0) { sv[wv] = best_val; si[wv] = best_idx; }
+    // workgroup argmax per batch row, ties -> lowest index (== argmax(logits, -1), Sampler.cpp:28)
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; r++) { sv[r][wv] = best_val[r]; si[r][wv] = best_idx[r]; }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      float bv = sv[0]; int bi = si[0];
+    if (threadIdx.x < R) {
+      const int r = threadIdx.x;
+      float bv = sv[r][0]; int bi = si[r][0];
       for (int w = 1; w < 4; w++)
-        if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
-      a.part_val[blockIdx.x] = bv;
-      a.part_idx[blockIdx.x] = bi;
+        if (sv[r][w] > bv || (sv[r][w] == bv && si[r][w] < bi)) { bv = sv[r][w]; bi = si[r][w]; }
+      a.part_val[(size_t)r * a.part_stride + blockIdx.x] = bv;
+      a.part_idx[(size_t)r * a.part_stride + blockIdx.x] = bi;
     }
   }
 }

@@ -78,7 +78,13 @@ struct tgx_ctx {
   bool embed_ok = false, lm_head_ok = false, final_norm_ok = false;
   std::vector<LayerW> L;
   float *rope_cos = nullptr, *rope_sin = nullptr;
-  std::vector<RowState> rows;
+  std::vector<RowState> rows;   // views into the per-row slabs below (constant row stride: batched GEMV walks them)
+  float *slab_x = nullptr, *slab_q = nullptr, *slab_kraw = nullptr, *slab_attn = nullptr, *slab_h = nullptr, *slab_logits = nullptr;
+  float *slab_work = nullptr, *slab_probs = nullptr, *slab_part_val = nullptr, *slab_attn_part = nullptr;
+  int *slab_part_idx = nullptr, *slab_tok = nullptr, *slab_pos = nullptr;
+  long long* slab_prompt = nullptr;
+  bf16_t *slab_k = nullptr, *slab_v = nullptr;
+  size_t kv_row_elems = 0, attn_part_row = 0;
 
   int64_t past = 0;       // host mirror of every row's device-resident pos
   int batch = 0;          // rows used by the last forward
@@ -240,30 +246,33 @@ int gemv_auto_ks(int K, int want) {
 }
 
 template <int PRO, int EPI, int NX>
-void launch_gemv_nx(tgx_ctx* c, const tgx::GemvArgs& a, int grid) {
-  hipLaunchKernelGGL((tgx::gemv_kernel<PRO, EPI, NX>), dim3(grid), dim3(256), 0, c->stream, a);
+void launch_gemv_nx(tgx_ctx* c, const tgx::GemvArgs& a, int grid, int R) {
+  const dim3 g(grid), b(256);
+  if (R == 4) hipLaunchKernelGGL((tgx::gemv_kernel<PRO, EPI, NX, 4>), g, b, 0, c->stream, a);
+  else if (R == 2) hipLaunchKernelGGL((tgx::gemv_kernel<PRO, EPI, NX, 2>), g, b, 0, c->stream, a);
+  else hipLaunchKernelGGL((tgx::gemv_kernel<PRO, EPI, NX, 1>), g, b, 0, c->stream, a);
 }
 
 template <int PRO, int EPI>
-void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls) {
+void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls, int R) {
   const Tune& tn = c->tune[cls];
   a.ks = (PRO == tgx::PRO_RMSNORM) ? 1 : gemv_auto_ks(a.K, tn.ks);
   const int grid = (EPI == tgx::EPI_LOGITS) ? c->lm_grid : gemv_grid(c, a.units, a.ks, tn.bpc);
   switch (gemv_nx(a.K, a.ks)) {
-    case 1: launch_gemv_nx<PRO, EPI, 1>(c, a, grid); break;
-    case 2: launch_gemv_nx<PRO, EPI, 2>(c, a, grid); break;
-    case 3: launch_gemv_nx<PRO, EPI, 3>(c, a, grid); break;
-    case 4: launch_gemv_nx<PRO, EPI, 4>(c, a, grid); break;
-    case 5: launch_gemv_nx<PRO, EPI, 5>(c, a, grid); break;
-    case 6: launch_gemv_nx<PRO, EPI, 6>(c, a, grid); break;
-    case 7: launch_gemv_nx<PRO, EPI, 7>(c, a, grid); break;
-    default: launch_gemv_nx<PRO, EPI, 8>(c, a, grid); break;
+    case 1: launch_gemv_nx<PRO, EPI, 1>(c, a, grid, R); break;
+    case 2: launch_gemv_nx<PRO, EPI, 2>(c, a, grid, R); break;
+    case 3: launch_gemv_nx<PRO, EPI, 3>(c, a, grid, R); break;
+    case 4: launch_gemv_nx<PRO, EPI, 4>(c, a, grid, R); break;
+    case 5: launch_gemv_nx<PRO, EPI, 5>(c, a, grid, R); break;
+    case 6: launch_gemv_nx<PRO, EPI, 6>(c, a, grid, R); break;
+    case 7: launch_gemv_nx<PRO, EPI, 7>(c, a, grid, R); break;
+    default: launch_gemv_nx<PRO, EPI, 8>(c, a, grid, R); break;
   }
 }
 
 template <int HD>
-void launch_attn_g(tgx_ctx* c, const tgx::AttnArgs& a, int G) {
-  const dim3 grid(a.kv_heads * a.nsplit), blk(256);
+void launch_attn_g(tgx_ctx* c, const tgx::AttnArgs& a, int G, int R) {
+  const dim3 grid(a.kv_heads * a.nsplit, R), blk(256);
   if (!(c->debug_skip & 1)) switch (G) {
     case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 1>), grid, blk, 0, c->stream, a); break;
     case 2: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 2>), grid, blk, 0, c->stream, a); break;
@@ -274,78 +283,92 @@ void launch_attn_g(tgx_ctx* c, const tgx::AttnArgs& a, int G) {
     case 7: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 7>), grid, blk, 0, c->stream, a); break;
     default: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 8>), grid, blk, 0, c->stream, a); break;
   }
-  if (!(c->debug_skip & 2)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads), dim3(256), 0, c->stream, a);
+  if (!(c->debug_skip & 2)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
 }
 
-void launch_attn(tgx_ctx* c, const tgx::AttnArgs& a) {
+void launch_attn(tgx_ctx* c, const tgx::AttnArgs& a, int R) {
   const int G = a.heads / a.kv_heads;
-  if (c->d.head_dim == 64) launch_attn_g<64>(c, a, G);
-  else launch_attn_g<128>(c, a, G);
+  if (c->d.head_dim == 64) launch_attn_g<64>(c, a, G, R);
+  else launch_attn_g<128>(c, a, G, R);
 }
 
-// One kernel class of one decoder layer.  `resid` is the residual stream the o_proj/down epilogues update
-// (row.x in the real pass; a scratch vector when tgx_profile_decode replays a class in isolation).
-void launch_layer_kernel(tgx_ctx* c, RowState& r, int l, int cls, float* resid) {
+void fill_strides(const tgx_ctx* c, tgx::GemvArgs& a) {
   const tgx_model_desc& d = c->d;
+  a.x_stride = 0; a.out_stride = 0;       // set per call site (x and out come from different slabs)
+  a.q_stride = (long long)d.heads * d.head_dim; a.kraw_stride = (long long)d.kv_heads * d.head_dim;
+  a.kv_stride = (long long)c->kv_row_elems; a.logits_stride = d.vocab; a.part_stride = c->lm_grid;
+}
+
+// One kernel class of one decoder layer for batch rows [row0, row0+R).  `resid` is the residual stream of row0 that the
+// o_proj/down epilogues update (slab_x in the real pass; a scratch vector when tgx_profile_decode replays a class).
+void launch_layer_kernel(tgx_ctx* c, int row0, int R, int l, int cls, float* resid) {
+  const tgx_model_desc& d = c->d;
+  RowState& r = c->rows[(size_t)row0];
   const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
   const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd;
   const LayerW& w = c->L[(size_t)l];
   switch (cls) {
     case TGX_KERNEL_QKV: {   // input_layernorm -> qkv_proj -> RoPE -> cache append   (DecoderLayer.h:40, Attention.h:94-106)
       tgx::GemvArgs a{};
-      a.W = w.wqkv; a.bias = w.bqkv; a.x = r.x; a.norm_w = w.in_norm; a.eps = d.norm_eps;
+      fill_strides(c, a);
+      a.W = w.wqkv; a.bias = w.bqkv; a.x = r.x; a.x_stride = H; a.norm_w = w.in_norm; a.eps = d.norm_eps;
       a.N = qd + 2 * kvd; a.K = H; a.units = a.N / 2;
       a.q_out = r.q; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos = r.pos;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx;
       a.raw_qk = d.qk_norm ? 1 : 0; a.k_raw = r.k_raw;
-      launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_QKV_ROPE>(c, a, TGX_KERNEL_QKV);
-      if (d.qk_norm) {   // q_norm / k_norm -> RoPE -> cache append (Attention.h:156-163)
+      launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_QKV_ROPE>(c, a, TGX_KERNEL_QKV, R);
+      if (d.qk_norm) for (int b = 0; b < R; b++) {   // q_norm / k_norm -> RoPE -> cache append (Attention.h:156-163)
+        RowState& rb = c->rows[(size_t)(row0 + b)];
         tgx::QkNormArgs n{};
-        n.q = r.q; n.k_raw = r.k_raw; n.k_cache = a.k_cache; n.q_norm_w = w.q_norm; n.k_norm_w = w.k_norm;
-        n.rope_cos = c->rope_cos; n.rope_sin = c->rope_sin; n.pos = r.pos;
+        n.q = rb.q; n.k_raw = rb.k_raw; n.k_cache = rb.kcache + (size_t)l * kv_layer; n.q_norm_w = w.q_norm; n.k_norm_w = w.k_norm;
+        n.rope_cos = c->rope_cos; n.rope_sin = c->rope_sin; n.pos = rb.pos;
         n.heads = d.heads; n.kv_heads = d.kv_heads; n.hd = hd; n.max_ctx = d.max_ctx; n.eps = d.norm_eps;
         hipLaunchKernelGGL(tgx::qk_norm_rope_kernel, dim3(d.heads + d.kv_heads), dim3(64), 0, c->stream, n);
       }
       break;
     }
-    case TGX_KERNEL_ATTN: {  // flashAttention(q, Kall, Vall) over keys [0, pos]       (Attention.h:108-111)
+    case TGX_KERNEL_ATTN: {  // flashAttention(q, Kall, Vall) over keys [0, pos[row]]; blockIdx.y = batch row (own cache, own length)
       tgx::AttnArgs a{};
       a.q = r.q; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
       a.pos = r.pos; a.part = r.attn_part; a.out = r.attn;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
       a.scale = 1.0f / sqrtf((float)hd);
-      launch_attn(c, a);
+      a.q_stride = qd; a.kv_stride = (long long)c->kv_row_elems; a.part_stride = (long long)c->attn_part_row;
+      launch_attn(c, a, R);
       break;
     }
     case TGX_KERNEL_OPROJ: { // o_proj + residual                                     (Attention.h:90, DecoderLayer.h:40)
       tgx::GemvArgs a{};
-      a.W = w.wo; a.x = r.attn; a.N = H; a.K = qd; a.units = (H + 1) / 2; a.out = resid; a.hd = 2;
-      launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_OPROJ);
+      fill_strides(c, a);
+      a.W = w.wo; a.x = r.attn; a.x_stride = qd; a.N = H; a.K = qd; a.units = (H + 1) / 2; a.out = resid; a.out_stride = H; a.hd = 2;
+      launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_OPROJ, R);
       break;
     }
     case TGX_KERNEL_GATEUP: { // post_attention_layernorm -> gate_up_proj -> siluMul  (DecoderLayer.h:41, GatedMLP.h:37-39)
       tgx::GemvArgs a{};
-      a.W = w.wgu; a.x = r.x; a.norm_w = w.post_norm; a.eps = d.norm_eps;
-      a.N = 2 * I; a.K = H; a.units = I; a.out = r.h; a.hd = 2;
-      launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_SILU_MUL>(c, a, TGX_KERNEL_GATEUP);
+      fill_strides(c, a);
+      a.W = w.wgu; a.x = r.x; a.x_stride = H; a.norm_w = w.post_norm; a.eps = d.norm_eps;
+      a.N = 2 * I; a.K = H; a.units = I; a.out = r.h; a.out_stride = I; a.hd = 2;
+      launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_SILU_MUL>(c, a, TGX_KERNEL_GATEUP, R);
       break;
     }
     case TGX_KERNEL_DOWN: {  // down_proj + residual                                  (GatedMLP.h:40, DecoderLayer.h:41)
       tgx::GemvArgs a{};
-      a.W = w.wdown; a.x = r.h; a.N = H; a.K = I; a.units = (H + 1) / 2; a.out = resid; a.hd = 2;
-      launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_DOWN);
+      fill_strides(c, a);
+      a.W = w.wdown; a.x = r.h; a.x_stride = I; a.N = H; a.K = I; a.units = (H + 1) / 2; a.out = resid; a.out_stride = H; a.hd = 2;
+      launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_DOWN, R);
       break;
     }
     default: break;
   }
 }
 
-// All decoder layers for the token whose embedding sits in row.x, at position *row.pos.
+// All decoder layers for rows [row0, row0+R): their current tokens' embeddings sit in slab_x, positions in slab_pos.
 // == for (auto& layer : layers_) x = layer->forward(x)  (GPTModel.h:53-55)
-void launch_layers(tgx_ctx* c, RowState& r) {
+void launch_layers(tgx_ctx* c, int row0, int R) {
   for (int l = 0; l < c->d.layers; l++) {
-    for (int cls = TGX_KERNEL_QKV; cls <= TGX_KERNEL_DOWN; cls++) launch_layer_kernel(c, r, l, cls, r.x);
+    for (int cls = TGX_KERNEL_QKV; cls <= TGX_KERNEL_DOWN; cls++) launch_layer_kernel(c, row0, R, l, cls, c->rows[(size_t)row0].x);
     for (int i = 0; i < c->debug_nops; i++) hipLaunchKernelGGL(tgx::nop_kernel, dim3(1), dim3(64), 0, c->stream, c->nop_word);
   }
 }
@@ -426,13 +449,15 @@ void launch_prefill(tgx_ctx* c, RowState& r, int S) {
 }
 
 // model.norm -> lm_head on the current position + per-workgroup argmax partials   (GPTModel.h:56-57)
-void launch_lm_head(tgx_ctx* c, RowState& r) {
+void launch_lm_head(tgx_ctx* c, int row0, int R) {
   const tgx_model_desc& d = c->d;
+  RowState& r = c->rows[(size_t)row0];
   tgx::GemvArgs a{};
-  a.W = d.tied ? c->embed : c->lm_head; a.x = r.x; a.norm_w = c->final_norm; a.eps = d.norm_eps;
+  fill_strides(c, a);
+  a.W = d.tied ? c->embed : c->lm_head; a.x = r.x; a.x_stride = d.hidden; a.norm_w = c->final_norm; a.eps = d.norm_eps;
   a.N = d.vocab; a.K = d.hidden; a.units = (d.vocab + 1) / 2; a.hd = 2;
   a.logits = r.logits; a.part_val = r.part_val; a.part_idx = r.part_idx;
-  launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_LOGITS>(c, a, TGX_KERNEL_LMHEAD);
+  launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_LOGITS>(c, a, TGX_KERNEL_LMHEAD, R);
 }
 
 bool is_greedy(const tgx_sampler_cfg* s) {   // Sampler.cpp:15-21
@@ -470,11 +495,13 @@ void launch_sample(tgx_ctx* c, int row, const tgx_sampler_cfg& cfg, bool advance
 // One decode step for all active rows: layers at pos, lm_head, then {sample, pos+=1, next embedding}.
 // == nextToken = genNextToken(nextToken)  (GPTEngine.cpp:94-99,165-168)
 void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
-  for (int b = 0; b < c->batch; b++) {
-    RowState& r = c->rows[(size_t)b];
-    launch_layers(c, r);
-    launch_lm_head(c, r);
-    launch_sample(c, b, cfg, /*advance_pos=*/true, /*log_step=*/true);
+  // batch rows share each pass over the weights in groups of 4 / 2 / 1 (the batched GEMV's R template)
+  for (int row0 = 0; row0 < c->batch;) {
+    const int rem = c->batch - row0, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
+    launch_layers(c, row0, R);
+    launch_lm_head(c, row0, R);
+    for (int b = row0; b < row0 + R; b++) launch_sample(c, b, cfg, /*advance_pos=*/true, /*log_step=*/true);
+    row0 += R;
   }
 }
 
@@ -697,28 +724,38 @@ int tgx_finalize(tgx_ctx* c) {
   if (c->attn_nsplit_opt > 0) c->attn_nsplit = c->attn_nsplit_opt;
 
   c->rows.resize((size_t)d.max_batch);
+  const size_t B = (size_t)d.max_batch;
   const size_t kv_elems = (size_t)d.layers * d.kv_heads * d.max_ctx * hd;
-  for (auto& r : c->rows) {
-    if ((rc = dev_alloc(c, &r.x, (size_t)H))) return rc;
-    if ((rc = dev_alloc(c, &r.q, (size_t)qd))) return rc;
-    if ((rc = dev_alloc(c, &r.k_raw, (size_t)kvd))) return rc;
-    if ((rc = dev_alloc(c, &r.attn, (size_t)qd))) return rc;
-    if ((rc = dev_alloc(c, &r.h, (size_t)I))) return rc;
-    if ((rc = dev_alloc(c, &r.logits, (size_t)V))) return rc;
-    if ((rc = dev_alloc(c, &r.work, (size_t)V))) return rc;
-    if ((rc = dev_alloc(c, &r.probs, (size_t)V))) return rc;
-    if ((rc = dev_alloc(c, &r.part_val, (size_t)c->lm_grid))) return rc;
-    if ((rc = dev_alloc(c, &r.part_idx, (size_t)c->lm_grid))) return rc;
-    if ((rc = dev_alloc(c, &r.attn_part, (size_t)d.heads * c->attn_nsplit * (hd + 4)))) return rc;
-    if ((rc = dev_alloc(c, &r.tok, 1))) return rc;
-    if ((rc = dev_alloc(c, &r.pos, 1))) return rc;
-    if ((rc = dev_alloc(c, &r.prompt, (size_t)d.max_ctx))) return rc;
-    if ((rc = dev_alloc(c, &r.kcache, kv_elems))) return rc;
-    if ((rc = dev_alloc(c, &r.vcache, kv_elems))) return rc;
-    HIP_OK(c, hipMemset(r.tok, 0, 4));
-    HIP_OK(c, hipMemset(r.pos, 0, 4));
-    HIP_OK(c, hipMemset(r.kcache, 0, kv_elems * 2));
-    HIP_OK(c, hipMemset(r.vcache, 0, kv_elems * 2));
+  c->kv_row_elems = kv_elems;
+  c->attn_part_row = (size_t)d.heads * c->attn_nsplit * (hd + 4);
+  if ((rc = dev_alloc(c, &c->slab_x, B * H))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_q, B * qd))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_kraw, B * kvd))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_attn, B * qd))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_h, B * I))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_logits, B * V))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_work, B * V))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_probs, B * V))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_part_val, B * c->lm_grid))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_part_idx, B * c->lm_grid))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_attn_part, B * c->attn_part_row))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_tok, B))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_pos, B))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_prompt, B * d.max_ctx))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_k, B * kv_elems))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_v, B * kv_elems))) return rc;
+  HIP_OK(c, hipMemset(c->slab_tok, 0, B * 4));
+  HIP_OK(c, hipMemset(c->slab_pos, 0, B * 4));
+  HIP_OK(c, hipMemset(c->slab_k, 0, B * kv_elems * 2));
+  HIP_OK(c, hipMemset(c->slab_v, 0, B * kv_elems * 2));
+  for (size_t b = 0; b < B; b++) {
+    RowState& r = c->rows[b];
+    r.x = c->slab_x + b * H; r.q = c->slab_q + b * qd; r.k_raw = c->slab_kraw + b * kvd; r.attn = c->slab_attn + b * qd;
+    r.h = c->slab_h + b * I; r.logits = c->slab_logits + b * V; r.work = c->slab_work + b * V; r.probs = c->slab_probs + b * V;
+    r.part_val = c->slab_part_val + b * c->lm_grid; r.part_idx = c->slab_part_idx + b * c->lm_grid;
+    r.attn_part = c->slab_attn_part + b * c->attn_part_row;
+    r.tok = c->slab_tok + b; r.pos = c->slab_pos + b; r.prompt = c->slab_prompt + b * d.max_ctx;
+    r.kcache = c->slab_k + b * kv_elems; r.vcache = c->slab_v + b * kv_elems;
   }
   c->log_cap = d.max_ctx > 1024 ? d.max_ctx : 1024;
   if ((rc = dev_alloc(c, &c->step, 1))) return rc;
@@ -751,10 +788,8 @@ void tgx_destroy(tgx_ctx* c) {
   fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x); fr(c->seed_dev);
   fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); }
-  for (auto& r : c->rows) {
-    fr(r.x); fr(r.q); fr(r.k_raw); fr(r.attn); fr(r.h); fr(r.logits); fr(r.work); fr(r.probs); fr(r.part_val); fr(r.part_idx); fr(r.attn_part);
-    fr(r.tok); fr(r.pos); fr(r.prompt); fr(r.kcache); fr(r.vcache);
-  }
+  fr(c->slab_x); fr(c->slab_q); fr(c->slab_kraw); fr(c->slab_attn); fr(c->slab_h); fr(c->slab_logits); fr(c->slab_work); fr(c->slab_probs);
+  fr(c->slab_part_val); fr(c->slab_part_idx); fr(c->slab_attn_part); fr(c->slab_tok); fr(c->slab_pos); fr(c->slab_prompt); fr(c->slab_k); fr(c->slab_v);
   if (c->host_ring) (void)hipHostFree(c->host_ring);
   for (auto& e : c->ticket_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->prof.ev) if (e) (void)hipEventDestroy(e);
@@ -780,7 +815,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
       int rc = ensure_prefill_ws(c, seq);
       if (rc) return rc;
       launch_prefill(c, r, seq);
-      launch_lm_head(c, r);
+      launch_lm_head(c, b, 1);
       hipLaunchKernelGGL(tgx::add_pos_kernel, dim3(1), dim3(64), 0, c->stream, r.pos, seq);
       continue;
     }
@@ -789,8 +824,8 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     e.ids = r.prompt; e.pos = r.pos; e.pos0 = (int)c->past; e.embed = c->embed; e.x = r.x; e.H = c->d.hidden; e.V = c->d.vocab; e.tok = r.tok;
     for (int s = 0; s < seq; s++) {
       hipLaunchKernelGGL(tgx::embed_prompt_kernel, dim3(1), dim3(256), 0, c->stream, e);
-      launch_layers(c, r);
-      if (s == seq - 1) launch_lm_head(c, r);
+      launch_layers(c, b, 1);
+      if (s == seq - 1) launch_lm_head(c, b, 1);
       hipLaunchKernelGGL(tgx::advance_pos_kernel, dim3(1), dim3(64), 0, c->stream, r.pos);
     }
   }
@@ -933,7 +968,6 @@ int tgx_profile_decode(tgx_ctx* c, int n_reps, int64_t* launches, double* total_
   if (c->past + 1 > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded");
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipStreamSynchronize(c->stream));
-  RowState& r = c->rows[0];
   for (int i = 0; i < TGX_KERNEL_COUNT; i++) { launches[i] = 0; total_ms[i] = 0.0; }
   // Each class is launched back-to-back over all layers (every launch streams a different layer's weights, so
   // nothing is served from the Infinity Cache) between two events on the launch stream.  The residual
@@ -942,8 +976,8 @@ int tgx_profile_decode(tgx_ctx* c, int n_reps, int64_t* launches, double* total_
     for (int cls = 0; cls < TGX_KERNEL_COUNT; cls++) {
       HIP_OK(c, hipEventRecord(c->prof.ev[0], c->stream));
       int n = 0;
-      if (cls == TGX_KERNEL_LMHEAD) { launch_lm_head(c, r); n = 1; }
-      else for (int l = 0; l < c->d.layers; l++, n++) launch_layer_kernel(c, r, c->prof_same_layer ? 0 : l, cls, c->scratch_x);
+      if (cls == TGX_KERNEL_LMHEAD) { launch_lm_head(c, 0, 1); n = 1; }
+      else for (int l = 0; l < c->d.layers; l++, n++) launch_layer_kernel(c, 0, 1, c->prof_same_layer ? 0 : l, cls, c->scratch_x);
       HIP_OK(c, hipEventRecord(c->prof.ev[1], c->stream));
       HIP_OK(c, hipEventSynchronize(c->prof.ev[1]));
       float ms = 0.f;

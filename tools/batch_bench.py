@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Decode rate vs batch size (rows share each weight pass through the batched GEMV): aggregate tokens/s for B = 1, 2, 4, 8.
+
+    python tools/batch_bench.py [--model llama-3.2-1b] [--prompt 512] [--steps 128]
+"""
+import argparse, dataclasses, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tinygpt_amd import known_desc, synth
+from tinygpt_amd.ffi import GREEDY, Model, product_backend
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="llama-3.2-1b")
+ap.add_argument("--prompt", type=int, default=512)
+ap.add_argument("--steps", type=int, default=128)
+ap.add_argument("--batches", default="1,2,4,8")
+args = ap.parse_args()
+batches = [int(b) for b in args.batches.split(",")]
+desc = dataclasses.replace(known_desc(args.model), max_batch=max(batches), max_ctx=args.prompt + 2 * args.steps + 64)
+m = Model(desc, product_backend())
+for name, bits in synth.synth_checkpoint(desc, 1234, 0.02):
+    m.upload(name, bits)
+m.finalize()
+for B in batches:
+    m.reset_cache()
+    ids = np.stack([synth.synth_prompt(desc.vocab, args.prompt, 77 + b) for b in range(B)])
+    m.forward(ids); m.sample(GREEDY)
+    m.decode(16, GREEDY, fetch=False); m.synchronize()
+    t0 = time.perf_counter(); m.decode(args.steps, GREEDY, fetch=False); m.synchronize(); dt = time.perf_counter() - t0
+    print(f"B={B}: {dt / args.steps * 1e3:.3f} ms/step, {B * args.steps / dt:.0f} tokens/s aggregate", flush=True)
