@@ -50,7 +50,20 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   float* part_row = a.part + blockIdx.y * a.part_stride;
   const int kvh = blockIdx.x / a.nsplit, sp = blockIdx.x - kvh * a.nsplit;
   const int part_i = lane % LPT, slot = lane / LPT;
-  // the query slices (q[g][part_i*8 .. +8)) are requested together with the position: one memory round trip, not two
+  // Token blocks of STEP = 4 waves x UNR wave-loads are dealt round-robin to the splits: split sp owns blocks sp,
+  // sp + nsplit, ...: the active splits are the first ceil(n_keys / STEP) of every kv head and each runs whole blocks;
+  // the addresses of a split's first block do not depend on the context length.
+  constexpr int STEP = 4 * TPW * UNR;
+  const bf16_t* kbase = k_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
+  const bf16_t* vbase = v_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
+  int t0 = sp * STEP + wv * TPW * UNR;
+  u32x4 kv[UNR], vv[UNR];
+#pragma unroll
+  for (int r = 0; r < UNR; r++) {
+    const int tc = min(t0 + r * TPW + slot, a.max_ctx - 1);
+    kv[r] = *reinterpret_cast<const u32x4*>(kbase + (size_t)tc * HD);
+    vv[r] = *reinterpret_cast<const u32x4*>(vbase + (size_t)tc * HD);
+  }
   float qf[G][8];
 #pragma unroll
   for (int g = 0; g < G; g++) {
@@ -60,15 +73,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     for (int j = 0; j < 4; j++) { qf[g][j] = q0[j]; qf[g][4 + j] = q1[j]; }
   }
   const int n_keys = a.pos[blockIdx.y] + 1;
-  // token range of this split: a multiple of one full workgroup pass so that waves stay on whole wave-loads
-  constexpr int STEP = 4 * TPW * UNR;
-  int chunk = (n_keys + a.nsplit - 1) / a.nsplit;
-  chunk = ((chunk + STEP - 1) / STEP) * STEP;
-  const int t_begin = sp * chunk;
-  const int t_end = min(n_keys, t_begin + chunk);
   const float qscale = a.scale * LOG2E;     // softmax in base 2: exp(x) = exp2(x * log2 e)
 
-  if (t_begin >= n_keys) {   // this split has no keys at the current context length (wave-uniform): publish "empty"
+  if (sp * STEP >= n_keys) {   // this split has no keys at the current context length (workgroup-uniform): publish "empty"
+    // (the compiler sinks the loads above below this branch; running empty splits through the masked path instead keeps
+    //  them ahead of the position load but measured 1262 vs 1260 tok/s at context 2.3k and 1267 vs 1289 at 300 — rejected)
     for (int g = threadIdx.x; g < G; g += 256) {
       float* dst = part_row + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
       dst[HD] = -INFINITY; dst[HD + 1] = 0.f;
@@ -88,21 +97,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     for (int j = 0; j < 8; j++) o[g][j] = 0.f;
   }
 
-  const bf16_t* kbase = k_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
-  const bf16_t* vbase = v_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
-  for (int t0 = t_begin + wv * TPW * UNR; t0 < t_end; t0 += STEP) {
-    u32x4 kv[UNR], vv[UNR];
-    bool valid[UNR];
+  while (true) {
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
-      const int t = t0 + r * TPW + slot;
-      valid[r] = t < t_end;
-      const int tc = valid[r] ? t : t_end - 1;
-      kv[r] = *reinterpret_cast<const u32x4*>(kbase + (size_t)tc * HD);
-      vv[r] = *reinterpret_cast<const u32x4*>(vbase + (size_t)tc * HD);
-    }
-#pragma unroll
-    for (int r = 0; r < UNR; r++) {
+      const bool valid = t0 + r * TPW + slot < n_keys;
       float kf[8], vf[8];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -115,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; j++) s = fmaf(qf[g][j], kf[j], s);
         s = row_group_sum<LPT>(s);
-        if (valid[r]) {
+        if (valid) {
           const float mn = fmaxf(m[g], s);
           const float alpha = exp2f(m[g] - mn);     // exp2(-inf) = 0 on the first key
           const float p = exp2f(s - mn);
@@ -125,6 +123,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
           m[g] = mn;
         }
       }
+    }
+    t0 += a.nsplit * STEP;            // this split's next block (contexts beyond nsplit*STEP tokens)
+    if (t0 >= n_keys) break;          // wave-uniform
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      const int tc = min(t0 + r * TPW + slot, n_keys - 1);
+      kv[r] = *reinterpret_cast<const u32x4*>(kbase + (size_t)tc * HD);
+      vv[r] = *reinterpret_cast<const u32x4*>(vbase + (size_t)tc * HD);
     }
   }
 
