@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--model", default="llama-3.2-1b", help="key of tinygpt_amd.desc.KNOWN_CONFIGS")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"], help="storage dtype of parameters and KV cache (the headline is bf16)")
     ap.add_argument("--prompt", type=int, default=2048, help="prefill length before the timed decode")
     ap.add_argument("--profile-reps", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true", help="eager launches (needed under rocprofv3 kernel tracing)")
@@ -112,7 +113,7 @@ def main():
     from tinygpt_amd import known_desc, synth
     from tinygpt_amd.ffi import GREEDY, Model, product_backend
 
-    desc = known_desc(args.model)
+    desc = known_desc(args.model, args.dtype)
     need_ctx = args.prompt + args.warmup + args.steps + 8
     if need_ctx > desc.max_ctx:
         sys.exit(f"prompt+warmup+steps = {need_ctx} exceeds contextSize {desc.max_ctx}")
@@ -161,7 +162,7 @@ def main():
 
     prof = model.profile_decode(args.profile_reps)
     n_gu, ms_gu = prof["gateup"]
-    gu_bytes = 2 * (2 * desc.inter) * desc.hidden
+    gu_bytes = (4 if args.dtype == "fp32" else 2) * (2 * desc.inter) * desc.hidden
     gu_us = ms_gu / n_gu * 1e3
     achieved = gu_bytes / (gu_us * 1e-6) / 1e9
     classes = {k: round(ms / n * 1e3, 3) for k, (n, ms) in prof.items() if n}
@@ -196,8 +197,8 @@ def main():
         "metric": "decode tokens/sec (and % HBM roofline), Llama-3.2-1B bf16 batch=1, 1 GPU",
         "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{desc.name} bf16, batch 1 per GPU: {args.prompt}-token prefill then greedy decode "
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{desc.name} {args.dtype}, batch 1 per GPU: {args.prompt}-token prefill then greedy decode "
                                f"(one step = one token, context {T0}..{T0 + args.steps - 1})",
                    "replicas": world, "prompt_tokens": args.prompt, "prefill_ms": round(prefill_ms, 1),
                    "prefill_tflops": round(prefill_tflops, 1), "prefill_mfma_frac_of_2500": round(2 * prefill_tflops / 2500.0, 4),

@@ -27,7 +27,7 @@
  *
  * Numerics contract.  compute_dtype bf16 means: parameters and the KV cache are STORED in
  * bf16 (round-to-nearest-even once, at upload / at cache append); every activation between ops and all
- * arithmetic is fp32.  compute_dtype fp32 stores everything in fp32.
+ * arithmetic is fp32.  compute_dtype fp16 is the same with IEEE half storage; fp32 stores everything in fp32.
  *   Linear      y = sum_k x_k w_k [+ b]                 fp32 accumulate over exact bf16->fp32 weights
  *   RMSNorm     y = w * (x * (1/sqrt(mean(x^2)+eps)))   (HF LlamaRMSNorm order)
  *   RoPE        fp32 cos/sin tables; y = x*cos + rot_half(x)*sin   (HF apply_rotary_pos_emb)
@@ -82,6 +82,7 @@ typedef struct {
 typedef struct tgxo_ctx {
   desc_t d;
   int bf16;
+  int f16;                       /* compute_dtype fp16: parameters and KV cache hold half-rounded values */
   int round_act;
   mat_t embed, wpe, lm_head;
   vec_t final_norm;
@@ -111,7 +112,7 @@ static inline uint16_t f32_to_bf16(float f) {
 }
 static inline float rbf(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 #define R(c, x) ((c)->round_act ? rbf(x) : (x))       /* activations: identity unless TGXO_TORCH_ROUNDING */
-#define RKV(c, x) ((c)->bf16 ? rbf(x) : (x))          /* KV-cache storage rounding */
+#define RKV(c, x) ((c)->bf16 ? rbf(x) : ((c)->f16 ? rhf(x) : (x)))   /* storage rounding: KV cache, norm weights, biases */
 
 static float half_to_f32(uint16_t h) {
   uint32_t s = (h >> 15) & 1, e = (h >> 10) & 0x1f, m = h & 0x3ff, u;
@@ -122,6 +123,25 @@ static float half_to_f32(uint16_t h) {
   else u = (s << 31) | ((e + 127 - 15) << 23) | (m << 13);
   float f; memcpy(&f, &u, 4); return f;
 }
+
+/* fp32 -> IEEE half, round-to-nearest-even, subnormals kept (== torch .to(float16), v_cvt_f16_f32) */
+static uint16_t f32_to_half(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);
+  if (a >= 0x47800000u) return (uint16_t)(sign | 0x7c00u);
+  if (a < 0x33000000u) return (uint16_t)sign;
+  const int e = (int)(a >> 23) - 127;
+  const uint32_t m = (a & 0x7fffffu) | 0x800000u;
+  const int shift = e >= -14 ? 13 : 13 + (-14 - e);
+  uint32_t q = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+  if (rem > halfway || (rem == halfway && (q & 1u))) q++;
+  uint32_t h = e >= -14 ? ((uint32_t)(e + 15) << 10) + (q - 0x400u) : q;
+  if (h >= 0x7c00u) h = 0x7c00u;
+  return (uint16_t)(sign | h);
+}
+static inline float rhf(float f) { return half_to_f32(f32_to_half(f)); }
 
 /* ---------------------------------------------------------------- allocation */
 static int mat_alloc(tgxo_ctx* c, mat_t* m, int64_t rows, int64_t cols, int bias) {
@@ -158,7 +178,7 @@ static void mat_store_rows(tgxo_ctx* c, mat_t* m, int64_t row0, int64_t nrows, c
     for (int64_t k = 0; k < m->cols; k++) {
       float v = src_is_in_out ? src_elem(host, dt, k * nrows + r) : src_elem(host, dt, r * m->cols + k);
       if (c->bf16) m->wb[(row0 + r) * m->cols + k] = f32_to_bf16(v);
-      else m->wf[(row0 + r) * m->cols + k] = v;
+      else m->wf[(row0 + r) * m->cols + k] = c->f16 ? rhf(v) : v;   /* fp16 mode: fp32 container, half-rounded values */
     }
   m->filled_rows += nrows;
 }
@@ -177,7 +197,7 @@ static int fail(tgxo_ctx* c, int code, const char* fmt, const char* a) {
 TGXO_EXPORT int tgxo_create(const desc_t* d, int device_ordinal, tgxo_ctx** out) {
   (void)device_ordinal;
   if (!d || !out) return fail(NULL, 1, "%s", "null argument");
-  if (d->compute_dtype != DT_F32 && d->compute_dtype != DT_BF16) return fail(NULL, 2, "%s", "oracle computes in fp32 or bf16");
+  if (d->compute_dtype != DT_F32 && d->compute_dtype != DT_BF16 && d->compute_dtype != DT_F16) return fail(NULL, 2, "%s", "unknown compute dtype");
   if (d->heads <= 0 || d->kv_heads <= 0 || d->heads % d->kv_heads) return fail(NULL, 1, "%s", "heads % kv_heads != 0");
   if (d->head_dim % 2) return fail(NULL, 1, "%s", "odd head_dim");
   tgxo_ctx* c = (tgxo_ctx*)calloc(1, sizeof(tgxo_ctx));
@@ -185,6 +205,7 @@ TGXO_EXPORT int tgxo_create(const desc_t* d, int device_ordinal, tgxo_ctx** out)
   c->d = *d;
   if (c->d.max_batch < 1) c->d.max_batch = 1;
   c->bf16 = d->compute_dtype == DT_BF16;
+  c->f16 = d->compute_dtype == DT_F16;
   { const char* e = getenv("TGXO_TORCH_ROUNDING"); c->round_act = c->bf16 && e && e[0] == '1'; }
   int H = d->hidden, I = d->inter, V = d->vocab;
   int qd = d->heads * d->head_dim, kvd = d->kv_heads * d->head_dim;

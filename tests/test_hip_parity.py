@@ -23,11 +23,11 @@ def hip():
     return product_backend()   # raises if the .so is missing: no fallback
 
 
-def make_pair(fam, hip, oracle_lib, max_batch=1):
+def make_pair(fam, hip, oracle_lib, max_batch=1, dtype="bf16"):
     from oracle.oracle_ffi import OracleModel
     from tinygpt_amd.ffi import Model
     cfg, g = load_golden(fam)
-    d = desc_from_hf_config(cfg, "bf16", max_batch=max_batch)
+    d = desc_from_hf_config(cfg, dtype, max_batch=max_batch)
     seed, std = int(g["seed"]), float(g["std"])
     gpu = Model(d, hip).load_synthetic(seed, std).finalize()
     ref = OracleModel(d).load_synthetic(seed, std).finalize()
@@ -146,6 +146,42 @@ def test_batched_decode_shares_weight_passes(family, hip, oracle_lib):
         (kg, vg), (kr, vr) = gpu.read_kv(row, 0), ref.read_kv(row, 0)
         for g_, r_ in ((kg, kr), (vg, vr)):
             assert np.all(np.abs(g_ - r_) <= 2.0 ** -7 * (np.abs(r_) + 1e-3 * np.abs(r_).max()))
+
+
+@pytest.mark.parametrize("fam", GPU_FAMILIES)
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_dtype_matrix(fam, dtype, hip, oracle_lib):
+    """--dtype fp16 / fp32 (main.cpp:35, README.md:17): parameters and KV cache stored in that dtype, same kernels
+    instantiated for it.  GPU vs oracle as for bf16; fp32 additionally sits on the HF fp32 goldens (1e-4), fp16
+    within the oracle's own bounds (2e-3 vs HF fp32, 8e-3 vs HF fp16)."""
+    import os
+    from conftest import GOLDEN
+    gpu, ref, g = make_pair(fam, hip, oracle_lib, dtype=dtype)
+    gpu.forward(g["prompt"]); ref.forward(g["prompt"])
+    lg = gpu.logits(rounded=False)
+    assert rel_err(lg, ref.logits(rounded=False)) < TOL_ORACLE
+    if dtype == "fp32":
+        want_ids = g["ids_fp32"]
+        assert rel_err(lg, g["logits_fp32"][:, 0]) < 1e-4
+    else:
+        g16 = np.load(os.path.join(GOLDEN, fam, "golden_fp16.npz"))
+        want_ids = g16["ids_fp16"]
+        assert rel_err(lg, g["logits_fp32"][:, 0]) < 2e-3
+        assert rel_err(lg, g16["logits_fp16"][:, 0]) < 8e-3
+    np.testing.assert_array_equal(gpu.sample(GREEDY), ref.sample(GREEDY))
+    n = want_ids.shape[1] - 1
+    d_gpu, d_ref = gpu.decode(n, GREEDY), ref.decode(n, GREEDY)
+    np.testing.assert_array_equal(d_gpu, d_ref)
+    np.testing.assert_array_equal(d_gpu.T, want_ids[:, 1:])
+    assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_ORACLE
+    # cache entries: the fp32 values before storage differ by summation order (~1e-6 of the tensor's scale); storing them
+    # adds at most one storage ulp at a rounding tie, and a flipped entry of layer l perturbs what layer l+1 caches by a
+    # small fraction of an ulp of the tensor's scale (measured <= 2.6e-5 * max for fp16)
+    ulp = 2.0 ** -10 if dtype == "fp16" else 0.0
+    for layer in range(gpu.desc.layers):
+        for g_, r_ in zip(gpu.read_kv(0, layer), ref.read_kv(0, layer)):
+            floor = 4e-6 if layer == 0 else max(4e-6, 0.1 * ulp)
+            assert np.all(np.abs(g_ - r_) <= ulp * np.abs(r_) + floor * np.abs(r_).max())
 
 
 def test_errors_are_loud(hip):

@@ -4,7 +4,7 @@
 // is gone: the QKV epilogue already stored this step's K/V row in place) and
 // function::flashAttention(q, Kall, Vall, isCausal=false) (Attention.h:108-109).
 //
-// Numerics contract: K/V are bf16 in the cache; scores = (q.k) * hd^-1/2, softmax and P.V are fp32; fp32 output.
+// Numerics contract: K/V are in the storage dtype (bf16 / fp16 / fp32) in the cache; scores = (q.k) * hd^-1/2, softmax and P.V are fp32; fp32 output.
 //
 // Roofline: HBM — 2 * kv_heads * (T+1) * hd * 2 bytes per launch (K and V rows read once; all G = heads/kv_heads
 // query heads of a group share one pass over their kv head).
@@ -22,8 +22,8 @@ namespace tgx {
 
 struct AttnArgs {
   const float* q;         // [heads][hd] fp32 (RoPE applied)
-  const bf16_t* k_cache;  // this layer/row: [kv_heads][max_ctx][hd]
-  const bf16_t* v_cache;
+  const void* k_cache;    // this layer/row: [kv_heads][max_ctx][hd], storage dtype (kernel template DT)
+  const void* v_cache;
   const int* pos;         // pastLength BEFORE this step; keys [0, pos] are attended
   float* part;            // [heads][nsplit][hd + 4]  (o[hd], m, l, pad) — 16-byte aligned records
   float* out;             // [heads*hd] fp32 (combine kernel)
@@ -33,8 +33,9 @@ struct AttnArgs {
   long long q_stride, kv_stride, part_stride;
 };
 
-template <int HD, int G>
+template <int DT, int HD, int G>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
+  typedef elem_t<DT> E;
   constexpr int LPT = HD / 8;         // lanes per token row
   constexpr int TPW = 64 / LPT;       // tokens per wave-load
   constexpr int NSTREAM = 4 * TPW;    // independent online-softmax streams per workgroup (wave x token slot)
@@ -45,8 +46,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* q_row = a.q + blockIdx.y * a.q_stride;
-  const bf16_t* k_row = a.k_cache + blockIdx.y * a.kv_stride;
-  const bf16_t* v_row = a.v_cache + blockIdx.y * a.kv_stride;
+  const E* k_row = static_cast<const E*>(a.k_cache) + blockIdx.y * a.kv_stride;
+  const E* v_row = static_cast<const E*>(a.v_cache) + blockIdx.y * a.kv_stride;
   float* part_row = a.part + blockIdx.y * a.part_stride;
   const int kvh = blockIdx.x / a.nsplit, sp = blockIdx.x - kvh * a.nsplit;
   const int part_i = lane % LPT, slot = lane / LPT;
@@ -54,15 +55,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   // sp + nsplit, ...: the active splits are the first ceil(n_keys / STEP) of every kv head and each runs whole blocks;
   // the addresses of a split's first block do not depend on the context length.
   constexpr int STEP = 4 * TPW * UNR;
-  const bf16_t* kbase = k_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
-  const bf16_t* vbase = v_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
+  const E* kbase = k_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
+  const E* vbase = v_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
   int t0 = sp * STEP + wv * TPW * UNR;
-  u32x4 kv[UNR], vv[UNR];
+  Slice8<DT> kv[UNR], vv[UNR];
 #pragma unroll
   for (int r = 0; r < UNR; r++) {
     const int tc = min(t0 + r * TPW + slot, a.max_ctx - 1);
-    kv[r] = *reinterpret_cast<const u32x4*>(kbase + (size_t)tc * HD);
-    vv[r] = *reinterpret_cast<const u32x4*>(vbase + (size_t)tc * HD);
+    kv[r] = load_slice<DT>(kbase + (size_t)tc * HD, 0);
+    vv[r] = load_slice<DT>(vbase + (size_t)tc * HD, 0);
   }
   float qf[G][8];
 #pragma unroll
@@ -102,11 +103,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     for (int r = 0; r < UNR; r++) {
       const bool valid = t0 + r * TPW + slot < n_keys;
       float kf[8], vf[8];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        kf[2 * j] = bf16_lo(kv[r][j]); kf[2 * j + 1] = bf16_hi(kv[r][j]);
-        vf[2 * j] = bf16_lo(vv[r][j]); vf[2 * j + 1] = bf16_hi(vv[r][j]);
-      }
+      slice_unpack<DT>(kv[r], kf);
+      slice_unpack<DT>(vv[r], vf);
 #pragma unroll
       for (int g = 0; g < G; g++) {
         float s = 0.f;
@@ -129,8 +127,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
       const int tc = min(t0 + r * TPW + slot, n_keys - 1);
-      kv[r] = *reinterpret_cast<const u32x4*>(kbase + (size_t)tc * HD);
-      vv[r] = *reinterpret_cast<const u32x4*>(vbase + (size_t)tc * HD);
+      kv[r] = load_slice<DT>(kbase + (size_t)tc * HD, 0);
+      vv[r] = load_slice<DT>(vbase + (size_t)tc * HD, 0);
     }
   }
 

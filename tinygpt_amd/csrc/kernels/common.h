@@ -28,19 +28,96 @@ __device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
   return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
 }
 
+// ---- storage dtype of parameters and of the KV cache (tgx_model_desc.compute_dtype; activations are fp32 in every
+// mode).  Kernels take the dtype as a template parameter; a *slice* is 8 consecutive elements — one
+// 16-byte load for the 16-bit types, two for fp32.
+enum { DT_BF16 = 0, DT_F16 = 1, DT_F32 = 2 };
+template <int DT> struct Elem { typedef unsigned short type; };
+template <> struct Elem<DT_F32> { typedef float type; };
+template <int DT> using elem_t = typename Elem<DT>::type;
+
+__device__ __forceinline__ float f16_bits_to_f32(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ unsigned short f32_to_f16_bits(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }   // v_cvt_f16_f32, RNE
+
+template <int DT> __device__ __forceinline__ float elem_to_f32(elem_t<DT> v) {
+  if constexpr (DT == DT_BF16) return bf16_to_f32(v);
+  else if constexpr (DT == DT_F16) return f16_bits_to_f32(v);
+  else return v;
+}
+template <int DT> __device__ __forceinline__ elem_t<DT> f32_to_elem(float f) {   // round-to-nearest-even into the storage dtype
+  if constexpr (DT == DT_BF16) return f32_to_bf16(f);
+  else if constexpr (DT == DT_F16) return f32_to_f16_bits(f);
+  else return f;
+}
+// two adjacent 16-bit elements packed in one dword -> fp32
+template <int DT> __device__ __forceinline__ float pair_lo(unsigned int u) {
+  if constexpr (DT == DT_BF16) return bf16_lo(u); else return f16_bits_to_f32((unsigned short)(u & 0xffffu));
+}
+template <int DT> __device__ __forceinline__ float pair_hi(unsigned int u) {
+  if constexpr (DT == DT_BF16) return bf16_hi(u); else return f16_bits_to_f32((unsigned short)(u >> 16));
+}
+
+template <int DT> struct Slice8 { u32x4 v; };
+template <> struct Slice8<DT_F32> { u32x4 v, w; };
+
 // ---- streaming (read-once) 16-byte load: global_load_dwordx4 ... nt -------------------------------
 __device__ __forceinline__ u32x4 load_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
 
-// acc += dot(8 bf16 weights in w, 8 fp32 activations in xa/xb) — exact products, fp32 FMA chain
-__device__ __forceinline__ float dot8(float acc, const u32x4 w, const f32x4 xa, const f32x4 xb) {
-  acc = fmaf(bf16_lo(w[0]), xa[0], acc);
-  acc = fmaf(bf16_hi(w[0]), xa[1], acc);
-  acc = fmaf(bf16_lo(w[1]), xa[2], acc);
-  acc = fmaf(bf16_hi(w[1]), xa[3], acc);
-  acc = fmaf(bf16_lo(w[2]), xb[0], acc);
-  acc = fmaf(bf16_hi(w[2]), xb[1], acc);
-  acc = fmaf(bf16_lo(w[3]), xb[2], acc);
-  acc = fmaf(bf16_hi(w[3]), xb[3], acc);
+// slice `i` (elements 8i .. 8i+7) of a row that starts at `row` (16-byte aligned); nt = read-once weight stream
+template <int DT> __device__ __forceinline__ Slice8<DT> load_slice_nt(const elem_t<DT>* row, size_t i) {
+  Slice8<DT> s;
+  if constexpr (DT == DT_F32) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(row) + 2 * i;
+    s.v = load_nt(p); s.w = load_nt(p + 1);
+  } else {
+    s.v = load_nt(reinterpret_cast<const u32x4*>(row) + i);
+  }
+  return s;
+}
+template <int DT> __device__ __forceinline__ Slice8<DT> load_slice(const elem_t<DT>* row, size_t i) {
+  Slice8<DT> s;
+  if constexpr (DT == DT_F32) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(row) + 2 * i;
+    s.v = p[0]; s.w = p[1];
+  } else {
+    s.v = reinterpret_cast<const u32x4*>(row)[i];
+  }
+  return s;
+}
+template <int DT> __device__ __forceinline__ void slice_unpack(const Slice8<DT>& s, float f[8]) {
+  if constexpr (DT == DT_F32) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) { f[t] = __uint_as_float(s.v[t]); f[4 + t] = __uint_as_float(s.w[t]); }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; t++) { f[2 * t] = pair_lo<DT>(s.v[t]); f[2 * t + 1] = pair_hi<DT>(s.v[t]); }
+  }
+}
+template <int DT> __device__ __forceinline__ void store_slice(elem_t<DT>* row, size_t i, const float f[8]) {
+  if constexpr (DT == DT_F32) {
+    f32x4* p = reinterpret_cast<f32x4*>(row) + 2 * i;
+    p[0] = f32x4{f[0], f[1], f[2], f[3]}; p[1] = f32x4{f[4], f[5], f[6], f[7]};
+  } else {
+    u32x4 o;
+#pragma unroll
+    for (int t = 0; t < 4; t++) o[t] = (unsigned int)f32_to_elem<DT>(f[2 * t]) | ((unsigned int)f32_to_elem<DT>(f[2 * t + 1]) << 16);
+    reinterpret_cast<u32x4*>(row)[i] = o;
+  }
+}
+
+// acc += dot(8 stored weights in w, 8 fp32 activations in xa/xb) — exact conversions, fp32 FMA chain in element order
+template <int DT>
+__device__ __forceinline__ float dot8(float acc, const Slice8<DT>& w, const f32x4 xa, const f32x4 xb) {
+  float f[8];
+  slice_unpack<DT>(w, f);
+  acc = fmaf(f[0], xa[0], acc);
+  acc = fmaf(f[1], xa[1], acc);
+  acc = fmaf(f[2], xa[2], acc);
+  acc = fmaf(f[3], xa[3], acc);
+  acc = fmaf(f[4], xb[0], acc);
+  acc = fmaf(f[5], xb[1], acc);
+  acc = fmaf(f[6], xb[2], acc);
+  acc = fmaf(f[7], xb[3], acc);
   return acc;
 }
 

@@ -1,4 +1,4 @@
-// gemv.h — the batch-1 weight-streaming kernel of the decode path: y = W[N,K] · x (bf16 weights, fp32
+// gemv.h — the weight-streaming kernel of the decode path: y = W[N,K] · x (bf16 / fp16 / fp32 weights, fp32
 // accumulate), with the ops the reference issues around each nn::Linear fused in as prologue/epilogue.
 //
 //   reference op sequence (per decode step)                         fused form here
@@ -33,10 +33,10 @@ enum { EPI_QKV_ROPE = 0, EPI_RESIDUAL = 1, EPI_SILU_MUL = 2, EPI_LOGITS = 3 };
 // lands in a register is multiplied into R activation vectors (the reference runs the whole batch through each
 // nn::Linear as a [B,1,K] x [K,N] product).  Per-row buffers are slabs with a constant row stride.
 struct GemvArgs {
-  const bf16_t* W;        // [N][K] row-major (torch Linear layout)
-  const bf16_t* bias;     // [N] or nullptr
+  const void* W;          // [N][K] row-major (torch Linear layout), elements of the storage dtype (kernel template DT)
+  const void* bias;       // [N] or nullptr
   const float* x;         // [R][x_stride] input activations (fp32 between ops)
-  const bf16_t* norm_w;   // [K] RMSNorm weight (PRO_RMSNORM)
+  const void* norm_w;     // [K] RMSNorm weight (PRO_RMSNORM)
   float eps;
   int N, K;
   int units;              // number of row pairs
@@ -44,8 +44,8 @@ struct GemvArgs {
   long long x_stride, out_stride, q_stride, kv_stride, logits_stride, part_stride, kraw_stride;   // elements between batch rows
   // EPI_QKV_ROPE
   float* q_out;           // [R][heads*hd] fp32
-  bf16_t* k_cache;        // this layer: [R][...kv_stride...]: [kv_heads][max_ctx][hd]
-  bf16_t* v_cache;
+  void* k_cache;          // this layer: [R][...kv_stride...]: [kv_heads][max_ctx][hd], storage dtype
+  void* v_cache;
   const float* rope_cos;  // [max_ctx][hd/2] fp32
   const float* rope_sin;
   const int* pos;         // [R] device-resident pastLength of each row
@@ -78,8 +78,9 @@ __device__ __forceinline__ void unit_rows(const GemvArgs& a, int u, int& ra, int
   }
 }
 
-template <int PRO, int EPI, int NX, int R>
+template <int DT, int PRO, int EPI, int NX, int R>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
+  typedef elem_t<DT> E;
   constexpr bool PIPE = NX * R <= 4;       // double-buffer the weight registers when the activations leave room
   __shared__ float ps[4][2 * R];
   __shared__ float sv[R][4];
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   const int nchunk = a.K >> 3;                                         // 16-byte weight slices per row
   const int per = ((nchunk + KS * 64 - 1) / (KS * 64)) * 64;           // slices per k-part (multiple of 64)
   const int c_begin = min(kpart * per, nchunk), c_end = min(c_begin + per, nchunk);
-  const u32x4* W4 = reinterpret_cast<const u32x4*>(a.W);
+  const E* W = static_cast<const E*>(a.W);
   const int stride = gridDim.x * UPB;
 
   int cidx[NX];
@@ -103,15 +104,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     cidx[j] = cok[j] ? c : max(c_end - 1, 0);    // clamped: always a legal slice of the row
   }
 
-  u32x4 wa[NX], wb[NX], na[PIPE ? NX : 1], nb[PIPE ? NX : 1];
-  auto load_unit = [&](int ub, u32x4* ta, u32x4* tb) {
+  Slice8<DT> wa[NX], wb[NX], na[PIPE ? NX : 1], nb[PIPE ? NX : 1];
+  auto load_unit = [&](int ub, Slice8<DT>* ta, Slice8<DT>* tb) {
     const int u = min(ub + slot, a.units - 1);
     int ra, rb; bool v;
     unit_rows<EPI>(a, u, ra, rb, v);
-    const u32x4* pa = W4 + (size_t)ra * nchunk;
-    const u32x4* pb = W4 + (size_t)rb * nchunk;
+    const E* pa = W + (size_t)ra * a.K;
+    const E* pb = W + (size_t)rb * a.K;
 #pragma unroll
-    for (int j = 0; j < NX; j++) { ta[j] = load_nt(pa + cidx[j]); tb[j] = load_nt(pb + cidx[j]); }
+    for (int j = 0; j < NX; j++) { ta[j] = load_slice_nt<DT>(pa, cidx[j]); tb[j] = load_slice_nt<DT>(pb, cidx[j]); }
   };
 
   // 1. the first unit's weights are in flight before anything else is touched
@@ -132,10 +133,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     }
   }
   if (PRO == PRO_RMSNORM) {   // KS == 1: the wave holds all of x.  HF order: weight * (x * rsqrt(mean(x^2)+eps))
-    const u32x4* wg = reinterpret_cast<const u32x4*>(a.norm_w);
-    u32x4 nw[NX];
+    const E* wg = static_cast<const E*>(a.norm_w);
+    Slice8<DT> nw[NX];
 #pragma unroll
-    for (int j = 0; j < NX; j++) nw[j] = wg[cidx[j]];        // in flight together with x
+    for (int j = 0; j < NX; j++) nw[j] = load_slice<DT>(wg, cidx[j]);        // in flight together with x
 #pragma unroll
     for (int r = 0; r < R; r++) {
       float ss = 0.f;
@@ -147,12 +148,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       const float inv = 1.0f / sqrtf(ss / (float)a.K + a.eps);
 #pragma unroll
       for (int j = 0; j < NX; j++) {
-        const u32x4 w = nw[j];
+        float w[8];
+        slice_unpack<DT>(nw[j], w);
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-          xr[r][j][2 * t] = bf16_lo(w[t]) * (xr[r][j][2 * t] * inv);
-          xr[r][j][2 * t + 1] = bf16_hi(w[t]) * (xr[r][j][2 * t + 1] * inv);
-        }
+        for (int t = 0; t < 8; t++) xr[r][j][t] = w[t] * (xr[r][j][t] * inv);
       }
     }
   }
@@ -195,8 +194,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       for (int j = 0; j < NX; j++) {
         const f32x4 xa = f32x4{xr[r][j][0], xr[r][j][1], xr[r][j][2], xr[r][j][3]};
         const f32x4 xb = f32x4{xr[r][j][4], xr[r][j][5], xr[r][j][6], xr[r][j][7]};
-        if (j & 1) { acc_a1 = dot8(acc_a1, wa[j], xa, xb); acc_b1 = dot8(acc_b1, wb[j], xa, xb); }
-        else       { acc_a0 = dot8(acc_a0, wa[j], xa, xb); acc_b0 = dot8(acc_b0, wb[j], xa, xb); }
+        if (j & 1) { acc_a1 = dot8<DT>(acc_a1, wa[j], xa, xb); acc_b1 = dot8<DT>(acc_b1, wb[j], xa, xb); }
+        else       { acc_a0 = dot8<DT>(acc_a0, wa[j], xa, xb); acc_b0 = dot8<DT>(acc_b0, wb[j], xa, xb); }
       }
       sa[r] = wave_sum(acc_a0 + acc_a1);
       sb[r] = wave_sum(acc_b0 + acc_b1);
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
           }
           continue;
         }
-        if (a.bias) { va += bf16_to_f32(a.bias[ra]); vb += bf16_to_f32(a.bias[rb]); }
+        if (a.bias) { const E* bias = static_cast<const E*>(a.bias); va += elem_to_f32<DT>(bias[ra]); vb += elem_to_f32<DT>(bias[rb]); }
         if (EPI == EPI_QKV_ROPE) {
           const int half = a.hd >> 1;
           const int hh = u / half, p = u - hh * half;
@@ -251,11 +250,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
           if (is_q) {
             float* q = a.q_out + (size_t)r * a.q_stride + hh * a.hd;
             q[p] = va; q[p + half] = vb;
-          } else {   // KVCacheManager::append: this position's K / V row, stored in bf16
-            bf16_t* dst = (is_k ? a.k_cache + ((size_t)(hh - a.heads) * a.max_ctx + pos[r]) * a.hd
-                                : a.v_cache + ((size_t)(hh - a.heads - a.kv_heads) * a.max_ctx + pos[r]) * a.hd) + (size_t)r * a.kv_stride;
-            dst[p] = f32_to_bf16(va);
-            dst[p + half] = f32_to_bf16(vb);
+          } else {   // KVCacheManager::append: this position's K / V row, rounded once into the storage dtype
+            E* dst = (is_k ? static_cast<E*>(a.k_cache) + ((size_t)(hh - a.heads) * a.max_ctx + pos[r]) * a.hd
+                           : static_cast<E*>(a.v_cache) + ((size_t)(hh - a.heads - a.kv_heads) * a.max_ctx + pos[r]) * a.hd) + (size_t)r * a.kv_stride;
+            dst[p] = f32_to_elem<DT>(va);
+            dst[p + half] = f32_to_elem<DT>(vb);
           }
         } else if (EPI == EPI_RESIDUAL) {
           float* o = a.out + (size_t)r * a.out_stride;
@@ -298,32 +297,34 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 struct QkNormArgs {
   float* q;               // [heads][hd] in/out
   const float* k_raw;     // [kv_heads][hd]
-  bf16_t* k_cache;        // this layer/row: [kv_heads][max_ctx][hd]
-  const bf16_t *q_norm_w, *k_norm_w;   // [hd]
+  void* k_cache;          // this layer/row: [kv_heads][max_ctx][hd], storage dtype
+  const void *q_norm_w, *k_norm_w;     // [hd]
   const float *rope_cos, *rope_sin;
   const int* pos;
   int heads, kv_heads, hd, max_ctx;
   float eps;
 };
+template <int DT>
 __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const QkNormArgs a) {
+  typedef elem_t<DT> E;
   const int hh = blockIdx.x, p = threadIdx.x, half = a.hd >> 1;
   const bool is_q = hh < a.heads;
   const float* src = is_q ? a.q + hh * a.hd : a.k_raw + (hh - a.heads) * a.hd;
-  const bf16_t* w = is_q ? a.q_norm_w : a.k_norm_w;
+  const E* w = static_cast<const E*>(is_q ? a.q_norm_w : a.k_norm_w);
   const bool act = p < half;
   float x0 = act ? src[p] : 0.f, x1 = act ? src[p + half] : 0.f;
   const float ss = wave_sum(x0 * x0 + x1 * x1);
   const float inv = 1.0f / sqrtf(ss / (float)a.hd + a.eps);
   if (!act) return;
-  x0 = bf16_to_f32(w[p]) * (x0 * inv);
-  x1 = bf16_to_f32(w[p + half]) * (x1 * inv);
+  x0 = elem_to_f32<DT>(w[p]) * (x0 * inv);
+  x1 = elem_to_f32<DT>(w[p + half]) * (x1 * inv);
   const int pos = *a.pos;
   const float cs = a.rope_cos[(size_t)pos * half + p], sn = a.rope_sin[(size_t)pos * half + p];
   const float r0 = x0 * cs - x1 * sn, r1 = x1 * cs + x0 * sn;
   if (is_q) { a.q[hh * a.hd + p] = r0; a.q[hh * a.hd + p + half] = r1; }
   else {
-    bf16_t* dst = a.k_cache + ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd;
-    dst[p] = f32_to_bf16(r0); dst[p + half] = f32_to_bf16(r1);
+    E* dst = static_cast<E*>(a.k_cache) + ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd;
+    dst[p] = f32_to_elem<DT>(r0); dst[p + half] = f32_to_elem<DT>(r1);
   }
 }
 
@@ -331,14 +332,16 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const QkNormArgs a) {
 // == argmax (Sampler.cpp:28) + tokens = concat(tokens, next) + KV pastLength += 1, and it gathers the next
 // step's embedding row (nn::Embedding, GPTModel.h:52) into the residual stream so the decode graph needs
 // no host input between steps.
-// nn::Embedding row gather: bf16 table row -> fp32 residual stream
-__device__ __forceinline__ void gather_embedding(const bf16_t* row, float* x, int H) {
-  const u32x4* src = reinterpret_cast<const u32x4*>(row);
+// nn::Embedding row gather: table row `t` (storage dtype) -> fp32 residual stream
+template <int DT>
+__device__ __forceinline__ void gather_embedding(const void* table, long long t, float* x, int H) {
+  const elem_t<DT>* row = static_cast<const elem_t<DT>*>(table) + (size_t)t * H;
   f32x4* dst = reinterpret_cast<f32x4*>(x);
   for (int c = threadIdx.x; c < (H >> 3); c += blockDim.x) {
-    const u32x4 v = src[c];
-    dst[2 * c] = f32x4{bf16_lo(v[0]), bf16_hi(v[0]), bf16_lo(v[1]), bf16_hi(v[1])};
-    dst[2 * c + 1] = f32x4{bf16_lo(v[2]), bf16_hi(v[2]), bf16_lo(v[3]), bf16_hi(v[3])};
+    float f[8];
+    slice_unpack<DT>(load_slice<DT>(row, c), f);
+    dst[2 * c] = f32x4{f[0], f[1], f[2], f[3]};
+    dst[2 * c + 1] = f32x4{f[4], f[5], f[6], f[7]};
   }
 }
 
@@ -355,12 +358,13 @@ struct FinalizeArgs {
   int row, rows;
   int log;               // 1: record the token in the rings (decode steps); 0: tgx_sample after a prefill
   int bump_step;         // 1 on the last row of a step
-  const bf16_t* embed;   // [V][H]
+  const void* embed;     // [V][H], storage dtype
   float* x;              // [H] residual stream of this row (fp32)
   int H;
   int advance_pos;       // 1: pos += 1 (the token just consumed is now in the cache)
 };
 
+template <int DT>
 __global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs a) {
   __shared__ float sv[256];
   __shared__ int si[256];
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs
     }
   }
   __syncthreads();
-  gather_embedding(a.embed + (size_t)s_tok * a.H, a.x, a.H);
+  gather_embedding<DT>(a.embed, s_tok, a.x, a.H);
 }
 
 // Prefill-by-steps helper: x <- embed[prompt[pos - pos0]] (nn::Embedding on one prompt position).
@@ -400,16 +404,17 @@ struct EmbedArgs {
   const long long* ids;  // [S] this row's prompt on the device
   const int* pos;
   int pos0;
-  const bf16_t* embed;
+  const void* embed;
   float* x;
   int H, V;
   int* tok;
 };
+template <int DT>
 __global__ __launch_bounds__(256) void embed_prompt_kernel(const EmbedArgs a) {
   const int i = *a.pos - a.pos0;
   long long t = a.ids[i];
   if (threadIdx.x == 0) *a.tok = (int)t;
-  gather_embedding(a.embed + (size_t)t * a.H, a.x, a.H);
+  gather_embedding<DT>(a.embed, t, a.x, a.H);
 }
 
 __global__ void advance_pos_kernel(int* pos) { if (threadIdx.x == 0) *pos = *pos + 1; }

@@ -93,6 +93,7 @@ __device__ void apply_cut(float* work, int V, unsigned int key, long long keep, 
   __syncthreads();
 }
 
+template <int DT>
 __global__ __launch_bounds__(SAMPLER_THREADS) void sample_kernel(const SampleArgs a) {
   __shared__ float sh_f[16];
   __shared__ unsigned int hist_cnt[256];
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(SAMPLER_THREADS) void sample_kernel(const SampleArg
     }
   }
   __syncthreads();
-  gather_embedding(a.fin.embed + (size_t)s_tok * a.fin.H, a.fin.x, a.fin.H);
+  gather_embedding<DT>(a.fin.embed, s_tok, a.fin.x, a.fin.H);
 }
 
 }  // namespace tgx

@@ -23,6 +23,7 @@
 #include "kernels/sampler.h"
 
 using tgx::bf16_t;
+typedef unsigned char ebyte;   // parameter / KV-cache storage in the compute dtype: offsets are elements * ctx.esz
 
 namespace {
 
@@ -30,9 +31,9 @@ constexpr int MAX_TICKET_EVENTS = 64;
 constexpr int HOST_RING = 256;
 
 struct LayerW {
-  bf16_t *in_norm = nullptr, *post_norm = nullptr;
-  bf16_t *wqkv = nullptr, *bqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wdown = nullptr;
-  bf16_t *q_norm = nullptr, *k_norm = nullptr;   // Qwen3 [head_dim]
+  ebyte *in_norm = nullptr, *post_norm = nullptr;
+  ebyte *wqkv = nullptr, *bqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wdown = nullptr;
+  ebyte *q_norm = nullptr, *k_norm = nullptr;   // Qwen3 [head_dim]
   bool q_norm_ok = false, k_norm_ok = false;
   int64_t qkv_rows = 0, gu_rows = 0;
   bool in_norm_ok = false, post_norm_ok = false, wo_ok = false, wdown_ok = false;
@@ -49,7 +50,7 @@ struct RowState {       // independent KV/sequence state of one batch row
   float* attn_part = nullptr;
   int *tok = nullptr, *pos = nullptr;
   long long* prompt = nullptr;
-  bf16_t *kcache = nullptr, *vcache = nullptr;   // [layers][kv_heads][max_ctx][hd]
+  ebyte *kcache = nullptr, *vcache = nullptr;   // [layers][kv_heads][max_ctx][hd] in the compute dtype
 };
 
 struct Tune {
@@ -74,7 +75,9 @@ struct tgx_ctx {
   std::string err;
   bool finalized = false;
 
-  bf16_t *embed = nullptr, *lm_head = nullptr, *final_norm = nullptr;
+  int dt = tgx::DT_BF16;   // storage dtype of parameters and KV cache (kernel template argument)
+  size_t esz = 2;          // bytes per stored element
+  ebyte *embed = nullptr, *lm_head = nullptr, *final_norm = nullptr;
   bool embed_ok = false, lm_head_ok = false, final_norm_ok = false;
   std::vector<LayerW> L;
   float *rope_cos = nullptr, *rope_sin = nullptr;
@@ -83,7 +86,7 @@ struct tgx_ctx {
   float *slab_work = nullptr, *slab_probs = nullptr, *slab_part_val = nullptr, *slab_attn_part = nullptr;
   int *slab_part_idx = nullptr, *slab_tok = nullptr, *slab_pos = nullptr;
   long long* slab_prompt = nullptr;
-  bf16_t *slab_k = nullptr, *slab_v = nullptr;
+  ebyte *slab_k = nullptr, *slab_v = nullptr;
   size_t kv_row_elems = 0, attn_part_row = 0;
 
   int64_t past = 0;       // host mirror of every row's device-resident pos
@@ -169,23 +172,47 @@ inline float host_half_to_f32(uint16_t h) {
   return f;
 }
 
-// host -> device copy with conversion to the compute dtype (== model().to(dtype), ModelLoader.cpp:84)
-int upload_bf16(tgx_ctx* c, bf16_t* dst, const void* host, int64_t n, int src_dtype) {
-  if (src_dtype == TGX_BF16) {
-    HIP_OK(c, hipMemcpy(dst, host, (size_t)n * 2, hipMemcpyHostToDevice));
+inline uint16_t host_f32_to_half(float f) {   // round-to-nearest-even, subnormals kept (== torch .to(float16))
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u, abs = u & 0x7fffffffu;
+  if (abs > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);
+  if (abs >= 0x47800000u) return (uint16_t)(sign | 0x7c00u);                // >= 65536 (or inf) -> inf; 65520..65536 handled below
+  if (abs < 0x33000000u) return (uint16_t)sign;                            // < 2^-25 -> 0
+  int e = (int)(abs >> 23) - 127;
+  uint32_t m = (abs & 0x7fffffu) | 0x800000u;                              // 24-bit significand
+  int shift = e >= -14 ? 13 : 13 + (-14 - e);                              // bits dropped (subnormal: more)
+  uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+  if (rem > halfway || (rem == halfway && (q & 1u))) q++;
+  uint32_t h = e >= -14 ? ((uint32_t)(e + 15) << 10) + (q - 0x400u) : q;  // carries propagate into the exponent
+  if (h >= 0x7c00u) h = 0x7c00u;
+  return (uint16_t)(sign | h);
+}
+
+// host -> device copy with conversion to the compute dtype (== model().to(dtype), ModelLoader.cpp:84):
+// widening is exact, narrowing rounds to nearest even once.
+int upload_param(tgx_ctx* c, ebyte* dst, const void* host, int64_t n, int src_dtype) {
+  const int want = c->d.compute_dtype;
+  if (src_dtype != TGX_BF16 && src_dtype != TGX_F32 && src_dtype != TGX_F16) return set_err(c, TGX_ERR_INVALID, "unknown source dtype %d", src_dtype);
+  if (src_dtype == want) {
+    HIP_OK(c, hipMemcpy(dst, host, (size_t)n * c->esz, hipMemcpyHostToDevice));
     return TGX_OK;
   }
-  std::vector<uint16_t> tmp((size_t)n);
-  if (src_dtype == TGX_F32) {
-    const float* s = (const float*)host;
-    for (int64_t i = 0; i < n; i++) tmp[(size_t)i] = host_f32_to_bf16(s[i]);
-  } else if (src_dtype == TGX_F16) {
-    const uint16_t* s = (const uint16_t*)host;
-    for (int64_t i = 0; i < n; i++) tmp[(size_t)i] = host_f32_to_bf16(host_half_to_f32(s[i]));
+  auto src = [&](int64_t i) -> float {
+    if (src_dtype == TGX_F32) return ((const float*)host)[i];
+    if (src_dtype == TGX_BF16) return host_bf16_to_f32(((const uint16_t*)host)[i]);
+    return host_half_to_f32(((const uint16_t*)host)[i]);
+  };
+  if (want == TGX_F32) {
+    std::vector<float> tmp((size_t)n);
+    for (int64_t i = 0; i < n; i++) tmp[(size_t)i] = src(i);
+    HIP_OK(c, hipMemcpy(dst, tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   } else {
-    return set_err(c, TGX_ERR_INVALID, "unknown source dtype %d", src_dtype);
+    std::vector<uint16_t> tmp((size_t)n);
+    if (want == TGX_BF16) for (int64_t i = 0; i < n; i++) tmp[(size_t)i] = host_f32_to_bf16(src(i));
+    else for (int64_t i = 0; i < n; i++) tmp[(size_t)i] = host_f32_to_half(src(i));
+    HIP_OK(c, hipMemcpy(dst, tmp.data(), (size_t)n * 2, hipMemcpyHostToDevice));
   }
-  HIP_OK(c, hipMemcpy(dst, tmp.data(), (size_t)n * 2, hipMemcpyHostToDevice));
   return TGX_OK;
 }
 
@@ -245,12 +272,37 @@ int gemv_auto_ks(int K, int want) {
   return ks;
 }
 
-template <int PRO, int EPI, int NX>
+// Runs `body` with DT bound to the context's storage dtype as a compile-time constant (kernel template argument).
+#define TGX_DT_SWITCH(dt_, ...)                                                          \
+  switch (dt_) {                                                                         \
+    case tgx::DT_BF16: { constexpr int DT = tgx::DT_BF16; __VA_ARGS__; } break;          \
+    case tgx::DT_F16: { constexpr int DT = tgx::DT_F16; __VA_ARGS__; } break;            \
+    default: { constexpr int DT = tgx::DT_F32; __VA_ARGS__; } break;                     \
+  }
+
+// the argument block of batch row `r` alone (every slab pointer advanced by r row strides)
+tgx::GemvArgs gemv_row(const tgx_ctx* c, tgx::GemvArgs a, int r) {
+  a.x += (size_t)r * a.x_stride;
+  if (a.out) a.out += (size_t)r * a.out_stride;
+  if (a.q_out) a.q_out += (size_t)r * a.q_stride;
+  if (a.k_raw) a.k_raw += (size_t)r * a.kraw_stride;
+  if (a.k_cache) a.k_cache = (ebyte*)a.k_cache + (size_t)r * a.kv_stride * c->esz;
+  if (a.v_cache) a.v_cache = (ebyte*)a.v_cache + (size_t)r * a.kv_stride * c->esz;
+  if (a.pos) a.pos += r;
+  if (a.logits) a.logits += (size_t)r * a.logits_stride;
+  if (a.part_val) a.part_val += (size_t)r * a.part_stride;
+  if (a.part_idx) a.part_idx += (size_t)r * a.part_stride;
+  return a;
+}
+
+template <int DT, int PRO, int EPI, int NX>
 void launch_gemv_nx(tgx_ctx* c, const tgx::GemvArgs& a, int grid, int R) {
   const dim3 g(grid), b(256);
-  if (R == 4) hipLaunchKernelGGL((tgx::gemv_kernel<PRO, EPI, NX, 4>), g, b, 0, c->stream, a);
-  else if (R == 2) hipLaunchKernelGGL((tgx::gemv_kernel<PRO, EPI, NX, 2>), g, b, 0, c->stream, a);
-  else hipLaunchKernelGGL((tgx::gemv_kernel<PRO, EPI, NX, 1>), g, b, 0, c->stream, a);
+  if constexpr (NX <= 4) {   // rows share the weight pass while R activation slices fit the register file
+    if (R == 4) { hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 4>), g, b, 0, c->stream, a); return; }
+    if (R == 2) { hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 2>), g, b, 0, c->stream, a); return; }
+  }
+  for (int r = 0; r < R; r++) hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 1>), g, b, 0, c->stream, gemv_row(c, a, r));
 }
 
 template <int PRO, int EPI>
@@ -258,38 +310,37 @@ void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls, int R) {
   const Tune& tn = c->tune[cls];
   a.ks = (PRO == tgx::PRO_RMSNORM) ? 1 : gemv_auto_ks(a.K, tn.ks);
   const int grid = (EPI == tgx::EPI_LOGITS) ? c->lm_grid : gemv_grid(c, a.units, a.ks, tn.bpc);
-  switch (gemv_nx(a.K, a.ks)) {
-    case 1: launch_gemv_nx<PRO, EPI, 1>(c, a, grid, R); break;
-    case 2: launch_gemv_nx<PRO, EPI, 2>(c, a, grid, R); break;
-    case 3: launch_gemv_nx<PRO, EPI, 3>(c, a, grid, R); break;
-    case 4: launch_gemv_nx<PRO, EPI, 4>(c, a, grid, R); break;
-    case 5: launch_gemv_nx<PRO, EPI, 5>(c, a, grid, R); break;
-    case 6: launch_gemv_nx<PRO, EPI, 6>(c, a, grid, R); break;
-    case 7: launch_gemv_nx<PRO, EPI, 7>(c, a, grid, R); break;
-    default: launch_gemv_nx<PRO, EPI, 8>(c, a, grid, R); break;
-  }
+  const int nx = gemv_nx(a.K, a.ks);
+  TGX_DT_SWITCH(c->dt, switch (nx) {
+    case 1: launch_gemv_nx<DT, PRO, EPI, 1>(c, a, grid, R); break;
+    case 2: launch_gemv_nx<DT, PRO, EPI, 2>(c, a, grid, R); break;
+    case 3: launch_gemv_nx<DT, PRO, EPI, 3>(c, a, grid, R); break;
+    case 4: launch_gemv_nx<DT, PRO, EPI, 4>(c, a, grid, R); break;
+    case 5: launch_gemv_nx<DT, PRO, EPI, 5>(c, a, grid, R); break;
+    case 6: launch_gemv_nx<DT, PRO, EPI, 6>(c, a, grid, R); break;
+    case 7: launch_gemv_nx<DT, PRO, EPI, 7>(c, a, grid, R); break;
+    default: launch_gemv_nx<DT, PRO, EPI, 8>(c, a, grid, R); break;
+  })
 }
 
-template <int HD>
+template <int DT, int HD>
 void launch_attn_g(tgx_ctx* c, const tgx::AttnArgs& a, int G, int R) {
   const dim3 grid(a.kv_heads * a.nsplit, R), blk(256);
   if (!(c->debug_skip & 1)) switch (G) {
-    case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 1>), grid, blk, 0, c->stream, a); break;
-    case 2: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 2>), grid, blk, 0, c->stream, a); break;
-    case 3: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 3>), grid, blk, 0, c->stream, a); break;
-    case 4: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 4>), grid, blk, 0, c->stream, a); break;
-    case 5: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 5>), grid, blk, 0, c->stream, a); break;
-    case 6: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 6>), grid, blk, 0, c->stream, a); break;
-    case 7: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 7>), grid, blk, 0, c->stream, a); break;
-    default: hipLaunchKernelGGL((tgx::attn_decode_kernel<HD, 8>), grid, blk, 0, c->stream, a); break;
+    case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1>), grid, blk, 0, c->stream, a); break;
+    case 2: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2>), grid, blk, 0, c->stream, a); break;
+    case 3: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 3>), grid, blk, 0, c->stream, a); break;
+    case 4: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4>), grid, blk, 0, c->stream, a); break;
+    case 5: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 5>), grid, blk, 0, c->stream, a); break;
+    case 6: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 6>), grid, blk, 0, c->stream, a); break;
+    default: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 7>), grid, blk, 0, c->stream, a); break;
   }
   if (!(c->debug_skip & 2)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
 }
 
 void launch_attn(tgx_ctx* c, const tgx::AttnArgs& a, int R) {
   const int G = a.heads / a.kv_heads;
-  if (c->d.head_dim == 64) launch_attn_g<64>(c, a, G, R);
-  else launch_attn_g<128>(c, a, G, R);
+  TGX_DT_SWITCH(c->dt, if (c->d.head_dim == 64) launch_attn_g<DT, 64>(c, a, G, R); else launch_attn_g<DT, 128>(c, a, G, R))
 }
 
 void fill_strides(const tgx_ctx* c, tgx::GemvArgs& a) {
@@ -305,7 +356,7 @@ void launch_layer_kernel(tgx_ctx* c, int row0, int R, int l, int cls, float* res
   const tgx_model_desc& d = c->d;
   RowState& r = c->rows[(size_t)row0];
   const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
-  const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd;
+  const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd * c->esz;   // bytes (ebyte pointers)
   const LayerW& w = c->L[(size_t)l];
   switch (cls) {
     case TGX_KERNEL_QKV: {   // input_layernorm -> qkv_proj -> RoPE -> cache append   (DecoderLayer.h:40, Attention.h:94-106)
@@ -324,7 +375,7 @@ void launch_layer_kernel(tgx_ctx* c, int row0, int R, int l, int cls, float* res
         n.q = rb.q; n.k_raw = rb.k_raw; n.k_cache = rb.kcache + (size_t)l * kv_layer; n.q_norm_w = w.q_norm; n.k_norm_w = w.k_norm;
         n.rope_cos = c->rope_cos; n.rope_sin = c->rope_sin; n.pos = rb.pos;
         n.heads = d.heads; n.kv_heads = d.kv_heads; n.hd = hd; n.max_ctx = d.max_ctx; n.eps = d.norm_eps;
-        hipLaunchKernelGGL(tgx::qk_norm_rope_kernel, dim3(d.heads + d.kv_heads), dim3(64), 0, c->stream, n);
+        TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::qk_norm_rope_kernel<DT>, dim3(d.heads + d.kv_heads), dim3(64), 0, c->stream, n))
       }
       break;
     }
@@ -400,7 +451,9 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
   return TGX_OK;
 }
 
-void launch_gemm(tgx_ctx* c, int epi, const bf16_t* B, const bf16_t* bias, float* C, int M, int N, int K, int ldc, bool three_terms = false) {
+void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float* C, int M, int N, int K, int ldc, bool three_terms = false) {
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(B_);   // the MFMA prefill runs for bf16 storage only (prefill_shapes_ok)
+  const bf16_t* bias = reinterpret_cast<const bf16_t*>(bias_);
   tgx::GemmArgs g{};
   g.A_hi = c->ws_ah; g.A_lo = c->ws_al; g.A_lo2 = three_terms ? c->ws_al2 : nullptr;
   g.B = B; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
@@ -416,6 +469,8 @@ void launch_prefill(tgx_ctx* c, RowState& r, int S) {
   const tgx_model_desc& d = c->d;
   const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
   const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd;
+  bf16_t* kc = reinterpret_cast<bf16_t*>(r.kcache);
+  bf16_t* vc = reinterpret_cast<bf16_t*>(r.vcache);
   hipLaunchKernelGGL(tgx::embed_rows_kernel, dim3(S), dim3(256), 0, c->stream, (const long long*)r.prompt, (const bf16_t*)c->embed, c->ws_x, H);
   for (int l = 0; l < d.layers; l++) {
     const LayerW& w = c->L[(size_t)l];
@@ -424,15 +479,15 @@ void launch_prefill(tgx_ctx* c, RowState& r, int S) {
     {
       tgx::RopeKvArgs a{};
       a.QKV = c->ws_out; a.q_hi = c->ws_qh; a.q_lo = c->ws_ql;
-      a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
+      a.k_cache = kc + (size_t)l * kv_layer; a.v_cache = vc + (size_t)l * kv_layer;
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = (int)c->past;
-      a.q_norm_w = d.qk_norm ? w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? w.k_norm : nullptr; a.eps = d.norm_eps;
+      a.q_norm_w = d.qk_norm ? (const bf16_t*)w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? (const bf16_t*)w.k_norm : nullptr; a.eps = d.norm_eps;
       hipLaunchKernelGGL(tgx::rope_kv_split_kernel, dim3(S), dim3(256), 0, c->stream, a);
     }
     {
       tgx::AttnPrefillArgs a{};
-      a.q_hi = c->ws_qh; a.q_lo = c->ws_ql; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
+      a.q_hi = c->ws_qh; a.q_lo = c->ws_ql; a.k_cache = kc + (size_t)l * kv_layer; a.v_cache = vc + (size_t)l * kv_layer;
       a.o_hi = c->ws_ah; a.o_lo = c->ws_al; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
       a.scale = 1.0f / sqrtf((float)hd);
       const dim3 grid((S + 63) / 64, d.heads), blk(256);
@@ -481,7 +536,7 @@ void launch_sample(tgx_ctx* c, int row, const tgx_sampler_cfg& cfg, bool advance
   RowState& r = c->rows[(size_t)row];
   if (is_greedy(&cfg)) {
     const tgx::FinalizeArgs a = make_finalize_args(c, row, advance_pos, log_step);
-    hipLaunchKernelGGL(tgx::finalize_greedy_kernel, dim3(1), dim3(256), 0, c->stream, a);
+    TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::finalize_greedy_kernel<DT>, dim3(1), dim3(256), 0, c->stream, a))
     return;
   }
   tgx::SampleArgs a{};
@@ -489,7 +544,7 @@ void launch_sample(tgx_ctx* c, int row, const tgx_sampler_cfg& cfg, bool advance
   a.temperature = cfg.temperature; a.top_k = cfg.top_k; a.top_p = cfg.top_p; a.min_p = cfg.min_p;
   a.seed = c->seed_dev;
   a.fin = make_finalize_args(c, row, advance_pos, log_step);
-  hipLaunchKernelGGL(tgx::sample_kernel, dim3(1), dim3(tgx::SAMPLER_THREADS), 0, c->stream, a);
+  TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::sample_kernel<DT>, dim3(1), dim3(tgx::SAMPLER_THREADS), 0, c->stream, a))
 }
 
 // One decode step for all active rows: layers at pos, lm_head, then {sample, pos+=1, next embedding}.
@@ -576,7 +631,7 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   const tgx_model_desc& d = *desc;
   if (d.family != TGX_FAMILY_LLAMA && d.family != TGX_FAMILY_QWEN2 && d.family != TGX_FAMILY_MISTRAL && d.family != TGX_FAMILY_QWEN3)
     return set_err(nullptr, TGX_ERR_UNSUPPORTED, "family %d is not implemented on mi355x (llama/qwen2/qwen3/mistral are)", d.family);
-  if (d.compute_dtype != TGX_BF16) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "mi355x backend computes in bf16 only");
+  if (d.compute_dtype != TGX_BF16 && d.compute_dtype != TGX_F16 && d.compute_dtype != TGX_F32) return set_err(nullptr, TGX_ERR_INVALID, "unknown compute dtype %d", d.compute_dtype);
   if (d.head_dim != 64 && d.head_dim != 128) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "head_dim %d (64 and 128 are built)", d.head_dim);
   if (d.heads <= 0 || d.kv_heads <= 0 || d.heads % d.kv_heads) return set_err(nullptr, TGX_ERR_INVALID, "heads %% kv_heads != 0");
   if (d.heads / d.kv_heads > 7) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "GQA group size %d > 7", d.heads / d.kv_heads);
@@ -594,6 +649,8 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   c->d = d;
   if (c->d.max_batch < 1) c->d.max_batch = 1;
   c->device = device_ordinal;
+  c->dt = d.compute_dtype == TGX_BF16 ? tgx::DT_BF16 : (d.compute_dtype == TGX_F16 ? tgx::DT_F16 : tgx::DT_F32);
+  c->esz = d.compute_dtype == TGX_F32 ? 4 : 2;
   HIP_OK(c, hipSetDevice(device_ordinal));
   hipDeviceProp_t prop;
   HIP_OK(c, hipGetDeviceProperties(&prop, device_ordinal));
@@ -604,19 +661,20 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
 
   const int H = d.hidden, I = d.inter, V = d.vocab, qd = d.heads * d.head_dim, kvd = d.kv_heads * d.head_dim;
   int rc;
-  if ((rc = dev_alloc(c, &c->embed, (size_t)V * H))) return rc;
-  if (!d.tied && (rc = dev_alloc(c, &c->lm_head, (size_t)V * H))) return rc;
-  if ((rc = dev_alloc(c, &c->final_norm, (size_t)H))) return rc;
+  const size_t es = c->esz;
+  if ((rc = dev_alloc(c, &c->embed, (size_t)V * H * es))) return rc;
+  if (!d.tied && (rc = dev_alloc(c, &c->lm_head, (size_t)V * H * es))) return rc;
+  if ((rc = dev_alloc(c, &c->final_norm, (size_t)H * es))) return rc;
   c->L.resize((size_t)d.layers);
   for (auto& w : c->L) {
-    if ((rc = dev_alloc(c, &w.in_norm, (size_t)H))) return rc;
-    if ((rc = dev_alloc(c, &w.post_norm, (size_t)H))) return rc;
-    if ((rc = dev_alloc(c, &w.wqkv, (size_t)(qd + 2 * kvd) * H))) return rc;
-    if (d.qkv_bias && (rc = dev_alloc(c, &w.bqkv, (size_t)(qd + 2 * kvd)))) return rc;
-    if ((rc = dev_alloc(c, &w.wo, (size_t)H * qd))) return rc;
-    if (d.qk_norm && ((rc = dev_alloc(c, &w.q_norm, (size_t)d.head_dim)) || (rc = dev_alloc(c, &w.k_norm, (size_t)d.head_dim)))) return rc;
-    if ((rc = dev_alloc(c, &w.wgu, (size_t)2 * I * H))) return rc;
-    if ((rc = dev_alloc(c, &w.wdown, (size_t)H * I))) return rc;
+    if ((rc = dev_alloc(c, &w.in_norm, (size_t)H * es))) return rc;
+    if ((rc = dev_alloc(c, &w.post_norm, (size_t)H * es))) return rc;
+    if ((rc = dev_alloc(c, &w.wqkv, (size_t)(qd + 2 * kvd) * H * es))) return rc;
+    if (d.qkv_bias && (rc = dev_alloc(c, &w.bqkv, (size_t)(qd + 2 * kvd) * es))) return rc;
+    if ((rc = dev_alloc(c, &w.wo, (size_t)H * qd * es))) return rc;
+    if (d.qk_norm && ((rc = dev_alloc(c, &w.q_norm, (size_t)d.head_dim * es)) || (rc = dev_alloc(c, &w.k_norm, (size_t)d.head_dim * es)))) return rc;
+    if ((rc = dev_alloc(c, &w.wgu, (size_t)2 * I * H * es))) return rc;
+    if ((rc = dev_alloc(c, &w.wdown, (size_t)H * I * es))) return rc;
   }
   return TGX_OK;
 }
@@ -630,18 +688,18 @@ int tgx_upload(tgx_ctx* c, const char* name, const void* host, const int64_t* sh
   if (!strcmp(name, "model.embed_tokens.weight")) {
     if (!shape_is(shape, nd, V, H)) return bad_shape();
     c->embed_ok = true;
-    return upload_bf16(c, c->embed, host, V * H, src_dtype);
+    return upload_param(c, c->embed, host, V * H, src_dtype);
   }
   if (!strcmp(name, "lm_head.weight")) {
     if (!shape_is(shape, nd, V, H)) return bad_shape();
     if (d.tied) return TGX_OK;   // aliased to embed_tokens (GPTModel.h:39-41)
     c->lm_head_ok = true;
-    return upload_bf16(c, c->lm_head, host, V * H, src_dtype);
+    return upload_param(c, c->lm_head, host, V * H, src_dtype);
   }
   if (!strcmp(name, "model.norm.weight")) {
     if (!shape_is(shape, nd, H, -1)) return bad_shape();
     c->final_norm_ok = true;
-    return upload_bf16(c, c->final_norm, host, H, src_dtype);
+    return upload_param(c, c->final_norm, host, H, src_dtype);
   }
   int l = -1;
   char rest[128] = {0};
@@ -650,21 +708,21 @@ int tgx_upload(tgx_ctx* c, const char* name, const void* host, const int64_t* sh
     if (!strcmp(rest, "input_layernorm.weight")) {
       if (!shape_is(shape, nd, H, -1)) return bad_shape();
       w.in_norm_ok = true;
-      return upload_bf16(c, w.in_norm, host, H, src_dtype);
+      return upload_param(c, w.in_norm, host, H, src_dtype);
     }
     if (d.qk_norm && (!strcmp(rest, "self_attn.q_norm.weight") || !strcmp(rest, "self_attn.k_norm.weight"))) {
       if (!shape_is(shape, nd, d.head_dim, -1)) return bad_shape();
       const bool isq = rest[10] == 'q';
       (isq ? w.q_norm_ok : w.k_norm_ok) = true;
-      return upload_bf16(c, isq ? w.q_norm : w.k_norm, host, d.head_dim, src_dtype);
+      return upload_param(c, isq ? w.q_norm : w.k_norm, host, d.head_dim, src_dtype);
     }
     if (!strcmp(rest, "post_attention_layernorm.weight")) {
       if (!shape_is(shape, nd, H, -1)) return bad_shape();
       w.post_norm_ok = true;
-      return upload_bf16(c, w.post_norm, host, H, src_dtype);
+      return upload_param(c, w.post_norm, host, H, src_dtype);
     }
     // MergedLinear row slices (Linear.h:64-79): [q | k | v] and [gate | up]
-    struct Slot { const char* n; bf16_t* base; bf16_t* bias; int64_t row0, rows, cols; int kind; };
+    struct Slot { const char* n; ebyte* base; ebyte* bias; int64_t row0, rows, cols; int kind; };
     const Slot slots[] = {
         {"self_attn.q_proj", w.wqkv, w.bqkv, 0, qd, H, 0},        {"self_attn.k_proj", w.wqkv, w.bqkv, qd, kvd, H, 0},
         {"self_attn.v_proj", w.wqkv, w.bqkv, qd + kvd, kvd, H, 0}, {"self_attn.o_proj", w.wo, nullptr, 0, H, qd, 1},
@@ -675,7 +733,7 @@ int tgx_upload(tgx_ctx* c, const char* name, const void* host, const int64_t* sh
       if (strncmp(rest, s.n, ln) || rest[ln] != '.') continue;
       if (!strcmp(rest + ln + 1, "weight")) {
         if (!shape_is(shape, nd, s.rows, s.cols)) return bad_shape();
-        int rc = upload_bf16(c, s.base + s.row0 * s.cols, host, s.rows * s.cols, src_dtype);
+        int rc = upload_param(c, s.base + (size_t)(s.row0 * s.cols) * c->esz, host, s.rows * s.cols, src_dtype);
         if (rc) return rc;
         if (s.kind == 0) w.qkv_rows += s.rows;
         else if (s.kind == 1) w.wo_ok = true;
@@ -686,7 +744,7 @@ int tgx_upload(tgx_ctx* c, const char* name, const void* host, const int64_t* sh
       if (!strcmp(rest + ln + 1, "bias") && s.bias) {
         if (!shape_is(shape, nd, s.rows, -1)) return bad_shape();
         w.bias_rows += s.rows;
-        return upload_bf16(c, s.bias + s.row0, host, s.rows, src_dtype);
+        return upload_param(c, s.bias + (size_t)s.row0 * c->esz, host, s.rows, src_dtype);
       }
     }
   }
@@ -742,12 +800,12 @@ int tgx_finalize(tgx_ctx* c) {
   if ((rc = dev_alloc(c, &c->slab_tok, B))) return rc;
   if ((rc = dev_alloc(c, &c->slab_pos, B))) return rc;
   if ((rc = dev_alloc(c, &c->slab_prompt, B * d.max_ctx))) return rc;
-  if ((rc = dev_alloc(c, &c->slab_k, B * kv_elems))) return rc;
-  if ((rc = dev_alloc(c, &c->slab_v, B * kv_elems))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_k, B * kv_elems * c->esz))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_v, B * kv_elems * c->esz))) return rc;
   HIP_OK(c, hipMemset(c->slab_tok, 0, B * 4));
   HIP_OK(c, hipMemset(c->slab_pos, 0, B * 4));
-  HIP_OK(c, hipMemset(c->slab_k, 0, B * kv_elems * 2));
-  HIP_OK(c, hipMemset(c->slab_v, 0, B * kv_elems * 2));
+  HIP_OK(c, hipMemset(c->slab_k, 0, B * kv_elems * c->esz));
+  HIP_OK(c, hipMemset(c->slab_v, 0, B * kv_elems * c->esz));
   for (size_t b = 0; b < B; b++) {
     RowState& r = c->rows[b];
     r.x = c->slab_x + b * H; r.q = c->slab_q + b * qd; r.k_raw = c->slab_kraw + b * kvd; r.attn = c->slab_attn + b * qd;
@@ -755,7 +813,7 @@ int tgx_finalize(tgx_ctx* c) {
     r.part_val = c->slab_part_val + b * c->lm_grid; r.part_idx = c->slab_part_idx + b * c->lm_grid;
     r.attn_part = c->slab_attn_part + b * c->attn_part_row;
     r.tok = c->slab_tok + b; r.pos = c->slab_pos + b; r.prompt = c->slab_prompt + b * d.max_ctx;
-    r.kcache = c->slab_k + b * kv_elems; r.vcache = c->slab_v + b * kv_elems;
+    r.kcache = c->slab_k + b * kv_elems * c->esz; r.vcache = c->slab_v + b * kv_elems * c->esz;
   }
   c->log_cap = d.max_ctx > 1024 ? d.max_ctx : 1024;
   if ((rc = dev_alloc(c, &c->step, 1))) return rc;
@@ -810,7 +868,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
   for (int b = 0; b < batch; b++) {
     RowState& r = c->rows[(size_t)b];
     HIP_OK(c, hipMemcpyAsync(r.prompt, ids + (size_t)b * seq, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream));
-    if (seq >= 4 && c->prefill_mfma && prefill_shapes_ok(c->d)) {
+    if (seq >= 4 && c->prefill_mfma && c->dt == tgx::DT_BF16 && prefill_shapes_ok(c->d)) {
       // batched prefill on the matrix cores; logits for the last position only (== forward + narrow, GPTEngine.cpp:96-97)
       int rc = ensure_prefill_ws(c, seq);
       if (rc) return rc;
@@ -823,7 +881,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     tgx::EmbedArgs e{};
     e.ids = r.prompt; e.pos = r.pos; e.pos0 = (int)c->past; e.embed = c->embed; e.x = r.x; e.H = c->d.hidden; e.V = c->d.vocab; e.tok = r.tok;
     for (int s = 0; s < seq; s++) {
-      hipLaunchKernelGGL(tgx::embed_prompt_kernel, dim3(1), dim3(256), 0, c->stream, e);
+      TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_prompt_kernel<DT>, dim3(1), dim3(256), 0, c->stream, e))
       launch_layers(c, b, 1);
       if (s == seq - 1) launch_lm_head(c, b, 1);
       hipLaunchKernelGGL(tgx::advance_pos_kernel, dim3(1), dim3(64), 0, c->stream, r.pos);
@@ -844,8 +902,9 @@ int tgx_read_logits(tgx_ctx* c, float* out, int rounded) {
   HIP_OK(c, hipStreamSynchronize(c->stream));
   const size_t V = (size_t)c->d.vocab;
   for (int b = 0; b < c->batch; b++) HIP_OK(c, hipMemcpy(out + b * V, c->rows[(size_t)b].logits, V * 4, hipMemcpyDeviceToHost));
-  if (rounded)
-    for (size_t i = 0; i < V * (size_t)c->batch; i++) out[i] = host_bf16_to_f32(host_f32_to_bf16(out[i]));
+  if (rounded && c->dt != tgx::DT_F32)
+    for (size_t i = 0; i < V * (size_t)c->batch; i++)
+      out[i] = c->dt == tgx::DT_BF16 ? host_bf16_to_f32(host_f32_to_bf16(out[i])) : host_half_to_f32(host_f32_to_half(out[i]));
   return TGX_OK;
 }
 
@@ -948,15 +1007,21 @@ int tgx_read_kv(tgx_ctx* c, int row, int layer, float* k_out, float* v_out) {
   HIP_OK(c, hipStreamSynchronize(c->stream));
   const tgx_model_desc& d = c->d;
   const size_t hd = (size_t)d.head_dim, per_head = (size_t)d.max_ctx * hd, T = (size_t)c->past;
-  std::vector<uint16_t> tmp(per_head);
+  std::vector<unsigned char> tmp(per_head * c->esz);
   for (int which = 0; which < 2; which++) {
     float* out = which ? v_out : k_out;
     if (!out) continue;
-    const bf16_t* base = (which ? c->rows[(size_t)row].vcache : c->rows[(size_t)row].kcache) + (size_t)layer * d.kv_heads * per_head;
+    const ebyte* base = (which ? c->rows[(size_t)row].vcache : c->rows[(size_t)row].kcache) + (size_t)layer * d.kv_heads * per_head * c->esz;
     for (int h = 0; h < d.kv_heads; h++) {
-      HIP_OK(c, hipMemcpy(tmp.data(), base + (size_t)h * per_head, T * hd * 2, hipMemcpyDeviceToHost));
+      HIP_OK(c, hipMemcpy(tmp.data(), base + (size_t)h * per_head * c->esz, T * hd * c->esz, hipMemcpyDeviceToHost));
       for (size_t t = 0; t < T; t++)
-        for (size_t k = 0; k < hd; k++) out[(t * d.kv_heads + h) * hd + k] = host_bf16_to_f32(tmp[t * hd + k]);   // BSHD view
+        for (size_t k = 0; k < hd; k++) {   // BSHD view
+          const size_t i = t * hd + k;
+          float v;
+          if (c->dt == tgx::DT_F32) memcpy(&v, tmp.data() + 4 * i, 4);
+          else { uint16_t u; memcpy(&u, tmp.data() + 2 * i, 2); v = c->dt == tgx::DT_BF16 ? host_bf16_to_f32(u) : host_half_to_f32(u); }
+          out[(t * d.kv_heads + h) * hd + k] = v;
+        }
     }
   }
   return TGX_OK;
@@ -1059,7 +1124,8 @@ int64_t tgx_bytes_per_token(const tgx_ctx* c, int64_t T) {
   const tgx_model_desc& d = c->d;
   const int64_t H = d.hidden, I = d.inter, V = d.vocab, L = d.layers, q = (int64_t)d.heads * d.head_dim, kv = (int64_t)d.kv_heads * d.head_dim;
   const int64_t per_layer = (q + 2 * kv) * H + (d.qkv_bias ? (q + 2 * kv) : 0) + H * q + 2 * I * H + H * I + 2 * H;
-  return 2 * (L * per_layer + H + V * H) + 2 * 2 * L * kv * T;
+  const int64_t b = (int64_t)c->esz;   // bytes per stored parameter / cache element
+  return b * (L * per_layer + H + V * H) + b * 2 * L * kv * T;
 }
 
 }  // extern "C"

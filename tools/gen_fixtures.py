@@ -170,6 +170,21 @@ def gen_family(name: str, cfg: dict):
           f"min top-2 gap {gap32:.1f}/{gap16:.1f} bf16-ulps, fp32-vs-bf16 same ids: {bool((t32 == t16).all())}")
 
 
+def gen_family_fp16(name: str, cfg: dict):
+    """fp16 companion of an existing fixture (same seed, same prompt): tests/golden/<name>/golden_fp16.npz.
+    Pins the fp16 row of the --dtype matrix (fp16 parameters + fp16 KV cache) without touching golden.npz."""
+    g = np.load(os.path.join(OUT, name, "golden.npz"))
+    seed = int(g["seed"])
+    _, m16 = build_hf(cfg, seed, torch.float16)
+    l16, t16, h16 = run_greedy(m16, torch.from_numpy(g["prompt"]), N_STEPS)
+    s = np.sort(l16, -1)
+    gap = float(((s[..., -1] - s[..., -2]) / (2.0 ** (np.floor(np.log2(np.maximum(np.abs(s[..., -1]), 1e-30))) - 10))).min())
+    np.savez_compressed(os.path.join(OUT, name, "golden_fp16.npz"), logits_fp16=l16, ids_fp16=t16, hidden_fp16=h16,
+                        gap_ulps=np.float32(gap))
+    print(f"{name}: fp16 greedy {t16[0][:8]}..., min top-2 gap {gap:.1f} fp16-ulps, same ids as fp32: "
+          f"{bool((t16 == g['ids_fp32']).all())}, max |fp16-fp32| logits {np.abs(l16 - g['logits_fp32']).max():.3e}")
+
+
 def gen_sampler():
     """Sampler.cpp:34-77 restated op-for-op with torch (fp32), for fixed logits vectors."""
     g = torch.Generator().manual_seed(7)
@@ -219,6 +234,11 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     print("torch", torch.__version__, "transformers", transformers.__version__)
     only = sys.argv[1:]
+    if only and only[0] == "--fp16":          # add golden_fp16.npz next to the existing fixtures (which stay untouched)
+        for name, cfg in FAMILIES.items():
+            if cfg["model_type"] != "gpt2" and (len(only) == 1 or name in only[1:]):
+                gen_family_fp16(name, cfg)
+        sys.exit(0)
     for name, cfg in FAMILIES.items():
         if not only or name in only:
             gen_family(name, cfg)
