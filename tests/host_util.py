@@ -34,10 +34,13 @@ def host_lib():
 
 
 class HostEngine:
-    def __init__(self, lib, model_dir=None, synthetic=None, device="mi355x", backend_lib=None, prefix="tgx_", dtype=1, max_batch=4):
+    def __init__(self, lib, model_dir=None, synthetic=None, device="mi355x", backend_lib=None, prefix="tgx_", dtype=1, max_batch=4, tokenizer_dir=None):
         self.lib = lib
-        self.h = lib.tgxe_create((model_dir or "").encode(), (synthetic or "").encode(), device.encode(),
-                                 (backend_lib or "").encode(), prefix.encode(), 0, dtype, max_batch)
+        lib.tgxe_create2.restype = c_void_p
+        lib.tgxe_create2.argtypes = [c_char_p, c_char_p, c_char_p, c_char_p, c_char_p, c_int, c_int, c_int, c_char_p]
+        self.h = lib.tgxe_create2((model_dir or "").encode(), (synthetic or "").encode(), device.encode(),
+                                  (backend_lib or "").encode(), prefix.encode(), 0, dtype, max_batch,
+                                  tokenizer_dir.encode() if tokenizer_dir else None)
 
     def prepare(self):
         return self.lib.tgxe_prepare(self.h) == 0
@@ -79,6 +82,36 @@ class HostEngine:
         assert rc == 0, self.error()
         return out[:n.value], new.value, ("stop", "length")[fin.value], seen
 
+    def generate_sync_text(self, texts, cap=1 << 16):
+        arr = (c_char_p * len(texts))(*[t.encode("utf-8") for t in texts])
+        out = np.zeros(cap, np.int32)
+        buf = ctypes.create_string_buffer(1 << 16)
+        n, new, tl = c_int64(), c_int64(), c_int64()
+        self.lib.tgxe_generate_sync_text.argtypes = [c_void_p, POINTER(c_char_p), c_int, POINTER(c_int32), c_int64, POINTER(c_int64),
+                                                     POINTER(c_int64), c_char_p, c_int64, POINTER(c_int64)]
+        rc = self.lib.tgxe_generate_sync_text(self.h, arr, len(texts), out.ctypes.data_as(POINTER(c_int32)), cap, ctypes.byref(n),
+                                              ctypes.byref(new), buf, 1 << 16, ctypes.byref(tl))
+        assert rc == 0, self.error()
+        return out[:n.value].reshape(len(texts), -1), new.value, buf.raw[:tl.value].split(b"\x1e")
+
+    def generate_async_text(self, text, on_chunk=None, cap=1 << 16):
+        chunks = []
+        TEXT_CB = CFUNCTYPE(c_int, POINTER(ctypes.c_char), c_int64, c_void_p)
+
+        def cb(ptr, length, _):
+            c = ctypes.string_at(ptr, length)
+            chunks.append(c)
+            return 1 if (on_chunk is None or on_chunk(c)) else 0
+
+        out = np.zeros(cap, np.int32)
+        n, new, fin = c_int64(), c_int64(), c_int()
+        self.lib.tgxe_generate_async_text.argtypes = [c_void_p, c_char_p, TEXT_CB, c_void_p, POINTER(c_int32), c_int64, POINTER(c_int64),
+                                                      POINTER(c_int64), POINTER(c_int)]
+        rc = self.lib.tgxe_generate_async_text(self.h, text.encode("utf-8"), TEXT_CB(cb), None, out.ctypes.data_as(POINTER(c_int32)), cap,
+                                               ctypes.byref(n), ctypes.byref(new), ctypes.byref(fin))
+        assert rc == 0, self.error()
+        return out[:n.value], new.value, ("stop", "length")[fin.value], chunks
+
     def close(self):
         if self.h:
             self.lib.tgxe_destroy(self.h)
@@ -115,3 +148,85 @@ def write_model_dir(path, cfg, seed, std, shards=1, dtype="bf16", eos=None):
         with open(os.path.join(path, "model.safetensors.index.json"), "w") as f:
             json.dump({"metadata": {}, "weight_map": wm}, f)
     return d
+
+
+class HostTokenizer:
+    """ctypes view of tgxh::Tokenizer (tinygpt_amd/host/tokenizer.h) through the tgxe_tok_* entry points."""
+
+    def __init__(self, lib, directory):
+        self.lib = lib
+        lib.tgxe_tok_create.restype = c_void_p
+        lib.tgxe_tok_create.argtypes = [c_char_p, c_char_p, c_char_p, c_int]
+        lib.tgxe_tok_destroy.argtypes = [c_void_p]
+        lib.tgxe_tok_encode.restype = c_int64
+        lib.tgxe_tok_encode.argtypes = [c_void_p, c_char_p, c_int64, c_int, POINTER(c_int32), c_int64]
+        lib.tgxe_tok_decode.restype = c_int64
+        lib.tgxe_tok_decode.argtypes = [c_void_p, POINTER(c_int32), c_int64, c_int, c_char_p, c_int64]
+        lib.tgxe_tok_special.restype = c_int32
+        lib.tgxe_tok_special.argtypes = [c_void_p, c_int]
+        lib.tgxe_tok_token_to_id.restype = c_int32
+        lib.tgxe_tok_token_to_id.argtypes = [c_void_p, c_char_p]
+        err = ctypes.create_string_buffer(512)
+        self.h = lib.tgxe_tok_create(os.path.join(directory, "tokenizer.json").encode(), os.path.join(directory, "tokenizer_config.json").encode(), err, 512)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+
+    def close(self):
+        if self.h:
+            self.lib.tgxe_tok_destroy(self.h)
+            self.h = None
+
+    def encode(self, text, allow_added=True):
+        b = text.encode("utf-8")
+        cap = 2 * len(b) + 16
+        buf = (c_int32 * cap)()
+        n = self.lib.tgxe_tok_encode(self.h, b, len(b), int(allow_added), buf, cap)
+        return list(buf[:n])
+
+    def _decode(self, ids, mode):
+        arr = (c_int32 * max(1, len(ids)))(*ids)
+        n = self.lib.tgxe_tok_decode(self.h, arr, len(ids), mode, None, 0)
+        out = ctypes.create_string_buffer(max(1, n))
+        if mode == 0:
+            self.lib.tgxe_tok_decode(self.h, arr, len(ids), 0, out, n)
+            return out.raw[:n]
+        # stream calls are stateful: the first call consumed the ids; the bytes sit in the handle's scratch
+        return self._scratch(n)
+
+    def _scratch(self, n):
+        self.lib.tgxe_tok_scratch.restype = c_int64
+        self.lib.tgxe_tok_scratch.argtypes = [c_void_p, c_char_p, c_int64]
+        out = ctypes.create_string_buffer(max(1, n))
+        self.lib.tgxe_tok_scratch(self.h, out, n)
+        return out.raw[:n]
+
+    def decode(self, ids):
+        return self._decode(list(ids), 0).decode("utf-8", errors="replace")
+
+    def decode_stream(self, ids):
+        return self._decode(list(ids), 1)
+
+    def decode_stream_flush(self):
+        return self._decode([], 2)
+
+    @property
+    def bos(self): return self.lib.tgxe_tok_special(self.h, 0)
+    @property
+    def eos(self): return self.lib.tgxe_tok_special(self.h, 1)
+    @property
+    def pad(self): return self.lib.tgxe_tok_special(self.h, 2)
+
+    def token_to_id(self, token):
+        return self.lib.tgxe_tok_token_to_id(self.h, token.encode("utf-8"))
+
+
+def regex_match_all(lib, pattern, text):
+    lib.tgxe_regex_match_all.restype = c_int64
+    lib.tgxe_regex_match_all.argtypes = [c_char_p, c_char_p, c_int64, POINTER(c_int64), c_int64]
+    b = text.encode("utf-8")
+    cap = len(b) + 1
+    buf = (c_int64 * (2 * cap))()
+    n = lib.tgxe_regex_match_all(pattern.encode("utf-8"), b, len(b), buf, cap)
+    if n < 0:
+        return None
+    return [[buf[2 * i], buf[2 * i + 1]] for i in range(n)]

@@ -40,3 +40,35 @@ def test_cli_runs_batch_of_four(tmp_path):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert out.stdout.count("Output ids:") == 4 and "speed:" in out.stdout and "token/s" in out.stdout
+
+
+def test_cli_text_prompts_on_gpu(tmp_path, oracle_lib):
+    """The reference harness end to end (main.cpp:12-17,97-114): the four text prompts -> tokenizer -> HIP decode path ->
+    detokenised outputs, batch 4 sharing each weight pass; the ids equal the CPU oracle's through the same host engine."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from host_util import HostEngine, HostTokenizer, host_lib
+    tok_dir = os.path.join(GOLDEN, "tokenizer", "llama3_style")
+    cfg, g = load_golden("llama_tiny")
+    cfg = dict(cfg, vocab_size=1280)
+    write_model_dir(str(tmp_path), cfg, 77, 0.08)
+    _, cli = build.build_host()
+    out = subprocess.run([cli, "--model", str(tmp_path), "--tokenizer", tok_dir, "--max-tokens", "8", "--temperature", "0", "--top-p", "1"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.count("Prompt:") == 4 and "'Hello, my name is'" in out.stdout and "token/s" in out.stdout
+    lib = host_lib()
+    texts = ["Hello, my name is", "The president of the United States is", "The capital of France is", "The future of AI is"]
+    gpu = HostEngine(lib, model_dir=str(tmp_path), tokenizer_dir=tok_dir, max_batch=4)
+    ref = HostEngine(lib, model_dir=str(tmp_path), tokenizer_dir=tok_dir, max_batch=4, backend_lib=oracle_lib.path, prefix="tgxo_")
+    assert gpu.prepare(), gpu.error()
+    assert ref.prepare(), ref.error()
+    gpu.reconfigure(max_new=8); ref.reconfigure(max_new=8)
+    ids_g, _, txt_g = gpu.generate_sync_text(texts)
+    ids_r, _, txt_r = ref.generate_sync_text(texts)
+    np.testing.assert_array_equal(ids_g, ids_r)
+    assert txt_g == txt_r
+    for b, t in enumerate(txt_g):
+        assert f"'{t.decode('utf-8', errors='replace')}'" in out.stdout or b"\n" in t     # the CLI printed the same continuations
+    gpu.close(); ref.close()

@@ -130,3 +130,81 @@ def test_bad_inputs_fail_loudly(lib, oracle_path, tmp_path):
     e = HostEngine(lib, model_dir=str(d2), backend_lib=oracle_path, prefix="tgxo_", dtype=0)
     assert not e.prepare() and "Unsupported model_type" in e.error()
     e.close()
+
+
+# ---- text entry points: tokenizer -> engine -> tokenizer (GPTEngine.cpp:101-174,180-232) -----------------------------------
+TOK_DIR = __import__("os").path.join(__import__("conftest").GOLDEN, "tokenizer", "llama3_style")
+
+
+def text_engine(lib, oracle_path, tmp_path, max_batch=4):
+    """llama_tiny widened to the 1200-token vocabulary of the llama3_style fixture tokenizer."""
+    cfg, g = load_golden("llama_tiny")
+    cfg = dict(cfg, vocab_size=1280)
+    write_model_dir(str(tmp_path), cfg, 77, 0.08)
+    e = HostEngine(lib, model_dir=str(tmp_path), backend_lib=oracle_path, prefix="tgxo_", dtype=1, max_batch=max_batch, tokenizer_dir=TOK_DIR)
+    assert e.prepare(), e.error()
+    return e
+
+
+def test_generate_sync_from_text_equals_id_path(lib, oracle_path, tmp_path):
+    """encodeTexts == tokenizer.encodeBatch + left pad with pad -> eos -> 0 (:101-144); output texts == decodeBatch of the
+    new tokens only (decodeTokens, :146-152)."""
+    from host_util import HostTokenizer
+    e = text_engine(lib, oracle_path, tmp_path)
+    tok = HostTokenizer(lib, TOK_DIR)
+    texts = ["Hello, my name is", "The president of the United States is", "The capital of France is", "The future of AI is"]
+    e.reconfigure(max_new=6)
+    ids_t, new_t, out_texts = e.generate_sync_text(texts)
+    prompts = [tok.encode(t) for t in texts]
+    assert all(p[0] == tok.bos for p in prompts)
+    pad = tok.pad if tok.pad >= 0 else (tok.eos if tok.eos >= 0 else 0)
+    e.reconfigure(max_new=6)                                   # resets the KV cache (:83)
+    ids_i, new_i, _ = e.generate_sync(prompts, pad=pad)
+    np.testing.assert_array_equal(ids_t, ids_i)
+    assert new_t == new_i == 6
+    S = ids_t.shape[1] - 6
+    assert S == max(len(p) for p in prompts)
+    assert (ids_t[2, : S - len(prompts[2])] == pad).all()      # left padding
+    for b in range(4):
+        assert out_texts[b].decode("utf-8", errors="replace") == tok.decode(list(ids_t[b, S:]))
+    e.close(); tok.close()
+
+
+def test_generate_async_text_streams_utf8_safe_chunks(lib, oracle_path, tmp_path):
+    from host_util import HostTokenizer
+    e = text_engine(lib, oracle_path, tmp_path, max_batch=1)
+    tok = HostTokenizer(lib, TOK_DIR)
+    e.reconfigure(max_new=24)
+    ids, new, fin, chunks = e.generate_async_text("你好, hello")
+    prompt = tok.encode("你好, hello")
+    np.testing.assert_array_equal(ids[:len(prompt)], prompt)
+    def truncated_tail(b):                                      # a lead byte at the end that announces more bytes than follow
+        for back in range(1, min(4, len(b)) + 1):
+            c = b[-back]
+            if c & 0xC0 == 0x80:
+                continue
+            need = 4 if c >= 0xF0 else 3 if c >= 0xE0 else 2 if c >= 0xC0 else 1
+            return need > back
+        return False
+    assert chunks and not any(truncated_tail(c) for c in chunks[:-1])   # never a split character (a random model may emit invalid bytes)
+    # the callback saw tokens T1..T(n-1) (the last future token is not reported when the loop ends by length, :196-217)
+    streamed = b"".join(chunks)
+    reported = list(ids[len(prompt):len(prompt) + new - (1 if fin == "length" else 0)])
+    assert streamed.decode("utf-8", errors="replace") == tok.decode(reported)
+    assert len(streamed) > 0
+    # abort from the callback: finish reason Stop, nothing flushed afterwards
+    e.reconfigure(max_new=24)
+    ids2, new2, fin2, chunks2 = e.generate_async_text("你好, hello", on_chunk=lambda c: False)
+    assert fin2 == "stop" and len(chunks2) == 1
+    e.close(); tok.close()
+
+
+def test_text_entry_points_need_a_tokenizer(lib, oracle_path, tmp_path):
+    e, g = make_engine(lib, oracle_path, tmp_path, "llama_tiny", 1)
+    arr_err = None
+    try:
+        e.generate_sync_text(["hi"])
+    except AssertionError as ex:
+        arr_err = str(ex)
+    assert arr_err and "no tokenizer" in arr_err
+    e.close()

@@ -48,7 +48,7 @@ CXXFLAGS = ["-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-exception
 
 def build_host(force: bool = False, verbose: bool = False):
     """The C++ host engine (no HIP needed: it dlopen()s the device shim): libtgx_host.so + the tgx_cli binary."""
-    srcs = [os.path.join(HOST, f) for f in ("loader.cpp", "engine.cpp")]
+    srcs = [os.path.join(HOST, f) for f in ("loader.cpp", "engine.cpp", "regex.cpp", "tokenizer.cpp")]
     deps = [os.path.join(HOST, f) for f in os.listdir(HOST)] + [os.path.join(HERE, "..", "include", "tgx.h")]
     os.makedirs(LIBDIR, exist_ok=True)
     for target, extra in ((HOST_LIB, [os.path.join(HOST, "engine_c.cpp"), "-shared"]), (HOST_CLI, [os.path.join(HOST, "main.cpp")])):

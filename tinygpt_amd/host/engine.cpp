@@ -51,8 +51,19 @@ bool GPTEngine::prepare() {
   } else {
     if (!load_model_dir(be_, config_.modelDir, config_.deviceOrdinal, config_.dtype, config_.maxBatch, model_, err_)) return fail("Prepare failed: " + err_);
   }
-  // EOS ids: generation_config first, else the model config's eos (the reference falls back to the tokenizer's)  (:50-61)
+  // tokenizer: optional for the id entry points, required for the text ones (ModelLoader.cpp:60-69 always loads it)
+  const std::string tdir = !config_.tokenizerDir.empty() ? config_.tokenizerDir : config_.modelDir;
+  if (!tdir.empty()) {
+    const std::string tj = tdir + "/tokenizer.json", tc = tdir + "/tokenizer_config.json";
+    if (FILE* f = fopen(tj.c_str(), "rb")) {
+      fclose(f);
+      if (!tokenizer_.initWithConfig(tj, tc)) return fail("load tokenizer failed: " + tokenizer_.lastError());
+      tokenizerOk_ = true;
+    } else if (!config_.tokenizerDir.empty()) return fail("Cannot open file: " + tj);
+  }
+  // EOS ids: generation_config first, else the tokenizer's eos, else the model config's (:50-61)
   for (int64_t id : model_.generation.eos_token_ids) baseEosTokenIds_.push_back((int32_t)id);
+  if (baseEosTokenIds_.empty() && tokenizerOk_ && tokenizer_.eosTokenId() >= 0) baseEosTokenIds_.push_back(tokenizer_.eosTokenId());
   if (baseEosTokenIds_.empty() && model_.config.eos_token_id >= 0) baseEosTokenIds_.push_back((int32_t)model_.config.eos_token_id);
   eosTokenIds_ = baseEosTokenIds_;
   prepared_ = true;
@@ -168,6 +179,39 @@ GPTOutput GPTEngine::generateAsync(const std::vector<int32_t>& prompt, const Gen
   out.newTokens = (int64_t)tokens.size() - S;
   out.tokenIds = std::move(tokens);
   out.finishReason = (hitEos || aborted) ? FinishReason::Stop : FinishReason::Length;
+  return out;
+}
+
+// ---- text entry points ---------------------------------------------------------------------------------------------
+int32_t GPTEngine::padTokenId() const {
+  if (tokenizerOk_ && tokenizer_.padTokenId() >= 0) return tokenizer_.padTokenId();
+  if (tokenizerOk_ && tokenizer_.eosTokenId() >= 0) return tokenizer_.eosTokenId();
+  return 0;                                              // default pad token id (GPTEngine.cpp:112)
+}
+
+GPTOutput GPTEngine::generateSync(const std::vector<std::string>& texts) {
+  if (!tokenizerOk_) { fail("generateSync(texts): no tokenizer loaded"); return GPTOutput(); }
+  const std::vector<std::vector<int32_t>> prompts = tokenizer_.encodeBatch(texts);
+  GPTOutput out = generateSync(prompts, padTokenId());
+  if (out.batch > 0) out.texts = tokenizer_.decodeBatch(out.tokenIds, (uint32_t)out.batch, (uint32_t)(out.tokenIds.size() / (size_t)out.batch - (size_t)out.newTokens));
+  return out;
+}
+
+GPTOutput GPTEngine::generateAsync(const std::string& text, const TextCallback& callback) {
+  if (!tokenizerOk_) { fail("generateAsync(text): no tokenizer loaded"); return GPTOutput(); }
+  tokenizer_.decodeStreamFlush();                        // a fresh stream
+  bool aborted = false;
+  const std::vector<int32_t> prompt = tokenizer_.encode(text);
+  GPTOutput out = generateAsync(prompt, [&](int32_t id) {
+    const std::string chunk = tokenizer_.decodeStream({id});
+    if (!chunk.empty() && callback && !callback(chunk)) { aborted = true; return false; }
+    return true;
+  });
+  if (!aborted) {                                        // flush bytes of an unfinished character (:219-227)
+    const std::string rest = tokenizer_.decodeStreamFlush();
+    if (!rest.empty() && callback) callback(rest);
+  }
+  if (out.batch > 0) out.texts = tokenizer_.decodeBatch(out.tokenIds, 1, (uint32_t)(out.tokenIds.size() - (size_t)out.newTokens));
   return out;
 }
 

@@ -1,8 +1,8 @@
 // engine.h — the host engine above the C ABI: the counterpart of GPTEngine (src/engine/GPTEngine.h:42-73,
-// GPTEngine.cpp:37-232) for token-id inputs.  Tokenisation / detokenisation stay outside;
-// everything else — left-padding without a mask, tail truncation to contextSize, prefill + maxNewTokens-1
-// decode steps, no EOS stop in generateSync, one-step-lookahead streaming with EOS/abort in generateAsync,
-// reconfigure() resetting the KV cache — follows the reference line by line in behaviour.
+// GPTEngine.cpp:37-232).  Text entry points (tokenizer.h) and token-id entry points share one path: encode,
+// left-padding without a mask, tail truncation to contextSize, prefill + maxNewTokens-1 decode steps, no EOS stop in
+// generateSync, one-step-lookahead streaming with EOS/abort and UTF-8-safe chunks in generateAsync, reconfigure()
+// resetting the KV cache — the reference's behaviour line by line.
 #pragma once
 #include <cstdint>
 #include <functional>
@@ -11,6 +11,7 @@
 
 #include "backend.h"
 #include "loader.h"
+#include "tokenizer.h"
 
 namespace tgxh {
 
@@ -35,16 +36,19 @@ struct GPTConfig {       // src/engine/GPTEngine.h:25-32 (+ where to find the de
   uint64_t seed = 0;
   std::string backendLib;            // default: <dir of this binary/library>/libtgx_mi355x.so
   std::string backendPrefix = "tgx_";
+  std::string tokenizerDir;          // tokenizer.json + tokenizer_config.json; default: modelDir (lets --synthetic runs take text)
 };
 
-struct GPTOutput {       // src/engine/GPTEngine.h:34-40 (texts omitted: ids only)
+struct GPTOutput {       // src/engine/GPTEngine.h:34-40
   int64_t batch = 0;
   int64_t newTokens = 0;
   std::vector<int32_t> tokenIds;     // [batch][padded prompt + new], row-major — prompt tokens included, like the reference
+  std::vector<std::string> texts;    // the new tokens of every row, decoded (text entry points only)
   FinishReason finishReason = FinishReason::Stop;
 };
 
 using GenerateCallback = std::function<bool(int32_t tokenId)>;   // return false to abort (GPTEngine.cpp:208-213)
+using TextCallback = std::function<bool(const std::string& chunk)>;   // the reference's GenerateCallback: complete UTF-8 only
 
 class GPTEngine {
  public:
@@ -58,6 +62,12 @@ class GPTEngine {
                    const std::vector<int32_t>& extraStopTokenIds = {});      // GPTEngine.cpp:67-84
   GPTOutput generateSync(const std::vector<std::vector<int32_t>>& prompts, int32_t padToken);   // :154-174
   GPTOutput generateAsync(const std::vector<int32_t>& prompt, const GenerateCallback& callback);   // :180-232
+  // text entry points (need a tokenizer: tokenizerDir / modelDir must hold tokenizer.json + tokenizer_config.json)
+  GPTOutput generateSync(const std::vector<std::string>& texts);                                   // :154-174 incl. encodeTexts :101-144
+  GPTOutput generateAsync(const std::string& text, const TextCallback& callback);                  // :180-232 incl. decodeStream
+  bool hasTokenizer() const { return tokenizerOk_; }
+  Tokenizer& tokenizer() { return tokenizer_; }
+  int32_t padTokenId() const;                                                                       // pad -> eos -> 0 (:108-114)
 
   bool isEosToken(int32_t id) const;
   const std::vector<int32_t>& eosTokenIds() const { return eosTokenIds_; }
@@ -78,6 +88,8 @@ class GPTEngine {
   std::vector<int32_t> baseEosTokenIds_, eosTokenIds_;
   std::string err_;
   bool prepared_ = false;
+  Tokenizer tokenizer_;
+  bool tokenizerOk_ = false;
 };
 
 // Deterministic synthetic checkpoint — bit-identical to tinygpt_amd/synth.py (same integer hash).

@@ -95,6 +95,13 @@ class JsonParser {
             if (pos_ + 4 > n_) return false;
             unsigned cp = (unsigned)strtoul(std::string(s_ + pos_, 4).c_str(), nullptr, 16);
             pos_ += 4;
+            if (cp >= 0xD800 && cp < 0xDC00 && pos_ + 6 <= n_ && s_[pos_] == '\\' && s_[pos_ + 1] == 'u') {   // surrogate pair
+              const unsigned lo = (unsigned)strtoul(std::string(s_ + pos_ + 2, 4).c_str(), nullptr, 16);
+              if (lo >= 0xDC00 && lo < 0xE000) { cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00); pos_ += 6; }
+            }
+            if (cp >= 0x10000) {
+              out += (char)(0xF0 | (cp >> 18)); out += (char)(0x80 | ((cp >> 12) & 0x3F)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F));
+            } else
             if (cp < 0x80) out += (char)cp;
             else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
             else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }

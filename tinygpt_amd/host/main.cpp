@@ -1,7 +1,9 @@
-// tgx_cli — the inference harness of the reference (examples/inference/main.cpp) for token-id prompts:
+// tgx_cli — the inference harness of the reference (examples/inference/main.cpp): the same four text prompts when a
+// tokenizer is available (--model dir or --tokenizer dir), token-id prompts otherwise;
 // same flags and defaults (--model --device --dtype --max-tokens --temperature --top-p), the same timing window
 // (generate only; load excluded, main.cpp:97-102) and the same "speed" convention (ALL ids incl. prompt / wall time,
 // main.cpp:112-114) — plus the new-token rate.  `--device mi355x` is the only device this binary executes on.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -11,8 +13,8 @@
 
 #include "engine.h"
 
-// the reference's four prompts as token ids need a tokenizer (out of scope); default prompts are given as ids.
-// gpt2 ids of INPUT_STRS (main.cpp:12-17), usable with any vocabulary >= 50257:
+// INPUT_STRS (main.cpp:12-17), and their gpt2 ids for runs without a tokenizer (usable with any vocabulary >= 50257)
+static const std::vector<std::string> kInputStrs = {"Hello, my name is", "The president of the United States is", "The capital of France is", "The future of AI is"};
 static const std::vector<std::vector<int32_t>> kDefaultPrompts = {
     {15496, 11, 616, 1438, 318}, {464, 1893, 286, 262, 1578, 1829, 318}, {464, 3139, 286, 4881, 318}, {464, 2003, 286, 9552, 318}};
 
@@ -27,7 +29,10 @@ static void usage(const char* prog) {
           "  --temperature <f>         sampling temperature (default: 0.8)\n"
           "  --top-p <f>               top-p sampling (default: 0.9)\n"
           "  --top-k <n> --min-p <f>   (default: off)\n"
-          "  --prompt-ids <a,b,c;d,e>  prompts as token ids, ';' between batch rows (default: the reference's 4 prompts as gpt2 ids)\n"
+          "  --tokenizer <dir>         tokenizer.json + tokenizer_config.json (default: the --model directory)\n"
+          "  --prompt <text>           a text prompt (repeatable; default with a tokenizer: the reference's 4 prompts)\n"
+          "  --stream                  batch-1 generateAsync: print UTF-8-safe chunks as they are produced\n"
+          "  --prompt-ids <a,b,c;d,e>  prompts as token ids, ';' between batch rows (default without a tokenizer: the 4 prompts as gpt2 ids)\n"
           "  --pad-id <n>              left-pad id (default: eos_token_id of the model, else 0)\n"
           "  --seed <n>                sampler seed (default: 0)\n",
           prog);
@@ -40,6 +45,8 @@ int main(int argc, char** argv) {
   cfg.samplerConfig.topP = 0.9f;
   std::string dtype = "bf16", prompt_ids;
   long pad_id = -1;
+  std::vector<std::string> text_prompts;
+  bool stream = false;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -54,6 +61,9 @@ int main(int argc, char** argv) {
     else if (a == "--top-k") cfg.samplerConfig.topK = atoll(next());
     else if (a == "--min-p") cfg.samplerConfig.minP = strtof(next(), nullptr);
     else if (a == "--prompt-ids") prompt_ids = next();
+    else if (a == "--prompt") text_prompts.push_back(next());
+    else if (a == "--tokenizer") cfg.tokenizerDir = next();
+    else if (a == "--stream") stream = true;
     else if (a == "--pad-id") pad_id = atol(next());
     else if (a == "--seed") cfg.seed = strtoull(next(), nullptr, 10);
     else if (a == "--backend-lib") cfg.backendLib = next();
@@ -76,10 +86,31 @@ int main(int argc, char** argv) {
       if (!ids.empty()) prompts.push_back(ids);
     }
   }
-  cfg.maxBatch = (int)prompts.size();
+  cfg.maxBatch = (int)std::max(std::max(prompts.size(), text_prompts.size()), kInputStrs.size());
 
   tgxh::GPTEngine engine(cfg);
   if (!engine.prepare()) { fprintf(stderr, "Prepare engine failed\n"); return 1; }
+
+  if (engine.hasTokenizer() && prompt_ids.empty()) {       // the reference's flow: texts in, texts out (main.cpp:97-114)
+    if (text_prompts.empty()) text_prompts = kInputStrs;
+    const auto t0 = std::chrono::steady_clock::now();
+    tgxh::GPTOutput out;
+    if (stream) {
+      printf("%s", text_prompts[0].c_str());
+      out = engine.generateAsync(text_prompts[0], [](const std::string& chunk) { fputs(chunk.c_str(), stdout); fflush(stdout); return true; });
+      printf("\n");
+    } else out = engine.generateSync(text_prompts);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (out.batch == 0) { fprintf(stderr, "generate failed: %s\n", engine.lastError().c_str()); return 1; }
+    if (!stream) {
+      printf("Generated Outputs:\n------------------------------------------------------------\n");
+      for (int64_t b = 0; b < out.batch; b++)
+        printf("Prompt:    '%s'\nOutput:    '%s'\n------------------------------------------------------------\n", text_prompts[(size_t)b].c_str(), out.texts[(size_t)b].c_str());
+    }
+    printf("Time cost: %lld ms, speed: %.2f token/s\n", (long long)ms, out.tokenIds.size() * 1000.0 / ms);
+    printf("new tokens: %lld, new-token rate: %.2f token/s\n", (long long)(out.batch * out.newTokens), out.batch * out.newTokens * 1000.0 / ms);
+    return 0;
+  }
   int32_t pad = pad_id >= 0 ? (int32_t)pad_id : (!engine.eosTokenIds().empty() ? engine.eosTokenIds()[0] : 0);
   for (auto& p : prompts) for (auto& t : p) if (t >= engine.desc().vocab) t = t % engine.desc().vocab;
 

@@ -1,0 +1,376 @@
+// regex.cpp — see regex.h.  Pattern -> syntax tree -> backtracking program (CHAR / CLASS / SPLIT / JMP / LOOK /
+// MATCH) run with an explicit stack, so a `\p{L}+` over a 500 000-letter word (the reference's long-text test,
+// test_tokenizer.cpp:250-262) costs heap, not recursion depth.
+#include "regex.h"
+
+#include <algorithm>
+#include <climits>
+
+#include "unicode_tables.h"
+
+namespace tgxh {
+
+// ---------------------------------------------------------------------------------------------- UTF-8 / classes
+size_t utf8_decode(const char* s, size_t n, uint32_t& cp) {
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(s);
+  const unsigned char c = p[0];
+  if (c < 0x80) { cp = c; return 1; }
+  int len = (c >= 0xF0 && c <= 0xF4) ? 4 : (c >= 0xE0) ? 3 : (c >= 0xC2 && c < 0xE0) ? 2 : 0;
+  if (len == 0 || (size_t)len > n || c > 0xF4) { cp = 0xFFFD; return 1; }
+  uint32_t v = c & (0xFF >> (len + 1));
+  for (int k = 1; k < len; k++) {
+    if ((p[k] & 0xC0) != 0x80) { cp = 0xFFFD; return 1; }
+    v = (v << 6) | (p[k] & 0x3F);
+  }
+  if ((len == 3 && (v < 0x800 || (v >= 0xD800 && v <= 0xDFFF))) || (len == 4 && (v < 0x10000 || v > 0x10FFFF))) { cp = 0xFFFD; return 1; }
+  cp = v;
+  return (size_t)len;
+}
+
+void utf8_append(std::string& out, uint32_t cp) {
+  if (cp < 0x80) out += (char)cp;
+  else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+  else if (cp < 0x10000) { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+  else { out += (char)(0xF0 | (cp >> 18)); out += (char)(0x80 | ((cp >> 12) & 0x3F)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+}
+
+static bool in_ranges(const unidata::Range* r, int n, uint32_t cp) {
+  int lo = 0, hi = n - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) / 2;
+    if (cp < r[mid].lo) hi = mid - 1;
+    else if (cp > r[mid].hi) lo = mid + 1;
+    else return true;
+  }
+  return false;
+}
+bool is_letter(uint32_t cp) { return in_ranges(unidata::kLetter, unidata::kLetterCount, cp); }
+bool is_number(uint32_t cp) { return in_ranges(unidata::kNumber, unidata::kNumberCount, cp); }
+bool is_white_space(uint32_t cp) {   // Unicode White_Space (what `\s` means for the regex engines behind tokenizers)
+  return (cp >= 0x9 && cp <= 0xD) || cp == 0x20 || cp == 0x85 || cp == 0xA0 || cp == 0x1680 || (cp >= 0x2000 && cp <= 0x200A) ||
+         cp == 0x2028 || cp == 0x2029 || cp == 0x202F || cp == 0x205F || cp == 0x3000;
+}
+static bool is_digit(uint32_t cp) { return cp >= '0' && cp <= '9'; }
+static bool is_word(uint32_t cp) { return cp == '_' || is_letter(cp) || is_number(cp); }
+static uint32_t fold_ascii(uint32_t cp) { return (cp >= 'A' && cp <= 'Z') ? cp + 32 : cp; }
+
+enum { P_L = 1, P_N = 2, P_S = 4, P_D = 8, P_W = 16 };
+
+bool Regex::CharClass::matches(uint32_t cp) const {
+  auto hit = [&](uint32_t c) {
+    for (const ClassItem& it : items) if (c >= it.lo && c <= it.hi) return true;
+    const uint32_t pos = props & 31u, neg = (props >> 5) & 31u;
+    if (pos || neg) {
+      const bool l = is_letter(c), n = is_number(c), s = is_white_space(c), d = is_digit(c), w = (c == '_') || l || n;
+      if (((pos & P_L) && l) || ((pos & P_N) && n) || ((pos & P_S) && s) || ((pos & P_D) && d) || ((pos & P_W) && w)) return true;
+      if (((neg & P_L) && !l) || ((neg & P_N) && !n) || ((neg & P_S) && !s) || ((neg & P_D) && !d) || ((neg & P_W) && !w)) return true;
+    }
+    return false;
+  };
+  bool m = hit(cp);
+  if (!m && icase) {
+    if (cp >= 'a' && cp <= 'z') m = hit(cp - 32);
+    else if (cp >= 'A' && cp <= 'Z') m = hit(cp + 32);
+  }
+  return m != negated;
+}
+
+// ---------------------------------------------------------------------------------------------- parser
+namespace {
+struct Node {
+  enum Kind { Char, Any, Class, Cat, Alt, Repeat, Look, Bol, Eol } kind = Cat;
+  uint32_t cp = 0;
+  bool icase = false;
+  int cls = -1;
+  int min = 0, max = 0;      // Repeat; max < 0 = unbounded
+  bool lazy = false, neg = false;
+  std::vector<Node> kids;
+};
+}  // namespace
+
+struct Regex::Parser {
+  Regex& re;
+  std::vector<uint32_t> p;   // pattern code points
+  size_t i = 0;
+  std::string err;
+  explicit Parser(Regex& r, const std::string& pat) : re(r) {
+    for (size_t k = 0; k < pat.size();) { uint32_t cp; k += utf8_decode(pat.data() + k, pat.size() - k, cp); p.push_back(cp); }
+  }
+  bool more() const { return i < p.size(); }
+  bool fail(const char* m) { if (err.empty()) err = m; return false; }
+
+  bool alt(Node& out, bool icase) {
+    Node first;
+    if (!cat(first, icase)) return false;
+    if (!(more() && p[i] == '|')) { out = std::move(first); return true; }
+    out = Node(); out.kind = Node::Alt;
+    out.kids.push_back(std::move(first));
+    while (more() && p[i] == '|') {
+      i++;
+      Node next;
+      if (!cat(next, icase)) return false;
+      out.kids.push_back(std::move(next));
+    }
+    return true;
+  }
+  bool cat(Node& out, bool icase) {
+    out = Node(); out.kind = Node::Cat;
+    while (more() && p[i] != '|' && p[i] != ')') {
+      Node a;
+      if (!atom(a, icase)) return false;
+      while (more() && (p[i] == '?' || p[i] == '*' || p[i] == '+' || p[i] == '{')) {
+        int mn, mx;
+        if (p[i] == '?') { mn = 0; mx = 1; i++; }
+        else if (p[i] == '*') { mn = 0; mx = -1; i++; }
+        else if (p[i] == '+') { mn = 1; mx = -1; i++; }
+        else {
+          size_t save = i++;
+          auto num = [&](int& v) { bool any = false; v = 0; while (more() && p[i] >= '0' && p[i] <= '9') { v = v * 10 + (int)(p[i++] - '0'); any = true; if (v > 1000) return false; } return any; };
+          if (!num(mn)) { i = save; break; }          // a literal '{'
+          mx = mn;
+          if (more() && p[i] == ',') { i++; if (more() && p[i] == '}') mx = -1; else if (!num(mx)) return fail("bad {n,m}"); }
+          if (!(more() && p[i] == '}')) return fail("unterminated {n,m}");
+          i++;
+          if (mx >= 0 && mx < mn) return fail("{n,m} with m < n");
+        }
+        Node r; r.kind = Node::Repeat; r.min = mn; r.max = mx;
+        if (more() && p[i] == '?') { r.lazy = true; i++; }
+        else if (more() && p[i] == '+') return fail("possessive quantifiers are not supported");
+        r.kids.push_back(std::move(a));
+        a = std::move(r);
+      }
+      out.kids.push_back(std::move(a));
+    }
+    return true;
+  }
+  bool prop(uint32_t& flags, bool negate) {   // after \p or \P : {L} {N} or single letter
+    std::string name;
+    if (more() && p[i] == '{') { i++; while (more() && p[i] != '}') name += (char)p[i++]; if (!more()) return fail("unterminated \\p{"); i++; }
+    else if (more()) name += (char)p[i++];
+    uint32_t bit;
+    if (name == "L" || name == "Letter") bit = P_L;
+    else if (name == "N" || name == "Number") bit = P_N;
+    else return fail("unsupported \\p{..} class (L and N are built)");
+    flags |= negate ? (bit << 5) : bit;
+    return true;
+  }
+  // one escape sequence: either a literal code point (lit) or class property flags
+  bool escape(uint32_t& lit, uint32_t& flags, bool& is_class) {
+    if (!more()) return fail("trailing backslash");
+    const uint32_t e = p[i++];
+    is_class = true;
+    switch (e) {
+      case 's': flags |= P_S; return true;          case 'S': flags |= P_S << 5; return true;
+      case 'd': flags |= P_D; return true;          case 'D': flags |= P_D << 5; return true;
+      case 'w': flags |= P_W; return true;          case 'W': flags |= P_W << 5; return true;
+      case 'p': return prop(flags, false);          case 'P': return prop(flags, true);
+      default: break;
+    }
+    is_class = false;
+    switch (e) {
+      case 'n': lit = '\n'; return true;  case 'r': lit = '\r'; return true;  case 't': lit = '\t'; return true;
+      case 'f': lit = '\f'; return true;  case 'v': lit = '\v'; return true;  case '0': lit = 0; return true;
+      case 'x': case 'u': {
+        uint32_t v = 0; int digits = 0;
+        if (more() && p[i] == '{') { i++; while (more() && p[i] != '}') { v = v * 16 + hexval(p[i++]); digits++; } if (!more()) return fail("unterminated \\x{"); i++; }
+        else { const int want = e == 'x' ? 2 : 4; while (digits < want && more() && hexval(p[i]) < 16) { v = v * 16 + hexval(p[i++]); digits++; } }
+        if (!digits) return fail("bad hex escape");
+        lit = v; return true;
+      }
+      default:
+        if ((e >= 'a' && e <= 'z') || (e >= 'A' && e <= 'Z') || (e >= '1' && e <= '9')) return fail("unsupported escape");
+        lit = e; return true;
+    }
+  }
+  static uint32_t hexval(uint32_t c) { return (c >= '0' && c <= '9') ? c - '0' : (c >= 'a' && c <= 'f') ? c - 'a' + 10 : (c >= 'A' && c <= 'F') ? c - 'A' + 10 : 99; }
+
+  bool char_class(Node& out, bool icase) {   // after '['
+    CharClass cc; cc.icase = icase;
+    if (more() && p[i] == '^') { cc.negated = true; i++; }
+    bool first = true;
+    while (more() && (p[i] != ']' || first)) {
+      first = false;
+      uint32_t lo; bool is_class = false;
+      if (p[i] == '\\') { i++; if (!escape(lo, cc.props, is_class)) return false; }
+      else lo = p[i++];
+      if (is_class) continue;
+      uint32_t hi = lo;
+      if (i + 1 < p.size() && p[i] == '-' && p[i + 1] != ']') {
+        i++;
+        bool c2 = false; uint32_t dummy = 0;
+        if (p[i] == '\\') { i++; if (!escape(hi, dummy, c2)) return false; if (c2) return fail("class escape as range end"); }
+        else hi = p[i++];
+        if (hi < lo) return fail("reversed range");
+      }
+      cc.items.push_back({lo, hi});
+    }
+    if (!more()) return fail("unterminated [");
+    i++;
+    out = Node(); out.kind = Node::Class; out.cls = (int)re.classes_.size();
+    re.classes_.push_back(std::move(cc));
+    return true;
+  }
+  bool atom(Node& out, bool icase) {
+    const uint32_t c = p[i++];
+    out = Node();
+    if (c == '(') {
+      bool ic = icase; int look = 0;   // 1 positive, 2 negative
+      if (more() && p[i] == '?') {
+        i++;
+        if (more() && p[i] == ':') i++;
+        else if (more() && p[i] == '=') { look = 1; i++; }
+        else if (more() && p[i] == '!') { look = 2; i++; }
+        else if (more() && p[i] == 'i' && i + 1 < p.size() && p[i + 1] == ':') { ic = true; i += 2; }
+        else return fail("unsupported group flag");
+      }
+      Node inner;
+      if (!alt(inner, ic)) return false;
+      if (!(more() && p[i] == ')')) return fail("unterminated (");
+      i++;
+      if (look) { out.kind = Node::Look; out.neg = look == 2; out.kids.push_back(std::move(inner)); }
+      else out = std::move(inner);
+      return true;
+    }
+    if (c == '[') return char_class(out, icase);
+    if (c == '.') { out.kind = Node::Any; return true; }
+    if (c == '^') { out.kind = Node::Bol; return true; }
+    if (c == '$') { out.kind = Node::Eol; return true; }
+    if (c == '*' || c == '+' || c == '?') return fail("quantifier without operand");
+    if (c == '\\') {
+      uint32_t lit = 0, flags = 0; bool is_class = false;
+      if (!escape(lit, flags, is_class)) return false;
+      if (is_class) {
+        CharClass cc; cc.props = flags; cc.icase = icase;
+        out.kind = Node::Class; out.cls = (int)re.classes_.size();
+        re.classes_.push_back(std::move(cc));
+        return true;
+      }
+      out.kind = Node::Char; out.cp = lit; out.icase = icase;
+      return true;
+    }
+    out.kind = Node::Char; out.cp = c; out.icase = icase;
+    return true;
+  }
+
+  // ---- code generation
+  void emit(const Node& n) {
+    std::vector<Inst>& g = re.prog_;
+    switch (n.kind) {
+      case Node::Char: { Inst in; in.op = CHAR; in.a = n.icase ? fold_ascii(n.cp) : n.cp; in.flag = n.icase; g.push_back(in); break; }
+      case Node::Any: { Inst in; in.op = ANY; g.push_back(in); break; }
+      case Node::Class: { Inst in; in.op = CLASS; in.a = (uint32_t)n.cls; g.push_back(in); break; }
+      case Node::Bol: { Inst in; in.op = BOL; g.push_back(in); break; }
+      case Node::Eol: { Inst in; in.op = EOL; g.push_back(in); break; }
+      case Node::Cat: for (const Node& k : n.kids) emit(k); break;
+      case Node::Alt: {
+        std::vector<size_t> jumps;
+        for (size_t k = 0; k < n.kids.size(); k++) {
+          if (k + 1 < n.kids.size()) {
+            const size_t sp = g.size();
+            Inst in; in.op = SPLIT; g.push_back(in);
+            g[sp].a = (uint32_t)g.size();
+            emit(n.kids[k]);
+            jumps.push_back(g.size());
+            Inst j; j.op = JMP; g.push_back(j);
+            g[sp].b = (uint32_t)g.size();
+          } else emit(n.kids[k]);
+        }
+        for (size_t j : jumps) g[j].a = (uint32_t)g.size();
+        break;
+      }
+      case Node::Repeat: {
+        const Node& body = n.kids[0];
+        for (int k = 0; k < n.min; k++) emit(body);
+        if (n.max < 0) {
+          const size_t sp = g.size();
+          Inst in; in.op = SPLIT; g.push_back(in);
+          const size_t b0 = g.size();
+          emit(body);
+          Inst j; j.op = JMP; j.a = (uint32_t)sp; g.push_back(j);
+          const size_t out = g.size();
+          g[sp].a = (uint32_t)(n.lazy ? out : b0); g[sp].b = (uint32_t)(n.lazy ? b0 : out);
+        } else {
+          std::vector<size_t> splits;
+          for (int k = n.min; k < n.max; k++) {
+            splits.push_back(g.size());
+            Inst in; in.op = SPLIT; g.push_back(in);
+            g[splits.back()].a = (uint32_t)g.size();   // patched below for lazy
+            emit(body);
+          }
+          const size_t out = g.size();
+          for (size_t sp : splits) {
+            const uint32_t b0 = (uint32_t)(sp + 1);
+            g[sp].a = n.lazy ? (uint32_t)out : b0; g[sp].b = n.lazy ? b0 : (uint32_t)out;
+          }
+        }
+        break;
+      }
+      case Node::Look: {
+        const size_t lk = g.size();
+        Inst in; in.op = LOOK; in.flag = n.neg; g.push_back(in);
+        g[lk].a = (uint32_t)g.size();
+        emit(n.kids[0]);
+        Inst m; m.op = MATCH; g.push_back(m);
+        g[lk].b = (uint32_t)g.size();
+        break;
+      }
+    }
+  }
+};
+
+Regex::Regex(const std::string& pattern) {
+  Parser ps(*this, pattern);
+  Node root;
+  if (!ps.alt(root, false)) { err_ = ps.err.empty() ? "syntax error" : ps.err; return; }
+  if (ps.more()) { err_ = "unbalanced )"; return; }
+  ps.emit(root);
+  Inst m; m.op = MATCH; prog_.push_back(m);
+}
+
+// ---------------------------------------------------------------------------------------------- matcher
+long Regex::run(size_t pc0, const std::vector<uint32_t>& cps, size_t i0) const {
+  struct Thread { uint32_t pc; size_t i; };
+  std::vector<Thread> stack;
+  stack.push_back({(uint32_t)pc0, i0});
+  const size_t n = cps.size();
+  size_t steps = 0;
+  while (!stack.empty()) {
+    Thread t = stack.back();
+    stack.pop_back();
+    for (;;) {
+      if (++steps > (size_t)400000000) return -1;   // pathological pattern guard
+      const Inst& in = prog_[t.pc];
+      bool ok = true;
+      switch (in.op) {
+        case CHAR: ok = t.i < n && (in.flag ? fold_ascii(cps[t.i]) == in.a : cps[t.i] == in.a); if (ok) { t.i++; t.pc++; } break;
+        case ANY: ok = t.i < n && cps[t.i] != '\n'; if (ok) { t.i++; t.pc++; } break;
+        case CLASS: ok = t.i < n && classes_[in.a].matches(cps[t.i]); if (ok) { t.i++; t.pc++; } break;
+        case BOL: ok = t.i == 0; if (ok) t.pc++; break;
+        case EOL: ok = t.i == n; if (ok) t.pc++; break;
+        case SPLIT: stack.push_back({in.b, t.i}); t.pc = in.a; break;
+        case JMP: t.pc = in.a; break;
+        case LOOK: ok = (run(in.a, cps, t.i) >= 0) != in.flag; if (ok) t.pc = in.b; break;
+        case MATCH: return (long)t.i;
+      }
+      if (!ok) break;
+    }
+  }
+  return -1;
+}
+
+void Regex::matchAll(const std::string& text, std::vector<Range>& out) const {
+  if (!valid()) return;
+  std::vector<uint32_t> cps;
+  std::vector<size_t> off;
+  cps.reserve(text.size()); off.reserve(text.size() + 1);
+  for (size_t k = 0; k < text.size();) { uint32_t cp; off.push_back(k); k += utf8_decode(text.data() + k, text.size() - k, cp); cps.push_back(cp); }
+  off.push_back(text.size());
+  size_t i = 0;
+  while (i < cps.size()) {
+    const long e = run(0, cps, i);
+    if (e > (long)i) { out.emplace_back(off[i], off[(size_t)e]); i = (size_t)e; }
+    else i++;
+  }
+}
+
+}  // namespace tgxh
