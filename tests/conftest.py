@@ -9,6 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The oracle is OpenMP code checking tiny fixtures: on a 256-thread host libgomp's default team makes every parallel region
+# a 256-way barrier (minutes per test on the GPU box).  Must be set before liboracle.so (libgomp) is loaded.
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 FAMILIES = ["llama_tiny", "qwen2_tiny", "mistral_tiny", "qwen3_tiny", "gpt2_tiny"]
 GPU_FAMILIES = ["llama_tiny", "qwen2_tiny", "mistral_tiny", "qwen3_tiny"]     # GPT-2 is the CPU-only plumbing config

@@ -55,9 +55,9 @@ def test_cli_text_prompts_on_gpu(tmp_path, oracle_lib):
     write_model_dir(str(tmp_path), cfg, 77, 0.08)
     _, cli = build.build_host()
     out = subprocess.run([cli, "--model", str(tmp_path), "--tokenizer", tok_dir, "--max-tokens", "8", "--temperature", "0", "--top-p", "1"],
-                         capture_output=True, text=True, timeout=300)
+                         capture_output=True, timeout=300)          # bytes: a random model may emit invalid UTF-8
     assert out.returncode == 0, out.stderr
-    assert out.stdout.count("Prompt:") == 4 and "'Hello, my name is'" in out.stdout and "token/s" in out.stdout
+    assert out.stdout.count(b"Prompt:") == 4 and b"'Hello, my name is'" in out.stdout and b"token/s" in out.stdout
     lib = host_lib()
     texts = ["Hello, my name is", "The president of the United States is", "The capital of France is", "The future of AI is"]
     gpu = HostEngine(lib, model_dir=str(tmp_path), tokenizer_dir=tok_dir, max_batch=4)
@@ -69,6 +69,6 @@ def test_cli_text_prompts_on_gpu(tmp_path, oracle_lib):
     ids_r, _, txt_r = ref.generate_sync_text(texts)
     np.testing.assert_array_equal(ids_g, ids_r)
     assert txt_g == txt_r
-    for b, t in enumerate(txt_g):
-        assert f"'{t.decode('utf-8', errors='replace')}'" in out.stdout or b"\n" in t     # the CLI printed the same continuations
+    for t in txt_g:
+        assert b"'" + t + b"'" in out.stdout                    # the CLI printed the same continuations
     gpu.close(); ref.close()
