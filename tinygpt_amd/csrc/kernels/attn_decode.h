@@ -31,6 +31,7 @@ struct AttnArgs {
   float scale;
   // batch rows: blockIdx.y = row; row r uses q + r*q_stride, caches + r*kv_stride, pos[r], part + r*part_stride, out + r*q_stride
   long long q_stride, kv_stride, part_stride;
+  int dbg;   // experiments only (tgx_set_option "debug.attn"): 1 skip K/V work, 2 skip the LDS merge, 4 exit at once — results invalid
 };
 
 template <int DT, int HD, int G>
@@ -38,12 +39,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   typedef elem_t<DT> E;
   constexpr int LPT = HD / 8;         // lanes per token row
   constexpr int TPW = 64 / LPT;       // tokens per wave-load
-  constexpr int NSTREAM = 4 * TPW;    // independent online-softmax streams per workgroup (wave x token slot)
   constexpr int UNR = 4;              // wave-loads of K and of V in flight per iteration
   constexpr float LOG2E = 1.4426950408889634f;
-  // per stream and query head: o[HD], m, l  (m in the exp2 domain)
-  __shared__ __attribute__((aligned(16))) float red[NSTREAM][G][HD + 4];
+  // per wave and query head: o[HD], m, l  (m in the exp2 domain)
+  __shared__ __attribute__((aligned(16))) float red[4][G][HD + 4];
 
+  if (a.dbg & 4) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* q_row = a.q + blockIdx.y * a.q_stride;
   const E* k_row = static_cast<const E*>(a.k_cache) + blockIdx.y * a.kv_stride;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     for (int j = 0; j < 8; j++) o[g][j] = 0.f;
   }
 
-  while (true) {
+  while (!(a.dbg & 1)) {
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
       const bool valid = t0 + r * TPW + slot < n_keys;
@@ -132,102 +133,131 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     }
   }
 
-  // every (wave, slot) stream parks its state in LDS; the per-stream rescale factors are computed once
-  // (NSTREAM*G threads, one exp2 each) and the 256 threads then only multiply-add
-  __shared__ float sm_scale[NSTREAM][G];
-  __shared__ float sm_M[G];
-  const int stream = wv * TPW + slot;
+  // 1. merge the TPW token-slot streams of a wave in registers: lanes with the same part_i exchange (m, l, o) over the lane
+  //    bits above LPT (butterfly: every lane ends with the same sums, in the same association order)
+  if (a.dbg & 2) {
+    if (wv == 0 && slot == 0)
+      for (int g = 0; g < G; g++) {
+        float* dst = part_row + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
+        for (int j = 0; j < 8; j++) dst[part_i * 8 + j] = o[g][j];
+        if (part_i == 0) { dst[HD] = m[g]; dst[HD + 1] = l[g]; }
+      }
+    return;
+  }
 #pragma unroll
   for (int g = 0; g < G; g++) {
-    f32x4* dst = reinterpret_cast<f32x4*>(&red[stream][g][part_i * 8]);
-    dst[0] = f32x4{o[g][0], o[g][1], o[g][2], o[g][3]};
-    dst[1] = f32x4{o[g][4], o[g][5], o[g][6], o[g][7]};
-    if (part_i == 0) { red[stream][g][HD] = m[g]; red[stream][g][HD + 1] = l[g]; }
+    float M = m[g];
+#pragma unroll
+    for (int off = LPT; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+    const float sc = (m[g] == -INFINITY) ? 0.f : exp2f(m[g] - M);
+    l[g] *= sc;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[g][j] *= sc;
+#pragma unroll
+    for (int off = LPT; off < 64; off <<= 1) {
+      l[g] += __shfl_xor(l[g], off, 64);
+#pragma unroll
+      for (int j = 0; j < 8; j++) o[g][j] += __shfl_xor(o[g][j], off, 64);
+    }
+    m[g] = M;
   }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < NSTREAM * G; idx += 256) {
-    const int g = idx / NSTREAM, st = idx - g * NSTREAM;
-    float M = -INFINITY;
-#pragma unroll 8
-    for (int s2 = 0; s2 < NSTREAM; s2++) M = fmaxf(M, red[s2][g][HD]);
-    const float ms = red[st][g][HD];
-    sm_scale[st][g] = (ms == -INFINITY) ? 0.f : exp2f(ms - M);
-    if (st == 0) sm_M[g] = M;
+  // 2. the four waves meet in LDS (one record per wave and query head), merged in wave order by G*HD threads
+  if (slot == 0) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      f32x4* dst = reinterpret_cast<f32x4*>(&red[wv][g][part_i * 8]);
+      dst[0] = f32x4{o[g][0], o[g][1], o[g][2], o[g][3]};
+      dst[1] = f32x4{o[g][4], o[g][5], o[g][6], o[g][7]};
+      if (part_i == 0) { red[wv][g][HD] = m[g]; red[wv][g][HD + 1] = l[g]; }
+    }
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < G * HD; idx += 256) {
     const int g = idx / HD, d = idx - g * HD;
-    float L = 0.f, acc = 0.f;
-#pragma unroll 8
-    for (int s2 = 0; s2 < NSTREAM; s2++) {
-      const float sc = sm_scale[s2][g];
-      acc = fmaf(red[s2][g][d], sc, acc);
-      if (d == 0) L = fmaf(red[s2][g][HD + 1], sc, L);
-    }
+    const float m0 = red[0][g][HD], m1 = red[1][g][HD], m2 = red[2][g][HD], m3 = red[3][g][HD];
+    const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    const float s0 = (m0 == -INFINITY) ? 0.f : exp2f(m0 - M), s1 = (m1 == -INFINITY) ? 0.f : exp2f(m1 - M);
+    const float s2 = (m2 == -INFINITY) ? 0.f : exp2f(m2 - M), s3 = (m3 == -INFINITY) ? 0.f : exp2f(m3 - M);
+    float acc = red[0][g][d] * s0;
+    acc = fmaf(red[1][g][d], s1, acc); acc = fmaf(red[2][g][d], s2, acc); acc = fmaf(red[3][g][d], s3, acc);
     float* dst = part_row + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
     dst[d] = acc;
-    if (d == 0) { dst[HD] = sm_M[g]; dst[HD + 1] = L; }
+    if (d == 0) {
+      float L = red[0][g][HD + 1] * s0;
+      L = fmaf(red[1][g][HD + 1], s1, L); L = fmaf(red[2][g][HD + 1], s2, L); L = fmaf(red[3][g][HD + 1], s3, L);
+      dst[HD] = M; dst[HD + 1] = L;
+    }
   }
 }
 
 // Merges the nsplit partials of every query head and writes the attention output (fp32)
 // (== the reshape to [B,S,qDim] that feeds o_proj, Attention.h:111).
-// One workgroup per query head; thread (s, dg) owns 8 dims of one split so that all partials are fetched
-// with one round of independent 16-byte loads; splits are then summed through LDS in a fixed order.
+// One workgroup per query head; thread (s, dg) owns 8 dims of one split, so all partials arrive with one round of
+// independent 16-byte loads.  Each wave folds its splits in registers (butterfly over the lane bits above DG, fixed
+// order), the four waves meet once in LDS.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnArgs a) {
-  constexpr int DG = HD / 8;            // dim groups of 8
-  constexpr int SPB = 256 / DG;         // splits handled per pass (32 for hd 64, 16 for hd 128)
-  __shared__ float sm_m[32], sm_l[32];
-  __shared__ float sm_o[SPB][HD + 4];
-  const int h = blockIdx.x, tid = threadIdx.x;
-  const float* part_row = a.part + blockIdx.y * a.part_stride;
+  constexpr int DG = HD / 8;            // lanes per split (dim groups of 8)
+  constexpr int SPB = 256 / DG;         // splits per pass (32 for hd 64, 16 for hd 128)
+  constexpr int NPASS = 32 / SPB;       // 1 or 2 passes cover the 32 possible splits
+  __shared__ __attribute__((aligned(16))) float sm_o[4][HD + 4];   // per wave: o[HD], M, L
+  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* p = a.part + blockIdx.y * a.part_stride + (size_t)h * a.nsplit * (HD + 4);
   float* out_row = a.out + blockIdx.y * a.q_stride;
-  const float* p = part_row + (size_t)h * a.nsplit * (HD + 4);
-  __shared__ float sm_e[32];
   const int dg = tid % DG, sl = tid / DG;
-  constexpr int NPASS = 32 / SPB;        // 1 (hd 64) or 2 (hd 128) passes cover the 32 possible splits
-  // all loads of the kernel are issued up front: the (m, l) scalars and this thread's data slices of every split
   f32x4 d0[NPASS], d1[NPASS];
+  float pm[NPASS], pl[NPASS];
 #pragma unroll
-  for (int ps = 0; ps < NPASS; ps++) {
+  for (int ps = 0; ps < NPASS; ps++) {   // every load of the kernel is issued here
     const int s = ps * SPB + sl;
-    d0[ps] = f32x4{0.f, 0.f, 0.f, 0.f}; d1[ps] = d0[ps];
+    d0[ps] = f32x4{0.f, 0.f, 0.f, 0.f}; d1[ps] = d0[ps]; pm[ps] = -INFINITY; pl[ps] = 0.f;
     if (s < a.nsplit) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(p + (size_t)s * (HD + 4) + dg * 8);
+      const float* rec = p + (size_t)s * (HD + 4);
+      const f32x4* src = reinterpret_cast<const f32x4*>(rec + dg * 8);
       d0[ps] = src[0]; d1[ps] = src[1];
+      pm[ps] = rec[HD]; pl[ps] = rec[HD + 1];
     }
   }
-  if (tid < a.nsplit) { sm_m[tid] = p[tid * (HD + 4) + HD]; sm_l[tid] = p[tid * (HD + 4) + HD + 1]; }
-  __syncthreads();
-  if (tid < a.nsplit) {   // one exp2 per split; empty splits (m = -inf) get weight 0 (their stale data is multiplied away)
-    float M0 = -INFINITY;
-    for (int s = 0; s < a.nsplit; s++) M0 = fmaxf(M0, sm_m[s]);
-    sm_e[tid] = (sm_m[tid] == -INFINITY) ? 0.f : exp2f(sm_m[tid] - M0);   // m is in the exp2 domain
-  }
-  __syncthreads();
-  float L = 0.f;
-  for (int s = 0; s < a.nsplit; s++) L = fmaf(sm_l[s], sm_e[s], L);
-  float acc = 0.f;                       // threads < HD accumulate dim `tid`
+  // this thread's splits -> one (M, L, o[8]); empty splits (m = -inf) hold stale data: select, never multiply
+  float M = pm[0];
+#pragma unroll
+  for (int ps = 1; ps < NPASS; ps++) M = fmaxf(M, pm[ps]);
+#pragma unroll
+  for (int off = DG; off < 64; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));     // wave maximum (m is in the exp2 domain)
+  float L = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ps = 0; ps < NPASS; ps++) {
-    const int s = ps * SPB + sl;
-    const bool live = s < a.nsplit && sm_e[s] != 0.f;
-    const float sc = live ? sm_e[s] : 0.f;
-    // empty splits hold stale (possibly non-finite) data: select, do not multiply
-    const f32x4 v0 = live ? d0[ps] * sc : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 v1 = live ? d1[ps] * sc : f32x4{0.f, 0.f, 0.f, 0.f};
-    float* dst = &sm_o[sl][dg * 8];
-    dst[0] = v0[0]; dst[1] = v0[1]; dst[2] = v0[2]; dst[3] = v0[3];
-    dst[4] = v1[0]; dst[5] = v1[1]; dst[6] = v1[2]; dst[7] = v1[3];
-    __syncthreads();
-    if (tid < HD) {
-#pragma unroll 8
-      for (int k = 0; k < SPB; k++) acc += sm_o[k][tid];
+    if (pm[ps] != -INFINITY) {
+      const float e = exp2f(pm[ps] - M);
+      L = fmaf(pl[ps], e, L);
+#pragma unroll
+      for (int j = 0; j < 4; j++) { o[j] = fmaf(d0[ps][j], e, o[j]); o[4 + j] = fmaf(d1[ps][j], e, o[4 + j]); }
     }
-    __syncthreads();
   }
-  if (tid < HD) out_row[h * HD + tid] = acc / L;
+#pragma unroll
+  for (int off = DG; off < 64; off <<= 1) {
+    L += __shfl_xor(L, off, 64);
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] += __shfl_xor(o[j], off, 64);
+  }
+  if (lane < DG) {
+    f32x4* dst = reinterpret_cast<f32x4*>(&sm_o[wv][dg * 8]);
+    dst[0] = f32x4{o[0], o[1], o[2], o[3]};
+    dst[1] = f32x4{o[4], o[5], o[6], o[7]};
+    if (lane == 0) { sm_o[wv][HD] = M; sm_o[wv][HD + 1] = L; }
+  }
+  __syncthreads();
+  if (tid < HD) {
+    const float m0 = sm_o[0][HD], m1 = sm_o[1][HD], m2 = sm_o[2][HD], m3 = sm_o[3][HD];
+    const float MM = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    const float s0 = (m0 == -INFINITY) ? 0.f : exp2f(m0 - MM), s1 = (m1 == -INFINITY) ? 0.f : exp2f(m1 - MM);
+    const float s2 = (m2 == -INFINITY) ? 0.f : exp2f(m2 - MM), s3 = (m3 == -INFINITY) ? 0.f : exp2f(m3 - MM);
+    float acc = sm_o[0][tid] * s0;
+    acc = fmaf(sm_o[1][tid], s1, acc); acc = fmaf(sm_o[2][tid], s2, acc); acc = fmaf(sm_o[3][tid], s3, acc);
+    float LL = sm_o[0][HD + 1] * s0;
+    LL = fmaf(sm_o[1][HD + 1], s1, LL); LL = fmaf(sm_o[2][HD + 1], s2, LL); LL = fmaf(sm_o[3][HD + 1], s3, LL);
+    out_row[h * HD + tid] = acc / LL;
+  }
 }
 
 }  // namespace tgx

@@ -360,7 +360,7 @@ struct FinalizeArgs {
   int bump_step;         // 1 on the last row of a step
   const void* embed;     // [V][H], storage dtype
   float* x;              // [H] residual stream of this row (fp32)
-  int H;
+  int H, V;
   int advance_pos;       // 1: pos += 1 (the token just consumed is now in the cache)
 };
 
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const int t = si[0];
+    const int t = (unsigned)si[0] < (unsigned)a.V ? si[0] : 0;   // all-NaN logits leave the sentinel index: never gather out of the table
     s_tok = t;
     *a.tok = t;
     if (a.advance_pos) *a.pos = *a.pos + 1;

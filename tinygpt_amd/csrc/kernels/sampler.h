@@ -233,6 +233,7 @@ __global__ __launch_bounds__(SAMPLER_THREADS) void sample_kernel(const SampleArg
       if (p > 0.f) { cum += (double)p; pick = i; if (u < cum) break; }
     }
     if (pick < 0) for (int i = 0; i < V; i++) if (a.work[i] != -INFINITY) pick = i;   // u beyond the total: last kept
+    if ((unsigned)pick >= (unsigned)a.V) pick = 0;   // all-NaN logits: stay inside the embedding table
     s_tok = pick;
     *a.fin.tok = pick;
     if (a.fin.advance_pos) *a.fin.pos = *a.fin.pos + 1;

@@ -118,6 +118,7 @@ struct tgx_ctx {
   bf16_t* ws_al2 = nullptr;                           // [S][H] third term for the QKV projection
   bf16_t *ws_qh = nullptr, *ws_ql = nullptr;          // [S][qd] rotated queries (hi, lo)
   bool prefill_mfma = true;
+  int debug_attn = 0;        // experiment: AttnArgs.dbg
   int debug_skip = 0;        // experiment: bit0 skip attn decode kernel, bit1 skip combine (results invalid)
   int prof_same_layer = 0;   // experiment: tgx_profile_decode replays ONE layer's weights (Infinity-Cache resident)
   int debug_nops = 0;     // extra no-op launches per layer (launch-overhead experiments only)
@@ -385,7 +386,7 @@ void launch_layer_kernel(tgx_ctx* c, int row0, int R, int l, int cls, float* res
       a.pos = r.pos; a.part = r.attn_part; a.out = r.attn;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
       a.scale = 1.0f / sqrtf((float)hd);
-      a.q_stride = qd; a.kv_stride = (long long)c->kv_row_elems; a.part_stride = (long long)c->attn_part_row;
+      a.q_stride = qd; a.kv_stride = (long long)c->kv_row_elems; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
       launch_attn(c, a, R);
       break;
     }
@@ -527,7 +528,7 @@ tgx::FinalizeArgs make_finalize_args(tgx_ctx* c, int row, bool advance_pos, bool
   a.log_cap = c->log_cap; a.ring_cap = HOST_RING;
   a.row = row; a.rows = c->batch;
   a.log = log_step ? 1 : 0; a.bump_step = (row == c->batch - 1) ? 1 : 0;
-  a.embed = c->embed; a.x = r.x; a.H = c->d.hidden; a.advance_pos = advance_pos ? 1 : 0;
+  a.embed = c->embed; a.x = r.x; a.H = c->d.hidden; a.V = c->d.vocab; a.advance_pos = advance_pos ? 1 : 0;
   return a;
 }
 
@@ -1093,6 +1094,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "graph")) { c->use_graph = value != 0; return TGX_OK; }
   if (!strcmp(key, "debug.nops")) { c->debug_nops = value; return TGX_OK; }
   if (!strcmp(key, "debug.skip")) { c->debug_skip = value; return TGX_OK; }
+  if (!strcmp(key, "debug.attn")) { c->debug_attn = value; return TGX_OK; }
   if (!strcmp(key, "prefill.mfma")) { c->prefill_mfma = value != 0; return TGX_OK; }
   if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
   if (!strcmp(key, "attn.nsplit")) {
