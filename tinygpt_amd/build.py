@@ -32,6 +32,8 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=()):
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    if os.environ.get("TGX_DISSECT") == "1":      # experiment build: the debug.gemv / debug.attn switches become live
+        extra_flags = list(extra_flags) + ["-DTGX_DISSECT=1"]
     cmd = [HIPCC] + FLAGS + list(extra_flags) + srcs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   // per wave and query head: o[HD], m, l  (m in the exp2 domain)
   __shared__ __attribute__((aligned(16))) float red[4][G][HD + 4];
 
-  if (a.dbg & 4) return;
+  if (TGX_DBG(a, 4)) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* q_row = a.q + blockIdx.y * a.q_stride;
   const E* k_row = static_cast<const E*>(a.k_cache) + blockIdx.y * a.kv_stride;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     for (int j = 0; j < 8; j++) o[g][j] = 0.f;
   }
 
-  while (!(a.dbg & 1)) {
+  while (!(TGX_DBG(a, 1))) {
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
       const bool valid = t0 + r * TPW + slot < n_keys;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
 
   // 1. merge the TPW token-slot streams of a wave in registers: lanes with the same part_i exchange (m, l, o) over the lane
   //    bits above LPT (butterfly: every lane ends with the same sums, in the same association order)
-  if (a.dbg & 2) {
+  if (TGX_DBG(a, 2)) {
     if (wv == 0 && slot == 0)
       for (int g = 0; g < G; g++) {
         float* dst = part_row + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);

@@ -13,6 +13,14 @@ typedef unsigned short bf16_t;   // bf16 bit pattern
 
 constexpr int WAVE = 64;
 
+// Experiment hooks (tools/gemv_dissect.py, tools/attn_dissect.py): parts of a kernel can be switched off through the `dbg`
+// field of its argument block — compiled in only with -DTGX_DISSECT=1 (TGX_DISSECT=1 python tinygpt_amd/build.py -f);
+// in the product build the tests fold to false (even a uniform branch on a kernel argument costs ~0.3 us per launch).
+#ifndef TGX_DISSECT
+#define TGX_DISSECT 0
+#endif
+#define TGX_DBG(args, bit) (TGX_DISSECT && ((args).dbg & (bit)))
+
 // ---- bf16 <-> fp32 (round-to-nearest-even; the R() of the numerics contract) ----
 __device__ __forceinline__ float bf16_lo(unsigned int u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned int u) { return __uint_as_float(u & 0xffff0000u); }

@@ -82,7 +82,7 @@ __device__ __forceinline__ void unit_rows(const GemvArgs& a, int u, int& ra, int
 template <int DT, int PRO, int EPI, int NX, int R>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   typedef elem_t<DT> E;
-  if (a.dbg & 4) return;
+  if (TGX_DBG(a, 4)) return;
   constexpr bool PIPE = NX * R <= 4;       // double-buffer the weight registers when the activations leave room
   __shared__ float ps[4][2 * R];
   __shared__ float sv[R][4];
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 
   // 1. the first unit's weights are in flight before anything else is touched
   int ub = blockIdx.x * UPB;
-  if (ub < a.units && !(a.dbg & 2)) load_unit(ub, wa, wb);
+  if (ub < a.units && !(TGX_DBG(a, 2))) load_unit(ub, wa, wb);
 
   // 2. this wave's slice of every row's activation vector -> registers (zero outside the range)
   float xr[R][NX][8];
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       for (int t = 0; t < 4; t++) { xr[r][j][t] = v0[t]; xr[r][j][4 + t] = v1[t]; }
     }
   }
-  if (PRO == PRO_RMSNORM && !(a.dbg & 1)) {   // KS == 1: the wave holds all of x.  HF order: weight * (x * rsqrt(mean(x^2)+eps))
+  if (PRO == PRO_RMSNORM && !(TGX_DBG(a, 1))) {   // KS == 1: the wave holds all of x.  HF order: weight * (x * rsqrt(mean(x^2)+eps))
     const E* wg = static_cast<const E*>(a.norm_w);
     Slice8<DT> nw[NX];
 #pragma unroll
@@ -166,11 +166,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 
   for (; ub < a.units; ub += stride) {   // trip count uniform per workgroup
     const bool has_next = ub + stride < a.units;
-    if (PIPE && has_next && !(a.dbg & 2)) load_unit(ub + stride, na, nb);
+    if (PIPE && has_next && !(TGX_DBG(a, 2))) load_unit(ub + stride, na, nb);
 
     // epilogue operands are fetched now so that their latency hides under the dot products
     const int u = ub + slot;
-    const bool writer = u < a.units && kpart == 0 && lane == 0 && !(a.dbg & 8);
+    const bool writer = u < a.units && kpart == 0 && lane == 0 && !(TGX_DBG(a, 8));
     int ra = 0, rb = 0; bool rb_valid = false;
     float e0[R], e1[R];                // RESIDUAL: x[ra], x[rb];  QKV_ROPE: cos, sin
 #pragma unroll
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     if (PIPE) {
 #pragma unroll
       for (int j = 0; j < NX; j++) { wa[j] = na[j]; wb[j] = nb[j]; }
-    } else if (has_next && !(a.dbg & 2)) {
+    } else if (has_next && !(TGX_DBG(a, 2))) {
       load_unit(ub + stride, wa, wb);
     }
   }

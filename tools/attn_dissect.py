@@ -2,6 +2,7 @@
 """Experiment: where do the ~12 us of the attention launch pair go?  ms/step of the decode graph with parts of the
 attention kernels disabled (results are invalid in those modes; timing only)."""
 import os, sys, time
+# needs the experiment build:  TGX_DISSECT=1 python tinygpt_amd/build.py -f   (rebuild without it afterwards)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tinygpt_amd import known_desc, synth

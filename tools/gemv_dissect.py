@@ -2,6 +2,7 @@
 """Experiment: what the fixed cost of each GEMV launch class consists of — ms/step of the decode graph with parts of the
 kernel of ONE class disabled (results invalid in those modes; timing only).  debug.gemv = mode | 1 << (8 + class)."""
 import os, sys, time
+# needs the experiment build:  TGX_DISSECT=1 python tinygpt_amd/build.py -f   (rebuild without it afterwards)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tinygpt_amd import known_desc, synth
