@@ -23,20 +23,33 @@ namespace tgx {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
-  hi = f32_to_bf16(x);
-  lo = f32_to_bf16(x - bf16_to_f32(hi));
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+// one 32x32x16 matrix-core product on 16-bit operands of the storage dtype (same register image for both dtypes)
+template <int DT>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (DT == DT_F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// x = hi + lo with hi = round16(x), lo = round16(x - hi) in the 16-bit storage dtype DT (bf16: 16 significant bits in two
+// terms; fp16: 22, with an absolute floor of 2^-25 where lo goes subnormal)
+template <int DT>
+__device__ __forceinline__ void split16(float x, bf16_t& hi, bf16_t& lo) {
+  hi = f32_to_elem<DT>(x);
+  lo = f32_to_elem<DT>(x - elem_to_f32<DT>(hi));
 }
 
 // ---- X[s][:] = embed[ids[s]] (fp32) ------------------------------------------------------------------------------
+template <int DT>
 __global__ __launch_bounds__(256) void embed_rows_kernel(const long long* ids, const bf16_t* embed, float* X, int H) {
   const long long t = ids[blockIdx.x];
   const u32x4* src = reinterpret_cast<const u32x4*>(embed + (size_t)t * H);
   f32x4* dst = reinterpret_cast<f32x4*>(X + (size_t)blockIdx.x * H);
   for (int c = threadIdx.x; c < (H >> 3); c += 256) {
     const u32x4 v = src[c];
-    dst[2 * c] = f32x4{bf16_lo(v[0]), bf16_hi(v[0]), bf16_lo(v[1]), bf16_hi(v[1])};
-    dst[2 * c + 1] = f32x4{bf16_lo(v[2]), bf16_hi(v[2]), bf16_lo(v[3]), bf16_hi(v[3])};
+    dst[2 * c] = f32x4{pair_lo<DT>(v[0]), pair_hi<DT>(v[0]), pair_lo<DT>(v[1]), pair_hi<DT>(v[1])};
+    dst[2 * c + 1] = f32x4{pair_lo<DT>(v[2]), pair_hi<DT>(v[2]), pair_lo<DT>(v[3]), pair_hi<DT>(v[3])};
   }
 }
 
@@ -44,6 +57,7 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const long long* ids, c
 // `lo2` (optional) receives a third term: x = hi + lo + lo2 carries ~24 mantissa bits.  The QKV projection uses it,
 // because its output is the only one that is rounded to bf16 again (the KV cache): with two terms (2^-18) a few
 // per cent of the cache entries round differently from the single-position path, with three the schedules agree.
+template <int DT>
 __global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* X, const bf16_t* w, float eps, int H, bf16_t* hi, bf16_t* lo, bf16_t* lo2) {
   __shared__ float sc[4];
   const float* x = X + (size_t)blockIdx.x * H;
@@ -52,19 +66,20 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* X, cons
   ss = block_sum_256(ss, sc);
   const float inv = 1.0f / sqrtf(ss / (float)H + eps);
   for (int i = threadIdx.x; i < H; i += 256) {
-    const float y = bf16_to_f32(w[i]) * (x[i] * inv);
+    const float y = elem_to_f32<DT>(w[i]) * (x[i] * inv);
     const size_t o = (size_t)blockIdx.x * H + i;
-    split_bf16(y, hi[o], lo[o]);
-    if (lo2) lo2[o] = f32_to_bf16(y - bf16_to_f32(hi[o]) - bf16_to_f32(lo[o]));
+    split16<DT>(y, hi[o], lo[o]);
+    if (lo2) lo2[o] = f32_to_elem<DT>(y - elem_to_f32<DT>(hi[o]) - elem_to_f32<DT>(lo[o]));
   }
 }
 
 // ---- siluMul on the merged gate|up output, as bf16 hi/lo ---------------------------------------------------------
+template <int DT>
 __global__ __launch_bounds__(256) void silu_mul_split_kernel(const float* GU, int I, bf16_t* hi, bf16_t* lo) {
   const float* g = GU + (size_t)blockIdx.x * 2 * I;
   for (int i = threadIdx.x; i < I; i += 256) {
     const float a = g[i], u = g[I + i];
-    split_bf16((a / (1.0f + expf(-a))) * u, hi[(size_t)blockIdx.x * I + i], lo[(size_t)blockIdx.x * I + i]);
+    split16<DT>((a / (1.0f + expf(-a))) * u, hi[(size_t)blockIdx.x * I + i], lo[(size_t)blockIdx.x * I + i]);
   }
 }
 
@@ -78,6 +93,7 @@ struct RopeKvArgs {
   const bf16_t *q_norm_w, *k_norm_w;   // Qwen3 per-head RMSNorm weights [hd] (nullptr: no QK-norm)
   float eps;
 };
+template <int DT>
 __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) {
   const int s = blockIdx.x, pos = a.past + s, half = a.hd >> 1;
   const int qd = a.heads * a.hd, kvd = a.kv_heads * a.hd;
@@ -93,8 +109,8 @@ __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) 
       for (int o = half >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
       const float inv = 1.0f / sqrtf(ss / (float)a.hd + a.eps);
       const bf16_t* w = hh < a.heads ? a.q_norm_w : a.k_norm_w;
-      x0 = bf16_to_f32(w[p]) * (x0 * inv);
-      x1 = bf16_to_f32(w[p + half]) * (x1 * inv);
+      x0 = elem_to_f32<DT>(w[p]) * (x0 * inv);
+      x1 = elem_to_f32<DT>(w[p + half]) * (x1 * inv);
     }
     if (hh < a.heads + a.kv_heads) {
       const float cs = a.rope_cos[(size_t)pos * half + p], sn = a.rope_sin[(size_t)pos * half + p];
@@ -103,13 +119,13 @@ __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) 
     }
     if (hh < a.heads) {
       const size_t o = (size_t)s * qd + hh * a.hd + p;
-      split_bf16(x0, a.q_hi[o], a.q_lo[o]);
-      split_bf16(x1, a.q_hi[o + half], a.q_lo[o + half]);
+      split16<DT>(x0, a.q_hi[o], a.q_lo[o]);
+      split16<DT>(x1, a.q_hi[o + half], a.q_lo[o + half]);
     } else {
       bf16_t* dst = (hh < a.heads + a.kv_heads) ? a.k_cache + ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd
                                                 : a.v_cache + ((size_t)(hh - a.heads - a.kv_heads) * a.max_ctx + pos) * a.hd;
-      dst[p] = f32_to_bf16(x0);
-      dst[p + half] = f32_to_bf16(x1);
+      dst[p] = f32_to_elem<DT>(x0);
+      dst[p + half] = f32_to_elem<DT>(x1);
     }
   }
 }
@@ -130,8 +146,8 @@ struct GemmArgs {
 
 constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = GBK + 8;
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16x2_kernel(const GemmArgs a) {
+template <int DT, int EPI>
+__global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t sAh[GBM * GLD];
   __shared__ __attribute__((aligned(16))) bf16_t sAl[GBM * GLD];
   __shared__ __attribute__((aligned(16))) bf16_t sB[GBN * GLD];
@@ -202,9 +218,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(const GemmArgs a) {
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-          if (three) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal2[i], fb[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fb[j], acc[i][j], 0, 0, 0);   // small terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fb[j], acc[i][j], 0, 0, 0);
+          if (three) acc[i][j] = mfma16<DT>(fal2[i], fb[j], acc[i][j]);
+          acc[i][j] = mfma16<DT>(fal[i], fb[j], acc[i][j]);   // small terms first
+          acc[i][j] = mfma16<DT>(fah[i], fb[j], acc[i][j]);
         }
     }
   }
@@ -216,7 +232,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x2_kernel(const GemmArgs a) {
     for (int j = 0; j < 2; j++) {
       const int col = n0 + wn * 64 + j * 32 + (lane & 31);
       if (col >= a.N) continue;
-      const float bv = a.bias ? bf16_to_f32(a.bias[col]) : 0.f;
+      const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -248,7 +264,7 @@ struct AttnPrefillSmem {
   static constexpr size_t bytes = (size_t)(2 * 64 * LQ + 64 * LQ + HD * LV + 2 * 64 * LV) * 2 + (size_t)64 * LS * 4 + 3 * 64 * 4;
 };
 
-template <int HD>
+template <int DT, int HD>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs a) {
   using SM = AttnPrefillSmem<HD>;
   constexpr int LQ = SM::LQ, LV = SM::LV, LS = SM::LS;
@@ -328,8 +344,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
         const bf16x8 fqh = *reinterpret_cast<const bf16x8*>(&sQh[(wm * 32 + (lane & 31)) * LQ + kcol]);
         const bf16x8 fql = *reinterpret_cast<const bf16x8*>(&sQl[(wm * 32 + (lane & 31)) * LQ + kcol]);
         const bf16x8 fk = *reinterpret_cast<const bf16x8*>(&sK[(wn * 32 + (lane & 31)) * LQ + kcol]);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fql, fk, sacc, 0, 0, 0);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fqh, fk, sacc, 0, 0, 0);
+        sacc = mfma16<DT>(fql, fk, sacc);
+        sacc = mfma16<DT>(fqh, fk, sacc);
       }
       const int kcolg = wn * 32 + (lane & 31);           // key column of this lane inside the tile
       const int key = key0 + kcolg;
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
         const float p = dead ? 0.f : exp2f(sv[t] - m_new);
         sum += p;
         bf16_t ph, pl;
-        split_bf16(p, ph, pl);
+        split16<DT>(p, ph, pl);
         sPh[row * LV + part * 16 + t] = ph;
         sPl[row * LV + part * 16 + t] = pl;
       }
@@ -382,8 +398,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
         const bf16x8 fph = *reinterpret_cast<const bf16x8*>(&sPh[(wm * 32 + (lane & 31)) * LV + kcol]);
         const bf16x8 fpl = *reinterpret_cast<const bf16x8*>(&sPl[(wm * 32 + (lane & 31)) * LV + kcol]);
         const bf16x8 fv = *reinterpret_cast<const bf16x8*>(&sVt[(wn * (HD / 2) + j * 32 + (lane & 31)) * LV + kcol]);
-        oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fpl, fv, oacc[j], 0, 0, 0);
-        oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fph, fv, oacc[j], 0, 0, 0);
+        oacc[j] = mfma16<DT>(fpl, fv, oacc[j]);
+        oacc[j] = mfma16<DT>(fph, fv, oacc[j]);
       }
     }
   }
@@ -398,7 +414,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
       if (q0 + qrow >= a.S) continue;
       const float v = oacc[j][r] / sL[qrow];
       const size_t o = (size_t)(q0 + qrow) * qd + (size_t)h * HD + d;
-      split_bf16(v, a.o_hi[o], a.o_lo[o]);
+      split16<DT>(v, a.o_hi[o], a.o_lo[o]);
     }
   }
 }

@@ -282,6 +282,11 @@ int gemv_auto_ks(int K, int want) {
     default: { constexpr int DT = tgx::DT_F32; __VA_ARGS__; } break;                     \
   }
 
+// The MFMA prefill kernels exist for the two 16-bit storage dtypes.
+#define TGX_DT16_SWITCH(dt_, ...)                                                        \
+  if ((dt_) == tgx::DT_F16) { constexpr int DT = tgx::DT_F16; __VA_ARGS__; }             \
+  else { constexpr int DT = tgx::DT_BF16; __VA_ARGS__; }
+
 // the argument block of batch row `r` alone (every slab pointer advanced by r row strides)
 tgx::GemvArgs gemv_row(const tgx_ctx* c, tgx::GemvArgs a, int r) {
   a.x += (size_t)r * a.x_stride;
@@ -455,15 +460,20 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
 }
 
 void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float* C, int M, int N, int K, int ldc, bool three_terms = false) {
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(B_);   // the MFMA prefill runs for bf16 storage only (prefill_shapes_ok)
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(B_);   // 16-bit storage (bf16 or fp16 bit patterns); fp32 storage never gets here
   const bf16_t* bias = reinterpret_cast<const bf16_t*>(bias_);
   tgx::GemmArgs g{};
   g.A_hi = c->ws_ah; g.A_lo = c->ws_al; g.A_lo2 = three_terms ? c->ws_al2 : nullptr;
   g.B = B; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
   const dim3 grid((N + tgx::GBN - 1) / tgx::GBN, (M + tgx::GBM - 1) / tgx::GBM), blk(256);
   const size_t dyn = three_terms ? (size_t)tgx::GBM * tgx::GLD * 2 : 0;      // LDS tile of the third term
-  if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_bf16x2_kernel<tgx::GEMM_RESIDUAL>), grid, blk, dyn, c->stream, g);
-  else hipLaunchKernelGGL((tgx::gemm_bf16x2_kernel<tgx::GEMM_STORE>), grid, blk, dyn, c->stream, g);
+  if (c->dt == tgx::DT_F16) {
+    if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_RESIDUAL>), grid, blk, dyn, c->stream, g);
+    else hipLaunchKernelGGL((tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_STORE>), grid, blk, dyn, c->stream, g);
+  } else {
+    if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_RESIDUAL>), grid, blk, dyn, c->stream, g);
+    else hipLaunchKernelGGL((tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_STORE>), grid, blk, dyn, c->stream, g);
+  }
 }
 
 // All layers for S prompt positions of one row at once; leaves the last position's hidden state in row.x.
@@ -474,11 +484,14 @@ void launch_prefill(tgx_ctx* c, RowState& r, int S) {
   const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd;
   bf16_t* kc = reinterpret_cast<bf16_t*>(r.kcache);
   bf16_t* vc = reinterpret_cast<bf16_t*>(r.vcache);
-  hipLaunchKernelGGL(tgx::embed_rows_kernel, dim3(S), dim3(256), 0, c->stream, (const long long*)r.prompt, (const bf16_t*)c->embed, c->ws_x, H);
+  TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_rows_kernel<DT>, dim3(S), dim3(256), 0, c->stream, (const long long*)r.prompt, (const bf16_t*)c->embed, c->ws_x, H))
   for (int l = 0; l < d.layers; l++) {
     const LayerW& w = c->L[(size_t)l];
-    hipLaunchKernelGGL(tgx::rmsnorm_split_kernel, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.in_norm, d.norm_eps, H, c->ws_ah, c->ws_al, c->ws_al2);
-    launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, S, qd + 2 * kvd, H, qd + 2 * kvd, /*three_terms=*/true);
+    // the QKV product feeds a second rounding (the KV cache): bf16 needs three split terms to reproduce the step path's cache
+    // entries (two leave 1-8 % of them one ulp off); fp16's two terms already carry 22 bits
+    const bool three = c->dt == tgx::DT_BF16;
+    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.in_norm, d.norm_eps, H, c->ws_ah, c->ws_al, three ? c->ws_al2 : (bf16_t*)nullptr))
+    launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, S, qd + 2 * kvd, H, qd + 2 * kvd, /*three_terms=*/three);
     {
       tgx::RopeKvArgs a{};
       a.QKV = c->ws_out; a.q_hi = c->ws_qh; a.q_lo = c->ws_ql;
@@ -486,7 +499,7 @@ void launch_prefill(tgx_ctx* c, RowState& r, int S) {
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = (int)c->past;
       a.q_norm_w = d.qk_norm ? (const bf16_t*)w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? (const bf16_t*)w.k_norm : nullptr; a.eps = d.norm_eps;
-      hipLaunchKernelGGL(tgx::rope_kv_split_kernel, dim3(S), dim3(256), 0, c->stream, a);
+      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rope_kv_split_kernel<DT>, dim3(S), dim3(256), 0, c->stream, a))
     }
     {
       tgx::AttnPrefillArgs a{};
@@ -494,13 +507,13 @@ void launch_prefill(tgx_ctx* c, RowState& r, int S) {
       a.o_hi = c->ws_ah; a.o_lo = c->ws_al; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
       a.scale = 1.0f / sqrtf((float)hd);
       const dim3 grid((S + 63) / 64, d.heads), blk(256);
-      if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<64>), grid, blk, tgx::AttnPrefillSmem<64>::bytes, c->stream, a);
-      else hipLaunchKernelGGL((tgx::attn_prefill_kernel<128>), grid, blk, tgx::AttnPrefillSmem<128>::bytes, c->stream, a);
+      TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64>), grid, blk, tgx::AttnPrefillSmem<64>::bytes, c->stream, a);
+                             else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128>), grid, blk, tgx::AttnPrefillSmem<128>::bytes, c->stream, a))
     }
     launch_gemm(c, tgx::GEMM_RESIDUAL, w.wo, nullptr, c->ws_x, S, H, qd, H);
-    hipLaunchKernelGGL(tgx::rmsnorm_split_kernel, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al, (bf16_t*)nullptr);
+    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al, (bf16_t*)nullptr))
     launch_gemm(c, tgx::GEMM_STORE, w.wgu, nullptr, c->ws_out, S, 2 * I, H, 2 * I);
-    hipLaunchKernelGGL(tgx::silu_mul_split_kernel, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_out, I, c->ws_ah, c->ws_al);
+    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::silu_mul_split_kernel<DT>, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_out, I, c->ws_ah, c->ws_al))
     launch_gemm(c, tgx::GEMM_RESIDUAL, w.wdown, nullptr, c->ws_x, S, H, I, H);
   }
   (void)hipMemcpyAsync(r.x, c->ws_x + (size_t)(S - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, c->stream);
@@ -830,11 +843,15 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipHostGetDevicePointer((void**)&c->host_ring_dev, c->host_ring, 0));
   for (int i = 0; i < MAX_TICKET_EVENTS; i++) HIP_OK(c, hipEventCreateWithFlags(&c->ticket_ev[i], hipEventDisableTiming));
   for (int i = 0; i < 2; i++) HIP_OK(c, hipEventCreate(&c->prof.ev[i]));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_bf16x2_kernel<tgx::GEMM_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_bf16x2_kernel<tgx::GEMM_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   // the prefill attention tile needs 72-105 KiB of dynamic LDS (opt-in above 64 KiB)
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<64>::bytes));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<128>::bytes));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_BF16, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<64>::bytes));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_BF16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<128>::bytes));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_F16, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<64>::bytes));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_F16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<128>::bytes));
   c->past = 0;
   c->finalized = true;
   return TGX_OK;
@@ -871,7 +888,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
   for (int b = 0; b < batch; b++) {
     RowState& r = c->rows[(size_t)b];
     HIP_OK(c, hipMemcpyAsync(r.prompt, ids + (size_t)b * seq, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream));
-    if (seq >= 4 && c->prefill_mfma && c->dt == tgx::DT_BF16 && prefill_shapes_ok(c->d)) {
+    if (seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && prefill_shapes_ok(c->d)) {
       // batched prefill on the matrix cores; logits for the last position only (== forward + narrow, GPTEngine.cpp:96-97)
       int rc = ensure_prefill_ws(c, seq);
       if (rc) return rc;
