@@ -20,7 +20,8 @@
 // the first weight load), streams 16-byte weight slices (coalesced 1 KiB per wave-load, 2*NX loads in flight
 // per lane, next unit prefetched while the current one is reduced), accumulates in fp32 and finishes each
 // dot product with a DPP wave reduction.  With KS > 1 the KS partial sums meet in LDS in a fixed order.
-// The RMSNorm prologue needs the whole vector in one wave, so norm-fused launches use KS = 1 (hidden <= 4096).
+// Norm-fused launches use KS = 1 at batch 1 (the wave holds the whole vector, hidden <= 4096); with batch rows the KS waves
+// of a unit exchange partial sums of squares through LDS so that R x NX slices still fit the registers.
 #pragma once
 #include "common.h"
 
@@ -134,11 +135,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       for (int t = 0; t < 4; t++) { xr[r][j][t] = v0[t]; xr[r][j][4 + t] = v1[t]; }
     }
   }
-  if (PRO == PRO_RMSNORM && !(TGX_DBG(a, 1))) {   // KS == 1: the wave holds all of x.  HF order: weight * (x * rsqrt(mean(x^2)+eps))
+  if (PRO == PRO_RMSNORM && !(TGX_DBG(a, 1))) {   // HF order: weight * (x * rsqrt(mean(x^2)+eps)).  KS == 1: the wave holds all of x;
+    // KS > 1 (batch rows at hidden sizes whose R x NX slices would not fit one wave): the KS waves of a unit exchange their
+    // partial sums of squares through LDS once, before the weight loop (every wave of the workgroup takes part)
     const E* wg = static_cast<const E*>(a.norm_w);
     Slice8<DT> nw[NX];
 #pragma unroll
     for (int j = 0; j < NX; j++) nw[j] = load_slice<DT>(wg, cidx[j]);        // in flight together with x
+    float ssq[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
       float ss = 0.f;
@@ -146,8 +150,25 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       for (int j = 0; j < NX; j++)
 #pragma unroll
         for (int t = 0; t < 8; t++) ss = fmaf(xr[r][j][t], xr[r][j][t], ss);
-      ss = wave_sum(ss);
-      const float inv = 1.0f / sqrtf(ss / (float)a.K + a.eps);
+      ssq[r] = wave_sum(ss);
+    }
+    if (KS > 1) {
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) ps[wv][r] = ssq[r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        float t = ps[slot * KS][r];
+        for (int k = 1; k < KS; k++) t += ps[slot * KS + k][r];
+        ssq[r] = t;
+      }
+      __syncthreads();             // ps is reused by the unit loop
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const float inv = 1.0f / sqrtf(ssq[r] / (float)a.K + a.eps);
 #pragma unroll
       for (int j = 0; j < NX; j++) {
         float w[8];

@@ -305,10 +305,10 @@ tgx::GemvArgs gemv_row(const tgx_ctx* c, tgx::GemvArgs a, int r) {
 template <int DT, int PRO, int EPI, int NX>
 void launch_gemv_nx(tgx_ctx* c, const tgx::GemvArgs& a, int grid, int R) {
   const dim3 g(grid), b(256);
-  if constexpr (NX <= 4) {   // rows share the weight pass while R activation slices fit the register file
-    if (R == 4) { hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 4>), g, b, 0, c->stream, a); return; }
-    if (R == 2) { hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 2>), g, b, 0, c->stream, a); return; }
-  }
+  // rows share the weight pass; R x NX activation slices of 8 floats stay in registers (4 x 8 x 8 = 256 of the 512 a wave
+  // of a 256-thread workgroup may use)
+  if (R == 4) { hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 4>), g, b, 0, c->stream, a); return; }
+  if (R == 2) { hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 2>), g, b, 0, c->stream, a); return; }
   for (int r = 0; r < R; r++) hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 1>), g, b, 0, c->stream, gemv_row(c, a, r));
 }
 
@@ -317,6 +317,7 @@ void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls, int R) {
   const Tune& tn = c->tune[cls];
   a.dbg = ((c->debug_gemv >> (8 + cls)) & 1) ? (c->debug_gemv & 15) : 0;
   a.ks = (PRO == tgx::PRO_RMSNORM) ? 1 : gemv_auto_ks(a.K, tn.ks);
+  while (R > 1 && a.ks < 4 && gemv_nx(a.K, a.ks) > 4) a.ks *= 2;   // batch rows: at most 4 slices per row and lane (measured: B = 2 and 4 on the 1B / 3B / 7B shapes)
   const int grid = (EPI == tgx::EPI_LOGITS) ? c->lm_grid : gemv_grid(c, a.units, a.ks, tn.bpc);
   const int nx = gemv_nx(a.K, a.ks);
   TGX_DT_SWITCH(c->dt, switch (nx) {
