@@ -207,3 +207,30 @@ def test_errors_are_loud(hip):
     bad = dataclasses.replace(desc_from_hf_config(cfg, "bf16"), head_dim=48)
     with pytest.raises(TgxError):
         Model(bad, hip)                                    # head_dim 64 and 128 are built (the reference builds TinyFA for the same two)
+
+
+@pytest.mark.parametrize("fam,ctx", [("llama_tiny", 4400), ("mistral_tiny", 2300)])
+def test_long_context_beyond_one_attention_pass(fam, ctx, hip, oracle_lib):
+    """Contexts longer than nsplit x (4 waves x UNR wave-loads) tokens make every attention split walk several token blocks
+    (attn_decode.h: block b goes to split b mod nsplit): 4096 tokens for head_dim 64, 2048 for head_dim 128.  Teacher-forced
+    against the oracle across the boundary; the long prompt also exercises the MFMA prefill at many key tiles."""
+    import dataclasses
+    from oracle.oracle_ffi import OracleModel
+    from tinygpt_amd.ffi import Model
+    cfg, g = load_golden(fam)
+    cfg = dict(cfg, max_position_embeddings=ctx + 64)
+    if "rope_scaling" in cfg:
+        cfg["rope_scaling"] = dict(cfg["rope_scaling"], original_max_position_embeddings=ctx + 64)   # llama: contextSize comes from here
+    d = desc_from_hf_config(cfg, "bf16")
+    assert d.max_ctx >= ctx + 16
+    gpu = Model(d, hip).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
+    ref = OracleModel(d).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
+    from tinygpt_amd import synth
+    prompt = synth.synth_prompt(d.vocab, ctx, 3)[None, :]
+    gpu.forward(prompt); ref.forward(prompt)
+    for step in range(6):
+        lg, lr = gpu.logits(rounded=False), ref.logits(rounded=False)
+        assert rel_err(lg, lr) < TOL_ORACLE, (step, rel_err(lg, lr))
+        tok = ref.sample(GREEDY)
+        gpu.forward(tok[None, :]); ref.forward(tok[None, :])
+    assert gpu.past_length == ref.past_length == ctx + 6
