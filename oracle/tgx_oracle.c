@@ -620,9 +620,10 @@ static int cmp_desc(const void* a, const void* b) {   /* value descending, index
 static void softmax_inplace(float* p, const float* l, int V) {
   float mx = -INFINITY;
   for (int i = 0; i < V; i++) if (l[i] > mx) mx = l[i];
-  float sum = 0.f;
-  for (int i = 0; i < V; i++) { p[i] = expf(l[i] - mx); sum += p[i]; }
-  float inv = 1.0f / sum;
+  double sum = 0.0;   /* the normaliser is accumulated in double and rounded once: the result does not depend on the order
+                       * of summation, so a parallel implementation can reproduce it bit for bit (sampler) */
+  for (int i = 0; i < V; i++) { p[i] = expf(l[i] - mx); sum += (double)p[i]; }
+  float inv = 1.0f / (float)sum;
   for (int i = 0; i < V; i++) p[i] *= inv;
 }
 

@@ -44,7 +44,7 @@ struct RowState {       // independent KV/sequence state of one batch row
   float *x = nullptr, *q = nullptr, *attn = nullptr, *h = nullptr;   // fp32 activations
   float* k_raw = nullptr;   // Qwen3: un-normalised k of the current position
   float* logits = nullptr;
-  float *work = nullptr, *probs = nullptr;   // sampler scratch / final probabilities [V]
+  float* probs = nullptr;   // final probabilities of the last sampled step [V]
   float* part_val = nullptr;
   int* part_idx = nullptr;
   float* attn_part = nullptr;
@@ -83,7 +83,7 @@ struct tgx_ctx {
   float *rope_cos = nullptr, *rope_sin = nullptr;
   std::vector<RowState> rows;   // views into the per-row slabs below (constant row stride: batched GEMV walks them)
   float *slab_x = nullptr, *slab_q = nullptr, *slab_kraw = nullptr, *slab_attn = nullptr, *slab_h = nullptr, *slab_logits = nullptr;
-  float *slab_work = nullptr, *slab_probs = nullptr, *slab_part_val = nullptr, *slab_attn_part = nullptr;
+  float *slab_probs = nullptr, *slab_part_val = nullptr, *slab_attn_part = nullptr;
   int *slab_part_idx = nullptr, *slab_tok = nullptr, *slab_pos = nullptr;
   long long* slab_prompt = nullptr;
   ebyte *slab_k = nullptr, *slab_v = nullptr;
@@ -106,6 +106,7 @@ struct tgx_ctx {
   int step_graph_batch = 0;
   tgx_sampler_cfg step_graph_cfg{};
   unsigned long long* seed_dev = nullptr;
+  tgx::SampScratch* samp_scratch = nullptr;   // [max_batch] histograms / thresholds / partial sums of the staged sampler
   bool have_probs = false;
   bool use_graph = true;
 
@@ -548,20 +549,48 @@ tgx::FinalizeArgs make_finalize_args(tgx_ctx* c, int row, bool advance_pos, bool
   return a;
 }
 
-// == Sampler::sample on this row's logits (Sampler.cpp:23-79) + token publish / pastLength / next embedding
-void launch_sample(tgx_ctx* c, int row, const tgx_sampler_cfg& cfg, bool advance_pos, bool log_step) {
-  RowState& r = c->rows[(size_t)row];
+// == Sampler::sample on the logits of rows [row0, row0+R) (Sampler.cpp:23-79) + token publish / pastLength / next embedding.
+// Greedy: one finalize launch per row.  Otherwise the staged sampler of kernels/sampler.h: ceil(V/1024) workgroups per row
+// (rows on blockIdx.y), one launch per digit level of each active filter, the partial-sum stages, then one pick per row.
+void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool advance_pos, bool log_step) {
   if (is_greedy(&cfg)) {
-    const tgx::FinalizeArgs a = make_finalize_args(c, row, advance_pos, log_step);
-    TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::finalize_greedy_kernel<DT>, dim3(1), dim3(256), 0, c->stream, a))
+    for (int b = row0; b < row0 + R; b++) {
+      const tgx::FinalizeArgs a = make_finalize_args(c, b, advance_pos, log_step);
+      TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::finalize_greedy_kernel<DT>, dim3(1), dim3(256), 0, c->stream, a))
+    }
     return;
   }
-  tgx::SampleArgs a{};
-  a.logits = r.logits; a.work = r.work; a.probs_out = r.probs; a.V = c->d.vocab;
+  const int V = c->d.vocab;
+  RowState& r = c->rows[(size_t)row0];
+  tgx::SampArgs a{};
+  a.logits = r.logits; a.logits_stride = V;
+  a.part_val = r.part_val; a.part_stride = c->lm_grid; a.n_part = c->lm_grid;
+  a.sc = c->samp_scratch + row0;
+  a.probs_out = r.probs; a.probs_stride = V;
+  a.V = V; a.idx_bits = 1;
+  while ((1 << a.idx_bits) < V) a.idx_bits++;
   a.temperature = cfg.temperature; a.top_k = cfg.top_k; a.top_p = cfg.top_p; a.min_p = cfg.min_p;
-  a.seed = c->seed_dev;
-  a.fin = make_finalize_args(c, row, advance_pos, log_step);
-  TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::sample_kernel<DT>, dim3(1), dim3(tgx::SAMPLER_THREADS), 0, c->stream, a))
+  const bool setK = cfg.top_k > 0, setP = cfg.top_p < 1.f, setM = cfg.min_p > 0.f;
+  const int nwg = (V + tgx::SAMP_TILE - 1) / tgx::SAMP_TILE;
+  const dim3 grid(nwg, R), blk(tgx::SAMP_WG);
+  if (setK) for (int l = 0; l < tgx::SAMP_LEVELS; l++) { a.level = l; hipLaunchKernelGGL(tgx::samp_level_kernel<0>, grid, blk, 0, c->stream, a); }
+  if (setP) for (int l = 0; l < tgx::SAMP_LEVELS; l++) { a.level = l; hipLaunchKernelGGL(tgx::samp_level_kernel<1>, grid, blk, 0, c->stream, a); }
+  // the first stage after a filter's last level derives that filter's threshold from the level-4 histogram; later stages read it
+  a.k_from_hist = (setK && !setP) ? 1 : 0;      // with top-p on, its first level already derived the top-k threshold
+  a.p_from_hist = setP ? 1 : 0;
+  if (setM) { hipLaunchKernelGGL(tgx::samp_sum_kernel<0>, grid, blk, 0, c->stream, a); a.k_from_hist = 0; a.p_from_hist = 0; }
+  hipLaunchKernelGGL(tgx::samp_sum_kernel<1>, grid, blk, 0, c->stream, a);
+  a.k_from_hist = 0; a.p_from_hist = 0;
+  hipLaunchKernelGGL(tgx::samp_sum_kernel<2>, grid, blk, 0, c->stream, a);
+  for (int b = row0; b < row0 + R; b++) {
+    tgx::SampPickArgs pa{};
+    pa.s = a;
+    pa.s.logits = c->rows[(size_t)b].logits; pa.s.part_val = c->rows[(size_t)b].part_val; pa.s.sc = c->samp_scratch;   // the pick kernel indexes sc by fin.row
+    pa.s.logits_stride = 0; pa.s.part_stride = 0;
+    pa.nwg = nwg; pa.seed = c->seed_dev;
+    pa.fin = make_finalize_args(c, b, advance_pos, log_step);
+    TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::samp_pick_kernel<DT>, dim3(1), dim3(tgx::SAMP_WG), 0, c->stream, pa))
+  }
 }
 
 // One decode step for all active rows: layers at pos, lm_head, then {sample, pos+=1, next embedding}.
@@ -572,7 +601,7 @@ void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
     const int rem = c->batch - row0, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
     launch_layers(c, row0, R);
     launch_lm_head(c, row0, R);
-    for (int b = row0; b < row0 + R; b++) launch_sample(c, b, cfg, /*advance_pos=*/true, /*log_step=*/true);
+    launch_sample(c, row0, R, cfg, /*advance_pos=*/true, /*log_step=*/true);
     row0 += R;
   }
 }
@@ -809,7 +838,6 @@ int tgx_finalize(tgx_ctx* c) {
   if ((rc = dev_alloc(c, &c->slab_attn, B * qd))) return rc;
   if ((rc = dev_alloc(c, &c->slab_h, B * I))) return rc;
   if ((rc = dev_alloc(c, &c->slab_logits, B * V))) return rc;
-  if ((rc = dev_alloc(c, &c->slab_work, B * V))) return rc;
   if ((rc = dev_alloc(c, &c->slab_probs, B * V))) return rc;
   if ((rc = dev_alloc(c, &c->slab_part_val, B * c->lm_grid))) return rc;
   if ((rc = dev_alloc(c, &c->slab_part_idx, B * c->lm_grid))) return rc;
@@ -826,7 +854,7 @@ int tgx_finalize(tgx_ctx* c) {
   for (size_t b = 0; b < B; b++) {
     RowState& r = c->rows[b];
     r.x = c->slab_x + b * H; r.q = c->slab_q + b * qd; r.k_raw = c->slab_kraw + b * kvd; r.attn = c->slab_attn + b * qd;
-    r.h = c->slab_h + b * I; r.logits = c->slab_logits + b * V; r.work = c->slab_work + b * V; r.probs = c->slab_probs + b * V;
+    r.h = c->slab_h + b * I; r.logits = c->slab_logits + b * V; r.probs = c->slab_probs + b * V;
     r.part_val = c->slab_part_val + b * c->lm_grid; r.part_idx = c->slab_part_idx + b * c->lm_grid;
     r.attn_part = c->slab_attn_part + b * c->attn_part_row;
     r.tok = c->slab_tok + b; r.pos = c->slab_pos + b; r.prompt = c->slab_prompt + b * d.max_ctx;
@@ -835,6 +863,9 @@ int tgx_finalize(tgx_ctx* c) {
   c->log_cap = d.max_ctx > 1024 ? d.max_ctx : 1024;
   if ((rc = dev_alloc(c, &c->step, 1))) return rc;
   if ((rc = dev_alloc(c, &c->seed_dev, 1))) return rc;
+  if ((rc = dev_alloc(c, &c->samp_scratch, (size_t)d.max_batch))) return rc;
+  HIP_OK(c, hipMemset(c->samp_scratch, 0, sizeof(tgx::SampScratch) * (size_t)d.max_batch));
+  if ((V + tgx::SAMP_TILE - 1) / tgx::SAMP_TILE > tgx::SAMP_MAX_WG) return set_err(c, TGX_ERR_UNSUPPORTED, "vocabulary %d exceeds the sampler's %d entries", V, tgx::SAMP_MAX_WG * tgx::SAMP_TILE);
   if ((rc = dev_alloc(c, &c->nop_word, 1))) return rc;
   if ((rc = dev_alloc(c, &c->scratch_x, (size_t)H))) return rc;
   HIP_OK(c, hipMemset(c->scratch_x, 0, (size_t)H * 4));
@@ -864,10 +895,10 @@ void tgx_destroy(tgx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x); fr(c->seed_dev);
+  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
   fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); }
-  fr(c->slab_x); fr(c->slab_q); fr(c->slab_kraw); fr(c->slab_attn); fr(c->slab_h); fr(c->slab_logits); fr(c->slab_work); fr(c->slab_probs);
+  fr(c->slab_x); fr(c->slab_q); fr(c->slab_kraw); fr(c->slab_attn); fr(c->slab_h); fr(c->slab_logits); fr(c->slab_probs);
   fr(c->slab_part_val); fr(c->slab_part_idx); fr(c->slab_attn_part); fr(c->slab_tok); fr(c->slab_pos); fr(c->slab_prompt); fr(c->slab_k); fr(c->slab_v);
   if (c->host_ring) (void)hipHostFree(c->host_ring);
   for (auto& e : c->ticket_ev) if (e) (void)hipEventDestroy(e);
@@ -938,7 +969,7 @@ int tgx_sample(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* o
     HIP_OK(c, hipMemcpy(c->seed_dev, &s, 8, hipMemcpyHostToDevice));
     c->have_probs = true;
   }
-  for (int b = 0; b < c->batch; b++) launch_sample(c, b, *cfg, /*advance_pos=*/false, /*log_step=*/false);
+  launch_sample(c, 0, c->batch, *cfg, /*advance_pos=*/false, /*log_step=*/false);
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipStreamSynchronize(c->stream));
   for (int b = 0; b < c->batch; b++) {
