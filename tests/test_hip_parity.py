@@ -234,3 +234,26 @@ def test_long_context_beyond_one_attention_pass(fam, ctx, hip, oracle_lib):
         tok = ref.sample(GREEDY)
         gpu.forward(tok[None, :]); ref.forward(tok[None, :])
     assert gpu.past_length == ref.past_length == ctx + 6
+
+
+def test_context_limit_is_exact(hip, oracle_lib):
+    """contextSize (llama: original_max_position_embeddings = 64 for the fixture, ModelLlama.h:26-31): the cache may be filled
+    to the last slot, one token more is refused with the context error and the state stays usable (reset, rerun)."""
+    from tinygpt_amd.ffi import TgxError
+    gpu, ref, g = make_pair("llama_tiny", hip, oracle_lib)
+    assert gpu.context_size == ref.context_size == 64
+    from tinygpt_amd import synth
+    prompt = synth.synth_prompt(gpu.desc.vocab, 60, 9)[None, :]
+    gpu.forward(prompt); ref.forward(prompt)
+    np.testing.assert_array_equal(gpu.sample(GREEDY), ref.sample(GREEDY))
+    np.testing.assert_array_equal(gpu.decode(4, GREEDY), ref.decode(4, GREEDY))      # positions 60..63: the cache is full
+    assert gpu.past_length == 64
+    assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_ORACLE
+    with pytest.raises(TgxError):
+        gpu.decode(1, GREEDY)
+    assert gpu.past_length == 64
+    gpu.reset_cache()
+    one = prompt[:, :1]
+    gpu.forward(one); ref.reset_cache(); ref.forward(one)                               # a single-token prompt (seq = 1 at past = 0)
+    assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_ORACLE
+    np.testing.assert_array_equal(gpu.sample(GREEDY), ref.sample(GREEDY))
