@@ -146,38 +146,46 @@ struct GemmArgs {
 
 constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = GBK + 8;
 
-template <int DT, int EPI>
+// MI = 32-row blocks per wave along M: 2 -> the 128x128 tile; 1 -> a 64x128 tile for the products with few column tiles
+// (N = hidden: o_proj, down_proj), which would otherwise put one workgroup on each CU and leave the matrix cores waiting
+// on every barrier.
+template <int DT, int EPI, int MI>
 __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t sAh[GBM * GLD];
-  __shared__ __attribute__((aligned(16))) bf16_t sAl[GBM * GLD];
+  constexpr int TM = 64 * MI;                 // tile rows
+  constexpr int AI = TM * 8 / 256;            // 16-byte A chunks per thread and K-step
+  __shared__ __attribute__((aligned(16))) bf16_t sAh[TM * GLD];
+  __shared__ __attribute__((aligned(16))) bf16_t sAl[TM * GLD];
   __shared__ __attribute__((aligned(16))) bf16_t sB[GBN * GLD];
-  extern __shared__ __attribute__((aligned(16))) bf16_t sAl2[];   // [GBM*GLD] only when the launch asks for it
+  extern __shared__ __attribute__((aligned(16))) bf16_t sAl2[];   // [TM*GLD] only when the launch asks for it
   const bool three = a.A_lo2 != nullptr;      // wave-uniform
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
-  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * GBN;
   const int kch = a.K >> 3;                                    // 16-byte chunks per row
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < MI; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   // staging map: chunk c = tid + 256*i -> tile row c/8, 16-byte column c%8
-  u32x4 rah[4], ral[4], ral2[4], rb[4];
+  u32x4 rah[AI], ral[AI], ral2[AI], rb[4];
   const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
   auto load_tiles = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
       const size_t koff = (size_t)(k0 >> 3) + kc;
-      const bool am = m0 + row < a.M, bn = n0 + row < a.N;
-      rah[i] = am ? reinterpret_cast<const u32x4*>(a.A_hi)[(size_t)(m0 + row) * kch + koff] : zero;
-      ral[i] = am ? reinterpret_cast<const u32x4*>(a.A_lo)[(size_t)(m0 + row) * kch + koff] : zero;
-      ral2[i] = (three && am) ? reinterpret_cast<const u32x4*>(a.A_lo2)[(size_t)(m0 + row) * kch + koff] : zero;
+      if (i < AI) {
+        const bool am = m0 + row < a.M;
+        rah[i < AI ? i : 0] = am ? reinterpret_cast<const u32x4*>(a.A_hi)[(size_t)(m0 + row) * kch + koff] : zero;
+        ral[i < AI ? i : 0] = am ? reinterpret_cast<const u32x4*>(a.A_lo)[(size_t)(m0 + row) * kch + koff] : zero;
+        ral2[i < AI ? i : 0] = (three && am) ? reinterpret_cast<const u32x4*>(a.A_lo2)[(size_t)(m0 + row) * kch + koff] : zero;
+      }
+      const bool bn = n0 + row < a.N;
       rb[i] = bn ? reinterpret_cast<const u32x4*>(a.B)[(size_t)(n0 + row) * kch + koff] : zero;
     }
   };
@@ -185,9 +193,11 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
-      *reinterpret_cast<u32x4*>(&sAh[row * GLD + kc * 8]) = rah[i];
-      *reinterpret_cast<u32x4*>(&sAl[row * GLD + kc * 8]) = ral[i];
-      if (three) *reinterpret_cast<u32x4*>(&sAl2[row * GLD + kc * 8]) = ral2[i];
+      if (i < AI) {
+        *reinterpret_cast<u32x4*>(&sAh[row * GLD + kc * 8]) = rah[i < AI ? i : 0];
+        *reinterpret_cast<u32x4*>(&sAl[row * GLD + kc * 8]) = ral[i < AI ? i : 0];
+        if (three) *reinterpret_cast<u32x4*>(&sAl2[row * GLD + kc * 8]) = ral2[i < AI ? i : 0];
+      }
       *reinterpret_cast<u32x4*>(&sB[row * GLD + kc * 8]) = rb[i];
     }
   };
@@ -201,10 +211,10 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
 #pragma unroll
     for (int kk = 0; kk < GBK / 16; kk++) {
       const int kcol = kk * 16 + 8 * (lane >> 5);
-      bf16x8 fah[2], fal[2], fal2[2], fb[2];
+      bf16x8 fah[MI], fal[MI], fal2[MI], fb[2];
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
-        const int row = wm * 64 + i * 32 + (lane & 31);
+      for (int i = 0; i < MI; i++) {
+        const int row = wm * (32 * MI) + i * 32 + (lane & 31);
         fah[i] = *reinterpret_cast<const bf16x8*>(&sAh[row * GLD + kcol]);
         fal[i] = *reinterpret_cast<const bf16x8*>(&sAl[row * GLD + kcol]);
         if (three) fal2[i] = *reinterpret_cast<const bf16x8*>(&sAl2[row * GLD + kcol]);
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
         fb[j] = *reinterpret_cast<const bf16x8*>(&sB[row * GLD + kcol]);
       }
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+      for (int i = 0; i < MI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           if (three) acc[i][j] = mfma16<DT>(fal2[i], fb[j], acc[i][j]);
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
 
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < MI; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int col = n0 + wn * 64 + j * 32 + (lane & 31);
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
       const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= a.M) continue;
         float* dst = a.C + (size_t)row * a.ldc + col;
         const float v = acc[i][j][r] + bv;

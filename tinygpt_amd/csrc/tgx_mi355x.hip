@@ -119,6 +119,7 @@ struct tgx_ctx {
   bf16_t* ws_al2 = nullptr;                           // [S][H] third term for the QKV projection
   bf16_t *ws_qh = nullptr, *ws_ql = nullptr;          // [S][qd] rotated queries (hi, lo)
   bool prefill_mfma = true;
+  int gemm_tm = 0;           // experiment: force the GEMM row tile (64 / 128); 0 = by the number of tiles
   int debug_attn = 0;        // experiment: AttnArgs.dbg
   int debug_gemv = 0;        // experiment: GemvArgs.dbg = value & 15 for the kernel classes selected by bits 8.. (1 << (8 + class))
   int debug_skip = 0;        // experiment: bit0 skip attn decode kernel, bit1 skip combine (results invalid)
@@ -467,15 +468,22 @@ void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float
   tgx::GemmArgs g{};
   g.A_hi = c->ws_ah; g.A_lo = c->ws_al; g.A_lo2 = three_terms ? c->ws_al2 : nullptr;
   g.B = B; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
-  const dim3 grid((N + tgx::GBN - 1) / tgx::GBN, (M + tgx::GBM - 1) / tgx::GBM), blk(256);
-  const size_t dyn = three_terms ? (size_t)tgx::GBM * tgx::GLD * 2 : 0;      // LDS tile of the third term
-  if (c->dt == tgx::DT_F16) {
-    if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_RESIDUAL>), grid, blk, dyn, c->stream, g);
-    else hipLaunchKernelGGL((tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_STORE>), grid, blk, dyn, c->stream, g);
-  } else {
-    if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_RESIDUAL>), grid, blk, dyn, c->stream, g);
-    else hipLaunchKernelGGL((tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_STORE>), grid, blk, dyn, c->stream, g);
-  }
+  // few column tiles (N = hidden) -> 64-row tiles, so that at least two workgroups share a CU
+  const bool few = ((N + tgx::GBN - 1) / tgx::GBN) * ((M + tgx::GBM - 1) / tgx::GBM) < 2 * c->num_cus;
+  // measured (tools/prefill_bench.py --gemm-tm, Llama-3.2-1B, S = 2048): this policy 15.0 ms, 64-row tiles also for the three-term
+  // QKV product 15.3, 128-row tiles everywhere 15.85, 64-row tiles everywhere 15.9
+  const bool small = c->gemm_tm ? c->gemm_tm == 64 : (few && !three_terms);
+  const int tm = small ? 64 : tgx::GBM;
+  const dim3 grid((N + tgx::GBN - 1) / tgx::GBN, (M + tm - 1) / tm), blk(256);
+  const size_t dyn = three_terms ? (size_t)tm * tgx::GLD * 2 : 0;      // LDS tile of the third term
+  TGX_DT16_SWITCH(c->dt,
+    if (small) {
+      if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_RESIDUAL, 1>), grid, blk, dyn, c->stream, g);
+      else hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_STORE, 1>), grid, blk, dyn, c->stream, g);
+    } else {
+      if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_RESIDUAL, 2>), grid, blk, dyn, c->stream, g);
+      else hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_STORE, 2>), grid, blk, dyn, c->stream, g);
+    })
 }
 
 // All layers for S prompt positions of one row at once; leaves the last position's hidden state in row.x.
@@ -875,10 +883,10 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipHostGetDevicePointer((void**)&c->host_ring_dev, c->host_ring, 0));
   for (int i = 0; i < MAX_TICKET_EVENTS; i++) HIP_OK(c, hipEventCreateWithFlags(&c->ticket_ev[i], hipEventDisableTiming));
   for (int i = 0; i < 2; i++) HIP_OK(c, hipEventCreate(&c->prof.ev[i]));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_STORE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_RESIDUAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_STORE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_RESIDUAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   // the prefill attention tile needs 72-105 KiB of dynamic LDS (opt-in above 64 KiB)
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_BF16, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<64>::bytes));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_BF16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<128>::bytes));
@@ -1146,6 +1154,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "debug.nops")) { c->debug_nops = value; return TGX_OK; }
   if (!strcmp(key, "debug.skip")) { c->debug_skip = value; return TGX_OK; }
   if (!strcmp(key, "debug.attn")) { c->debug_attn = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.gemm_tm")) { c->gemm_tm = value; return TGX_OK; }
   if (!strcmp(key, "debug.gemv")) { c->debug_gemv = value; return TGX_OK; }
   if (!strcmp(key, "prefill.mfma")) { c->prefill_mfma = value != 0; return TGX_OK; }
   if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
