@@ -25,15 +25,14 @@ constexpr int WAVE = 64;
 __device__ __forceinline__ float bf16_lo(unsigned int u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned int u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((unsigned int)b) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // v_cvt_pk_bf16_f32: round-to-nearest-even in hardware (gfx950)
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 __device__ __forceinline__ float rbf(float f) { return bf16_to_f32(f32_to_bf16(f)); }
-__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
-  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {   // one v_cvt_pk_bf16_f32
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
 // ---- storage dtype of parameters and of the KV cache (tgx_model_desc.compute_dtype; activations are fp32 in every

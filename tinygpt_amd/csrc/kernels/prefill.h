@@ -324,24 +324,50 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
   const int n_kt = last_q_pos / 64 + 1;
   const float qs = a.scale * LOG2E;
 
+  // K/V tiles travel global -> registers -> LDS; the next tile's global loads are issued before the current tile's MFMAs so
+  // that their latency hides under the compute (one round trip per tile was ~40 % of the kernel's time)
+  constexpr int NCH = 64 * CH / 256;           // 16-byte chunks per thread and tile (2 for hd 64, 4 for hd 128)
+  u32x4 kvr[NCH], vvr[NCH];
+  auto fetch_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      const int c = tid + 256 * i, row = c / CH, kc = c - row * CH;
+      const int key = kt * 64 + row;
+      kvr[i] = u32x4{0u, 0u, 0u, 0u}; vvr[i] = kvr[i];
+      if (key <= last_q_pos) {
+        kvr[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * HD + kc * 8);
+        vvr[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * HD + kc * 8);
+      }
+    }
+  };
+  fetch_tile(0);
   for (int kt = 0; kt < n_kt; kt++) {
     const int key0 = kt * 64;
     __syncthreads();                           // previous tile fully consumed (and Q / state initialised)
-    for (int c = tid; c < 64 * CH; c += 256) {
-      const int row = c / CH, kc = c - row * CH;
-      const int key = key0 + row;
-      u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = kv;
-      if (key <= last_q_pos) {
-        kv = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * HD + kc * 8);
-        vv = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * HD + kc * 8);
-      }
-      *reinterpret_cast<u32x4*>(&sK[row * LQ + kc * 8]) = kv;
 #pragma unroll
-      for (int t = 0; t < 4; t++) {            // transpose: Vt[d][key]
-        sVt[(kc * 8 + 2 * t) * LV + row] = (bf16_t)(vv[t] & 0xffffu);
-        sVt[(kc * 8 + 2 * t + 1) * LV + row] = (bf16_t)(vv[t] >> 16);
+    for (int i = 0; i < NCH; i++) {
+      const int c = tid + 256 * i, row = c / CH, kc = c - row * CH;
+      const u32x4 kv = kvr[i], vv = vvr[i];
+      *reinterpret_cast<u32x4*>(&sK[row * LQ + kc * 8]) = kv;
+      // transpose Vt[d][key]: the lane CH away holds the neighbouring key of the same 8 dims; the even-key lane writes dims
+      // 0..3, the odd-key lane dims 4..7, each as dwords {key even, key odd} — 4 dword stores instead of 8 half-word stores
+      {
+        u32x4 ov;
+#pragma unroll
+        for (int t = 0; t < 4; t++) ov[t] = (unsigned int)__shfl_xor((int)vv[t], CH, 64);
+        const bool odd = row & 1;
+        const int rk = row & ~1;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const unsigned int mine = odd ? vv[2 + t] : vv[t], other = odd ? ov[2 + t] : ov[t];
+          const unsigned int ev = odd ? other : mine, od = odd ? mine : other;      // values of the even / odd key
+          const int d0 = kc * 8 + (odd ? 4 : 0) + 2 * t;
+          *reinterpret_cast<unsigned int*>(&sVt[d0 * LV + rk]) = (ev & 0xffffu) | (od << 16);
+          *reinterpret_cast<unsigned int*>(&sVt[(d0 + 1) * LV + rk]) = (ev >> 16) | (od & 0xffff0000u);
+        }
       }
     }
+    if (kt + 1 < n_kt) fetch_tile(kt + 1);     // in flight during this tile's QK^T, softmax and PV
     __syncthreads();
     // S quadrant: queries wm*32.., keys wn*32..
     {
@@ -374,7 +400,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
       float sv[16];
       float mx = -INFINITY;
 #pragma unroll
-      for (int t = 0; t < 16; t++) { sv[t] = sS[row * LS + part * 16 + t]; mx = fmaxf(mx, sv[t]); }
+      for (int q4 = 0; q4 < 4; q4++) {          // four 16-byte LDS reads (rows are 272 B apart: 16-byte aligned)
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(&sS[row * LS + part * 16 + q4 * 4]);
+#pragma unroll
+        for (int t = 0; t < 4; t++) { sv[q4 * 4 + t] = t4[t]; mx = fmaxf(mx, t4[t]); }
+      }
       mx = fmaxf(mx, dpp_mov<0xB1, 0xf>(mx));
       mx = fmaxf(mx, dpp_mov<0x4E, 0xf>(mx));
       const float m_old = sM[row];
@@ -382,14 +412,21 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
       const bool dead = m_new == -INFINITY;              // padded query row: nothing attended yet
       const float alpha = dead ? 1.f : exp2f(m_old - m_new);
       float sum = 0.f;
+      unsigned int wh[8], wl[8];                 // 16 probabilities as hi / lo 16-bit pairs: two 16-byte LDS stores per array
 #pragma unroll
       for (int t = 0; t < 16; t++) {
         const float p = dead ? 0.f : exp2f(sv[t] - m_new);
         sum += p;
         bf16_t ph, pl;
         split16<DT>(p, ph, pl);
-        sPh[row * LV + part * 16 + t] = ph;
-        sPl[row * LV + part * 16 + t] = pl;
+        if (t & 1) { wh[t >> 1] |= (unsigned int)ph << 16; wl[t >> 1] |= (unsigned int)pl << 16; }
+        else { wh[t >> 1] = ph; wl[t >> 1] = pl; }
+      }
+      {
+        u32x4* dh = reinterpret_cast<u32x4*>(&sPh[row * LV + part * 16]);
+        u32x4* dl = reinterpret_cast<u32x4*>(&sPl[row * LV + part * 16]);
+        dh[0] = u32x4{wh[0], wh[1], wh[2], wh[3]}; dh[1] = u32x4{wh[4], wh[5], wh[6], wh[7]};
+        dl[0] = u32x4{wl[0], wl[1], wl[2], wl[3]}; dl[1] = u32x4{wl[4], wl[5], wl[6], wl[7]};
       }
       sum += dpp_mov<0xB1, 0xf>(sum);
       sum += dpp_mov<0x4E, 0xf>(sum);
@@ -426,6 +463,189 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
       const size_t o = (size_t)(q0 + qrow) * qd + (size_t)h * HD + d;
       split16<DT>(v, a.o_hi[o], a.o_lo[o]);
     }
+  }
+}
+
+// ---- causal GQA flash attention, second version: scores and probabilities never leave the registers ------------------------
+// One workgroup = 128 queries of one query head (4 waves x 32 queries); K / V tiles of 64 keys go global -> registers -> LDS
+// (V transposed), shared by the four waves.  Each wave computes S^T = K.Q^T — the MFMA's output layout then gives every lane
+// ONE query column (16 keys per 32-key sub-tile; the other half-wave holds the other 16), so the online softmax is lane-local
+// plus one exchange with lane^32, the running maximum / sum / rescale are per-lane scalars, and the probabilities are already
+// in the B-operand order of the next MFMA: O^T += V^T.P^T, where the V^T fragment is read in the SAME key permutation
+// (keys 4hh..4hh+3 and 8+4hh..8+4hh+3 of every 16: two 8-byte LDS reads).  Q (hi, lo) lives in registers for the whole kernel.
+template <int DT, int HD>
+__global__ __launch_bounds__(256) void attn_prefill2_kernel(const AttnPrefillArgs a) {
+  constexpr int LQ = HD + 8;                  // 16-bit row stride of the K tile (144 / 272 B: conflict-free 16-byte fragment reads)
+  constexpr int LV = 64 + 4;                  // 16-bit row stride of the V^T tile (136 B: 34 dwords, odd/2 -> the 32 rows of a fragment read hit 64 distinct banks)
+  constexpr int KS = HD / 16;                 // MFMA k-steps over the head dimension
+  constexpr int NB = HD / 32;                 // 32-row output-dim blocks
+  constexpr int CH = HD / 8;                  // 16-byte chunks per head row
+  constexpr int NCH = 64 * CH / 256;          // chunks per thread and tile
+  constexpr float LOG2E = 1.4426950408889634f;
+  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * LQ];
+  __shared__ __attribute__((aligned(16))) bf16_t sVt[HD * LV];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5, ql = lane & 31;
+  const int h = blockIdx.y, G = a.heads / a.kv_heads, kvh = h / G;
+  const int qd = a.heads * HD;
+  const int q0 = blockIdx.x * 128 + wv * 32;          // first query of this wave
+  const int qi = q0 + ql;                              // this lane's query
+  const bool qvalid = qi < a.S;
+  const int qpos = a.past + qi;
+
+  bf16x8 qh[KS], qlo[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) {
+    u32x4 vh = u32x4{0u, 0u, 0u, 0u}, vl = vh;
+    if (qvalid) {
+      const size_t o = (size_t)qi * qd + (size_t)h * HD + kk * 16 + 8 * hh;
+      vh = *reinterpret_cast<const u32x4*>(a.q_hi + o);
+      vl = *reinterpret_cast<const u32x4*>(a.q_lo + o);
+    }
+    qh[kk] = __builtin_bit_cast(bf16x8, vh);
+    qlo[kk] = __builtin_bit_cast(bf16x8, vl);
+  }
+  f32x16 oacc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) oacc[b][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const bf16_t* kbase = a.k_cache + (size_t)kvh * a.max_ctx * HD;
+  const bf16_t* vbase = a.v_cache + (size_t)kvh * a.max_ctx * HD;
+  const int wg_last_pos = a.past + min((int)blockIdx.x * 128 + 127, a.S - 1);   // keys beyond it are never attended by this workgroup
+  const int n_kt = wg_last_pos / 64 + 1;
+  const int wave_last_pos = a.past + min(q0 + 31, a.S - 1);
+  const bool wave_live = q0 < a.S;
+  const float qs = a.scale * LOG2E;
+
+  u32x4 kvr[NCH], vvr[NCH];
+  auto fetch_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      const int c = tid + 256 * i, row = c / CH, kc = c - row * CH;
+      const int key = kt * 64 + row;
+      kvr[i] = u32x4{0u, 0u, 0u, 0u}; vvr[i] = kvr[i];
+      if (key <= wg_last_pos) {
+        kvr[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * HD + kc * 8);
+        vvr[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * HD + kc * 8);
+      }
+    }
+  };
+  fetch_tile(0);
+  for (int kt = 0; kt < n_kt; kt++) {
+    const int key0 = kt * 64;
+    __syncthreads();                           // the previous tile is consumed by every wave
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      const int c = tid + 256 * i, row = c / CH, kc = c - row * CH;
+      const u32x4 kv = kvr[i], vv = vvr[i];
+      *reinterpret_cast<u32x4*>(&sK[row * LQ + kc * 8]) = kv;
+      u32x4 ov;                                // the lane CH away holds the neighbouring key: write {even key, odd key} dwords
+#pragma unroll
+      for (int t = 0; t < 4; t++) ov[t] = (unsigned int)__shfl_xor((int)vv[t], CH, 64);
+      const bool odd = row & 1;
+      const int rk = row & ~1;
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const unsigned int mine = odd ? vv[2 + t] : vv[t], other = odd ? ov[2 + t] : ov[t];
+        const unsigned int ev = odd ? other : mine, od = odd ? mine : other;
+        const int d0 = kc * 8 + (odd ? 4 : 0) + 2 * t;
+        *reinterpret_cast<unsigned int*>(&sVt[d0 * LV + rk]) = (ev & 0xffffu) | (od << 16);
+        *reinterpret_cast<unsigned int*>(&sVt[(d0 + 1) * LV + rk]) = (ev >> 16) | (od & 0xffff0000u);
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < n_kt) fetch_tile(kt + 1);     // in flight during this tile's MFMAs
+    if (!wave_live || key0 > wave_last_pos) continue;    // wave-uniform: nothing of this tile is visible to the wave's queries
+
+    // S^T sub-tiles: sacc[sub][r] = score of key key0 + 32 sub + (r&3) + 8 (r>>2) + 4 hh for this lane's query
+    f32x16 sacc[2];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) sacc[sub][r] = 0.f;
+      const int kb = key0 + 32 * sub;
+      if (kb <= wave_last_pos) {
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) {
+          const bf16x8 fk = *reinterpret_cast<const bf16x8*>(&sK[(32 * sub + ql) * LQ + kk * 16 + 8 * hh]);
+          sacc[sub] = mfma16<DT>(fk, qlo[kk], sacc[sub]);
+          sacc[sub] = mfma16<DT>(fk, qh[kk], sacc[sub]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const bool ok = qvalid && key <= qpos;           // isCausal (Attention.h:108) with the cache offset
+        sacc[sub][r] = ok ? sacc[sub][r] * qs : -INFINITY;
+        mx = fmaxf(mx, sacc[sub][r]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const bool dead = m_new == -INFINITY;               // padded query: nothing attended yet
+    const float alpha = dead ? 1.f : exp2f(m_run - m_new);
+    float sum = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float p = dead ? 0.f : exp2f(sacc[sub][r] - m_new);
+        sacc[sub][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    l_run = l_run * alpha + sum;
+    m_run = m_new;
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) oacc[b][r] *= alpha;
+
+    // O^T += V^T . P^T over the four 16-key steps of the tile; B-operand element j of step s is register 8 s' + j of its sub-tile
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      if (key0 + 32 * sub > wave_last_pos) continue;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        unsigned int wh[4], wl[4];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          bf16_t ph, pl;
+          split16<DT>(sacc[sub][8 * s2 + j], ph, pl);
+          if (j & 1) { wh[j >> 1] |= (unsigned int)ph << 16; wl[j >> 1] |= (unsigned int)pl << 16; }
+          else { wh[j >> 1] = ph; wl[j >> 1] = pl; }
+        }
+        const bf16x8 fph = __builtin_bit_cast(bf16x8, u32x4{wh[0], wh[1], wh[2], wh[3]});
+        const bf16x8 fpl = __builtin_bit_cast(bf16x8, u32x4{wl[0], wl[1], wl[2], wl[3]});
+        const int kloc = 32 * sub + 16 * s2 + 4 * hh;     // tile-local key of element 0; elements 4..7 are 8 keys further
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          const bf16_t* vrow = &sVt[(32 * b + ql) * LV + kloc];
+          const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
+          const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 8);
+          const bf16x8 fv = __builtin_bit_cast(bf16x8, u32x4{v0[0], v0[1], v1[0], v1[1]});
+          oacc[b] = mfma16<DT>(fv, fpl, oacc[b]);
+          oacc[b] = mfma16<DT>(fv, fph, oacc[b]);
+        }
+      }
+    }
+  }
+
+  // normalise and emit as hi / lo 16-bit pairs (the o_proj GEMM's A operand): lane = query, registers = output dims
+  if (qvalid) {
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int d = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float v = oacc[b][r] / l_run;
+        const size_t o = (size_t)qi * qd + (size_t)h * HD + d;
+        split16<DT>(v, a.o_hi[o], a.o_lo[o]);
+      }
   }
 }
 
