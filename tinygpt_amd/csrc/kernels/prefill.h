@@ -255,9 +255,6 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
 }
 
 // ---- causal GQA flash attention over the cache, queries past..past+S-1 -------------------------------------------------
-// One workgroup = 64 queries of one query head; key tiles of 64.  S = Q·Kᵀ and O += P·V run on MFMA 32x32x16 with Q and P
-// split hi/lo; softmax is an online fp32 pass through LDS (4 lanes per row).  V is staged transposed so the PV B-fragment
-// (8 consecutive keys of one output dim) is a single 16-byte LDS read.
 struct AttnPrefillArgs {
   const bf16_t *q_hi, *q_lo;     // [S][heads*hd]
   const bf16_t *k_cache, *v_cache;   // [kv_heads][max_ctx][hd]
@@ -266,207 +263,8 @@ struct AttnPrefillArgs {
   float scale;                   // hd^-1/2
 };
 
-template <int HD>
-struct AttnPrefillSmem {
-  static constexpr int LQ = HD + 8;     // bf16 row stride of Q / K tiles
-  static constexpr int LV = 64 + 8;     // bf16 row stride of Vt / P tiles (64 keys)
-  static constexpr int LS = 64 + 4;     // fp32 row stride of the score tile
-  static constexpr size_t bytes = (size_t)(2 * 64 * LQ + 64 * LQ + HD * LV + 2 * 64 * LV) * 2 + (size_t)64 * LS * 4 + 3 * 64 * 4;
-};
-
-template <int DT, int HD>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs a) {
-  using SM = AttnPrefillSmem<HD>;
-  constexpr int LQ = SM::LQ, LV = SM::LV, LS = SM::LS;
-  constexpr int NJ = HD / 64;                 // 32-wide output-dim tiles per wave
-  constexpr float LOG2E = 1.4426950408889634f;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* sQh = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* sQl = sQh + 64 * LQ;
-  bf16_t* sK = sQl + 64 * LQ;
-  bf16_t* sVt = sK + 64 * LQ;
-  bf16_t* sPh = sVt + HD * LV;
-  bf16_t* sPl = sPh + 64 * LV;
-  float* sS = reinterpret_cast<float*>(sPl + 64 * LV);
-  float* sM = sS + 64 * LS;
-  float* sL = sM + 64;
-  float* sAlpha = sL + 64;
-
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-  const int h = blockIdx.y, G = a.heads / a.kv_heads, kvh = h / G;
-  const int q0 = blockIdx.x * 64;              // first query (index into this pass) of the tile
-  const int qd = a.heads * HD;
-  constexpr int CH = HD / 8;                   // 16-byte chunks per head row
-
-  // Q tile (hi, lo) -> LDS; rows beyond S are zero
-  for (int c = tid; c < 64 * CH; c += 256) {
-    const int row = c / CH, kc = c - row * CH;
-    u32x4 vh = u32x4{0u, 0u, 0u, 0u}, vl = vh;
-    if (q0 + row < a.S) {
-      const size_t o = (size_t)(q0 + row) * qd + (size_t)h * HD + kc * 8;
-      vh = *reinterpret_cast<const u32x4*>(a.q_hi + o);
-      vl = *reinterpret_cast<const u32x4*>(a.q_lo + o);
-    }
-    *reinterpret_cast<u32x4*>(&sQh[row * LQ + kc * 8]) = vh;
-    *reinterpret_cast<u32x4*>(&sQl[row * LQ + kc * 8]) = vl;
-  }
-  if (tid < 64) { sM[tid] = -INFINITY; sL[tid] = 0.f; }
-
-  f32x16 oacc[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; j++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) oacc[j][r] = 0.f;
-
-  const bf16_t* kbase = a.k_cache + (size_t)kvh * a.max_ctx * HD;
-  const bf16_t* vbase = a.v_cache + (size_t)kvh * a.max_ctx * HD;
-  const int last_q_pos = a.past + min(q0 + 63, a.S - 1);       // keys beyond this are never attended by the tile
-  const int n_kt = last_q_pos / 64 + 1;
-  const float qs = a.scale * LOG2E;
-
-  // K/V tiles travel global -> registers -> LDS; the next tile's global loads are issued before the current tile's MFMAs so
-  // that their latency hides under the compute (one round trip per tile was ~40 % of the kernel's time)
-  constexpr int NCH = 64 * CH / 256;           // 16-byte chunks per thread and tile (2 for hd 64, 4 for hd 128)
-  u32x4 kvr[NCH], vvr[NCH];
-  auto fetch_tile = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < NCH; i++) {
-      const int c = tid + 256 * i, row = c / CH, kc = c - row * CH;
-      const int key = kt * 64 + row;
-      kvr[i] = u32x4{0u, 0u, 0u, 0u}; vvr[i] = kvr[i];
-      if (key <= last_q_pos) {
-        kvr[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * HD + kc * 8);
-        vvr[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * HD + kc * 8);
-      }
-    }
-  };
-  fetch_tile(0);
-  for (int kt = 0; kt < n_kt; kt++) {
-    const int key0 = kt * 64;
-    __syncthreads();                           // previous tile fully consumed (and Q / state initialised)
-#pragma unroll
-    for (int i = 0; i < NCH; i++) {
-      const int c = tid + 256 * i, row = c / CH, kc = c - row * CH;
-      const u32x4 kv = kvr[i], vv = vvr[i];
-      *reinterpret_cast<u32x4*>(&sK[row * LQ + kc * 8]) = kv;
-      // transpose Vt[d][key]: the lane CH away holds the neighbouring key of the same 8 dims; the even-key lane writes dims
-      // 0..3, the odd-key lane dims 4..7, each as dwords {key even, key odd} — 4 dword stores instead of 8 half-word stores
-      {
-        u32x4 ov;
-#pragma unroll
-        for (int t = 0; t < 4; t++) ov[t] = (unsigned int)__shfl_xor((int)vv[t], CH, 64);
-        const bool odd = row & 1;
-        const int rk = row & ~1;
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          const unsigned int mine = odd ? vv[2 + t] : vv[t], other = odd ? ov[2 + t] : ov[t];
-          const unsigned int ev = odd ? other : mine, od = odd ? mine : other;      // values of the even / odd key
-          const int d0 = kc * 8 + (odd ? 4 : 0) + 2 * t;
-          *reinterpret_cast<unsigned int*>(&sVt[d0 * LV + rk]) = (ev & 0xffffu) | (od << 16);
-          *reinterpret_cast<unsigned int*>(&sVt[(d0 + 1) * LV + rk]) = (ev >> 16) | (od & 0xffff0000u);
-        }
-      }
-    }
-    if (kt + 1 < n_kt) fetch_tile(kt + 1);     // in flight during this tile's QK^T, softmax and PV
-    __syncthreads();
-    // S quadrant: queries wm*32.., keys wn*32..
-    {
-      f32x16 sacc;
-#pragma unroll
-      for (int r = 0; r < 16; r++) sacc[r] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < HD / 16; kk++) {
-        const int kcol = kk * 16 + 8 * (lane >> 5);
-        const bf16x8 fqh = *reinterpret_cast<const bf16x8*>(&sQh[(wm * 32 + (lane & 31)) * LQ + kcol]);
-        const bf16x8 fql = *reinterpret_cast<const bf16x8*>(&sQl[(wm * 32 + (lane & 31)) * LQ + kcol]);
-        const bf16x8 fk = *reinterpret_cast<const bf16x8*>(&sK[(wn * 32 + (lane & 31)) * LQ + kcol]);
-        sacc = mfma16<DT>(fql, fk, sacc);
-        sacc = mfma16<DT>(fqh, fk, sacc);
-      }
-      const int kcolg = wn * 32 + (lane & 31);           // key column of this lane inside the tile
-      const int key = key0 + kcolg;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int qrow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int qpos = a.past + q0 + qrow;
-        const bool ok = key <= qpos && q0 + qrow < a.S;  // isCausal (Attention.h:108) with the cache offset
-        sS[qrow * LS + kcolg] = ok ? sacc[r] * qs : -INFINITY;
-      }
-    }
-    __syncthreads();
-    // online softmax (base 2): 4 lanes per query row, 16 keys each
-    {
-      const int row = tid >> 2, part = tid & 3;
-      float sv[16];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int q4 = 0; q4 < 4; q4++) {          // four 16-byte LDS reads (rows are 272 B apart: 16-byte aligned)
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(&sS[row * LS + part * 16 + q4 * 4]);
-#pragma unroll
-        for (int t = 0; t < 4; t++) { sv[q4 * 4 + t] = t4[t]; mx = fmaxf(mx, t4[t]); }
-      }
-      mx = fmaxf(mx, dpp_mov<0xB1, 0xf>(mx));
-      mx = fmaxf(mx, dpp_mov<0x4E, 0xf>(mx));
-      const float m_old = sM[row];
-      const float m_new = fmaxf(m_old, mx);
-      const bool dead = m_new == -INFINITY;              // padded query row: nothing attended yet
-      const float alpha = dead ? 1.f : exp2f(m_old - m_new);
-      float sum = 0.f;
-      unsigned int wh[8], wl[8];                 // 16 probabilities as hi / lo 16-bit pairs: two 16-byte LDS stores per array
-#pragma unroll
-      for (int t = 0; t < 16; t++) {
-        const float p = dead ? 0.f : exp2f(sv[t] - m_new);
-        sum += p;
-        bf16_t ph, pl;
-        split16<DT>(p, ph, pl);
-        if (t & 1) { wh[t >> 1] |= (unsigned int)ph << 16; wl[t >> 1] |= (unsigned int)pl << 16; }
-        else { wh[t >> 1] = ph; wl[t >> 1] = pl; }
-      }
-      {
-        u32x4* dh = reinterpret_cast<u32x4*>(&sPh[row * LV + part * 16]);
-        u32x4* dl = reinterpret_cast<u32x4*>(&sPl[row * LV + part * 16]);
-        dh[0] = u32x4{wh[0], wh[1], wh[2], wh[3]}; dh[1] = u32x4{wh[4], wh[5], wh[6], wh[7]};
-        dl[0] = u32x4{wl[0], wl[1], wl[2], wl[3]}; dl[1] = u32x4{wl[4], wl[5], wl[6], wl[7]};
-      }
-      sum += dpp_mov<0xB1, 0xf>(sum);
-      sum += dpp_mov<0x4E, 0xf>(sum);
-      __syncthreads();                                   // every lane has read sM[row] before it is replaced
-      if (part == 0) { sM[row] = m_new; sL[row] = sL[row] * alpha + sum; sAlpha[row] = alpha; }
-    }
-    __syncthreads();
-    // O quadrant: queries wm*32.., dims wn*(HD/2)..
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) oacc[j][r] *= sAlpha[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const int kcol = kk * 16 + 8 * (lane >> 5);
-        const bf16x8 fph = *reinterpret_cast<const bf16x8*>(&sPh[(wm * 32 + (lane & 31)) * LV + kcol]);
-        const bf16x8 fpl = *reinterpret_cast<const bf16x8*>(&sPl[(wm * 32 + (lane & 31)) * LV + kcol]);
-        const bf16x8 fv = *reinterpret_cast<const bf16x8*>(&sVt[(wn * (HD / 2) + j * 32 + (lane & 31)) * LV + kcol]);
-        oacc[j] = mfma16<DT>(fpl, fv, oacc[j]);
-        oacc[j] = mfma16<DT>(fph, fv, oacc[j]);
-      }
-    }
-  }
-  __syncthreads();
-  // normalise and emit as bf16 hi/lo (the o_proj GEMM's A operand)
-#pragma unroll
-  for (int j = 0; j < NJ; j++) {
-    const int d = wn * (HD / 2) + j * 32 + (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int qrow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (q0 + qrow >= a.S) continue;
-      const float v = oacc[j][r] / sL[qrow];
-      const size_t o = (size_t)(q0 + qrow) * qd + (size_t)h * HD + d;
-      split16<DT>(v, a.o_hi[o], a.o_lo[o]);
-    }
-  }
-}
-
-// ---- causal GQA flash attention, second version: scores and probabilities never leave the registers ------------------------
+// Scores and probabilities never leave the registers (the first version of this round routed them through LDS with four
+// barriers per tile: 262 us per layer at S = 2048 against 165 us for this one).
 // One workgroup = 128 queries of one query head (4 waves x 32 queries); K / V tiles of 64 keys go global -> registers -> LDS
 // (V transposed), shared by the four waves.  Each wave computes S^T = K.Q^T — the MFMA's output layout then gives every lane
 // ONE query column (16 keys per 32-key sub-tile; the other half-wave holds the other 16), so the online softmax is lane-local
@@ -474,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
 // in the B-operand order of the next MFMA: O^T += V^T.P^T, where the V^T fragment is read in the SAME key permutation
 // (keys 4hh..4hh+3 and 8+4hh..8+4hh+3 of every 16: two 8-byte LDS reads).  Q (hi, lo) lives in registers for the whole kernel.
 template <int DT, int HD>
-__global__ __launch_bounds__(256) void attn_prefill2_kernel(const AttnPrefillArgs a) {
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs a) {
   constexpr int LQ = HD + 8;                  // 16-bit row stride of the K tile (144 / 272 B: conflict-free 16-byte fragment reads)
   constexpr int LV = 64 + 4;                  // 16-bit row stride of the V^T tile (136 B: 34 dwords, odd/2 -> the 32 rows of a fragment read hit 64 distinct banks)
   constexpr int KS = HD / 16;                 // MFMA k-steps over the head dimension
@@ -560,9 +358,10 @@ __global__ __launch_bounds__(256) void attn_prefill2_kernel(const AttnPrefillArg
     if (kt + 1 < n_kt) fetch_tile(kt + 1);     // in flight during this tile's MFMAs
     if (!wave_live || key0 > wave_last_pos) continue;    // wave-uniform: nothing of this tile is visible to the wave's queries
 
-    // S^T sub-tiles: sacc[sub][r] = score of key key0 + 32 sub + (r&3) + 8 (r>>2) + 4 hh for this lane's query
+    // S^T sub-tiles: sacc[sub][r] = raw score (q.k) of key key0 + 32 sub + (r&3) + 8 (r>>2) + 4 hh for this lane's query
     f32x16 sacc[2];
     float mx = -INFINITY;
+    const bool diag = key0 + 63 > a.past + q0;           // wave-uniform: some (key, query) pair of this tile needs the causal mask
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
 #pragma unroll
@@ -576,24 +375,27 @@ __global__ __launch_bounds__(256) void attn_prefill2_kernel(const AttnPrefillArg
           sacc[sub] = mfma16<DT>(fk, qh[kk], sacc[sub]);
         }
       }
+      if (diag || !qvalid || kb > wave_last_pos) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const bool ok = qvalid && key <= qpos;           // isCausal (Attention.h:108) with the cache offset
-        sacc[sub][r] = ok ? sacc[sub][r] * qs : -INFINITY;
-        mx = fmaxf(mx, sacc[sub][r]);
+        for (int r = 0; r < 16; r++) {
+          const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (!(qvalid && key <= qpos)) sacc[sub][r] = -INFINITY;     // isCausal (Attention.h:108) with the cache offset
+        }
       }
+#pragma unroll
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[sub][r]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * qs;          // qs > 0: scaling commutes with the maximum
     const float m_new = fmaxf(m_run, mx);
     const bool dead = m_new == -INFINITY;               // padded query: nothing attended yet
-    const float alpha = dead ? 1.f : exp2f(m_run - m_new);
+    const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
+    const float neg_m = dead ? 0.f : -m_new;
     float sum = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; sub++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const float p = dead ? 0.f : exp2f(sacc[sub][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[sub][r], qs, neg_m));   // exp2(-inf) = 0 for masked entries
         sacc[sub][r] = p;
         sum += p;
       }

@@ -119,7 +119,6 @@ struct tgx_ctx {
   bf16_t* ws_al2 = nullptr;                           // [S][H] third term for the QKV projection
   bf16_t *ws_qh = nullptr, *ws_ql = nullptr;          // [S][qd] rotated queries (hi, lo)
   bool prefill_mfma = true;
-  int prefill_attn = 2;      // 2: register-resident scores (attn_prefill2_kernel); 1: the first version
   int gemm_tm = 0;           // experiment: force the GEMM row tile (64 / 128); 0 = by the number of tiles
   int debug_attn = 0;        // experiment: AttnArgs.dbg
   int debug_gemv = 0;        // experiment: GemvArgs.dbg = value & 15 for the kernel classes selected by bits 8.. (1 << (8 + class))
@@ -517,15 +516,9 @@ void launch_prefill(tgx_ctx* c, RowState& r, int S) {
       a.q_hi = c->ws_qh; a.q_lo = c->ws_ql; a.k_cache = kc + (size_t)l * kv_layer; a.v_cache = vc + (size_t)l * kv_layer;
       a.o_hi = c->ws_ah; a.o_lo = c->ws_al; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
       a.scale = 1.0f / sqrtf((float)hd);
-      if (c->prefill_attn == 1) {          // first version (scores through LDS): kept for A/B runs (option prefill.attn = 1)
-        const dim3 grid((S + 63) / 64, d.heads), blk(256);
-        TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64>), grid, blk, tgx::AttnPrefillSmem<64>::bytes, c->stream, a);
-                               else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128>), grid, blk, tgx::AttnPrefillSmem<128>::bytes, c->stream, a))
-      } else {
-        const dim3 grid((S + 127) / 128, d.heads), blk(256);
-        TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill2_kernel<DT, 64>), grid, blk, 0, c->stream, a);
-                               else hipLaunchKernelGGL((tgx::attn_prefill2_kernel<DT, 128>), grid, blk, 0, c->stream, a))
-      }
+      const dim3 grid((S + 127) / 128, d.heads), blk(256);
+      TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64>), grid, blk, 0, c->stream, a);
+                             else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128>), grid, blk, 0, c->stream, a))
     }
     launch_gemm(c, tgx::GEMM_RESIDUAL, w.wo, nullptr, c->ws_x, S, H, qd, H);
     TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al, (bf16_t*)nullptr))
@@ -895,10 +888,6 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_STORE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_RESIDUAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   // the prefill attention tile needs 72-105 KiB of dynamic LDS (opt-in above 64 KiB)
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_BF16, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<64>::bytes));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_BF16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<128>::bytes));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_F16, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<64>::bytes));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_F16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::AttnPrefillSmem<128>::bytes));
   c->past = 0;
   c->finalized = true;
   return TGX_OK;
@@ -1162,7 +1151,6 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "debug.skip")) { c->debug_skip = value; return TGX_OK; }
   if (!strcmp(key, "debug.attn")) { c->debug_attn = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_tm")) { c->gemm_tm = value; return TGX_OK; }
-  if (!strcmp(key, "prefill.attn")) { c->prefill_attn = value; return TGX_OK; }
   if (!strcmp(key, "debug.gemv")) { c->debug_gemv = value; return TGX_OK; }
   if (!strcmp(key, "prefill.mfma")) { c->prefill_mfma = value != 0; return TGX_OK; }
   if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
