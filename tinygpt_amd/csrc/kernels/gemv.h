@@ -422,22 +422,19 @@ __global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs
   gather_embedding<DT>(a.embed, s_tok, a.x, a.H);
 }
 
-// Prefill-by-steps helper: x <- embed[prompt[pos - pos0]] (nn::Embedding on one prompt position).
-struct EmbedArgs {
-  const long long* ids;  // [S] this row's prompt on the device
-  const int* pos;
-  int pos0;
+// Prefill-by-steps: chunk row r <- embedding of prompt token r, position pos0 + r (one workgroup per chunk row).
+struct EmbedChunkArgs {
+  const long long* ids;  // the chunk's first prompt token on the device
   const void* embed;
-  float* x;
-  int H, V;
-  int* tok;
+  float* x;              // [R][H] chunk residual streams
+  int* pos;              // [R] chunk positions
+  int H, pos0;
 };
 template <int DT>
-__global__ __launch_bounds__(256) void embed_prompt_kernel(const EmbedArgs a) {
-  const int i = *a.pos - a.pos0;
-  long long t = a.ids[i];
-  if (threadIdx.x == 0) *a.tok = (int)t;
-  gather_embedding<DT>(a.embed, t, a.x, a.H);
+__global__ __launch_bounds__(256) void embed_chunk_kernel(const EmbedChunkArgs a) {
+  const int r = blockIdx.x;
+  if (threadIdx.x == 0) a.pos[r] = a.pos0 + r;
+  gather_embedding<DT>(a.embed, a.ids[r], a.x + (size_t)r * a.H, a.H);
 }
 
 __global__ void advance_pos_kernel(int* pos) { if (threadIdx.x == 0) *pos = *pos + 1; }

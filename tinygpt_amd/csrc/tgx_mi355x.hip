@@ -88,6 +88,11 @@ struct tgx_ctx {
   long long* slab_prompt = nullptr;
   ebyte *slab_k = nullptr, *slab_v = nullptr;
   size_t kv_row_elems = 0, attn_part_row = 0;
+  // prefill-by-steps processes up to 4 consecutive POSITIONS of one sequence per pass (rows of the batched kernels that share one
+  // KV cache: kv_stride 0, pos[r] = past + r): fp32 storage, prompts shorter than 4 tokens, shapes the GEMM tile does not cover
+  RowState chunk[4];
+  float *ch_x = nullptr, *ch_q = nullptr, *ch_kraw = nullptr, *ch_attn = nullptr, *ch_h = nullptr, *ch_part = nullptr;
+  int* ch_pos = nullptr;
 
   int64_t past = 0;       // host mirror of every row's device-resident pos
   int batch = 0;          // rows used by the last forward
@@ -361,11 +366,11 @@ void fill_strides(const tgx_ctx* c, tgx::GemvArgs& a) {
   a.kv_stride = (long long)c->kv_row_elems; a.logits_stride = d.vocab; a.part_stride = c->lm_grid;
 }
 
-// One kernel class of one decoder layer for batch rows [row0, row0+R).  `resid` is the residual stream of row0 that the
+// One kernel class of one decoder layer for R rows (batch rows of the slabs, or the chunk rows of a prefill-by-steps pass).  `resid` is the residual stream of row0 that the
 // o_proj/down epilogues update (slab_x in the real pass; a scratch vector when tgx_profile_decode replays a class).
-void launch_layer_kernel(tgx_ctx* c, int row0, int R, int l, int cls, float* resid) {
+void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float* resid, long long kv_stride) {
   const tgx_model_desc& d = c->d;
-  RowState& r = c->rows[(size_t)row0];
+  RowState& r = rv[0];   // R consecutive row views with the slabs' row strides; kv_stride = 0 when the rows are positions of ONE sequence
   const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
   const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd * c->esz;   // bytes (ebyte pointers)
   const LayerW& w = c->L[(size_t)l];
@@ -375,13 +380,13 @@ void launch_layer_kernel(tgx_ctx* c, int row0, int R, int l, int cls, float* res
       fill_strides(c, a);
       a.W = w.wqkv; a.bias = w.bqkv; a.x = r.x; a.x_stride = H; a.norm_w = w.in_norm; a.eps = d.norm_eps;
       a.N = qd + 2 * kvd; a.K = H; a.units = a.N / 2;
-      a.q_out = r.q; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
+      a.q_out = r.q; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer; a.kv_stride = kv_stride;
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos = r.pos;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx;
       a.raw_qk = d.qk_norm ? 1 : 0; a.k_raw = r.k_raw;
       launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_QKV_ROPE>(c, a, TGX_KERNEL_QKV, R);
       if (d.qk_norm) for (int b = 0; b < R; b++) {   // q_norm / k_norm -> RoPE -> cache append (Attention.h:156-163)
-        RowState& rb = c->rows[(size_t)(row0 + b)];
+        RowState& rb = rv[b];
         tgx::QkNormArgs n{};
         n.q = rb.q; n.k_raw = rb.k_raw; n.k_cache = rb.kcache + (size_t)l * kv_layer; n.q_norm_w = w.q_norm; n.k_norm_w = w.k_norm;
         n.rope_cos = c->rope_cos; n.rope_sin = c->rope_sin; n.pos = rb.pos;
@@ -396,7 +401,7 @@ void launch_layer_kernel(tgx_ctx* c, int row0, int R, int l, int cls, float* res
       a.pos = r.pos; a.part = r.attn_part; a.out = r.attn;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
       a.scale = 1.0f / sqrtf((float)hd);
-      a.q_stride = qd; a.kv_stride = (long long)c->kv_row_elems; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
+      a.q_stride = qd; a.kv_stride = kv_stride; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
       launch_attn(c, a, R);
       break;
     }
@@ -428,12 +433,13 @@ void launch_layer_kernel(tgx_ctx* c, int row0, int R, int l, int cls, float* res
 
 // All decoder layers for rows [row0, row0+R): their current tokens' embeddings sit in slab_x, positions in slab_pos.
 // == for (auto& layer : layers_) x = layer->forward(x)  (GPTModel.h:53-55)
-void launch_layers(tgx_ctx* c, int row0, int R) {
+void launch_layers(tgx_ctx* c, RowState* rv, int R, long long kv_stride) {
   for (int l = 0; l < c->d.layers; l++) {
-    for (int cls = TGX_KERNEL_QKV; cls <= TGX_KERNEL_DOWN; cls++) launch_layer_kernel(c, row0, R, l, cls, c->rows[(size_t)row0].x);
+    for (int cls = TGX_KERNEL_QKV; cls <= TGX_KERNEL_DOWN; cls++) launch_layer_kernel(c, rv, R, l, cls, rv[0].x, kv_stride);
     for (int i = 0; i < c->debug_nops; i++) hipLaunchKernelGGL(tgx::nop_kernel, dim3(1), dim3(64), 0, c->stream, c->nop_word);
   }
 }
+void launch_layers(tgx_ctx* c, int row0, int R) { launch_layers(c, &c->rows[(size_t)row0], R, (long long)c->kv_row_elems); }
 
 // ---- batched prefill (kernels/prefill.h) -------------------------------------------------------------------------
 bool prefill_shapes_ok(const tgx_model_desc& d) {
@@ -868,6 +874,18 @@ int tgx_finalize(tgx_ctx* c) {
     r.tok = c->slab_tok + b; r.pos = c->slab_pos + b; r.prompt = c->slab_prompt + b * d.max_ctx;
     r.kcache = c->slab_k + b * kv_elems * c->esz; r.vcache = c->slab_v + b * kv_elems * c->esz;
   }
+  if ((rc = dev_alloc(c, &c->ch_x, 4 * (size_t)H))) return rc;
+  if ((rc = dev_alloc(c, &c->ch_q, 4 * (size_t)qd))) return rc;
+  if ((rc = dev_alloc(c, &c->ch_kraw, 4 * (size_t)kvd))) return rc;
+  if ((rc = dev_alloc(c, &c->ch_attn, 4 * (size_t)qd))) return rc;
+  if ((rc = dev_alloc(c, &c->ch_h, 4 * (size_t)I))) return rc;
+  if ((rc = dev_alloc(c, &c->ch_part, 4 * c->attn_part_row))) return rc;
+  if ((rc = dev_alloc(c, &c->ch_pos, 4))) return rc;
+  for (size_t k = 0; k < 4; k++) {
+    RowState& r = c->chunk[k];
+    r.x = c->ch_x + k * H; r.q = c->ch_q + k * qd; r.k_raw = c->ch_kraw + k * kvd; r.attn = c->ch_attn + k * qd; r.h = c->ch_h + k * I;
+    r.attn_part = c->ch_part + k * c->attn_part_row; r.pos = c->ch_pos + k;
+  }
   c->log_cap = d.max_ctx > 1024 ? d.max_ctx : 1024;
   if ((rc = dev_alloc(c, &c->step, 1))) return rc;
   if ((rc = dev_alloc(c, &c->seed_dev, 1))) return rc;
@@ -900,6 +918,7 @@ void tgx_destroy(tgx_ctx* c) {
   if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
+  fr(c->ch_x); fr(c->ch_q); fr(c->ch_kraw); fr(c->ch_attn); fr(c->ch_h); fr(c->ch_part); fr(c->ch_pos);
   fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); }
   fr(c->slab_x); fr(c->slab_q); fr(c->slab_kraw); fr(c->slab_attn); fr(c->slab_h); fr(c->slab_logits); fr(c->slab_probs);
@@ -933,14 +952,22 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
       hipLaunchKernelGGL(tgx::add_pos_kernel, dim3(1), dim3(64), 0, c->stream, r.pos, seq);
       continue;
     }
-    // short prompts (and shapes the GEMM tile does not cover): `seq` single-position passes — identical results
-    tgx::EmbedArgs e{};
-    e.ids = r.prompt; e.pos = r.pos; e.pos0 = (int)c->past; e.embed = c->embed; e.x = r.x; e.H = c->d.hidden; e.V = c->d.vocab; e.tok = r.tok;
-    for (int s = 0; s < seq; s++) {
-      TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_prompt_kernel<DT>, dim3(1), dim3(256), 0, c->stream, e))
-      launch_layers(c, b, 1);
-      if (s == seq - 1) launch_lm_head(c, b, 1);
-      hipLaunchKernelGGL(tgx::advance_pos_kernel, dim3(1), dim3(64), 0, c->stream, r.pos);
+    // prefill by steps (fp32 storage, prompts shorter than 4 tokens, shapes the GEMM tile does not cover): up to 4 consecutive
+    // positions per pass through the decode kernels — the chunk rows share this row's cache (kv_stride 0), each attends the
+    // keys up to its own position, so the result equals position-by-position passes at a quarter of the weight traffic
+    for (int s0 = 0; s0 < seq;) {
+      const int rem = seq - s0, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
+      tgx::EmbedChunkArgs e{};
+      e.ids = r.prompt + s0; e.embed = c->embed; e.x = c->ch_x; e.H = c->d.hidden; e.pos = c->ch_pos; e.pos0 = (int)c->past + s0;
+      TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_chunk_kernel<DT>, dim3(R), dim3(256), 0, c->stream, e))
+      for (int k = 0; k < R; k++) { c->chunk[k].kcache = r.kcache; c->chunk[k].vcache = r.vcache; }
+      launch_layers(c, c->chunk, R, 0);
+      s0 += R;
+      if (s0 == seq) {                                   // the last position's hidden state feeds lm_head; publish token and length
+        (void)hipMemcpyAsync(r.x, c->chunk[R - 1].x, (size_t)c->d.hidden * 4, hipMemcpyDeviceToDevice, c->stream);
+        hipLaunchKernelGGL(tgx::add_pos_kernel, dim3(1), dim3(64), 0, c->stream, r.pos, seq);
+        launch_lm_head(c, b, 1);
+      }
     }
   }
   HIP_OK(c, hipGetLastError());
@@ -1098,7 +1125,7 @@ int tgx_profile_decode(tgx_ctx* c, int n_reps, int64_t* launches, double* total_
       HIP_OK(c, hipEventRecord(c->prof.ev[0], c->stream));
       int n = 0;
       if (cls == TGX_KERNEL_LMHEAD) { launch_lm_head(c, 0, 1); n = 1; }
-      else for (int l = 0; l < c->d.layers; l++, n++) launch_layer_kernel(c, 0, 1, c->prof_same_layer ? 0 : l, cls, c->scratch_x);
+      else for (int l = 0; l < c->d.layers; l++, n++) launch_layer_kernel(c, &c->rows[0], 1, c->prof_same_layer ? 0 : l, cls, c->scratch_x, (long long)c->kv_row_elems);
       HIP_OK(c, hipEventRecord(c->prof.ev[1], c->stream));
       HIP_OK(c, hipEventSynchronize(c->prof.ev[1]));
       float ms = 0.f;
