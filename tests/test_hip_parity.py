@@ -257,3 +257,25 @@ def test_context_limit_is_exact(hip, oracle_lib):
     gpu.forward(one); ref.reset_cache(); ref.forward(one)                               # a single-token prompt (seq = 1 at past = 0)
     assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_ORACLE
     np.testing.assert_array_equal(gpu.sample(GREEDY), ref.sample(GREEDY))
+
+
+@pytest.mark.parametrize("heads,kv", [(5, 1), (7, 1), (8, 2), (16, 2)])
+def test_large_gqa_groups_split_across_workgroups(heads, kv, hip, oracle_lib):
+    """More than 4 query heads per kv head (Qwen2.5-0.5B has 7): the attention decode kernel takes them in groups on blockIdx.z,
+    the last group possibly short.  Qwen3 fixture geometry (explicit head_dim) with the head counts overridden."""
+    from oracle.oracle_ffi import OracleModel
+    from tinygpt_amd.ffi import Model
+    cfg, g = load_golden("qwen3_tiny")
+    cfg = dict(cfg, num_attention_heads=heads, num_key_value_heads=kv)
+    d = desc_from_hf_config(cfg, "bf16")
+    gpu = Model(d, hip).load_synthetic(11, 0.08).finalize()
+    ref = OracleModel(d).load_synthetic(11, 0.08).finalize()
+    from tinygpt_amd import synth
+    prompt = synth.synth_prompt(d.vocab, 70, 4)[None, :]
+    gpu.set_option("prefill.mfma", 0)                      # prefill through the decode kernels too (chunks of 4 positions)
+    gpu.forward(prompt); ref.forward(prompt)
+    assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_ORACLE
+    for _ in range(5):
+        tok = ref.sample(GREEDY)
+        gpu.forward(tok[None, :]); ref.forward(tok[None, :])
+        assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_ORACLE

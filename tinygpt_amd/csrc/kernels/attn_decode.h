@@ -31,6 +31,7 @@ struct AttnArgs {
   float scale;
   // batch rows: blockIdx.y = row; row r uses q + r*q_stride, caches + r*kv_stride, pos[r], part + r*part_stride, out + r*q_stride
   long long q_stride, kv_stride, part_stride;
+  int gfull;  // query heads per kv head; the G heads of a workgroup are gfull-group blockIdx.z * G .. +G-1 (the last group may be short)
   int dbg;   // experiments only (tgx_set_option "debug.attn"): 1 skip K/V work, 2 skip the LDS merge, 4 exit at once — results invalid
 };
 
@@ -52,6 +53,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   float* part_row = a.part + blockIdx.y * a.part_stride;
   const int kvh = blockIdx.x / a.nsplit, sp = blockIdx.x - kvh * a.nsplit;
   const int part_i = lane % LPT, slot = lane / LPT;
+  const int g_base = blockIdx.z * G;                                   // first head (within the kv group) of this workgroup
+  auto head_of = [&](int g) { return kvh * a.gfull + min(g_base + g, a.gfull - 1); };   // clamped: a short last group reloads its last head
+  auto head_live = [&](int g) { return g_base + g < a.gfull; };
   // Token blocks of STEP = 4 waves x UNR wave-loads are dealt round-robin to the splits: split sp owns blocks sp,
   // sp + nsplit, ...: the active splits are the first ceil(n_keys / STEP) of every kv head and each runs whole blocks;
   // the addresses of a split's first block do not depend on the context length.
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   float qf[G][8];
 #pragma unroll
   for (int g = 0; g < G; g++) {
-    const f32x4* qp = reinterpret_cast<const f32x4*>(q_row + (size_t)(kvh * G + g) * HD + part_i * 8);
+    const f32x4* qp = reinterpret_cast<const f32x4*>(q_row + (size_t)head_of(g) * HD + part_i * 8);
     const f32x4 q0 = qp[0], q1 = qp[1];
 #pragma unroll
     for (int j = 0; j < 4; j++) { qf[g][j] = q0[j]; qf[g][4 + j] = q1[j]; }
@@ -81,7 +85,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     // (the compiler sinks the loads above below this branch; running empty splits through the masked path instead keeps
     //  them ahead of the position load but measured 1262 vs 1260 tok/s at context 2.3k and 1267 vs 1289 at 300 — rejected)
     for (int g = threadIdx.x; g < G; g += 256) {
-      float* dst = part_row + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
+      if (!head_live(g)) continue;
+      float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);
       dst[HD] = -INFINITY; dst[HD + 1] = 0.f;
     }
     return;
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   if (TGX_DBG(a, 2)) {
     if (wv == 0 && slot == 0)
       for (int g = 0; g < G; g++) {
-        float* dst = part_row + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
+        float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);
         for (int j = 0; j < 8; j++) dst[part_i * 8 + j] = o[g][j];
         if (part_i == 0) { dst[HD] = m[g]; dst[HD + 1] = l[g]; }
       }
@@ -180,7 +185,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     const float s2 = (m2 == -INFINITY) ? 0.f : exp2f(m2 - M), s3 = (m3 == -INFINITY) ? 0.f : exp2f(m3 - M);
     float acc = red[0][g][d] * s0;
     acc = fmaf(red[1][g][d], s1, acc); acc = fmaf(red[2][g][d], s2, acc); acc = fmaf(red[3][g][d], s3, acc);
-    float* dst = part_row + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
+    if (!head_live(g)) continue;
+    float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);
     dst[d] = acc;
     if (d == 0) {
       float L = red[0][g][HD + 1] * s0;

@@ -340,23 +340,23 @@ void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls, int R) {
 }
 
 template <int DT, int HD>
-void launch_attn_g(tgx_ctx* c, const tgx::AttnArgs& a, int G, int R) {
-  const dim3 grid(a.kv_heads * a.nsplit, R), blk(256);
+void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
+  // the query heads of a kv group are processed by one workgroup up to 4, by two workgroups (blockIdx.z) above that: the
+  // per-head state (8 output registers, the merges) is what a workgroup's time grows with
+  const int gfull = a.heads / a.kv_heads, ngroups = gfull > 4 ? (gfull + 3) / 4 : 1, G = (gfull + ngroups - 1) / ngroups;
+  a.gfull = gfull;
+  const dim3 grid(a.kv_heads * a.nsplit, R, ngroups), blk(256);
   if (!(c->debug_skip & 1)) switch (G) {
     case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1>), grid, blk, 0, c->stream, a); break;
     case 2: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2>), grid, blk, 0, c->stream, a); break;
     case 3: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 3>), grid, blk, 0, c->stream, a); break;
-    case 4: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4>), grid, blk, 0, c->stream, a); break;
-    case 5: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 5>), grid, blk, 0, c->stream, a); break;
-    case 6: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 6>), grid, blk, 0, c->stream, a); break;
-    default: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 7>), grid, blk, 0, c->stream, a); break;
+    default: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4>), grid, blk, 0, c->stream, a); break;
   }
   if (!(c->debug_skip & 2)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
 }
 
 void launch_attn(tgx_ctx* c, const tgx::AttnArgs& a, int R) {
-  const int G = a.heads / a.kv_heads;
-  TGX_DT_SWITCH(c->dt, if (c->d.head_dim == 64) launch_attn_g<DT, 64>(c, a, G, R); else launch_attn_g<DT, 128>(c, a, G, R))
+  TGX_DT_SWITCH(c->dt, if (c->d.head_dim == 64) launch_attn_g<DT, 64>(c, a, R); else launch_attn_g<DT, 128>(c, a, R))
 }
 
 void fill_strides(const tgx_ctx* c, tgx::GemvArgs& a) {
@@ -694,7 +694,7 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   if (d.compute_dtype != TGX_BF16 && d.compute_dtype != TGX_F16 && d.compute_dtype != TGX_F32) return set_err(nullptr, TGX_ERR_INVALID, "unknown compute dtype %d", d.compute_dtype);
   if (d.head_dim != 64 && d.head_dim != 128) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "head_dim %d (64 and 128 are built)", d.head_dim);
   if (d.heads <= 0 || d.kv_heads <= 0 || d.heads % d.kv_heads) return set_err(nullptr, TGX_ERR_INVALID, "heads %% kv_heads != 0");
-  if (d.heads / d.kv_heads > 7) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "GQA group size %d > 7", d.heads / d.kv_heads);
+  if (d.heads / d.kv_heads > 16) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "GQA group size %d > 16", d.heads / d.kv_heads);
   if (d.hidden % 8 || d.inter % 8 || (d.heads * d.head_dim) % 8) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "hidden/intermediate sizes must be multiples of 8");
   if (d.hidden <= 0 || d.layers <= 0 || d.inter <= 0 || d.vocab <= 0 || d.max_ctx <= 0) return set_err(nullptr, TGX_ERR_INVALID, "non-positive model dimension");
   if (d.hidden > 4096) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "hidden_size %d > 4096: the norm-fused GEMV keeps x in one wave's registers", d.hidden);
