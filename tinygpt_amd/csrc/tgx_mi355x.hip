@@ -126,6 +126,7 @@ struct tgx_ctx {
   bool prefill_mfma = true;
   int gemm_tm = 0;           // experiment: force the GEMM row tile (64 / 128); 0 = by the number of tiles
   int debug_attn = 0;        // experiment: AttnArgs.dbg
+  int attn_gmax = 0;         // experiment: query heads per attention workgroup (default 2)
   int debug_gemv = 0;        // experiment: GemvArgs.dbg = value & 15 for the kernel classes selected by bits 8.. (1 << (8 + class))
   int debug_skip = 0;        // experiment: bit0 skip attn decode kernel, bit1 skip combine (results invalid)
   int prof_same_layer = 0;   // experiment: tgx_profile_decode replays ONE layer's weights (Infinity-Cache resident)
@@ -341,9 +342,12 @@ void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls, int R) {
 
 template <int DT, int HD>
 void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
-  // the query heads of a kv group are processed by one workgroup up to 4, by two workgroups (blockIdx.z) above that: the
-  // per-head state (8 output registers, the merges) is what a workgroup's time grows with
-  const int gfull = a.heads / a.kv_heads, ngroups = gfull > 4 ? (gfull + 3) / 4 : 1, G = (gfull + ngroups - 1) / ngroups;
+  // the query heads of a kv group go to workgroups two at a time (blockIdx.z): the per-head state (8 output registers, the
+  // merges) is what a workgroup's time grows with, while the K/V tile the groups re-read is small and mostly L2-resident.
+  // Measured (option attn.gmax; tok/s at 4 / 2 / 1 heads per workgroup): Llama-3.2-1B ctx 2.3k 1364 / 1391 / 1388, ctx 8k
+  // 1282 / 1312 / 1295; Qwen2.5-0.5B (7 heads per kv head) 1512 / 1610 / 1621; Mistral-7B 337 / 340 / 339
+  const int gmax = c->attn_gmax > 0 ? c->attn_gmax : 2;
+  const int gfull = a.heads / a.kv_heads, ngroups = gfull > gmax ? (gfull + gmax - 1) / gmax : 1, G = (gfull + ngroups - 1) / ngroups;
   a.gfull = gfull;
   const dim3 grid(a.kv_heads * a.nsplit, R, ngroups), blk(256);
   if (!(c->debug_skip & 1)) switch (G) {
@@ -1177,6 +1181,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "debug.nops")) { c->debug_nops = value; return TGX_OK; }
   if (!strcmp(key, "debug.skip")) { c->debug_skip = value; return TGX_OK; }
   if (!strcmp(key, "debug.attn")) { c->debug_attn = value; return TGX_OK; }
+  if (!strcmp(key, "attn.gmax")) { c->attn_gmax = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_tm")) { c->gemm_tm = value; return TGX_OK; }
   if (!strcmp(key, "debug.gemv")) { c->debug_gemv = value; return TGX_OK; }
   if (!strcmp(key, "prefill.mfma")) { c->prefill_mfma = value != 0; return TGX_OK; }
