@@ -108,6 +108,8 @@ struct tgx_ctx {
   int32_t last_sampled0 = -1;
 
   hipGraphExec_t step_graph = nullptr;
+  hipGraphExec_t multi_graph = nullptr;   // graph_steps consecutive decode steps (tgx_decode with many steps)
+  int graph_steps = 8;                    // measured: 1 -> 1389 tok/s, 8 -> 1396, 16 -> 1399 (the gap between two graph launches is ~4 us)
   int step_graph_batch = 0;
   tgx_sampler_cfg step_graph_cfg{};
   unsigned long long* seed_dev = nullptr;
@@ -628,18 +630,35 @@ bool same_cfg(const tgx_sampler_cfg& a, const tgx_sampler_cfg& b) {
   return a.temperature == b.temperature && a.top_k == b.top_k && a.top_p == b.top_p && a.min_p == b.min_p;
 }
 
-int ensure_step_graph(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
-  if (!c->use_graph) return TGX_OK;
-  if (c->step_graph && c->step_graph_batch == c->batch && same_cfg(c->step_graph_cfg, cfg)) return TGX_OK;
-  if (c->step_graph) { (void)hipStreamSynchronize(c->stream); (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
+// The decode step as a hipGraph, captured once per (batch, sampler config): `steps` consecutive steps per graph — token,
+// position and step counter live on the device, so a multi-step graph is the same launch sequence repeated.
+int capture_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, int steps, hipGraphExec_t* out) {
   hipGraph_t g = nullptr;
   HIP_OK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-  launch_decode_step(c, cfg);
+  for (int i = 0; i < steps; i++) launch_decode_step(c, cfg);
   HIP_OK(c, hipStreamEndCapture(c->stream, &g));
-  HIP_OK(c, hipGraphInstantiate(&c->step_graph, g, nullptr, nullptr, 0));
+  HIP_OK(c, hipGraphInstantiate(out, g, nullptr, nullptr, 0));
   (void)hipGraphDestroy(g);
-  c->step_graph_batch = c->batch;
-  c->step_graph_cfg = cfg;
+  return TGX_OK;
+}
+
+void drop_step_graphs(tgx_ctx* c) {
+  if (!c->step_graph && !c->multi_graph) return;
+  (void)hipStreamSynchronize(c->stream);
+  if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
+  if (c->multi_graph) { (void)hipGraphExecDestroy(c->multi_graph); c->multi_graph = nullptr; }
+}
+
+int ensure_step_graph(tgx_ctx* c, const tgx_sampler_cfg& cfg, bool want_multi) {
+  if (!c->use_graph) return TGX_OK;
+  if (!(c->step_graph && c->step_graph_batch == c->batch && same_cfg(c->step_graph_cfg, cfg))) {
+    drop_step_graphs(c);
+    int rc = capture_steps(c, cfg, 1, &c->step_graph);
+    if (rc) return rc;
+    c->step_graph_batch = c->batch;
+    c->step_graph_cfg = cfg;
+  }
+  if (want_multi && !c->multi_graph && c->graph_steps > 1) return capture_steps(c, cfg, c->graph_steps, &c->multi_graph);
   return TGX_OK;
 }
 
@@ -651,9 +670,12 @@ int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int 
     c->have_probs = true;
   }
   if (c->use_graph) {
-    int rc = ensure_step_graph(c, cfg);
+    const int K = c->graph_steps;
+    int rc = ensure_step_graph(c, cfg, /*want_multi=*/n >= 2 * K);
     if (rc) return rc;
-    for (int i = 0; i < n; i++) HIP_OK(c, hipGraphLaunch(c->step_graph, c->stream));
+    int i = 0;
+    if (c->multi_graph) for (; i + K <= n; i += K) HIP_OK(c, hipGraphLaunch(c->multi_graph, c->stream));
+    for (; i < n; i++) HIP_OK(c, hipGraphLaunch(c->step_graph, c->stream));
   } else {
     for (int i = 0; i < n; i++) launch_decode_step(c, cfg);
     HIP_OK(c, hipGetLastError());
@@ -919,7 +941,7 @@ void tgx_destroy(tgx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
+  drop_step_graphs(c);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
   fr(c->ch_x); fr(c->ch_q); fr(c->ch_kraw); fr(c->ch_attn); fr(c->ch_h); fr(c->ch_part); fr(c->ch_pos);
@@ -1176,8 +1198,9 @@ int tgx_set_logits(tgx_ctx* c, const float* logits, int batch) {
 int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!c || !key) return TGX_ERR_INVALID;
   static const char* cls_names[TGX_KERNEL_COUNT] = {"qkv", "attn", "oproj", "gateup", "down", "lmhead"};
-  if (c->step_graph) { (void)hipStreamSynchronize(c->stream); (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
+  drop_step_graphs(c);
   if (!strcmp(key, "graph")) { c->use_graph = value != 0; return TGX_OK; }
+  if (!strcmp(key, "graph.steps")) { if (value < 1 || value > 64) return set_err(c, TGX_ERR_INVALID, "graph.steps out of range"); c->graph_steps = value; return TGX_OK; }
   if (!strcmp(key, "debug.nops")) { c->debug_nops = value; return TGX_OK; }
   if (!strcmp(key, "debug.skip")) { c->debug_skip = value; return TGX_OK; }
   if (!strcmp(key, "debug.attn")) { c->debug_attn = value; return TGX_OK; }
