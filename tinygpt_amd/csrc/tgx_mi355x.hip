@@ -326,7 +326,7 @@ template <int PRO, int EPI>
 void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls, int R) {
   const Tune& tn = c->tune[cls];
   a.dbg = ((c->debug_gemv >> (8 + cls)) & 1) ? (c->debug_gemv & 15) : 0;
-  a.ks = (PRO == tgx::PRO_RMSNORM) ? 1 : gemv_auto_ks(a.K, tn.ks);
+  a.ks = gemv_auto_ks(a.K, tn.ks);   // norm-fused launches K-split too (their waves exchange the sums of squares through LDS)
   while (R > 1 && a.ks < 4 && gemv_nx(a.K, a.ks) > 4) a.ks *= 2;   // batch rows: at most 4 slices per row and lane (measured: B = 2 and 4 on the 1B / 3B / 7B shapes)
   const int grid = (EPI == tgx::EPI_LOGITS) ? c->lm_grid : gemv_grid(c, a.units, a.ks, tn.bpc);
   const int nx = gemv_nx(a.K, a.ks);
@@ -744,6 +744,9 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   HIP_OK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   if (const char* e = getenv("TGX_NO_GRAPH")) c->use_graph = !(e[0] == '1');
   c->tune[TGX_KERNEL_DOWN].ks = 4;   // K = intermediate_size: 4 waves split each row pair
+  // qkv is the most latency-bound launch (few rows): 4 waves per row pair shorten every wave's load -> reduce chain; measured
+  // ks 1 -> 4: Llama-3.2-1B 1395 -> 1411 tok/s, 3B 628 -> 637, Mistral-7B 341 -> 347; hidden 896 (Qwen2.5-0.5B) loses 2 %
+  c->tune[TGX_KERNEL_QKV].ks = d.hidden >= 2048 ? 4 : 1;
 
   const int H = d.hidden, I = d.inter, V = d.vocab, qd = d.heads * d.head_dim, kvd = d.kv_heads * d.head_dim;
   int rc;
