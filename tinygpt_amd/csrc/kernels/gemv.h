@@ -376,7 +376,7 @@ struct FinalizeArgs {
   int* pos;              // this row's pastLength
   int* step;             // decode steps finalized so far (monotonic; index into the token rings)
   int* tok_log;          // [log_cap][rows] device ring of produced tokens
-  volatile int* host_ring;   // [ring_cap][rows] pinned host mirror (AsyncTokenPipeline read-back)
+  volatile int* host_ring;   // [ring_cap][rows] pinned host mirror (AsyncTokenPipeline read-back); nullptr: not mirrored (multi-step graphs)
   int log_cap, ring_cap;
   int row, rows;
   int log;               // 1: record the token in the rings (decode steps); 0: tgx_sample after a prefill
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs
     if (a.log) {
       const int st = *a.step;
       a.tok_log[(st % a.log_cap) * a.rows + a.row] = t;
-      a.host_ring[(st % a.ring_cap) * a.rows + a.row] = t;
+      if (a.host_ring) a.host_ring[(st % a.ring_cap) * a.rows + a.row] = t;
       if (a.bump_step) *a.step = st + 1;
     }
   }

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(SAMP_WG) void samp_pick_kernel(const SampPickArgs p
     if (pa.fin.log) {
       const int st = *pa.fin.step;
       pa.fin.tok_log[(st % pa.fin.log_cap) * pa.fin.rows + pa.fin.row] = pick;
-      pa.fin.host_ring[(st % pa.fin.ring_cap) * pa.fin.rows + pa.fin.row] = pick;
+      if (pa.fin.host_ring) pa.fin.host_ring[(st % pa.fin.ring_cap) * pa.fin.rows + pa.fin.row] = pick;
       if (pa.fin.bump_step) *pa.fin.step = st + 1;
     }
   }

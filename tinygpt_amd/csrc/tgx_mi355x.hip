@@ -109,6 +109,7 @@ struct tgx_ctx {
 
   hipGraphExec_t step_graph = nullptr;
   hipGraphExec_t multi_graph = nullptr;   // graph_steps consecutive decode steps (tgx_decode with many steps)
+  bool mirror_to_host = true;             // finalize / pick kernels also store the token into the pinned host ring (tgx_fetch_token)
   int graph_steps = 8;                    // measured: 1 -> 1389 tok/s, 8 -> 1396, 16 -> 1399 (the gap between two graph launches is ~4 us)
   int step_graph_batch = 0;
   tgx_sampler_cfg step_graph_cfg{};
@@ -561,7 +562,7 @@ tgx::FinalizeArgs make_finalize_args(tgx_ctx* c, int row, bool advance_pos, bool
   RowState& r = c->rows[(size_t)row];
   tgx::FinalizeArgs a{};
   a.part_val = r.part_val; a.part_idx = r.part_idx; a.n_part = c->lm_grid;
-  a.tok = r.tok; a.pos = r.pos; a.step = c->step; a.tok_log = c->tok_log; a.host_ring = c->host_ring_dev;
+  a.tok = r.tok; a.pos = r.pos; a.step = c->step; a.tok_log = c->tok_log; a.host_ring = c->mirror_to_host ? c->host_ring_dev : nullptr;
   a.log_cap = c->log_cap; a.ring_cap = HOST_RING;
   a.row = row; a.rows = c->batch;
   a.log = log_step ? 1 : 0; a.bump_step = (row == c->batch - 1) ? 1 : 0;
@@ -634,9 +635,13 @@ bool same_cfg(const tgx_sampler_cfg& a, const tgx_sampler_cfg& b) {
 // position and step counter live on the device, so a multi-step graph is the same launch sequence repeated.
 int capture_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, int steps, hipGraphExec_t* out) {
   hipGraph_t g = nullptr;
+  // multi-step graphs serve tgx_decode, which reads the ids from the device log afterwards: no per-step store over PCIe
+  c->mirror_to_host = steps == 1;
   HIP_OK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   for (int i = 0; i < steps; i++) launch_decode_step(c, cfg);
-  HIP_OK(c, hipStreamEndCapture(c->stream, &g));
+  const hipError_t cap = hipStreamEndCapture(c->stream, &g);
+  c->mirror_to_host = true;
+  HIP_OK(c, cap);
   HIP_OK(c, hipGraphInstantiate(out, g, nullptr, nullptr, 0));
   (void)hipGraphDestroy(g);
   return TGX_OK;
