@@ -20,8 +20,8 @@
 // the first weight load), streams 16-byte weight slices (coalesced 1 KiB per wave-load, 2*NX loads in flight
 // per lane, next unit prefetched while the current one is reduced), accumulates in fp32 and finishes each
 // dot product with a DPP wave reduction.  With KS > 1 the KS partial sums meet in LDS in a fixed order.
-// Norm-fused launches use KS = 1 at batch 1 (the wave holds the whole vector, hidden <= 4096); with batch rows the KS waves
-// of a unit exchange partial sums of squares through LDS so that R x NX slices still fit the registers.
+// Norm-fused launches with KS > 1 (the qkv launch: 4 waves per row pair shorten every wave's load -> reduce chain; batch rows at
+// hidden sizes whose R x NX slices would not fit one wave) exchange their partial sums of squares through LDS once.
 #pragma once
 #include "common.h"
 

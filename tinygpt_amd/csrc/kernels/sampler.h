@@ -22,7 +22,8 @@
 //                                                              walks the selected 1024 entries
 // The pick kernel also performs the duties of finalize_greedy_kernel (token publish, pastLength+1, token rings, next
 // embedding row).  Launches per sampled step: 5 per active top-k/top-p filter + 2 (+1 with min-p) + 1 pick per row;
-// T = 0.8 / top-p 0.9 (the CLI defaults): 8 launches, ~30 us for V = 128 256 (the one-workgroup version took 600 us).
+// T = 0.8 / top-p 0.9 (the CLI defaults): 8 launches, +50 us per decode step for V = 128 256 (the one-workgroup version of
+// this round added 600 us; profiles/r01_sampler_cost.txt).
 #pragma once
 #include "common.h"
 #include "gemv.h"
