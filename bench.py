@@ -126,6 +126,9 @@ def main():
     model.finalize()
 
     prompt = synth.synth_prompt(desc.vocab, args.prompt, 1234 + rank)[None, :]
+    model.forward(prompt)                                           # untimed: allocates the prefill workspace, warms the code objects
+    model.synchronize()
+    model.reset_cache()
     t0 = time.perf_counter()
     model.forward(prompt)
     model.synchronize()
