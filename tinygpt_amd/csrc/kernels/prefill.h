@@ -8,7 +8,7 @@
 //     gate_up / down_proj             GatedMLP.h:38,40
 //   split + RoPE(q,k) + cache append  Attention.h:96-106       rope_kv_split_kernel
 //   flashAttention(causal)            Attention.h:108-109      attn_prefill_kernel       (MFMA QKᵀ and PV, online softmax)
-//   siluMul                           Activation.h:16          silu_mul_split_kernel
+//   siluMul                           Activation.h:16          fused into the gate_up product's epilogue (GEMM_SILU)
 //
 // Precision: activations are fp32 between ops, the matrix cores take bf16.  Every fp32 MFMA operand x is split as
 // x = hi + lo (hi = bf16(x), lo = bf16(x - hi)) and multiplied in two MFMAs against the exact bf16 weights / K / V,
@@ -73,16 +73,6 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* X, cons
   }
 }
 
-// ---- siluMul on the merged gate|up output, as bf16 hi/lo ---------------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(256) void silu_mul_split_kernel(const float* GU, int I, bf16_t* hi, bf16_t* lo) {
-  const float* g = GU + (size_t)blockIdx.x * 2 * I;
-  for (int i = threadIdx.x; i < I; i += 256) {
-    const float a = g[i], u = g[I + i];
-    split16<DT>((a / (1.0f + expf(-a))) * u, hi[(size_t)blockIdx.x * I + i], lo[(size_t)blockIdx.x * I + i]);
-  }
-}
-
 // ---- split -> RoPE(q), RoPE(k) at pastLength+s -> cache append; q as bf16 hi/lo ------------------------------------
 struct RopeKvArgs {
   const float* QKV;        // [S][qd + 2*kvd] fp32 (bias already added)
@@ -134,7 +124,7 @@ __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) 
 // 128x128 workgroup tile, BK = 64, 4 waves as 2x2 (each 64x64 = 2x2 MFMA tiles, 64 accumulator VGPRs).  Tiles are
 // staged global -> registers -> LDS with the next K-step's global loads in flight during the MFMAs; LDS rows are
 // padded to 144 B so the 16-byte fragment reads of a 16-lane group fall on 16 distinct bank quads.
-enum { GEMM_STORE = 0, GEMM_RESIDUAL = 1 };
+enum { GEMM_STORE = 0, GEMM_RESIDUAL = 1, GEMM_SILU = 2 };
 struct GemmArgs {
   const bf16_t *A_hi, *A_lo;   // [M][K]
   const bf16_t* A_lo2;         // optional third term (nullptr: two-term product)
@@ -142,6 +132,11 @@ struct GemmArgs {
   const bf16_t* bias;          // [N] or nullptr
   float* C;                    // [M][ldc]
   int M, N, K, ldc;
+  // GEMM_SILU (the gate_up product): tile columns alternate gate row i / up row i (B row of column n = (n odd ? inter : 0) + n/2),
+  // so a lane pair holds (gate_i, up_i) and the epilogue emits siluMul directly as the hi / lo operand of the down product:
+  // the [M][2*inter] fp32 intermediate and the separate siluMul pass disappear (GatedMLP.h:37-39, Activation.h:16)
+  int inter;
+  bf16_t *out_hi, *out_lo;     // [M][inter]
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = GBK + 8;
@@ -186,7 +181,9 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
         ral2[i < AI ? i : 0] = (three && am) ? reinterpret_cast<const u32x4*>(a.A_lo2)[(size_t)(m0 + row) * kch + koff] : zero;
       }
       const bool bn = n0 + row < a.N;
-      rb[i] = bn ? reinterpret_cast<const u32x4*>(a.B)[(size_t)(n0 + row) * kch + koff] : zero;
+      const int nb = n0 + row;
+      const size_t brow = EPI == GEMM_SILU ? (size_t)((nb & 1) ? a.inter : 0) + (size_t)(nb >> 1) : (size_t)nb;
+      rb[i] = bn ? reinterpret_cast<const u32x4*>(a.B)[brow * kch + koff] : zero;
     }
   };
   auto store_tiles = [&]() {
@@ -241,6 +238,18 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (EPI == GEMM_SILU) {      // even lanes hold gate_i, odd lanes up_i (i = col / 2): the pair meets over the DPP crossbar
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float v = acc[i][j][r];
+          const float other = dpp_mov<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]: the neighbour lane's value
+          const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if ((lane & 1) || col >= a.N || row >= a.M) continue;
+          const size_t o = (size_t)row * a.inter + (size_t)(col >> 1);
+          split16<DT>((v / (1.0f + expf(-v))) * other, a.out_hi[o], a.out_lo[o]);
+        }
+        continue;
+      }
       if (col >= a.N) continue;
       const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
 #pragma unroll

@@ -126,6 +126,7 @@ struct tgx_ctx {
   bf16_t *ws_ah = nullptr, *ws_al = nullptr;          // [S][max(H, qd, I)] GEMM A operand (hi, lo)
   bf16_t* ws_al2 = nullptr;                           // [S][H] third term for the QKV projection
   bf16_t *ws_qh = nullptr, *ws_ql = nullptr;          // [S][qd] rotated queries (hi, lo)
+  bf16_t *ws_hh = nullptr, *ws_hl = nullptr;          // [S][I] siluMul output (hi, lo): the down product's A operand
   bool prefill_mfma = true;
   int gemm_tm = 0;           // experiment: force the GEMM row tile (64 / 128); 0 = by the number of tiles
   int debug_attn = 0;        // experiment: AttnArgs.dbg
@@ -457,12 +458,12 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
   if (S <= c->ws_rows) return TGX_OK;
   const tgx_model_desc& d = c->d;
   const size_t H = (size_t)d.hidden, qd = (size_t)d.heads * d.head_dim, kvd = (size_t)d.kv_heads * d.head_dim, I = (size_t)d.inter;
-  const size_t wout = std::max(qd + 2 * kvd, 2 * I), wa = std::max(std::max(H, qd), I);
+  const size_t wout = qd + 2 * kvd, wa = std::max(H, qd);   // the gate_up product leaves no fp32 intermediate (GEMM_SILU)
   HIP_OK(c, hipStreamSynchronize(c->stream));
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql);
+  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl);
   c->ws_al2 = nullptr;
-  c->ws_x = nullptr; c->ws_out = nullptr; c->ws_ah = c->ws_al = c->ws_qh = c->ws_ql = nullptr; c->ws_rows = 0;
+  c->ws_x = nullptr; c->ws_out = nullptr; c->ws_ah = c->ws_al = c->ws_qh = c->ws_ql = c->ws_hh = c->ws_hl = nullptr; c->ws_rows = 0;
   const size_t rows = (size_t)S;
   HIP_OK(c, hipMalloc((void**)&c->ws_x, rows * H * 4));
   HIP_OK(c, hipMalloc((void**)&c->ws_out, rows * wout * 4));
@@ -471,26 +472,31 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
   HIP_OK(c, hipMalloc((void**)&c->ws_al2, rows * H * 2));
   HIP_OK(c, hipMalloc((void**)&c->ws_qh, rows * qd * 2));
   HIP_OK(c, hipMalloc((void**)&c->ws_ql, rows * qd * 2));
+  HIP_OK(c, hipMalloc((void**)&c->ws_hh, rows * I * 2));
+  HIP_OK(c, hipMalloc((void**)&c->ws_hl, rows * I * 2));
   c->ws_rows = S;
   return TGX_OK;
 }
 
-void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float* C, int M, int N, int K, int ldc, bool three_terms = false) {
+void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float* C, int M, int N, int K, int ldc, bool three_terms = false,
+                 const bf16_t* a_hi = nullptr, const bf16_t* a_lo = nullptr) {
   const bf16_t* B = reinterpret_cast<const bf16_t*>(B_);   // 16-bit storage (bf16 or fp16 bit patterns); fp32 storage never gets here
   const bf16_t* bias = reinterpret_cast<const bf16_t*>(bias_);
   tgx::GemmArgs g{};
-  g.A_hi = c->ws_ah; g.A_lo = c->ws_al; g.A_lo2 = three_terms ? c->ws_al2 : nullptr;
+  g.A_hi = a_hi ? a_hi : c->ws_ah; g.A_lo = a_lo ? a_lo : c->ws_al; g.A_lo2 = three_terms ? c->ws_al2 : nullptr;
+  g.inter = N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
   g.B = B; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc;
   // few column tiles (N = hidden) -> 64-row tiles, so that at least two workgroups share a CU
   const bool few = ((N + tgx::GBN - 1) / tgx::GBN) * ((M + tgx::GBM - 1) / tgx::GBM) < 2 * c->num_cus;
   // measured (tools/prefill_bench.py --gemm-tm, Llama-3.2-1B, S = 2048): this policy 15.0 ms, 64-row tiles also for the three-term
   // QKV product 15.3, 128-row tiles everywhere 15.85, 64-row tiles everywhere 15.9
-  const bool small = c->gemm_tm ? c->gemm_tm == 64 : (few && !three_terms);
+  const bool small = epi == tgx::GEMM_SILU ? false : (c->gemm_tm ? c->gemm_tm == 64 : (few && !three_terms));
   const int tm = small ? 64 : tgx::GBM;
   const dim3 grid((N + tgx::GBN - 1) / tgx::GBN, (M + tm - 1) / tm), blk(256);
   const size_t dyn = three_terms ? (size_t)tm * tgx::GLD * 2 : 0;      // LDS tile of the third term
   TGX_DT16_SWITCH(c->dt,
-    if (small) {
+    if (epi == tgx::GEMM_SILU) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_SILU, 2>), grid, blk, dyn, c->stream, g);
+    else if (small) {
       if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_RESIDUAL, 1>), grid, blk, dyn, c->stream, g);
       else hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_STORE, 1>), grid, blk, dyn, c->stream, g);
     } else {
@@ -535,9 +541,8 @@ void launch_prefill(tgx_ctx* c, RowState& r, int S) {
     }
     launch_gemm(c, tgx::GEMM_RESIDUAL, w.wo, nullptr, c->ws_x, S, H, qd, H);
     TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al, (bf16_t*)nullptr))
-    launch_gemm(c, tgx::GEMM_STORE, w.wgu, nullptr, c->ws_out, S, 2 * I, H, 2 * I);
-    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::silu_mul_split_kernel<DT>, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_out, I, c->ws_ah, c->ws_al))
-    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wdown, nullptr, c->ws_x, S, H, I, H);
+    launch_gemm(c, tgx::GEMM_SILU, w.wgu, nullptr, nullptr, S, 2 * I, H, 2 * I);      // gate_up + siluMul -> ws_hh / ws_hl
+    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wdown, nullptr, c->ws_x, S, H, I, H, false, c->ws_hh, c->ws_hl);
   }
   (void)hipMemcpyAsync(r.x, c->ws_x + (size_t)(S - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, c->stream);
 }
@@ -953,7 +958,7 @@ void tgx_destroy(tgx_ctx* c) {
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
   fr(c->ch_x); fr(c->ch_q); fr(c->ch_kraw); fr(c->ch_attn); fr(c->ch_h); fr(c->ch_part); fr(c->ch_pos);
-  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql);
+  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); }
   fr(c->slab_x); fr(c->slab_q); fr(c->slab_kraw); fr(c->slab_attn); fr(c->slab_h); fr(c->slab_logits); fr(c->slab_probs);
   fr(c->slab_part_val); fr(c->slab_part_idx); fr(c->slab_attn_part); fr(c->slab_tok); fr(c->slab_pos); fr(c->slab_prompt); fr(c->slab_k); fr(c->slab_v);
