@@ -51,7 +51,6 @@ bool is_white_space(uint32_t cp) {   // Unicode White_Space (what `\s` means for
          cp == 0x2028 || cp == 0x2029 || cp == 0x202F || cp == 0x205F || cp == 0x3000;
 }
 static bool is_digit(uint32_t cp) { return cp >= '0' && cp <= '9'; }
-static bool is_word(uint32_t cp) { return cp == '_' || is_letter(cp) || is_number(cp); }
 static uint32_t fold_ascii(uint32_t cp) { return (cp >= 'A' && cp <= 'Z') ? cp + 32 : cp; }
 
 enum { P_L = 1, P_N = 2, P_S = 4, P_D = 8, P_W = 16 };
