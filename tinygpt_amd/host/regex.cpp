@@ -34,18 +34,35 @@ void utf8_append(std::string& out, uint32_t cp) {
   else { out += (char)(0xF0 | (cp >> 18)); out += (char)(0x80 | ((cp >> 12) & 0x3F)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
 }
 
-static bool in_ranges(const unidata::Range* r, int n, uint32_t cp) {
-  int lo = 0, hi = n - 1;
+// general category index (unicode_tables.h kCategoryNames) of a code point
+static int category_of(uint32_t cp) {
+  int lo = 0, hi = unidata::kCategoryCount - 1;
   while (lo <= hi) {
     const int mid = (lo + hi) / 2;
-    if (cp < r[mid].lo) hi = mid - 1;
-    else if (cp > r[mid].hi) lo = mid + 1;
-    else return true;
+    if (cp < unidata::kCategory[mid].lo) hi = mid - 1;
+    else if (cp > unidata::kCategory[mid].hi) lo = mid + 1;
+    else return unidata::kCategory[mid].cat;
   }
-  return false;
+  return unidata::kCategoryNameCount - 1;   // Cn
 }
-bool is_letter(uint32_t cp) { return in_ranges(unidata::kLetter, unidata::kLetterCount, cp); }
-bool is_number(uint32_t cp) { return in_ranges(unidata::kNumber, unidata::kNumberCount, cp); }
+// bit mask over the category indices for a \p{..} name: a two-letter category, or a one-letter group ("L" = Lu|Ll|Lt|Lm|Lo)
+static uint32_t category_mask(const std::string& name) {
+  uint32_t m = 0;
+  for (int i = 0; i < unidata::kCategoryNameCount; i++) {
+    const char* c = unidata::kCategoryNames[i];
+    if ((name.size() == 2 && name[0] == c[0] && name[1] == c[1]) || (name.size() == 1 && name[0] == c[0])) m |= 1u << i;
+  }
+  if (name == "Letter") return category_mask("L");
+  if (name == "Number") return category_mask("N");
+  if (name == "Punctuation") return category_mask("P");
+  if (name == "Symbol") return category_mask("S");
+  if (name == "Mark") return category_mask("M");
+  if (name == "Separator") return category_mask("Z");
+  return m;
+}
+static const uint32_t kMaskL = 0x1Fu, kMaskN = 0x700u;      // Lu..Lo = indices 0-4, Nd Nl No = 8-10
+bool is_letter(uint32_t cp) { return (kMaskL >> category_of(cp)) & 1u; }
+bool is_number(uint32_t cp) { return (kMaskN >> category_of(cp)) & 1u; }
 bool is_white_space(uint32_t cp) {   // Unicode White_Space (what `\s` means for the regex engines behind tokenizers)
   return (cp >= 0x9 && cp <= 0xD) || cp == 0x20 || cp == 0x85 || cp == 0xA0 || cp == 0x1680 || (cp >= 0x2000 && cp <= 0x200A) ||
          cp == 0x2028 || cp == 0x2029 || cp == 0x202F || cp == 0x205F || cp == 0x3000;
@@ -53,16 +70,19 @@ bool is_white_space(uint32_t cp) {   // Unicode White_Space (what `\s` means for
 static bool is_digit(uint32_t cp) { return cp >= '0' && cp <= '9'; }
 static uint32_t fold_ascii(uint32_t cp) { return (cp >= 'A' && cp <= 'Z') ? cp + 32 : cp; }
 
-enum { P_L = 1, P_N = 2, P_S = 4, P_D = 8, P_W = 16 };
+enum { P_S = 4, P_D = 8, P_W = 16 };   // white space, ASCII digit, word; \\p{..} classes live in the category masks
 
 bool Regex::CharClass::matches(uint32_t cp) const {
   auto hit = [&](uint32_t c) {
     for (const ClassItem& it : items) if (c >= it.lo && c <= it.hi) return true;
     const uint32_t pos = props & 31u, neg = (props >> 5) & 31u;
-    if (pos || neg) {
-      const bool l = is_letter(c), n = is_number(c), s = is_white_space(c), d = is_digit(c), w = (c == '_') || l || n;
-      if (((pos & P_L) && l) || ((pos & P_N) && n) || ((pos & P_S) && s) || ((pos & P_D) && d) || ((pos & P_W) && w)) return true;
-      if (((neg & P_L) && !l) || ((neg & P_N) && !n) || ((neg & P_S) && !s) || ((neg & P_D) && !d) || ((neg & P_W) && !w)) return true;
+    if (cat_pos || cat_neg || pos || neg) {
+      const int cat = category_of(c);
+      if ((cat_pos >> cat) & 1u) return true;
+      for (uint32_t nm : cat_neg_list) if (!((nm >> cat) & 1u)) return true;   // \P{X}: any code point outside X
+      const bool s = is_white_space(c), d = is_digit(c), w = (c == '_') || ((kMaskL | kMaskN) >> cat & 1u);
+      if (((pos & P_S) && s) || ((pos & P_D) && d) || ((pos & P_W) && w)) return true;
+      if (((neg & P_S) && !s) || ((neg & P_D) && !d) || ((neg & P_W) && !w)) return true;
     }
     return false;
   };
@@ -142,27 +162,27 @@ struct Regex::Parser {
     }
     return true;
   }
-  bool prop(uint32_t& flags, bool negate) {   // after \p or \P : {L} {N} or single letter
+  // after \p or \P: {Name} or a single letter; Name = a Unicode general category (Lu, Nd, ...) or a one-letter group (L, N, P, S, M, Z, C)
+  bool prop(CharClass& cc, bool negate) {
     std::string name;
     if (more() && p[i] == '{') { i++; while (more() && p[i] != '}') name += (char)p[i++]; if (!more()) return fail("unterminated \\p{"); i++; }
     else if (more()) name += (char)p[i++];
-    uint32_t bit;
-    if (name == "L" || name == "Letter") bit = P_L;
-    else if (name == "N" || name == "Number") bit = P_N;
-    else return fail("unsupported \\p{..} class (L and N are built)");
-    flags |= negate ? (bit << 5) : bit;
+    const uint32_t mask = category_mask(name);
+    if (!mask) return fail("unsupported \\p{..} class (Unicode general categories are built; scripts and binary properties are not)");
+    if (negate) { cc.cat_neg |= mask; cc.cat_neg_list.push_back(mask); } else cc.cat_pos |= mask;
     return true;
   }
   // one escape sequence: either a literal code point (lit) or class property flags
-  bool escape(uint32_t& lit, uint32_t& flags, bool& is_class) {
+  bool escape(uint32_t& lit, CharClass& cc, bool& is_class) {
     if (!more()) return fail("trailing backslash");
     const uint32_t e = p[i++];
+    uint32_t& flags = cc.props;
     is_class = true;
     switch (e) {
       case 's': flags |= P_S; return true;          case 'S': flags |= P_S << 5; return true;
       case 'd': flags |= P_D; return true;          case 'D': flags |= P_D << 5; return true;
       case 'w': flags |= P_W; return true;          case 'W': flags |= P_W << 5; return true;
-      case 'p': return prop(flags, false);          case 'P': return prop(flags, true);
+      case 'p': return prop(cc, false);             case 'P': return prop(cc, true);
       default: break;
     }
     is_class = false;
@@ -190,13 +210,13 @@ struct Regex::Parser {
     while (more() && (p[i] != ']' || first)) {
       first = false;
       uint32_t lo; bool is_class = false;
-      if (p[i] == '\\') { i++; if (!escape(lo, cc.props, is_class)) return false; }
+      if (p[i] == '\\') { i++; if (!escape(lo, cc, is_class)) return false; }
       else lo = p[i++];
       if (is_class) continue;
       uint32_t hi = lo;
       if (i + 1 < p.size() && p[i] == '-' && p[i + 1] != ']') {
         i++;
-        bool c2 = false; uint32_t dummy = 0;
+        bool c2 = false; CharClass dummy;
         if (p[i] == '\\') { i++; if (!escape(hi, dummy, c2)) return false; if (c2) return fail("class escape as range end"); }
         else hi = p[i++];
         if (hi < lo) return fail("reversed range");
@@ -236,10 +256,11 @@ struct Regex::Parser {
     if (c == '$') { out.kind = Node::Eol; return true; }
     if (c == '*' || c == '+' || c == '?') return fail("quantifier without operand");
     if (c == '\\') {
-      uint32_t lit = 0, flags = 0; bool is_class = false;
-      if (!escape(lit, flags, is_class)) return false;
+      uint32_t lit = 0; bool is_class = false;
+      CharClass cc;
+      if (!escape(lit, cc, is_class)) return false;
       if (is_class) {
-        CharClass cc; cc.props = flags; cc.icase = icase;
+        cc.icase = icase;
         out.kind = Node::Class; out.cls = (int)re.classes_.size();
         re.classes_.push_back(std::move(cc));
         return true;

@@ -1,7 +1,8 @@
 // regex.h — a small backtracking regular-expression matcher over Unicode code points, sized for the
 // pre-tokenizer patterns HF tokenizer.json files carry (GPT-2, Llama-3, Qwen2/3 `Split` patterns):
 // alternation, groups `( )`, `(?: )`, `(?i: )`, look-ahead `(?= )` / `(?! )`, classes with ranges and
-// negation, `\p{L}` `\p{N}` `\s` `\d` `\w` (and their negations), quantifiers `? * + {n} {n,} {n,m}`
+// negation, `\p{..}` for every Unicode general category or one-letter group (`\p{L}` `\p{Lu}` `\p{N}` `\p{P}` `\p{S}` `\p{M}` ...),
+// `\s` `\d` `\w` (and their negations), quantifiers `? * + {n} {n,} {n,m}`
 // (greedy or lazy).  Perl semantics: leftmost match, first alternative that leads to a match.
 // The reference wraps PCRE2 for the same job (src/tokenizer/Regex.cpp); only the behaviour at the
 // `matchAll` boundary is reproduced here, validated against the `tokenizers` library (tests/golden/tokenizer).
@@ -36,8 +37,11 @@ class Regex {
   struct CharClass {
     std::vector<ClassItem> items;
     bool negated = false, icase = false;
-    // property flags: bit0 L, bit1 N, bit2 White_Space, bit3 digit, bit4 word; the upper 5 bits are the negated properties
+    // \s \d \w flags (bit2 White_Space, bit3 ASCII digit, bit4 word; the next 5 bits are their negations)
     uint32_t props = 0;
+    // \p{..}: bit mask over the general-category indices of unicode_tables.h; every \P{..} keeps its own mask
+    uint32_t cat_pos = 0, cat_neg = 0;
+    std::vector<uint32_t> cat_neg_list;
     bool matches(uint32_t cp) const;
   };
   enum Op { CHAR, ANY, CLASS, SPLIT, JMP, LOOK, MATCH, BOL, EOL };

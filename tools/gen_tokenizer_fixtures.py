@@ -28,6 +28,11 @@ REF = "/root/reference"
 
 GPT2_PAT = r"""'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"""
 LLAMA3_PAT = r"""(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"""
+O200K_PAT = (r"""[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+(?i:'s|'t|'re|'ve|'m|'ll|'d)?|"""
+             r"""[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*(?i:'s|'t|'re|'ve|'m|'ll|'d)?|"""
+             r"""\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+""")          # GPT-4o style: sub-categories and marks
+DSV3_PAT = (r"""[!"#$%&'()*+,\-./:;<=>?@\[\\\]^_`{|}~][A-Za-z]+|[^\r\n\p{L}\p{P}\p{S}]?[\p{L}\p{M}]+| ?[\p{P}\p{S}]+[\r\n]*|"""
+            r"""\s*[\r\n]+|\s+(?!\S)|\s+""")                                                    # DeepSeek-V3 style: \p{P} \p{S} \p{M}
 QWEN2_PAT = r"""(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"""
 
 TEXTS = [
@@ -37,6 +42,7 @@ TEXTS = [
     "snake_case CamelCase kebab-case 3.14159 1e-9 0xDEADBEEF", "x = y**2 + z[0] // {a: b} <tag attr=\"v\"/> &amp;",
     "don't DON'T we'll WE'LL they're", "a", " ", "  ", "\n", "multiple    spaces     here", "ends with space ",
     "Ünïcödé Ωmega ß straße ǅ ǆ ١٢٣ ४५६ Ⅻ ½", "emoji 👩‍👩‍👧‍👦 family and flags 🇯🇵🇺🇸", "the quick brown fox jumps over the lazy dog " * 8,
+    "HTTPServer2Go parseXMLFile iPhone15Pro e\u0301le\u0300ve ÉCOLE École", "€100 + $5 = ¥? © 2024 — “quoted” … «guillemets» x≠y ∑∫√ ₿ №5 ‰",
 ]
 
 
@@ -127,7 +133,7 @@ def hf_vectors(toks):
 
 def regex_vectors():
     out = []
-    for name, pat in (("gpt2", GPT2_PAT), ("llama3", LLAMA3_PAT), ("qwen2", QWEN2_PAT)):
+    for name, pat in (("gpt2", GPT2_PAT), ("llama3", LLAMA3_PAT), ("qwen2", QWEN2_PAT), ("o200k", O200K_PAT), ("dsv3", DSV3_PAT)):
         rx = regex.compile(pat)
         for t in TEXTS:
             b = t.encode("utf-8")
