@@ -108,3 +108,24 @@ def test_special_token_ids(lib):
     g = HostTokenizer(lib, os.path.join(TOK, "gpt2"))
     assert (g.bos, g.eos, g.pad) == (-1, -1, -1)            # tokenizer_config.json is just {"model_max_length": 1024}
     m.close(); g.close()
+
+
+def test_unicode_normalization_forms(lib):
+    """NFC / NFD / NFKC / NFKD (UnicodeNorm.h; the reference links utf8proc) against Python's unicodedata on composed and
+    decomposed Latin, reordered combining marks, Hangul syllables and jamo, compatibility ligatures / circled / halfwidth /
+    squared forms, singletons (OHM, ANGSTROM, KELVIN) and composition exclusions."""
+    import ctypes
+    import unicodedata as ud
+    lib.tgxe_normalize.restype = ctypes.c_int64
+    lib.tgxe_normalize.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64]
+    texts = ["plain ascii", "café café Å Å Å Ω K", "ạ̇ ạ̇ ḍ̇ q̣̇",
+             "한글 한 가 각", "ﬁ ﬂ ① ㌀ ｶﾞ Ｆｕｌｌ ２０２４ ™ ℃ ½ ⁵ ₂", "क़ ড় གྷ ⫝̸ יִ",
+             "̈́ ̀ ʹ ; · 豈 﨎", "Ünïcödé Ωmega ß straße ǅ ǆ ١٢٣ ४५६ Ⅻ", "́leading mark, 각ᆨ extra jamo",
+             "ệ ệ ệ ệ", "😀👩‍👩‍👧‍👦 🇯🇵", "ﷺ ㌀ ㏿ ᵀ0"]
+    for form_id, form in enumerate(["NFC", "NFD", "NFKC", "NFKD"]):
+        for t in texts:
+            b = t.encode("utf-8")
+            n = lib.tgxe_normalize(form_id, b, len(b), None, 0)
+            out = ctypes.create_string_buffer(max(1, n))
+            lib.tgxe_normalize(form_id, b, len(b), out, n)
+            assert out.raw[:n].decode("utf-8") == ud.normalize(form, t), (form, t)

@@ -150,3 +150,10 @@ TGXE_API int64_t tgxe_regex_match_all(const char* pattern, const char* text, int
   for (int64_t i = 0; i < (int64_t)m.size() && i < cap_pairs; i++) { out[2 * i] = (int64_t)m[(size_t)i].first; out[2 * i + 1] = (int64_t)m[(size_t)i].second; }
   return (int64_t)m.size();
 }
+
+// Unicode normalisation for the normalizer tests: form 0 NFC, 1 NFD, 2 NFKC, 3 NFKD; returns the byte length, copies up to cap
+TGXE_API int64_t tgxe_normalize(int form, const char* text, int64_t len, char* out, int64_t cap) {
+  const std::string r = tgxh::normalize_unicode(std::string(text, (size_t)len), form == 0 || form == 2, form >= 2);
+  if (out && cap > 0) memcpy(out, r.data(), (size_t)((int64_t)r.size() < cap ? (int64_t)r.size() : cap));
+  return (int64_t)r.size();
+}

@@ -79,7 +79,7 @@ bool valid_utf8(const std::string& s) {
   return true;
 }
 
-// ---- Unicode normalisation (canonical): NFD = full decomposition + canonical ordering; NFC = NFD + composition
+// ---- Unicode normalisation: NF(K)D = full (compatibility) decomposition + canonical ordering; NF(K)C = that + composition
 int ccc_of(uint32_t cp) {
   int lo = 0, hi = unidata::kCccCount - 1;
   while (lo <= hi) {
@@ -90,7 +90,16 @@ int ccc_of(uint32_t cp) {
   }
   return 0;
 }
-void decompose(uint32_t cp, std::vector<uint32_t>& out) {
+void decompose(uint32_t cp, std::vector<uint32_t>& out, bool compat) {
+  if (compat) {                          // full NFKD of the code points whose compatibility mapping differs from the canonical one
+    int lo = 0, hi = unidata::kCompatCount - 1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) / 2;
+      if (cp < unidata::kCompat[mid].cp) hi = mid - 1;
+      else if (cp > unidata::kCompat[mid].cp) lo = mid + 1;
+      else { for (int k = 0; k < unidata::kCompat[mid].len; k++) out.push_back(unidata::kCompatData[unidata::kCompat[mid].off + k]); return; }
+    }
+  }
   if (cp >= 0xAC00 && cp <= 0xD7A3) {   // Hangul syllable -> L V (T)
     const uint32_t s = cp - 0xAC00, t = s % 28;
     out.push_back(0x1100 + s / 588); out.push_back(0x1161 + (s % 588) / 28);
@@ -119,12 +128,14 @@ uint32_t compose_pair(uint32_t a, uint32_t b) {
   }
   return 0;
 }
-std::string normalize_canonical(const std::string& text, bool compose) {
-  bool plain = true;
-  for (unsigned char c : text) if (c >= 0xCC) { plain = false; break; }   // below U+0300 nothing decomposes into marks we would reorder...
-  if (plain && compose) return text;                                       // ...and precomposed Latin-1/Extended-A text is already NFC
+}  // namespace
+std::string normalize_unicode(const std::string& text, bool compose, bool compat) {
+  bool ascii = true, plain = true;
+  for (unsigned char c : text) { if (c >= 0x80) ascii = false; if (c >= 0xCC) { plain = false; break; } }
+  if (ascii) return text;                                                  // ASCII is stable under all four forms
+  if (plain && compose && !compat) return text;                            // below U+0300 precomposed text is already NFC
   std::vector<uint32_t> cps;
-  for (size_t i = 0; i < text.size();) { uint32_t cp; i += utf8_decode(text.data() + i, text.size() - i, cp); decompose(cp, cps); }
+  for (size_t i = 0; i < text.size();) { uint32_t cp; i += utf8_decode(text.data() + i, text.size() - i, cp); decompose(cp, cps, compat); }
   for (size_t i = 1; i < cps.size(); i++) {          // canonical ordering: stable sort of each run of non-starters by class
     const int c = ccc_of(cps[i]);
     if (!c) continue;
@@ -152,6 +163,7 @@ std::string normalize_canonical(const std::string& text, bool compose) {
   for (uint32_t cp : cps) utf8_append(res, cp);
   return res;
 }
+namespace {
 
 std::string read_file(const std::string& path, bool& ok) {
   std::ifstream in(path, std::ios::binary);
@@ -203,7 +215,7 @@ void split_by_matches(const std::string& s, const std::vector<Range>& matches, B
 }  // namespace
 
 struct Tokenizer::Step {
-  enum Type { NFC, NFD, ByteLevel, Split, Metaspace, Replace, ByteFallback, Fuse, Strip } type;
+  enum Type { NFC, NFD, NFKC, NFKD, ByteLevel, Split, Metaspace, Replace, ByteFallback, Fuse, Strip } type;
   bool flag_a = false, flag_b = false;           // ByteLevel: add_prefix_space, use_regex; Metaspace: split
   std::shared_ptr<Regex> regex;                  // Split / ByteLevel(use_regex)
   std::string str_a, str_b;                      // Split: literal pattern; Metaspace: replacement, scheme; Replace: from, to; Strip: content
@@ -231,6 +243,8 @@ bool Tokenizer::parseSteps(const void* jv, std::vector<Step>& out, const char* w
   Step s;
   if (type == "NFC") s.type = Step::NFC;
   else if (type == "NFD") s.type = Step::NFD;
+  else if (type == "NFKC") s.type = Step::NFKC;
+  else if (type == "NFKD") s.type = Step::NFKD;
   else if (type == "ByteLevel") {
     s.type = Step::ByteLevel;
     s.flag_a = j.get_bool("add_prefix_space", false);
@@ -365,7 +379,7 @@ bool Tokenizer::initWithConfig(const std::string& tokenizerPath, const std::stri
   if (const Json* p = j.get("pre_tokenizer")) if (!parseSteps(p, preTokenizer_, "pre_tokenizer")) return false;
   if (const Json* p = j.get("post_processor")) if (!parseSteps(p, post_unused, "post_processor")) return false;
   if (const Json* d = j.get("decoder")) if (!parseSteps(d, decoder_, "decoder")) return false;
-  for (const Step& s : normalizer_) if (s.type != Step::NFC && s.type != Step::NFD) return fail("normalizer: only NFC / NFD are supported");
+  for (const Step& s : normalizer_) if (s.type > Step::NFKD) return fail("normalizer: only NFC / NFD / NFKC / NFKD are supported");
 
   // tokenizer_config.json (TokenizerConfig.cpp:343-371): a token is either a string or an AddedToken object
   auto token_of = [&](const char* key) -> std::string {
@@ -465,7 +479,7 @@ void Tokenizer::bpe(const std::string& piece, std::vector<int32_t>& out) const {
 // normalizer -> pre-tokenizer -> model -> template (Tokenizer.cpp:306-321)
 std::vector<int32_t> Tokenizer::encodeWithModel(const std::string& text) const {
   std::string norm = text;
-  for (const Step& s : normalizer_) norm = normalize_canonical(norm, s.type == Step::NFC);
+  for (const Step& s : normalizer_) norm = normalize_unicode(norm, s.type == Step::NFC || s.type == Step::NFKC, s.type == Step::NFKC || s.type == Step::NFKD);
   std::vector<std::string> pieces{norm};
   for (const Step& s : preTokenizer_) {
     std::vector<std::string> next;

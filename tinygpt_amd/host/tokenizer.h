@@ -3,7 +3,7 @@
 // observable behaviour on the reference's golden vectors (test/test_tokenizer.cpp:86-262).
 //
 // Supported tokenizer.json components (the set the reference builds, TokenizerConfig.cpp:27-40):
-//   normalizer     NFC / NFD (NFKC / NFKD are refused), Sequence
+//   normalizer     NFC / NFD / NFKC / NFKD (generated Unicode tables), Sequence
 //   pre_tokenizer  ByteLevel, Split (regex or string pattern, all five delimiter behaviours), Metaspace, Sequence
 //   model          BPE (vocab + merges, ignore_merges, byte_fallback <0xXX> tokens)
 //   post_processor TemplateProcessing (single sequence), ByteLevel (no-op), Sequence
@@ -21,6 +21,9 @@
 #include "regex.h"
 
 namespace tgxh {
+
+// Unicode normalisation forms (UnicodeNorm.h: NFC / NFD / NFKC / NFKD components)
+std::string normalize_unicode(const std::string& text, bool compose, bool compat);
 
 class Tokenizer {
  public:
