@@ -1,0 +1,28 @@
+"""The oracle at the REAL Llama-3.2-1B geometry (1.24 B parameters, vocabulary 128 256, llama3 RoPE scaling 32 / 8192) against
+HF transformers fp32 (tools/gen_fullsize_fixture.py): top-64 logits and 64 probe logits of a 12-token prompt and 3 forced
+steps.  ~25 s on 8 cores (2.5 GB of synthetic bf16 weights widened to fp32 inside the oracle)."""
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+from tinygpt_amd import known_desc
+
+
+def test_oracle_matches_hf_at_full_llama_3_2_1b_geometry(oracle_lib):
+    from oracle.oracle_ffi import OracleModel
+    g = np.load(os.path.join(GOLDEN, "llama_3_2_1b_full", "golden.npz"))
+    d = known_desc("llama-3.2-1b", "fp32")
+    d.max_ctx = 64                                     # KV capacity only
+    m = OracleModel(d).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
+    m.forward(g["prompt"])
+    for step in range(4):
+        l = m.logits(rounded=False)[0]
+        scale = float(np.abs(g["top_v"][step]).max())
+        assert np.abs(l[g["top_i"][step]] - g["top_v"][step]).max() < 1e-4 * scale, step
+        assert np.abs(l[g["probe"]] - g["probe_v"][step]).max() < 1e-4 * scale, step
+        assert int(np.argmax(l)) == int(g["top_i"][step][0])
+        if step == 3:
+            break
+        m.forward(np.array([[int(g["forced"][step])]], dtype=np.int64))
+    m.close()
