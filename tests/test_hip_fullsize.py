@@ -87,15 +87,16 @@ def test_full_size_sharded_checkpoint_through_cpp_engine(tmp_path):
     np.testing.assert_array_equal(ids[0, 40:], want)
 
 
-def test_llama_3_2_1b_full_size_vs_hf_golden():
+@pytest.mark.parametrize("key,fixture", [("llama-3.2-1b", "llama_3_2_1b_full"), ("qwen2.5-0.5b", "qwen2_5_0_5b_full")])
+def test_full_size_vs_hf_golden(key, fixture):
     """The HIP path at the real Llama-3.2-1B geometry against HF transformers fp32 (tests/golden/llama_3_2_1b_full, produced by
     tools/gen_fullsize_fixture.py): bf16 storage differs from HF-fp32 only by the KV rounding (bound 2e-2, as on the fixtures);
     fp32 storage must sit on it (1e-4).  The weights are the synthetic bf16 checkpoint in both."""
     import os
     from conftest import GOLDEN
-    g = np.load(os.path.join(GOLDEN, "llama_3_2_1b_full", "golden.npz"))
+    g = np.load(os.path.join(GOLDEN, fixture, "golden.npz"))
     for dtype, tol in (("bf16", 2e-2), ("fp32", 1e-4)):
-        d = known_desc("llama-3.2-1b", dtype)
+        d = known_desc(key, dtype)
         d.max_ctx = 64
         m = Model(d, product_backend()).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
         m.forward(g["prompt"])

@@ -4,15 +4,18 @@ steps.  ~25 s on 8 cores (2.5 GB of synthetic bf16 weights widened to fp32 insid
 import os
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN
 from tinygpt_amd import known_desc
 
 
-def test_oracle_matches_hf_at_full_llama_3_2_1b_geometry(oracle_lib):
+@pytest.mark.parametrize("key,fixture", [("llama-3.2-1b", "llama_3_2_1b_full"), ("qwen2.5-0.5b", "qwen2_5_0_5b_full")])
+def test_oracle_matches_hf_at_full_geometry(key, fixture, oracle_lib):
+    """Also Qwen2.5-0.5B (QKV bias, 14 / 2 heads, theta 1e6, V = 151 936, tied head) at its real size."""
     from oracle.oracle_ffi import OracleModel
-    g = np.load(os.path.join(GOLDEN, "llama_3_2_1b_full", "golden.npz"))
-    d = known_desc("llama-3.2-1b", "fp32")
+    g = np.load(os.path.join(GOLDEN, fixture, "golden.npz"))
+    d = known_desc(key, "fp32")
     d.max_ctx = 64                                     # KV capacity only
     m = OracleModel(d).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
     m.forward(g["prompt"])

@@ -14,18 +14,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tinygpt_amd import synth  # noqa: E402
 from tinygpt_amd.desc import KNOWN_CONFIGS, desc_from_hf_config  # noqa: E402
-from transformers import LlamaConfig, LlamaForCausalLM  # noqa: E402
+from transformers import LlamaConfig, LlamaForCausalLM, Qwen2Config, Qwen2ForCausalLM  # noqa: E402
 
 SEED, STD = 1234, 0.02
 
 
-def main():
-    cfg = dict(KNOWN_CONFIGS["llama-3.2-1b"])
+MODELS = {"llama-3.2-1b": (LlamaConfig, LlamaForCausalLM, "llama_3_2_1b_full"), "qwen2.5-0.5b": (Qwen2Config, Qwen2ForCausalLM, "qwen2_5_0_5b_full")}
+
+
+def main(key="llama-3.2-1b"):
+    ccls, mcls, out_name = MODELS[key]
+    cfg = dict(KNOWN_CONFIGS[key])
     desc = desc_from_hf_config(cfg, "fp32")
     kw = {k: v for k, v in cfg.items() if k not in ("model_type", "torch_dtype", "_name_or_path")}
     torch.set_num_threads(8)
     with torch.device("meta"):
-        model = LlamaForCausalLM(LlamaConfig(**kw, attn_implementation="eager"))
+        model = mcls(ccls(**kw, attn_implementation="eager"))
     model = model.to_empty(device="cpu").eval()
     sd = {}
     for name, bits in synth.synth_checkpoint(desc, SEED, STD):
@@ -34,8 +38,7 @@ def main():
     assert not unexpected and all(m.endswith("lm_head.weight") for m in missing), (missing, unexpected)
     model.tie_weights()
     # rotary inv_freq is a non-persistent buffer: rebuild it (to_empty left it uninitialised)
-    from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
-    model.model.rotary_emb = LlamaRotaryEmbedding(config=model.config)
+    model.model.rotary_emb = type(model.model.rotary_emb)(config=model.config)
     prompt = synth.synth_prompt(desc.vocab, 12, SEED)[None, :]
     rng = np.random.default_rng(7)
     probe = np.sort(rng.choice(desc.vocab, 64, replace=False)).astype(np.int64)
@@ -53,7 +56,7 @@ def main():
             forced.append(tok)
             out = model(torch.tensor([[tok]]), past_key_values=pkv, use_cache=True)
             pkv = out.past_key_values
-    d = os.path.join(ROOT, "tests", "golden", "llama_3_2_1b_full")
+    d = os.path.join(ROOT, "tests", "golden", out_name)
     os.makedirs(d, exist_ok=True)
     np.savez_compressed(os.path.join(d, "golden.npz"), prompt=prompt, forced=np.int64(forced), top_v=np.float32(top_v), top_i=np.int64(top_i),
                         probe=probe, probe_v=np.float32(probe_v), seed=np.int64(SEED), std=np.float32(STD))
@@ -61,4 +64,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    for k in (sys.argv[1:] or list(MODELS)):
+        main(k)
