@@ -202,9 +202,13 @@ TGX_API int tgx_read_probs(tgx_ctx* ctx, float* out);
  * exercised on its own (the reference's Sampler takes any [B,V] tensor, Sampler.h:30). */
 TGX_API int tgx_set_logits(tgx_ctx* ctx, const float* logits, int batch);
 
-/* Launch-geometry knobs for tuning sweeps (never change results): "<class>.ks" (waves sharing a row pair's K
- * range: 1/2/4), "<class>.bpc" (grid cap, workgroups per CU) with class in {qkv,oproj,gateup,down,lmhead};
- * "attn.nsplit" and "lmhead.bpc" only before tgx_finalize; "graph" 0/1 (hipGraph replay vs eager launches). */
+/* Launch-geometry knobs for tuning sweeps (results stay within the parity tolerances; summation order may change):
+ *   "<class>.ks"   waves sharing a row pair's K range (1/2/4), class in {qkv,oproj,gateup,down,lmhead}
+ *   "<class>.bpc"  grid cap in workgroups per CU ("lmhead.bpc" only before tgx_finalize)
+ *   "attn.nsplit"  KV splits per kv head (<= 32, before tgx_finalize); "attn.gmax" query heads per attention workgroup
+ *   "graph" 0/1    hipGraph replay vs eager launches; "graph.steps" decode steps per graph for long tgx_decode calls
+ *   "prefill.mfma" 0/1  batched matrix-core prefill vs passes through the decode kernels; "prefill.gemm_tm" 64/128 row tile
+ *   "debug.*"      experiment switches (tools/*_dissect.py; live only in a -DTGX_DISSECT=1 build) */
 TGX_API int tgx_set_option(tgx_ctx* ctx, const char* key, int value);
 
 /* Algorithmic HBM bytes one decoded token streams at context length T (SURVEY.md §8d formula). */
