@@ -208,7 +208,7 @@ TGX_API int tgx_set_logits(tgx_ctx* ctx, const float* logits, int batch);
  *   "attn.nsplit"  KV splits per kv head (<= 32, before tgx_finalize); "attn.gmax" query heads per attention workgroup
  *   "graph" 0/1    hipGraph replay vs eager launches; "graph.steps" decode steps per graph for long tgx_decode calls
  *   "prefill.mfma" 0/1  batched matrix-core prefill vs passes through the decode kernels; "prefill.gemm_tm" 64/128 row tile
- *   "debug.*"      experiment switches (tools/*_dissect.py; live only in a -DTGX_DISSECT=1 build) */
+ *   "debug.*"      experiment switches (tools/gemv_dissect.py, tools/attn_dissect.py; live only in a -DTGX_DISSECT=1 build) */
 TGX_API int tgx_set_option(tgx_ctx* ctx, const char* key, int value);
 
 /* Algorithmic HBM bytes one decoded token streams at context length T (SURVEY.md §8d formula). */

@@ -35,7 +35,9 @@ struct Backend {
   const char* (*last_error)(const tgx_ctx*) = nullptr;
 
   bool open(const std::string& path, const std::string& prefix) {
-    handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    // RTLD_NODELETE: the shim's runtime owns threads (HIP's signal/event workers; libgomp's team under the CPU oracle) that
+    // outlive the last context, so dlclose() must drop the handle without unmapping their code.
+    handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_NODELETE);
     if (!handle) { error = std::string("dlopen failed: ") + dlerror(); return false; }
     bool ok = true;
     auto sym = [&](const char* name, bool required) -> void* {
