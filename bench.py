@@ -86,7 +86,7 @@ def cpu_baseline(desc, tensors, seconds):
     cores_used = best_n
     m.close()
     return {"value": round(n / dt, 3), "unit": "tokens/s", "cores": cores_used, "host_cores": cores, "kind": "port",
-            "sample": f"oracle/liboracle.so (C+OpenMP restatement), same synthetic {desc.name or 'model'} bf16, "
+            "sample": f"oracle/liboracle.so (C+OpenMP restatement), same synthetic {desc.name or 'model'} {desc.compute_dtype}, "
                       f"16-token prompt, {n} greedy decode tokens at the best OpenMP team size ({cores_used} of {cores} host threads), context ~30..{30 + n}"}
 
 
@@ -165,18 +165,19 @@ def main():
 
     prof = model.profile_decode(args.profile_reps)
     n_gu, ms_gu = prof["gateup"]
-    gu_bytes = (4 if args.dtype == "fp32" else 2) * (2 * desc.inter) * desc.hidden
+    gu_bytes = (4 if args.dtype == "fp32" else 2) * ((1 if desc.family == "gpt2" else 2) * desc.inter) * desc.hidden   # GPT-2: c_fc alone
     gu_us = ms_gu / n_gu * 1e3
     achieved = gu_bytes / (gu_us * 1e-6) / 1e9
     classes = {k: round(ms / n * 1e3, 3) for k, (n, ms) in prof.items() if n}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     traffic = None
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and desc.family == "llama" and desc.hidden == 2048 and desc.inter == 8192 and args.dtype == "bf16":   # measured for this launch only
         try:
             traffic = json.load(open(pmc_path)).get("gateup_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "gemv_kernel<PRO_RMSNORM,EPI_SILU_MUL> (gate_up)", "achieved": round(achieved, 1),
+    kname = "gemv_kernel<PRO_LAYERNORM,EPI_GELU> (ln_2 + c_fc + gelu)" if desc.family == "gpt2" else "gemv_kernel<PRO_RMSNORM,EPI_SILU_MUL> (gate_up)"
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": gu_bytes, "avg_launch_us": round(gu_us, 3),
                 "kernel_classes_avg_us": classes,
@@ -192,7 +193,7 @@ def main():
 
     # batched prefill (MFMA): algorithmic flops of the S x H·W^T products (one bf16 pass; the kernel issues two, hi and lo)
     L, H, I = desc.layers, desc.hidden, desc.inter
-    gemm_flops = 2.0 * args.prompt * L * ((desc.q_dim + 2 * desc.kv_dim) * H + H * desc.q_dim + 3 * I * H)
+    gemm_flops = 2.0 * args.prompt * L * ((desc.q_dim + 2 * desc.kv_dim) * H + H * desc.q_dim + (2 if desc.family == "gpt2" else 3) * I * H)
     attn_flops = 4.0 * L * desc.heads * desc.head_dim * args.prompt * (args.prompt + 1) / 2.0
     prefill_tflops = (gemm_flops + attn_flops) / (prefill_ms * 1e-3) / 1e12
 

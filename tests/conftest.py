@@ -14,8 +14,9 @@ if ROOT not in sys.path:
 os.environ.setdefault("OMP_NUM_THREADS", "8")
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-FAMILIES = ["llama_tiny", "qwen2_tiny", "mistral_tiny", "qwen3_tiny", "gpt2_tiny"]
-GPU_FAMILIES = ["llama_tiny", "qwen2_tiny", "mistral_tiny", "qwen3_tiny"]     # GPT-2 is the CPU-only plumbing config
+FAMILIES = ["llama_tiny", "qwen2_tiny", "mistral_tiny", "qwen3_tiny", "gpt2_tiny", "gpt2_hd64"]
+# gpt2_tiny (head_dim 32) stays an oracle-only fixture; gpt2_hd64 has the head_dim of every released GPT-2 size
+GPU_FAMILIES = ["llama_tiny", "qwen2_tiny", "mistral_tiny", "qwen3_tiny", "gpt2_hd64"]
 
 
 def pytest_configure(config):

@@ -40,6 +40,43 @@ def test_llama_3_2_1b_full_size_vs_oracle(oracle_lib):
     assert gpu.past_length == ref.past_length == 48 + 5
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gpt2_124m_full_size_vs_oracle(dtype, oracle_lib):
+    """BASELINE.json configs[0] (GPT-2 124M: LayerNorm, Conv1D + bias, gelu_new, learned positions, tied head) at full size on
+    the GPU, teacher-forced against the oracle: the reference's CPU case (fp32) and the CLI's default dtype (bf16); a batch of
+    the CLI's shape (4 rows, left-padded with id 0, no mask)."""
+    from oracle.oracle_ffi import OracleModel
+    d = known_desc("gpt2", dtype)
+    d.max_batch = 4
+    tensors = list(synth.synth_checkpoint(d, 1234, 0.02))
+    gpu, ref = Model(d, product_backend()), OracleModel(d)
+    for name, bits in tensors:
+        gpu.upload(name, bits); ref.upload(name, bits)
+    gpu.finalize(); ref.finalize()
+    rows = []
+    for r, ln in enumerate([5, 7, 5, 5]):
+        rows.append(np.concatenate([np.zeros(7 - ln, np.int64), synth.synth_prompt(d.vocab - 1, ln, 1234 + r) + 1]))
+    prompt = np.stack(rows)
+    gpu.forward(prompt); ref.forward(prompt)
+    for step in range(6):
+        lg, lr = gpu.logits(rounded=False), ref.logits(rounded=False)
+        assert rel_err(lg, lr) < 1e-3, (step, rel_err(lg, lr))
+        tok_ref = ref.sample(GREEDY)
+        tok_gpu = gpu.sample(GREEDY)
+        for b in range(4):
+            top2 = np.sort(lr[b])[-2:]
+            if (top2[1] - top2[0]) > 2e-3 * np.abs(lr).max():
+                assert tok_gpu[b] == tok_ref[b], (step, b)
+        gpu.forward(tok_ref[:, None]); ref.forward(tok_ref[:, None])
+    assert gpu.past_length == ref.past_length == 7 + 6
+    assert gpu.bytes_per_token(0) == d.bytes_per_token(0, 4 if dtype == "fp32" else 2)
+    # free-running decode to the end of the 1024-entry context: the last step reads wpe[1023], the next one is refused
+    gpu.reset_cache(); gpu.forward(synth.synth_prompt(d.vocab, 1000, 5)[None, :]); gpu.sample(GREEDY)
+    assert gpu.decode(24, GREEDY).shape == (24, 1) and gpu.past_length == 1024
+    with pytest.raises(Exception, match="context size"):
+        gpu.decode(1, GREEDY)
+
+
 @pytest.mark.parametrize("name", ["qwen2.5-0.5b", "llama-3.2-3b", "mistral-7b-v0.3"])
 def test_other_baseline_geometries_decode_properties(name):
     """Real layer geometry of the other BASELINE configs (4 layers, 8k vocabulary to bound upload time):

@@ -30,6 +30,24 @@ def test_engine_on_mi355x_matches_hf_ids(tmp_path, fam, shards):
     e.close()
 
 
+@pytest.mark.parametrize("dtype,key", [(0, "ids_fp32"), (1, "ids_bf16")])
+def test_gpt2_left_padded_batch_of_four_on_mi355x(tmp_path, dtype, key):
+    """BASELINE.json configs[0] semantics on the GPU: GPT-2 checkpoint in the hub layout (Conv1D [in][out] weights, fp32 file),
+    the CLI's 4 prompts of lengths 5/7/5/5 left-padded with id 0 and run WITHOUT a mask (GPTEngine.cpp:95,130-138);
+    ids == HF's on the padded batch, for --dtype fp32 (the reference's CPU case) and bf16 (its CLI default)."""
+    cfg, g = load_golden("gpt2_hd64")
+    write_model_dir(str(tmp_path), cfg, int(g["seed"]), float(g["std"]), dtype="fp32")
+    e = HostEngine(host_lib(), model_dir=str(tmp_path), device="mi355x", dtype=dtype, max_batch=4)
+    assert e.prepare(), e.error()
+    prompts = [row[np.argmax(row != 0):] for row in g["prompt"]]
+    assert [len(p) for p in prompts] == [5, 7, 5, 5]
+    e.reconfigure(max_new=g[key].shape[1])
+    ids, new, fin = e.generate_sync(prompts, pad=0)
+    np.testing.assert_array_equal(ids[:, :7], g["prompt"])
+    np.testing.assert_array_equal(ids[:, 7:], g[key])
+    e.close()
+
+
 def test_cli_runs_batch_of_four(tmp_path):
     """tgx_cli with the reference's flags on a 4-row batch (left-padded, no mask), greedy: rows equal the engine's."""
     cfg, g = load_golden("qwen2_tiny")
@@ -40,6 +58,18 @@ def test_cli_runs_batch_of_four(tmp_path):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert out.stdout.count("Output ids:") == 4 and "speed:" in out.stdout and "token/s" in out.stdout
+
+
+def test_cli_baseline_config0_gpt2_on_gpu():
+    """BASELINE.json configs[0] through the harness: GPT-2 124M geometry, fp32, the CLI's four prompts as gpt2 ids left-padded to 7,
+    greedy, 32 new tokens (main.cpp:12-17,33-37) — on the GPU instead of the reference's CPU device."""
+    _, cli = build.build_host()
+    out = subprocess.run([cli, "--synthetic", "gpt2", "--device", "mi355x", "--dtype", "fp32", "--max-tokens", "32", "--temperature", "0", "--top-p", "1"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.count("Output ids:") == 4 and "Prompt ids: 0 0 464 3139 286 4881 318" in out.stdout and "token/s" in out.stdout
+    rows = [l.split(":")[1].split() for l in out.stdout.splitlines() if l.startswith("Output ids:")]
+    assert all(len(r) == 32 for r in rows)
 
 
 def test_cli_text_prompts_on_gpu(tmp_path, oracle_lib):

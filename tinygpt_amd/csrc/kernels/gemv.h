@@ -27,8 +27,8 @@
 
 namespace tgx {
 
-enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
-enum { EPI_QKV_ROPE = 0, EPI_RESIDUAL = 1, EPI_SILU_MUL = 2, EPI_LOGITS = 3 };
+enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_LAYERNORM = 2 };   // LAYERNORM: GPT-2's nn::LayerNorm with bias (ModelGPT2.h:120-135)
+enum { EPI_QKV_ROPE = 0, EPI_RESIDUAL = 1, EPI_SILU_MUL = 2, EPI_LOGITS = 3, EPI_GELU = 4 };   // GELU: GPT-2's c_fc -> gelu (ModelGPT2.h:96-107)
 
 // Batch rows: R rows (1, 2 or 4) of independent sequences share ONE pass over the weights — every weight slice that
 // lands in a register is multiplied into R activation vectors (the reference runs the whole batch through each
@@ -37,7 +37,8 @@ struct GemvArgs {
   const void* W;          // [N][K] row-major (torch Linear layout), elements of the storage dtype (kernel template DT)
   const void* bias;       // [N] or nullptr
   const float* x;         // [R][x_stride] input activations (fp32 between ops)
-  const void* norm_w;     // [K] RMSNorm weight (PRO_RMSNORM)
+  const void* norm_w;     // [K] RMSNorm / LayerNorm weight
+  const void* norm_b;     // [K] LayerNorm bias (PRO_LAYERNORM)
   float eps;
   int N, K;
   int units;              // number of row pairs
@@ -54,13 +55,18 @@ struct GemvArgs {
   int heads, kv_heads, hd, max_ctx;
   int raw_qk;             // Qwen3 (q/k RMSNorm before RoPE): emit un-rotated q and k, qk_norm_rope_kernel finishes them
   float* k_raw;           // [R][kv_heads*hd] fp32 staging for k when raw_qk
-  // EPI_RESIDUAL: out[n] += acc;  EPI_SILU_MUL: out[i] = silu(g) * u      (fp32)
+  // EPI_RESIDUAL: out[n] += acc;  EPI_SILU_MUL: out[i] = silu(g) * u;  EPI_GELU: out[n] = gelu_new(acc)      (fp32)
   float* out;
   // EPI_LOGITS
   float* logits;          // [R][N] fp32
   float* part_val;        // [R][gridDim.x] best logit of this workgroup
   int* part_idx;
 };
+
+// HF "gelu_new" (GPT-2's activation_function): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__device__ __forceinline__ float gelu_new(float x) {
+  return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
 
 template <int EPI>
 __device__ __forceinline__ void unit_rows(const GemvArgs& a, int u, int& ra, int& rb, bool& rb_valid) {
@@ -135,6 +141,64 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       for (int t = 0; t < 4; t++) { xr[r][j][t] = v0[t]; xr[r][j][4 + t] = v1[t]; }
     }
   }
+  // sum of one value per batch row over the KS waves that share a unit, in wave order (every wave of the workgroup takes part)
+  auto ks_sum = [&](float* v) {
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; r++) ps[wv][r] = v[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      float t = ps[slot * KS][r];
+      for (int k = 1; k < KS; k++) t += ps[slot * KS + k][r];
+      v[r] = t;
+    }
+    __syncthreads();               // ps is reused (second statistic, unit loop)
+  };
+  if (PRO == PRO_LAYERNORM) {   // torch LayerNorm: ((x - mean) * rsqrt(var + eps)) * weight + bias, biased variance, two passes
+    const E* wg = static_cast<const E*>(a.norm_w);
+    const E* bg = static_cast<const E*>(a.norm_b);
+    Slice8<DT> nw[NX], nbias[NX];
+#pragma unroll
+    for (int j = 0; j < NX; j++) { nw[j] = load_slice<DT>(wg, cidx[j]); nbias[j] = load_slice<DT>(bg, cidx[j]); }
+    float st[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      float sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < NX; j++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) sm += xr[r][j][t];       // lanes outside the range hold zeros
+      st[r] = wave_sum(sm);
+    }
+    if (KS > 1) ks_sum(st);
+    float mean[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      mean[r] = st[r] / (float)a.K;
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < NX; j++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) { const float dlt = cok[j] ? xr[r][j][t] - mean[r] : 0.f; sq = fmaf(dlt, dlt, sq); }
+      st[r] = wave_sum(sq);
+    }
+    if (KS > 1) ks_sum(st);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const float inv = 1.0f / sqrtf(st[r] / (float)a.K + a.eps);
+#pragma unroll
+      for (int j = 0; j < NX; j++) {
+        float w[8], bb[8];
+        slice_unpack<DT>(nw[j], w);
+        slice_unpack<DT>(nbias[j], bb);
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+          xr[r][j][t] = cok[j] ? __fadd_rn(__fmul_rn(__fmul_rn(xr[r][j][t] - mean[r], inv), w[t]), bb[t]) : 0.f;
+      }
+    }
+  }
   if (PRO == PRO_RMSNORM && !(TGX_DBG(a, 1))) {   // HF order: weight * (x * rsqrt(mean(x^2)+eps)).  KS == 1: the wave holds all of x;
     // KS > 1 (batch rows at hidden sizes whose R x NX slices would not fit one wave): the KS waves of a unit exchange their
     // partial sums of squares through LDS once, before the weight loop (every wave of the workgroup takes part)
@@ -152,20 +216,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
         for (int t = 0; t < 8; t++) ss = fmaf(xr[r][j][t], xr[r][j][t], ss);
       ssq[r] = wave_sum(ss);
     }
-    if (KS > 1) {
-      if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < R; r++) ps[wv][r] = ssq[r];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        float t = ps[slot * KS][r];
-        for (int k = 1; k < KS; k++) t += ps[slot * KS + k][r];
-        ssq[r] = t;
-      }
-      __syncthreads();             // ps is reused by the unit loop
-    }
+    if (KS > 1) ks_sum(ssq);
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const float inv = 1.0f / sqrtf(ssq[r] / (float)a.K + a.eps);
@@ -285,6 +336,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
           if (rb_valid) o[rb] = e1[r] + vb;
         } else if (EPI == EPI_SILU_MUL) {
           a.out[(size_t)r * a.out_stride + u] = (va / (1.0f + expf(-va))) * vb;
+        } else if (EPI == EPI_GELU) {
+          float* o = a.out + (size_t)r * a.out_stride;
+          o[ra] = gelu_new(va);
+          if (rb_valid) o[rb] = gelu_new(vb);
         }
       }
     }
@@ -356,13 +411,21 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const QkNormArgs a) {
 // step's embedding row (nn::Embedding, GPTModel.h:52) into the residual stream so the decode graph needs
 // no host input between steps.
 // nn::Embedding row gather: table row `t` (storage dtype) -> fp32 residual stream
+// GPT-2 adds the learned position row: wte(ids) + wpe(arange(past, past + S))  (ModelGPT2.h:165-169)
 template <int DT>
-__device__ __forceinline__ void gather_embedding(const void* table, long long t, float* x, int H) {
+__device__ __forceinline__ void gather_embedding(const void* table, long long t, float* x, int H, const void* wpe = nullptr, int p = 0) {
   const elem_t<DT>* row = static_cast<const elem_t<DT>*>(table) + (size_t)t * H;
+  const elem_t<DT>* prow = static_cast<const elem_t<DT>*>(wpe) + (size_t)p * H;
   f32x4* dst = reinterpret_cast<f32x4*>(x);
   for (int c = threadIdx.x; c < (H >> 3); c += blockDim.x) {
     float f[8];
     slice_unpack<DT>(load_slice<DT>(row, c), f);
+    if (wpe) {
+      float g[8];
+      slice_unpack<DT>(load_slice<DT>(prow, c), g);
+#pragma unroll
+      for (int k = 0; k < 8; k++) f[k] += g[k];
+    }
     dst[2 * c] = f32x4{f[0], f[1], f[2], f[3]};
     dst[2 * c + 1] = f32x4{f[4], f[5], f[6], f[7]};
   }
@@ -385,13 +448,15 @@ struct FinalizeArgs {
   float* x;              // [H] residual stream of this row (fp32)
   int H, V;
   int advance_pos;       // 1: pos += 1 (the token just consumed is now in the cache)
+  const void* wpe;       // GPT-2: [n_pos][H] learned positions (nullptr otherwise); the next token sits at the advanced pos
+  int n_pos;
 };
 
 template <int DT>
 __global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs a) {
   __shared__ float sv[256];
   __shared__ int si[256];
-  __shared__ int s_tok;
+  __shared__ int s_tok, s_pos;
   float bv = -INFINITY; int bi = 0x7fffffff;
   for (int i = threadIdx.x; i < a.n_part; i += 256) {
     const float v = a.part_val[i]; const int ix = a.part_idx[i];
@@ -410,7 +475,9 @@ __global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs
     const int t = (unsigned)si[0] < (unsigned)a.V ? si[0] : 0;   // all-NaN logits leave the sentinel index: never gather out of the table
     s_tok = t;
     *a.tok = t;
-    if (a.advance_pos) *a.pos = *a.pos + 1;
+    const int np = *a.pos + (a.advance_pos ? 1 : 0);
+    if (a.advance_pos) *a.pos = np;
+    s_pos = np < a.n_pos ? np : a.n_pos - 1;    // a full context takes no further step: stay inside wpe
     if (a.log) {
       const int st = *a.step;
       a.tok_log[(st % a.log_cap) * a.rows + a.row] = t;
@@ -419,7 +486,7 @@ __global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs
     }
   }
   __syncthreads();
-  gather_embedding<DT>(a.embed, s_tok, a.x, a.H);
+  gather_embedding<DT>(a.embed, s_tok, a.x, a.H, a.wpe, a.wpe ? s_pos : 0);
 }
 
 // Prefill-by-steps: chunk row r <- embedding of prompt token r, position pos0 + r (one workgroup per chunk row).
@@ -429,12 +496,13 @@ struct EmbedChunkArgs {
   float* x;              // [R][H] chunk residual streams
   int* pos;              // [R] chunk positions
   int H, pos0;
+  const void* wpe;       // GPT-2 learned positions or nullptr
 };
 template <int DT>
 __global__ __launch_bounds__(256) void embed_chunk_kernel(const EmbedChunkArgs a) {
   const int r = blockIdx.x;
   if (threadIdx.x == 0) a.pos[r] = a.pos0 + r;
-  gather_embedding<DT>(a.embed, a.ids[r], a.x + (size_t)r * a.H, a.H);
+  gather_embedding<DT>(a.embed, a.ids[r], a.x + (size_t)r * a.H, a.H, a.wpe, a.pos0 + r);
 }
 
 __global__ void advance_pos_kernel(int* pos) { if (threadIdx.x == 0) *pos = *pos + 1; }

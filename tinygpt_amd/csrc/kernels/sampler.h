@@ -387,7 +387,7 @@ template <int DT>
 __global__ __launch_bounds__(SAMP_WG) void samp_pick_kernel(const SampPickArgs pa) {
   __shared__ float shf[4];
   __shared__ double shd[4];
-  __shared__ int s_wg, s_pick, s_last;
+  __shared__ int s_wg, s_pick, s_last, s_pos;
   __shared__ double s_run;
   const SampArgs& a = pa.s;
   const int row = pa.fin.row, tid = threadIdx.x, nwg = pa.nwg;
@@ -454,7 +454,9 @@ __global__ __launch_bounds__(SAMP_WG) void samp_pick_kernel(const SampPickArgs p
     if ((unsigned)pick >= (unsigned)a.V) pick = 0;       // all-NaN logits: stay inside the embedding table
     s_pick = pick;
     *pa.fin.tok = pick;
-    if (pa.fin.advance_pos) *pa.fin.pos = *pa.fin.pos + 1;
+    const int np = *pa.fin.pos + (pa.fin.advance_pos ? 1 : 0);
+    if (pa.fin.advance_pos) *pa.fin.pos = np;
+    s_pos = np < pa.fin.n_pos ? np : pa.fin.n_pos - 1;
     if (pa.fin.log) {
       const int st = *pa.fin.step;
       pa.fin.tok_log[(st % pa.fin.log_cap) * pa.fin.rows + pa.fin.row] = pick;
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(SAMP_WG) void samp_pick_kernel(const SampPickArgs p
     }
   }
   __syncthreads();
-  gather_embedding<DT>(pa.fin.embed, s_pick, pa.fin.x, pa.fin.H);
+  gather_embedding<DT>(pa.fin.embed, s_pick, pa.fin.x, pa.fin.H, pa.fin.wpe, pa.fin.wpe ? s_pos : 0);
 }
 
 }  // namespace tgx

@@ -38,6 +38,9 @@ struct LayerW {
   int64_t qkv_rows = 0, gu_rows = 0;
   bool in_norm_ok = false, post_norm_ok = false, wo_ok = false, wdown_ok = false;
   int64_t bias_rows = 0;
+  // GPT-2 (ModelGPT2.h:23-135): LayerNorm biases and a bias on every Conv1D; wgu holds c_fc [inter][hidden]
+  ebyte *in_norm_b = nullptr, *post_norm_b = nullptr, *bo = nullptr, *bfc = nullptr, *bdown = nullptr;
+  int gpt2_filled = 0;      // bit per GPT-2 tensor of the layer (12 of them)
 };
 
 struct RowState {       // independent KV/sequence state of one batch row
@@ -78,7 +81,9 @@ struct tgx_ctx {
   int dt = tgx::DT_BF16;   // storage dtype of parameters and KV cache (kernel template argument)
   size_t esz = 2;          // bytes per stored element
   ebyte *embed = nullptr, *lm_head = nullptr, *final_norm = nullptr;
-  bool embed_ok = false, lm_head_ok = false, final_norm_ok = false;
+  ebyte *wpe = nullptr, *final_norm_b = nullptr;      // GPT-2: learned positions [n_positions][H], ln_f.bias
+  bool embed_ok = false, lm_head_ok = false, final_norm_ok = false, wpe_ok = false, final_norm_b_ok = false;
+  bool gpt2 = false;
   std::vector<LayerW> L;
   float *rope_cos = nullptr, *rope_sin = nullptr;
   std::vector<RowState> rows;   // views into the per-row slabs below (constant row stride: batched GEMV walks them)
@@ -235,6 +240,50 @@ bool shape_is(const int64_t* s, int nd, int64_t a, int64_t b) {
   return nd == 2 && s[0] == a && s[1] == b;
 }
 
+// GPT-2 checkpoints (hub layout without the "transformer." prefix, ModelGPT2.h:226; the prefixed form is accepted too).
+// Conv1D weights are stored [in][out] (ModelGPT2.h:26): transposed on the host into the [out][in] rows the GEMV streams.
+int upload_gpt2(tgx_ctx* c, const char* name, const void* host, const int64_t* shape, int nd, int src_dtype) {
+  const tgx_model_desc& d = c->d;
+  const int64_t H = d.hidden, I = d.inter, V = d.vocab;
+  auto bad_shape = [&]() { return set_err(c, TGX_ERR_SHAPE, "shape not equal for tensor: %s", name); };
+  if (!strncmp(name, "transformer.", 12)) name += 12;
+  if (!strcmp(name, "wte.weight")) { if (!shape_is(shape, nd, V, H)) return bad_shape(); c->embed_ok = true; return upload_param(c, c->embed, host, V * H, src_dtype); }
+  if (!strcmp(name, "wpe.weight")) { if (!shape_is(shape, nd, d.n_positions, H)) return bad_shape(); c->wpe_ok = true; return upload_param(c, c->wpe, host, (int64_t)d.n_positions * H, src_dtype); }
+  if (!strcmp(name, "ln_f.weight")) { if (!shape_is(shape, nd, H, -1)) return bad_shape(); c->final_norm_ok = true; return upload_param(c, c->final_norm, host, H, src_dtype); }
+  if (!strcmp(name, "ln_f.bias")) { if (!shape_is(shape, nd, H, -1)) return bad_shape(); c->final_norm_b_ok = true; return upload_param(c, c->final_norm_b, host, H, src_dtype); }
+  if (!strcmp(name, "lm_head.weight")) { if (!shape_is(shape, nd, V, H)) return bad_shape(); return TGX_OK; }   // aliases wte
+  int l = -1;
+  char rest[128] = {0};
+  if (sscanf(name, "h.%d.%127s", &l, rest) == 2 && l >= 0 && l < d.layers) {
+    LayerW& w = c->L[(size_t)l];
+    struct Vec { const char* n; ebyte* p; int64_t len; };
+    const Vec vecs[] = {{"ln_1.weight", w.in_norm, H}, {"ln_1.bias", w.in_norm_b, H}, {"ln_2.weight", w.post_norm, H}, {"ln_2.bias", w.post_norm_b, H},
+                        {"attn.c_attn.bias", w.bqkv, 3 * H}, {"attn.c_proj.bias", w.bo, H}, {"mlp.c_fc.bias", w.bfc, I}, {"mlp.c_proj.bias", w.bdown, H}};
+    for (int i = 0; i < 8; i++)
+      if (!strcmp(rest, vecs[i].n)) {
+        if (!shape_is(shape, nd, vecs[i].len, -1)) return bad_shape();
+        w.gpt2_filled |= 1 << i;
+        return upload_param(c, vecs[i].p, host, vecs[i].len, src_dtype);
+      }
+    struct Mat { const char* n; ebyte* p; int64_t in, out; };
+    const Mat mats[] = {{"attn.c_attn.weight", w.wqkv, H, 3 * H}, {"attn.c_proj.weight", w.wo, H, H}, {"mlp.c_fc.weight", w.wgu, H, I}, {"mlp.c_proj.weight", w.wdown, I, H}};
+    for (int i = 0; i < 4; i++)
+      if (!strcmp(rest, mats[i].n)) {
+        if (!shape_is(shape, nd, mats[i].in, mats[i].out)) return bad_shape();
+        if (src_dtype != TGX_BF16 && src_dtype != TGX_F32 && src_dtype != TGX_F16) return set_err(c, TGX_ERR_INVALID, "unknown source dtype %d", src_dtype);
+        const size_t es = src_dtype == TGX_F32 ? 4 : 2, n_in = (size_t)mats[i].in, n_out = (size_t)mats[i].out;
+        std::vector<unsigned char> t(n_in * n_out * es);
+        const unsigned char* src = static_cast<const unsigned char*>(host);
+        for (size_t k = 0; k < n_in; k++)
+          for (size_t n = 0; n < n_out; n++) memcpy(&t[(n * n_in + k) * es], src + (k * n_out + n) * es, es);
+        w.gpt2_filled |= 1 << (8 + i);
+        return upload_param(c, mats[i].p, t.data(), (int64_t)(n_in * n_out), src_dtype);
+      }
+    if (!strcmp(rest, "attn.bias") || !strcmp(rest, "attn.masked_bias")) return TGX_OK;   // causal-mask buffers of old hub checkpoints: not parameters
+  }
+  return set_err(c, TGX_ERR_NAME, "Unexpected key: %s", name);
+}
+
 // nn::RoPE tables (ctor at ModelLlama.h:41-42): HF LlamaRotaryEmbedding incl. llama3 scaling, fp32.
 void build_rope_host(const tgx_model_desc& d, std::vector<float>& cs, std::vector<float>& sn) {
   const int half = d.head_dim / 2;
@@ -332,16 +381,25 @@ void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls, int R) {
   while (R > 1 && a.ks < 4 && gemv_nx(a.K, a.ks) > 4) a.ks *= 2;   // batch rows: at most 4 slices per row and lane (measured: B = 2 and 4 on the 1B / 3B / 7B shapes)
   const int grid = (EPI == tgx::EPI_LOGITS) ? c->lm_grid : gemv_grid(c, a.units, a.ks, tn.bpc);
   const int nx = gemv_nx(a.K, a.ks);
-  TGX_DT_SWITCH(c->dt, switch (nx) {
-    case 1: launch_gemv_nx<DT, PRO, EPI, 1>(c, a, grid, R); break;
-    case 2: launch_gemv_nx<DT, PRO, EPI, 2>(c, a, grid, R); break;
-    case 3: launch_gemv_nx<DT, PRO, EPI, 3>(c, a, grid, R); break;
-    case 4: launch_gemv_nx<DT, PRO, EPI, 4>(c, a, grid, R); break;
-    case 5: launch_gemv_nx<DT, PRO, EPI, 5>(c, a, grid, R); break;
-    case 6: launch_gemv_nx<DT, PRO, EPI, 6>(c, a, grid, R); break;
-    case 7: launch_gemv_nx<DT, PRO, EPI, 7>(c, a, grid, R); break;
-    default: launch_gemv_nx<DT, PRO, EPI, 8>(c, a, grid, R); break;
-  })
+  if constexpr (PRO == tgx::PRO_LAYERNORM || EPI == tgx::EPI_GELU) {   // GPT-2 (hidden <= 2048, checked in tgx_create): at most 4 slices per lane
+    TGX_DT_SWITCH(c->dt, switch (nx) {
+      case 1: launch_gemv_nx<DT, PRO, EPI, 1>(c, a, grid, R); break;
+      case 2: launch_gemv_nx<DT, PRO, EPI, 2>(c, a, grid, R); break;
+      case 3: launch_gemv_nx<DT, PRO, EPI, 3>(c, a, grid, R); break;
+      default: launch_gemv_nx<DT, PRO, EPI, 4>(c, a, grid, R); break;
+    })
+  } else {
+    TGX_DT_SWITCH(c->dt, switch (nx) {
+      case 1: launch_gemv_nx<DT, PRO, EPI, 1>(c, a, grid, R); break;
+      case 2: launch_gemv_nx<DT, PRO, EPI, 2>(c, a, grid, R); break;
+      case 3: launch_gemv_nx<DT, PRO, EPI, 3>(c, a, grid, R); break;
+      case 4: launch_gemv_nx<DT, PRO, EPI, 4>(c, a, grid, R); break;
+      case 5: launch_gemv_nx<DT, PRO, EPI, 5>(c, a, grid, R); break;
+      case 6: launch_gemv_nx<DT, PRO, EPI, 6>(c, a, grid, R); break;
+      case 7: launch_gemv_nx<DT, PRO, EPI, 7>(c, a, grid, R); break;
+      default: launch_gemv_nx<DT, PRO, EPI, 8>(c, a, grid, R); break;
+    })
+  }
 }
 
 template <int DT, int HD>
@@ -392,6 +450,11 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos = r.pos;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx;
       a.raw_qk = d.qk_norm ? 1 : 0; a.k_raw = r.k_raw;
+      if (c->gpt2) {   // ln_1 -> c_attn (+bias) -> split into heads -> cache append; no rotation: the tables hold cos = 1, sin = 0 (ModelGPT2.h:60-75)
+        a.norm_b = w.in_norm_b;
+        launch_gemv<tgx::PRO_LAYERNORM, tgx::EPI_QKV_ROPE>(c, a, TGX_KERNEL_QKV, R);
+        break;
+      }
       launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_QKV_ROPE>(c, a, TGX_KERNEL_QKV, R);
       if (d.qk_norm) for (int b = 0; b < R; b++) {   // q_norm / k_norm -> RoPE -> cache append (Attention.h:156-163)
         RowState& rb = rv[b];
@@ -416,7 +479,7 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
     case TGX_KERNEL_OPROJ: { // o_proj + residual                                     (Attention.h:90, DecoderLayer.h:40)
       tgx::GemvArgs a{};
       fill_strides(c, a);
-      a.W = w.wo; a.x = r.attn; a.x_stride = qd; a.N = H; a.K = qd; a.units = (H + 1) / 2; a.out = resid; a.out_stride = H; a.hd = 2;
+      a.W = w.wo; a.bias = w.bo; a.x = r.attn; a.x_stride = qd; a.N = H; a.K = qd; a.units = (H + 1) / 2; a.out = resid; a.out_stride = H; a.hd = 2;
       launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_OPROJ, R);
       break;
     }
@@ -424,6 +487,12 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
       tgx::GemvArgs a{};
       fill_strides(c, a);
       a.W = w.wgu; a.x = r.x; a.x_stride = H; a.norm_w = w.post_norm; a.eps = d.norm_eps;
+      if (c->gpt2) {   // ln_2 -> c_fc (+bias) -> gelu_new   (ModelGPT2.h:96-107,131-134)
+        a.norm_b = w.post_norm_b; a.bias = w.bfc;
+        a.N = I; a.K = H; a.units = (I + 1) / 2; a.out = r.h; a.out_stride = I; a.hd = 2;
+        launch_gemv<tgx::PRO_LAYERNORM, tgx::EPI_GELU>(c, a, TGX_KERNEL_GATEUP, R);
+        break;
+      }
       a.N = 2 * I; a.K = H; a.units = I; a.out = r.h; a.out_stride = I; a.hd = 2;
       launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_SILU_MUL>(c, a, TGX_KERNEL_GATEUP, R);
       break;
@@ -431,7 +500,7 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
     case TGX_KERNEL_DOWN: {  // down_proj + residual                                  (GatedMLP.h:40, DecoderLayer.h:41)
       tgx::GemvArgs a{};
       fill_strides(c, a);
-      a.W = w.wdown; a.x = r.h; a.x_stride = I; a.N = H; a.K = I; a.units = (H + 1) / 2; a.out = resid; a.out_stride = H; a.hd = 2;
+      a.W = w.wdown; a.bias = w.bdown; a.x = r.h; a.x_stride = I; a.N = H; a.K = I; a.units = (H + 1) / 2; a.out = resid; a.out_stride = H; a.hd = 2;
       launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_DOWN, R);
       break;
     }
@@ -556,6 +625,11 @@ void launch_lm_head(tgx_ctx* c, int row0, int R) {
   a.W = d.tied ? c->embed : c->lm_head; a.x = r.x; a.x_stride = d.hidden; a.norm_w = c->final_norm; a.eps = d.norm_eps;
   a.N = d.vocab; a.K = d.hidden; a.units = (d.vocab + 1) / 2; a.hd = 2;
   a.logits = r.logits; a.part_val = r.part_val; a.part_idx = r.part_idx;
+  if (c->gpt2) {   // ln_f -> wte^T (tied head, ModelGPT2.h:170-176)
+    a.norm_b = c->final_norm_b;
+    launch_gemv<tgx::PRO_LAYERNORM, tgx::EPI_LOGITS>(c, a, TGX_KERNEL_LMHEAD, R);
+    return;
+  }
   launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_LOGITS>(c, a, TGX_KERNEL_LMHEAD, R);
 }
 
@@ -572,6 +646,7 @@ tgx::FinalizeArgs make_finalize_args(tgx_ctx* c, int row, bool advance_pos, bool
   a.row = row; a.rows = c->batch;
   a.log = log_step ? 1 : 0; a.bump_step = (row == c->batch - 1) ? 1 : 0;
   a.embed = c->embed; a.x = r.x; a.H = c->d.hidden; a.V = c->d.vocab; a.advance_pos = advance_pos ? 1 : 0;
+  a.wpe = c->gpt2 ? c->wpe : nullptr; a.n_pos = c->d.n_positions > 0 ? c->d.n_positions : 1;
   return a;
 }
 
@@ -725,8 +800,13 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   if (!desc || !out_ctx) return set_err(nullptr, TGX_ERR_INVALID, "null argument");
   *out_ctx = nullptr;
   const tgx_model_desc& d = *desc;
-  if (d.family != TGX_FAMILY_LLAMA && d.family != TGX_FAMILY_QWEN2 && d.family != TGX_FAMILY_MISTRAL && d.family != TGX_FAMILY_QWEN3)
-    return set_err(nullptr, TGX_ERR_UNSUPPORTED, "family %d is not implemented on mi355x (llama/qwen2/qwen3/mistral are)", d.family);
+  if (d.family != TGX_FAMILY_LLAMA && d.family != TGX_FAMILY_QWEN2 && d.family != TGX_FAMILY_MISTRAL && d.family != TGX_FAMILY_QWEN3 && d.family != TGX_FAMILY_GPT2)
+    return set_err(nullptr, TGX_ERR_UNSUPPORTED, "family %d is not implemented on mi355x (gpt2/llama/qwen2/qwen3/mistral are)", d.family);
+  const bool gpt2 = d.family == TGX_FAMILY_GPT2;
+  if (gpt2 && (d.kv_heads != d.heads || d.heads * d.head_dim != d.hidden)) return set_err(nullptr, TGX_ERR_INVALID, "gpt2: n_head * head_dim must equal n_embd, no grouped heads");
+  if (gpt2 && d.hidden > 2048) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "gpt2: n_embd %d > 2048 (the LayerNorm-fused launches are built for up to 4 slices per lane)", d.hidden);
+  if (gpt2 && d.n_positions < d.max_ctx) return set_err(nullptr, TGX_ERR_INVALID, "gpt2: n_positions %d < context size %d", d.n_positions, d.max_ctx);
+  if (gpt2 && d.qk_norm) return set_err(nullptr, TGX_ERR_INVALID, "gpt2 has no q/k norm");
   if (d.compute_dtype != TGX_BF16 && d.compute_dtype != TGX_F16 && d.compute_dtype != TGX_F32) return set_err(nullptr, TGX_ERR_INVALID, "unknown compute dtype %d", d.compute_dtype);
   if (d.head_dim != 64 && d.head_dim != 128) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "head_dim %d (64 and 128 are built)", d.head_dim);
   if (d.heads <= 0 || d.kv_heads <= 0 || d.heads % d.kv_heads) return set_err(nullptr, TGX_ERR_INVALID, "heads %% kv_heads != 0");
@@ -743,6 +823,8 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   if (!c) return set_err(nullptr, TGX_ERR_NOMEM, "host allocation failed");
   *out_ctx = c;
   c->d = d;
+  c->gpt2 = gpt2;
+  if (gpt2) { c->d.tied = 1; c->d.qkv_bias = 1; }     // the head is wte (ModelGPT2.h:170-176); every Conv1D has a bias
   if (c->d.max_batch < 1) c->d.max_batch = 1;
   c->device = device_ordinal;
   c->dt = d.compute_dtype == TGX_BF16 ? tgx::DT_BF16 : (d.compute_dtype == TGX_F16 ? tgx::DT_F16 : tgx::DT_F32);
@@ -762,18 +844,21 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   int rc;
   const size_t es = c->esz;
   if ((rc = dev_alloc(c, &c->embed, (size_t)V * H * es))) return rc;
-  if (!d.tied && (rc = dev_alloc(c, &c->lm_head, (size_t)V * H * es))) return rc;
+  if (!c->d.tied && (rc = dev_alloc(c, &c->lm_head, (size_t)V * H * es))) return rc;
   if ((rc = dev_alloc(c, &c->final_norm, (size_t)H * es))) return rc;
+  if (gpt2 && ((rc = dev_alloc(c, &c->wpe, (size_t)d.n_positions * H * es)) || (rc = dev_alloc(c, &c->final_norm_b, (size_t)H * es)))) return rc;
   c->L.resize((size_t)d.layers);
   for (auto& w : c->L) {
     if ((rc = dev_alloc(c, &w.in_norm, (size_t)H * es))) return rc;
     if ((rc = dev_alloc(c, &w.post_norm, (size_t)H * es))) return rc;
     if ((rc = dev_alloc(c, &w.wqkv, (size_t)(qd + 2 * kvd) * H * es))) return rc;
-    if (d.qkv_bias && (rc = dev_alloc(c, &w.bqkv, (size_t)(qd + 2 * kvd) * es))) return rc;
+    if (c->d.qkv_bias && (rc = dev_alloc(c, &w.bqkv, (size_t)(qd + 2 * kvd) * es))) return rc;
     if ((rc = dev_alloc(c, &w.wo, (size_t)H * qd * es))) return rc;
     if (d.qk_norm && ((rc = dev_alloc(c, &w.q_norm, (size_t)d.head_dim * es)) || (rc = dev_alloc(c, &w.k_norm, (size_t)d.head_dim * es)))) return rc;
-    if ((rc = dev_alloc(c, &w.wgu, (size_t)2 * I * H * es))) return rc;
+    if ((rc = dev_alloc(c, &w.wgu, (size_t)(gpt2 ? 1 : 2) * I * H * es))) return rc;
     if ((rc = dev_alloc(c, &w.wdown, (size_t)H * I * es))) return rc;
+    if (gpt2 && ((rc = dev_alloc(c, &w.in_norm_b, (size_t)H * es)) || (rc = dev_alloc(c, &w.post_norm_b, (size_t)H * es)) || (rc = dev_alloc(c, &w.bo, (size_t)H * es)) ||
+                 (rc = dev_alloc(c, &w.bfc, (size_t)I * es)) || (rc = dev_alloc(c, &w.bdown, (size_t)H * es)))) return rc;
   }
   return TGX_OK;
 }
@@ -784,6 +869,7 @@ int tgx_upload(tgx_ctx* c, const char* name, const void* host, const int64_t* sh
   const tgx_model_desc& d = c->d;
   const int64_t H = d.hidden, I = d.inter, V = d.vocab, qd = (int64_t)d.heads * d.head_dim, kvd = (int64_t)d.kv_heads * d.head_dim;
   auto bad_shape = [&]() { return set_err(c, TGX_ERR_SHAPE, "shape not equal for tensor: %s", name); };
+  if (c->gpt2) return upload_gpt2(c, name, host, shape, nd, src_dtype);
   if (!strcmp(name, "model.embed_tokens.weight")) {
     if (!shape_is(shape, nd, V, H)) return bad_shape();
     c->embed_ok = true;
@@ -855,10 +941,17 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipSetDevice(c->device));
   const tgx_model_desc& d = c->d;
   const int H = d.hidden, I = d.inter, V = d.vocab, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
-  if (!c->embed_ok) return set_err(c, TGX_ERR_STATE, "Missing key: model.embed_tokens.weight");
+  if (c->gpt2) {
+    if (!c->embed_ok) return set_err(c, TGX_ERR_STATE, "Missing key: wte.weight");
+    if (!c->wpe_ok) return set_err(c, TGX_ERR_STATE, "Missing key: wpe.weight");
+    if (!c->final_norm_ok || !c->final_norm_b_ok) return set_err(c, TGX_ERR_STATE, "Missing key: ln_f.%s", c->final_norm_ok ? "bias" : "weight");
+    for (int l = 0; l < d.layers; l++)
+      if (c->L[(size_t)l].gpt2_filled != 0xfff) return set_err(c, TGX_ERR_STATE, "Missing key in h.%d", l);
+  }
+  if (!c->gpt2 && !c->embed_ok) return set_err(c, TGX_ERR_STATE, "Missing key: model.embed_tokens.weight");
   if (!d.tied && !c->lm_head_ok) return set_err(c, TGX_ERR_STATE, "Missing key: lm_head.weight");
-  if (!c->final_norm_ok) return set_err(c, TGX_ERR_STATE, "Missing key: model.norm.weight");
-  for (int l = 0; l < d.layers; l++) {
+  if (!c->gpt2 && !c->final_norm_ok) return set_err(c, TGX_ERR_STATE, "Missing key: model.norm.weight");
+  for (int l = 0; l < d.layers && !c->gpt2; l++) {
     const LayerW& w = c->L[(size_t)l];
     if (!w.in_norm_ok || !w.post_norm_ok || w.qkv_rows != qd + 2 * kvd || !w.wo_ok || w.gu_rows != 2 * (int64_t)I || !w.wdown_ok)
       return set_err(c, TGX_ERR_STATE, "Missing key in model.layers.%d", l);
@@ -868,7 +961,10 @@ int tgx_finalize(tgx_ctx* c) {
   if (c->finalized) return TGX_OK;
 
   std::vector<float> cs, sn;
-  build_rope_host(d, cs, sn);
+  if (c->gpt2) {      // no rotary embedding: the qkv epilogue's rotation becomes the identity
+    cs.assign((size_t)d.max_ctx * (hd / 2), 1.0f);
+    sn.assign((size_t)d.max_ctx * (hd / 2), 0.0f);
+  } else build_rope_host(d, cs, sn);
   int rc;
   if ((rc = dev_alloc(c, &c->rope_cos, cs.size()))) return rc;
   if ((rc = dev_alloc(c, &c->rope_sin, sn.size()))) return rc;
@@ -956,10 +1052,10 @@ void tgx_destroy(tgx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   drop_step_graphs(c);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
+  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->wpe); fr(c->final_norm_b); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
   fr(c->ch_x); fr(c->ch_q); fr(c->ch_kraw); fr(c->ch_attn); fr(c->ch_h); fr(c->ch_part); fr(c->ch_pos);
   fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl);
-  for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); }
+  for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); fr(w.in_norm_b); fr(w.post_norm_b); fr(w.bo); fr(w.bfc); fr(w.bdown); }
   fr(c->slab_x); fr(c->slab_q); fr(c->slab_kraw); fr(c->slab_attn); fr(c->slab_h); fr(c->slab_logits); fr(c->slab_probs);
   fr(c->slab_part_val); fr(c->slab_part_idx); fr(c->slab_attn_part); fr(c->slab_tok); fr(c->slab_pos); fr(c->slab_prompt); fr(c->slab_k); fr(c->slab_v);
   if (c->host_ring) (void)hipHostFree(c->host_ring);
@@ -982,7 +1078,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
   for (int b = 0; b < batch; b++) {
     RowState& r = c->rows[(size_t)b];
     HIP_OK(c, hipMemcpyAsync(r.prompt, ids + (size_t)b * seq, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream));
-    if (seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && prefill_shapes_ok(c->d)) {
+    if (seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && !c->gpt2 && prefill_shapes_ok(c->d)) {
       // batched prefill on the matrix cores; logits for the last position only (== forward + narrow, GPTEngine.cpp:96-97)
       int rc = ensure_prefill_ws(c, seq);
       if (rc) return rc;
@@ -991,13 +1087,13 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
       hipLaunchKernelGGL(tgx::add_pos_kernel, dim3(1), dim3(64), 0, c->stream, r.pos, seq);
       continue;
     }
-    // prefill by steps (fp32 storage, prompts shorter than 4 tokens, shapes the GEMM tile does not cover): up to 4 consecutive
+    // prefill by steps (fp32 storage, GPT-2, prompts shorter than 4 tokens, shapes the GEMM tile does not cover): up to 4 consecutive
     // positions per pass through the decode kernels — the chunk rows share this row's cache (kv_stride 0), each attends the
     // keys up to its own position, so the result equals position-by-position passes at a quarter of the weight traffic
     for (int s0 = 0; s0 < seq;) {
       const int rem = seq - s0, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
       tgx::EmbedChunkArgs e{};
-      e.ids = r.prompt + s0; e.embed = c->embed; e.x = c->ch_x; e.H = c->d.hidden; e.pos = c->ch_pos; e.pos0 = (int)c->past + s0;
+      e.ids = r.prompt + s0; e.embed = c->embed; e.x = c->ch_x; e.H = c->d.hidden; e.pos = c->ch_pos; e.pos0 = (int)c->past + s0; e.wpe = c->gpt2 ? c->wpe : nullptr;
       TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_chunk_kernel<DT>, dim3(R), dim3(256), 0, c->stream, e))
       for (int k = 0; k < R; k++) { c->chunk[k].kcache = r.kcache; c->chunk[k].vcache = r.vcache; }
       launch_layers(c, c->chunk, R, 0);
@@ -1250,8 +1346,12 @@ int64_t tgx_bytes_per_token(const tgx_ctx* c, int64_t T) {
   if (!c) return -1;
   const tgx_model_desc& d = c->d;
   const int64_t H = d.hidden, I = d.inter, V = d.vocab, L = d.layers, q = (int64_t)d.heads * d.head_dim, kv = (int64_t)d.kv_heads * d.head_dim;
-  const int64_t per_layer = (q + 2 * kv) * H + (d.qkv_bias ? (q + 2 * kv) : 0) + H * q + 2 * I * H + H * I + 2 * H;
   const int64_t b = (int64_t)c->esz;   // bytes per stored parameter / cache element
+  if (c->gpt2) {   // c_attn, c_proj, c_fc, mlp.c_proj with their biases, two LayerNorms (weight + bias); ln_f, one wpe row, the wte head
+    const int64_t per_layer = 3 * H * H + 3 * H + H * H + H + I * H + I + H * I + H + 4 * H;
+    return b * (L * per_layer + 2 * H + H + V * H) + b * 2 * L * kv * T;
+  }
+  const int64_t per_layer = (q + 2 * kv) * H + (d.qkv_bias ? (q + 2 * kv) : 0) + H * q + 2 * I * H + H * I + 2 * H;
   return b * (L * per_layer + H + V * H) + b * 2 * L * kv * T;
 }
 

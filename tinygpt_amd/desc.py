@@ -148,6 +148,9 @@ class ModelDesc:
     def bytes_per_token(self, T: int, elem: int = 2) -> int:
         H, I, V, L = self.hidden, self.inter, self.vocab, self.layers
         q, kv = self.q_dim, self.kv_dim
+        if self.family == "gpt2":   # c_attn, c_proj, c_fc, mlp.c_proj with biases, two LayerNorms (w + b); ln_f, one wpe row, the wte head
+            per_layer = 3 * H * H + 3 * H + H * H + H + I * H + I + H * I + H + 4 * H
+            return elem * (L * per_layer + 2 * H + H + V * H) + elem * 2 * L * kv * T
         per_layer = (q + 2 * kv) * H + ((q + 2 * kv) if self.qkv_bias else 0) + H * q + 2 * I * H + H * I + 2 * H
         return elem * (L * per_layer + H + V * H) + elem * 2 * L * kv * T
 

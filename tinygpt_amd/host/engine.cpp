@@ -282,6 +282,15 @@ bool known_config(const std::string& key, int compute_dtype, int max_batch, Mode
       {"qwen2.5-0.5b", TGX_FAMILY_QWEN2, 896, 24, 14, 2, 4864, 151936, 1, 1, 32768, 1e-6f, 1000000.f, 0},
       {"mistral-7b-v0.3", TGX_FAMILY_MISTRAL, 4096, 32, 32, 8, 14336, 32768, 0, 0, 32768, 1e-5f, 1000000.f, 0},
   };
+  if (key == "gpt2") {   // GPT-2 124M (BASELINE.json configs[0]): head = wte, n_ctx = n_positions = 1024
+    out = ModelConfig();
+    tgx_model_desc& d = out.desc;
+    d.family = TGX_FAMILY_GPT2; d.hidden = 768; d.layers = 12; d.heads = d.kv_heads = 12; d.head_dim = 64; d.inter = 3072; d.vocab = 50257;
+    d.max_ctx = 1024; d.n_positions = 1024; d.qkv_bias = 1; d.tied = 1; d.compute_dtype = compute_dtype; d.norm_eps = 1e-5f;
+    d.max_batch = max_batch < 1 ? 1 : max_batch;
+    out.model_type = "gpt2";
+    return true;
+  }
   for (const K& k : table) {
     if (key != k.name) continue;
     out = ModelConfig();
@@ -309,6 +318,19 @@ bool load_synthetic(const Backend& be, const ModelConfig& cfg, int device_ordina
     if (be.upload(*ctx, name.c_str(), buf.data(), shape, c < 0 ? 1 : 2, TGX_BF16) != TGX_OK) { err = be.last_error(*ctx); return false; }
     return true;
   };
+  if (d.family == TGX_FAMILY_GPT2) {   // hub layout, Conv1D weights [in][out] (ModelGPT2.h:26,226); same names and shapes as desc.py
+    bool ok = put("wte.weight", V, H) && put("wpe.weight", d.n_positions, H);
+    for (int l = 0; ok && l < d.layers; l++) {
+      const std::string p = "h." + std::to_string(l) + ".";
+      ok = put(p + "ln_1.weight", H, -1) && put(p + "ln_1.bias", H, -1) && put(p + "attn.c_attn.weight", H, 3 * H) && put(p + "attn.c_attn.bias", 3 * H, -1) &&
+           put(p + "attn.c_proj.weight", H, H) && put(p + "attn.c_proj.bias", H, -1) && put(p + "ln_2.weight", H, -1) && put(p + "ln_2.bias", H, -1) &&
+           put(p + "mlp.c_fc.weight", H, I) && put(p + "mlp.c_fc.bias", I, -1) && put(p + "mlp.c_proj.weight", I, H) && put(p + "mlp.c_proj.bias", H, -1);
+    }
+    ok = ok && put("ln_f.weight", H, -1) && put("ln_f.bias", H, -1);
+    if (ok && be.finalize(*ctx) != TGX_OK) { err = be.last_error(*ctx); ok = false; }
+    if (!ok) { be.destroy(*ctx); *ctx = nullptr; }
+    return ok;
+  }
   bool ok = put("model.embed_tokens.weight", V, H);
   for (int l = 0; ok && l < d.layers; l++) {
     const std::string p = "model.layers." + std::to_string(l) + ".";
