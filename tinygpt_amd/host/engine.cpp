@@ -1,5 +1,7 @@
 #include "engine.h"
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -111,14 +113,18 @@ GPTOutput GPTEngine::generateSync(const std::vector<std::vector<int32_t>>& promp
   const int64_t n_new = std::max<int64_t>(1, config_.maxNewTokens);
 
   // prefill (mask ignored, like the reference: "TODO padding mask", GPTEngine.cpp:95)
+  const auto t0 = std::chrono::steady_clock::now();
   if (be_.forward(model_.ctx, ids.data(), B, (int)S) != TGX_OK) { fail(std::string("forward: ") + be_.last_error(model_.ctx)); return out; }
   std::vector<int64_t> first((size_t)B), rest((size_t)(B * (n_new - 1)));
   if (be_.sample(model_.ctx, &sc, config_.seed, first.data()) != TGX_OK) { fail(std::string("sample: ") + be_.last_error(model_.ctx)); return out; }
+  const auto t1 = std::chrono::steady_clock::now();
   // decode: maxNewTokens-1 iterations, no EOS check (:165-172)
   if (n_new > 1 && be_.decode(model_.ctx, &sc, config_.seed, (int)(n_new - 1), rest.data()) != TGX_OK) {
     fail(std::string("decode: ") + be_.last_error(model_.ctx));
     return out;
   }
+  out.firstTokenMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  out.decodeMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
   out.batch = B;
   out.newTokens = n_new;
   out.tokenIds.resize((size_t)(B * (S + n_new)));
@@ -138,9 +144,11 @@ GPTOutput GPTEngine::generateAsync(const std::vector<int32_t>& prompt, const Gen
   int64_t S = 0;
   std::vector<int64_t> ids = alignPrompts({prompt}, 0, S);
   const tgx_sampler_cfg sc = to_c(config_.samplerConfig);
+  const auto t0 = std::chrono::steady_clock::now();
   if (be_.forward(model_.ctx, ids.data(), 1, (int)S) != TGX_OK) { fail(std::string("forward: ") + be_.last_error(model_.ctx)); return out; }
   int64_t cur = 0;
   if (be_.sample(model_.ctx, &sc, config_.seed, &cur) != TGX_OK) { fail(std::string("sample: ") + be_.last_error(model_.ctx)); return out; }
+  const auto t1 = std::chrono::steady_clock::now();
   std::vector<int32_t> tokens;
   for (int64_t i = 0; i < S; i++) tokens.push_back((int32_t)ids[(size_t)i]);
   tokens.push_back((int32_t)cur);
@@ -175,6 +183,8 @@ GPTOutput GPTEngine::generateAsync(const std::vector<int32_t>& prompt, const Gen
     if (pipelined && be_.fetch_token(model_.ctx, ticket_cur, &last) != TGX_OK) fail(std::string("fetch: ") + be_.last_error(model_.ctx));
     tokens.push_back(last);
   }
+  out.firstTokenMs = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  out.decodeMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
   out.batch = 1;
   out.newTokens = (int64_t)tokens.size() - S;
   out.tokenIds = std::move(tokens);

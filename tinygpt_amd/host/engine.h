@@ -45,6 +45,9 @@ struct GPTOutput {       // src/engine/GPTEngine.h:34-40
   std::vector<int32_t> tokenIds;     // [batch][padded prompt + new], row-major — prompt tokens included, like the reference
   std::vector<std::string> texts;    // the new tokens of every row, decoded (text entry points only)
   FinishReason finishReason = FinishReason::Stop;
+  // not in the reference's struct: the generate call split at the first token (SURVEY.md §8 row H asks the harness for decode-only tok/s)
+  double firstTokenMs = 0.0;         // encode-to-first-token: prefill + first sample
+  double decodeMs = 0.0;             // the remaining newTokens-1 steps
 };
 
 using GenerateCallback = std::function<bool(int32_t tokenId)>;   // return false to abort (GPTEngine.cpp:208-213)

@@ -2,7 +2,7 @@
 // tokenizer is available (--model dir or --tokenizer dir), token-id prompts otherwise;
 // same flags and defaults (--model --device --dtype --max-tokens --temperature --top-p), the same timing window
 // (generate only; load excluded, main.cpp:97-102) and the same "speed" convention (ALL ids incl. prompt / wall time,
-// main.cpp:112-114) — plus the new-token rate.  `--device mi355x` is the only device this binary executes on.
+// main.cpp:112-114) — plus the new-token rate, the time to first token and the decode-only rate.  `--device mi355x` is the only device this binary executes on.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -109,6 +109,7 @@ int main(int argc, char** argv) {
     }
     printf("Time cost: %lld ms, speed: %.2f token/s\n", (long long)ms, out.tokenIds.size() * 1000.0 / ms);
     printf("new tokens: %lld, new-token rate: %.2f token/s\n", (long long)(out.batch * out.newTokens), out.batch * out.newTokens * 1000.0 / ms);
+    if (out.newTokens > 1) printf("time to first token: %.1f ms, decode-only rate: %.2f token/s\n", out.firstTokenMs, out.batch * (out.newTokens - 1) * 1000.0 / out.decodeMs);
     return 0;
   }
   int32_t pad = pad_id >= 0 ? (int32_t)pad_id : (!engine.eosTokenIds().empty() ? engine.eosTokenIds()[0] : 0);
@@ -130,5 +131,6 @@ int main(int argc, char** argv) {
   }
   printf("Time cost: %lld ms, speed: %.2f token/s\n", (long long)ms, out.tokenIds.size() * 1000.0 / ms);
   printf("new tokens: %lld, new-token rate: %.2f token/s\n", (long long)(out.batch * out.newTokens), out.batch * out.newTokens * 1000.0 / ms);
+  if (out.newTokens > 1) printf("time to first token: %.1f ms, decode-only rate: %.2f token/s\n", out.firstTokenMs, out.batch * (out.newTokens - 1) * 1000.0 / out.decodeMs);
   return 0;
 }
