@@ -124,7 +124,7 @@ def test_full_size_sharded_checkpoint_through_cpp_engine(tmp_path):
     np.testing.assert_array_equal(ids[0, 40:], want)
 
 
-@pytest.mark.parametrize("key,fixture", [("llama-3.2-1b", "llama_3_2_1b_full"), ("qwen2.5-0.5b", "qwen2_5_0_5b_full")])
+@pytest.mark.parametrize("key,fixture", [("llama-3.2-1b", "llama_3_2_1b_full"), ("qwen2.5-0.5b", "qwen2_5_0_5b_full"), ("qwen3-0.6b", "qwen3_0_6b_full"), ("gpt2", "gpt2_124m_full")])
 def test_full_size_vs_hf_golden(key, fixture):
     """The HIP path at the real Llama-3.2-1B geometry against HF transformers fp32 (tests/golden/llama_3_2_1b_full, produced by
     tools/gen_fullsize_fixture.py): bf16 storage differs from HF-fp32 only by the KV rounding (bound 2e-2, as on the fixtures);

@@ -10,7 +10,7 @@ from conftest import GOLDEN
 from tinygpt_amd import known_desc
 
 
-@pytest.mark.parametrize("key,fixture", [("llama-3.2-1b", "llama_3_2_1b_full"), ("qwen2.5-0.5b", "qwen2_5_0_5b_full")])
+@pytest.mark.parametrize("key,fixture", [("llama-3.2-1b", "llama_3_2_1b_full"), ("qwen2.5-0.5b", "qwen2_5_0_5b_full"), ("qwen3-0.6b", "qwen3_0_6b_full"), ("gpt2", "gpt2_124m_full")])
 def test_oracle_matches_hf_at_full_geometry(key, fixture, oracle_lib):
     """Also Qwen2.5-0.5B (QKV bias, 14 / 2 heads, theta 1e6, V = 151 936, tied head) at its real size."""
     from oracle.oracle_ffi import OracleModel

@@ -227,6 +227,12 @@ KNOWN_CONFIGS = {
                         "vocab_size": 32768, "tie_word_embeddings": False, "rms_norm_eps": 1e-5,
                         "rope_theta": 1000000.0, "max_position_embeddings": 32768, "torch_dtype": "bfloat16",
                         "_name_or_path": "Mistral-7B-v0.3"},
+    # Qwen3-0.6B (public config.json): per-head q/k RMSNorm, explicit head_dim 128 with q_dim 2048 != hidden 1024
+    "qwen3-0.6b": {"model_type": "qwen3", "hidden_size": 1024, "num_hidden_layers": 28, "num_attention_heads": 16,
+                   "num_key_value_heads": 8, "head_dim": 128, "intermediate_size": 3072, "vocab_size": 151936,
+                   "tie_word_embeddings": True, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0,
+                   "max_position_embeddings": 40960, "torch_dtype": "bfloat16", "attention_bias": False,
+                   "_name_or_path": "Qwen3-0.6B"},
     "gpt2": {"model_type": "gpt2", "n_embd": 768, "n_layer": 12, "n_head": 12, "n_ctx": 1024, "n_positions": 1024,
              "vocab_size": 50257, "layer_norm_epsilon": 1e-5, "activation_function": "gelu_new",
              "torch_dtype": "float32", "_name_or_path": "gpt2"},

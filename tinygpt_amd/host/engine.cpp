@@ -301,6 +301,15 @@ bool known_config(const std::string& key, int compute_dtype, int max_batch, Mode
     out.model_type = "gpt2";
     return true;
   }
+  if (key == "qwen3-0.6b") {   // explicit head_dim (q_dim 2048 != hidden 1024), per-head q/k RMSNorm (ModelQwen3.h:23-40)
+    out = ModelConfig();
+    tgx_model_desc& d = out.desc;
+    d.family = TGX_FAMILY_QWEN3; d.hidden = 1024; d.layers = 28; d.heads = 16; d.kv_heads = 8; d.head_dim = 128; d.inter = 3072; d.vocab = 151936;
+    d.max_ctx = 40960; d.tied = 1; d.qk_norm = 1; d.compute_dtype = compute_dtype; d.norm_eps = 1e-6f; d.rope_theta = 1000000.f;
+    d.max_batch = max_batch < 1 ? 1 : max_batch;
+    out.model_type = "qwen3";
+    return true;
+  }
   for (const K& k : table) {
     if (key != k.name) continue;
     out = ModelConfig();
@@ -347,6 +356,7 @@ bool load_synthetic(const Backend& be, const ModelConfig& cfg, int device_ordina
     ok = put(p + "input_layernorm.weight", H, -1) && put(p + "self_attn.q_proj.weight", qd, H) && put(p + "self_attn.k_proj.weight", kvd, H) &&
          put(p + "self_attn.v_proj.weight", kvd, H);
     if (ok && d.qkv_bias) ok = put(p + "self_attn.q_proj.bias", qd, -1) && put(p + "self_attn.k_proj.bias", kvd, -1) && put(p + "self_attn.v_proj.bias", kvd, -1);
+    if (ok && d.qk_norm) ok = put(p + "self_attn.q_norm.weight", d.head_dim, -1) && put(p + "self_attn.k_norm.weight", d.head_dim, -1);
     ok = ok && put(p + "self_attn.o_proj.weight", H, qd) && put(p + "post_attention_layernorm.weight", H, -1) &&
          put(p + "mlp.gate_proj.weight", I, H) && put(p + "mlp.up_proj.weight", I, H) && put(p + "mlp.down_proj.weight", H, I);
   }
