@@ -282,3 +282,29 @@ def test_large_gqa_groups_split_across_workgroups(heads, kv, hip, oracle_lib):
         tok = ref.sample(GREEDY)
         gpu.forward(tok[None, :]); ref.forward(tok[None, :])
         assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_ORACLE
+
+
+@pytest.mark.parametrize("name,lens", [("llama-3.2-1b", [1, 31, 128, 511, 512, 513, 1025]), ("mistral-7b-v0.3", [7, 255, 256, 257, 700])])
+def test_direct_attention_equals_split(name, lens, hip):
+    """Short contexts run attention as one 16-wave workgroup per query head that writes the normalised output itself
+    (attn.direct_max; no split partials, no combine launch).  Same keys, same fp32 arithmetic in another association order:
+    logits equal the split form's to fp32 rounding, greedy ids equal, at contexts around its block size (512 tokens at
+    head_dim 64, 256 at 128)."""
+    import copy
+    from tinygpt_amd import known_desc, synth
+    from tinygpt_amd.ffi import Model
+    d = copy.deepcopy(known_desc(name))
+    d.layers, d.vocab, d.max_ctx = 2, 4096, 2048
+    m = Model(d, hip).load_synthetic(1234, 0.02).finalize()
+    for n in lens:
+        prompt = synth.synth_prompt(d.vocab, n, 100 + n)[None, :]
+        outs = []
+        for direct_max in (0, 1 << 20):
+            m.set_option("attn.direct_max", direct_max)
+            m.reset_cache(); m.forward(prompt)
+            first = m.sample(GREEDY).copy()
+            rest = m.decode(4, GREEDY).copy()          # contexts n+1 .. n+4
+            outs.append((first, rest, m.logits(rounded=False).copy()))
+        np.testing.assert_array_equal(outs[0][0], outs[1][0])
+        np.testing.assert_array_equal(outs[0][1], outs[1][1])
+        assert rel_err(outs[1][2], outs[0][2]) < 1e-5, (n, rel_err(outs[1][2], outs[0][2]))

@@ -32,18 +32,22 @@ struct AttnArgs {
   // batch rows: blockIdx.y = row; row r uses q + r*q_stride, caches + r*kv_stride, pos[r], part + r*part_stride, out + r*q_stride
   long long q_stride, kv_stride, part_stride;
   int gfull;  // query heads per kv head; the G heads of a workgroup are gfull-group blockIdx.z * G .. +G-1 (the last group may be short)
+  int direct;  // 1: short context — one workgroup per (kv head, head group) walks every block and writes the normalised output itself
+               //    (grid.x = kv_heads, no partials, no combine launch); chosen on the host from pastLength (attn.direct_max)
   int dbg;   // experiments only (tgx_set_option "debug.attn"): 1 skip K/V work, 2 skip the LDS merge, 4 exit at once — results invalid
 };
 
-template <int DT, int HD, int G>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
+// NW = waves per workgroup: 4 for the split form; 16 for the direct form (short contexts), where ONE workgroup covers a block of
+// NW * TPW * UNR tokens (512 at head_dim 64, 256 at 128) per pass over the load -> softmax chain.
+template <int DT, int HD, int G, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) {
   typedef elem_t<DT> E;
   constexpr int LPT = HD / 8;         // lanes per token row
   constexpr int TPW = 64 / LPT;       // tokens per wave-load
   constexpr int UNR = 4;              // wave-loads of K and of V in flight per iteration
   constexpr float LOG2E = 1.4426950408889634f;
   // per wave and query head: o[HD], m, l  (m in the exp2 domain)
-  __shared__ __attribute__((aligned(16))) float red[4][G][HD + 4];
+  __shared__ __attribute__((aligned(16))) float red[NW][G][HD + 4];
 
   if (TGX_DBG(a, 4)) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -51,15 +55,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   const E* k_row = static_cast<const E*>(a.k_cache) + blockIdx.y * a.kv_stride;
   const E* v_row = static_cast<const E*>(a.v_cache) + blockIdx.y * a.kv_stride;
   float* part_row = a.part + blockIdx.y * a.part_stride;
-  const int kvh = blockIdx.x / a.nsplit, sp = blockIdx.x - kvh * a.nsplit;
+  const int nsp = a.direct ? 1 : a.nsplit;
+  const int kvh = blockIdx.x / nsp, sp = blockIdx.x - kvh * nsp;
   const int part_i = lane % LPT, slot = lane / LPT;
   const int g_base = blockIdx.z * G;                                   // first head (within the kv group) of this workgroup
   auto head_of = [&](int g) { return kvh * a.gfull + min(g_base + g, a.gfull - 1); };   // clamped: a short last group reloads its last head
   auto head_live = [&](int g) { return g_base + g < a.gfull; };
-  // Token blocks of STEP = 4 waves x UNR wave-loads are dealt round-robin to the splits: split sp owns blocks sp,
+  // Token blocks of STEP = NW waves x UNR wave-loads are dealt round-robin to the splits: split sp owns blocks sp,
   // sp + nsplit, ...: the active splits are the first ceil(n_keys / STEP) of every kv head and each runs whole blocks;
   // the addresses of a split's first block do not depend on the context length.
-  constexpr int STEP = 4 * TPW * UNR;
+  constexpr int STEP = NW * TPW * UNR;
   const E* kbase = k_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
   const E* vbase = v_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
   int t0 = sp * STEP + wv * TPW * UNR;
@@ -84,9 +89,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   if (sp * STEP >= n_keys) {   // this split has no keys at the current context length (workgroup-uniform): publish "empty"
     // (the compiler sinks the loads above below this branch; running empty splits through the masked path instead keeps
     //  them ahead of the position load but measured 1262 vs 1260 tok/s at context 2.3k and 1267 vs 1289 at 300 — rejected)
-    for (int g = threadIdx.x; g < G; g += 256) {
+    for (int g = threadIdx.x; g < G; g += 64 * NW) {
       if (!head_live(g)) continue;
-      float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);
+      float* dst = part_row + ((size_t)head_of(g) * nsp + sp) * (HD + 4);
       dst[HD] = -INFINITY; dst[HD + 1] = 0.f;
     }
     return;
@@ -105,6 +110,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   }
 
   while (!(TGX_DBG(a, 1))) {
+    if (t0 < n_keys) {          // wave-uniform: a wave whose whole range lies beyond the context skips the arithmetic
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
       const bool valid = t0 + r * TPW + slot < n_keys;
@@ -128,7 +134,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
         }
       }
     }
-    t0 += a.nsplit * STEP;            // this split's next block (contexts beyond nsplit*STEP tokens)
+    }
+    t0 += nsp * STEP;                 // this split's next block (contexts beyond nsplit*STEP tokens)
     if (t0 >= n_keys) break;          // wave-uniform
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
   if (TGX_DBG(a, 2)) {
     if (wv == 0 && slot == 0)
       for (int g = 0; g < G; g++) {
-        float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);
+        float* dst = part_row + ((size_t)head_of(g) * nsp + sp) * (HD + 4);
         for (int j = 0; j < 8; j++) dst[part_i * 8 + j] = o[g][j];
         if (part_i == 0) { dst[HD] = m[g]; dst[HD + 1] = l[g]; }
       }
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     }
     m[g] = M;
   }
-  // 2. the four waves meet in LDS (one record per wave and query head), merged in wave order by G*HD threads
+  // 2. the waves meet in LDS (one record per wave and query head), merged in wave order by G*HD threads
   if (slot == 0) {
 #pragma unroll
     for (int g = 0; g < G; g++) {
@@ -177,22 +184,27 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs a) {
     }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < G * HD; idx += 256) {
+  for (int idx = threadIdx.x; idx < G * HD; idx += 64 * NW) {
     const int g = idx / HD, d = idx - g * HD;
-    const float m0 = red[0][g][HD], m1 = red[1][g][HD], m2 = red[2][g][HD], m3 = red[3][g][HD];
-    const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-    const float s0 = (m0 == -INFINITY) ? 0.f : exp2f(m0 - M), s1 = (m1 == -INFINITY) ? 0.f : exp2f(m1 - M);
-    const float s2 = (m2 == -INFINITY) ? 0.f : exp2f(m2 - M), s3 = (m3 == -INFINITY) ? 0.f : exp2f(m3 - M);
-    float acc = red[0][g][d] * s0;
-    acc = fmaf(red[1][g][d], s1, acc); acc = fmaf(red[2][g][d], s2, acc); acc = fmaf(red[3][g][d], s3, acc);
+    float M = red[0][g][HD];
+#pragma unroll
+    for (int w = 1; w < NW; w++) M = fmaxf(M, red[w][g][HD]);
+    float acc = 0.f, L = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const float mw = red[w][g][HD];
+      const float sw = (mw == -INFINITY) ? 0.f : exp2f(mw - M);
+      acc = w == 0 ? red[0][g][d] * sw : fmaf(red[w][g][d], sw, acc);
+      L = w == 0 ? red[0][g][HD + 1] * sw : fmaf(red[w][g][HD + 1], sw, L);
+    }
     if (!head_live(g)) continue;
+    if (a.direct) {   // the only split: softmax normalisation here, straight into the o_proj input
+      a.out[blockIdx.y * a.q_stride + (size_t)head_of(g) * HD + d] = acc / L;
+      continue;
+    }
     float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);
     dst[d] = acc;
-    if (d == 0) {
-      float L = red[0][g][HD + 1] * s0;
-      L = fmaf(red[1][g][HD + 1], s1, L); L = fmaf(red[2][g][HD + 1], s2, L); L = fmaf(red[3][g][HD + 1], s3, L);
-      dst[HD] = M; dst[HD + 1] = L;
-    }
+    if (d == 0) { dst[HD] = M; dst[HD + 1] = L; }
   }
 }
 

@@ -136,6 +136,9 @@ struct tgx_ctx {
   int gemm_tm = 0;           // experiment: force the GEMM row tile (64 / 128); 0 = by the number of tiles
   int debug_attn = 0;        // experiment: AttnArgs.dbg
   int attn_gmax = 0;         // experiment: query heads per attention workgroup (default 2)
+  int attn_direct_max = 384; // contexts up to this many keys take the one-workgroup-per-head attention (no split, no combine launch); set in tgx_create
+  bool attn_direct = false;  // mode of the launches being issued / captured
+  bool step_graph_direct = false;
   int debug_gemv = 0;        // experiment: GemvArgs.dbg = value & 15 for the kernel classes selected by bits 8.. (1 << (8 + class))
   int debug_skip = 0;        // experiment: bit0 skip attn decode kernel, bit1 skip combine (results invalid)
   int prof_same_layer = 0;   // experiment: tgx_profile_decode replays ONE layer's weights (Infinity-Cache resident)
@@ -411,6 +414,13 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
   const int gmax = c->attn_gmax > 0 ? c->attn_gmax : 2;
   const int gfull = a.heads / a.kv_heads, ngroups = gfull > gmax ? (gfull + gmax - 1) / gmax : 1, G = (gfull + ngroups - 1) / ngroups;
   a.gfull = gfull;
+  a.direct = c->attn_direct ? 1 : 0;
+  if (a.direct) {   // short context: one 16-wave workgroup per query head, no combine launch.  Measured (tok/s, direct vs split at context
+    // ~120 / ~300 / ~430): see DESIGN.md §5; 1 head per workgroup beats 2 and 4 here (the K/V block is L2-resident, the softmax chain is not)
+    const dim3 grid(a.kv_heads, R, gfull), blk(1024);
+    if (!(c->debug_skip & 1)) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 16>), grid, blk, 0, c->stream, a);
+    return;
+  }
   const dim3 grid(a.kv_heads * a.nsplit, R, ngroups), blk(256);
   if (!(c->debug_skip & 1)) switch (G) {
     case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1>), grid, blk, 0, c->stream, a); break;
@@ -736,12 +746,13 @@ void drop_step_graphs(tgx_ctx* c) {
 
 int ensure_step_graph(tgx_ctx* c, const tgx_sampler_cfg& cfg, bool want_multi) {
   if (!c->use_graph) return TGX_OK;
-  if (!(c->step_graph && c->step_graph_batch == c->batch && same_cfg(c->step_graph_cfg, cfg))) {
+  if (!(c->step_graph && c->step_graph_batch == c->batch && same_cfg(c->step_graph_cfg, cfg) && c->step_graph_direct == c->attn_direct)) {
     drop_step_graphs(c);
     int rc = capture_steps(c, cfg, 1, &c->step_graph);
     if (rc) return rc;
     c->step_graph_batch = c->batch;
     c->step_graph_cfg = cfg;
+    c->step_graph_direct = c->attn_direct;
   }
   if (want_multi && !c->multi_graph && c->graph_steps > 1) return capture_steps(c, cfg, c->graph_steps, &c->multi_graph);
   return TGX_OK;
@@ -754,6 +765,9 @@ int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int 
     HIP_OK(c, hipStreamSynchronize(c->stream));     // `s` is a stack variable
     c->have_probs = true;
   }
+  // short contexts: attention without the split / combine pair (one launch less per layer); the graphs are re-captured when a
+  // call crosses the limit
+  c->attn_direct = c->past + n <= c->attn_direct_max;
   if (c->use_graph) {
     const int K = c->graph_steps;
     int rc = ensure_step_graph(c, cfg, /*want_multi=*/n >= 2 * K);
@@ -835,6 +849,9 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_OK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   if (const char* e = getenv("TGX_NO_GRAPH")) c->use_graph = !(e[0] == '1');
+  // measured crossover of the direct and the split attention (tools/sweep.py --grid attn.direct_max=0,100000): context ~850-1100 at
+  // head_dim 64 (Qwen2.5-0.5B, Llama-3.2-1B), ~500 at 128 (Mistral-7B: half the tokens per wave-load)
+  c->attn_direct_max = d.head_dim == 64 ? 768 : 384;
   c->tune[TGX_KERNEL_DOWN].ks = 4;   // K = intermediate_size: 4 waves split each row pair
   // qkv is the most latency-bound launch (few rows): 4 waves per row pair shorten every wave's load -> reduce chain; measured
   // ks 1 -> 4: Llama-3.2-1B 1395 -> 1411 tok/s, 3B 628 -> 637, Mistral-7B 341 -> 347; hidden 896 (Qwen2.5-0.5B) loses 2 %
@@ -1090,6 +1107,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     // prefill by steps (fp32 storage, GPT-2, prompts shorter than 4 tokens, shapes the GEMM tile does not cover): up to 4 consecutive
     // positions per pass through the decode kernels — the chunk rows share this row's cache (kv_stride 0), each attends the
     // keys up to its own position, so the result equals position-by-position passes at a quarter of the weight traffic
+    c->attn_direct = c->past + seq <= c->attn_direct_max;
     for (int s0 = 0; s0 < seq;) {
       const int rem = seq - s0, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
       tgx::EmbedChunkArgs e{};
@@ -1252,6 +1270,7 @@ int tgx_profile_decode(tgx_ctx* c, int n_reps, int64_t* launches, double* total_
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < TGX_KERNEL_COUNT; i++) { launches[i] = 0; total_ms[i] = 0.0; }
+  c->attn_direct = c->past + 1 <= c->attn_direct_max;
   // Each class is launched back-to-back over all layers (every launch streams a different layer's weights, so
   // nothing is served from the Infinity Cache) between two events on the launch stream.  The residual
   // epilogues write to a scratch vector: the model state (x, KV cache up to pastLength, token) is untouched.
@@ -1314,6 +1333,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "debug.skip")) { c->debug_skip = value; return TGX_OK; }
   if (!strcmp(key, "debug.attn")) { c->debug_attn = value; return TGX_OK; }
   if (!strcmp(key, "attn.gmax")) { c->attn_gmax = value; return TGX_OK; }
+  if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_tm")) { c->gemm_tm = value; return TGX_OK; }
   if (!strcmp(key, "debug.gemv")) { c->debug_gemv = value; return TGX_OK; }
   if (!strcmp(key, "prefill.mfma")) { c->prefill_mfma = value != 0; return TGX_OK; }
