@@ -107,6 +107,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)     # control plane only: barrier + MAX
+    if os.environ.get("TGX_BENCH_SHARE_GPU") == "1" and torch.cuda.is_available():   # testing the N > 1 flow on a 1-GPU box: ranks share devices
+        local_rank %= torch.cuda.device_count()
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
