@@ -74,6 +74,23 @@ def test_truncation_keeps_tail(lib, oracle_path, tmp_path):
     e.close()
 
 
+def test_empty_and_overlong_requests_fail_loudly(lib, oracle_path, tmp_path):
+    """Edge cases of the engine boundary: a batch of empty prompts has nothing to prefill; a prompt that fills the context
+    leaves no room for a second token (the reference would walk off its RoPE table, Attention.h:81-83) — both are errors
+    with a message, never a crash or a silent truncation of the output."""
+    e, g = make_engine(lib, oracle_path, tmp_path, "llama_tiny", dtype=0)
+    e.reconfigure(max_new=4)
+    with pytest.raises(Exception, match="out of range|empty"):
+        e.generate_sync([np.zeros(0, np.int64)])
+    full = (np.arange(64) * 5 + 1) % 256                       # contextSize of the fixture (llama3-scaled) is 64
+    with pytest.raises(Exception, match="context size"):
+        e.generate_sync([full])
+    e.reconfigure(max_new=1)                                    # exactly one new token still fits: logits of position 63
+    ids, new, _ = e.generate_sync([full])
+    assert new == 1 and ids.shape == (1, 65)
+    e.close()
+
+
 def test_generate_async_stream_eos_abort(lib, oracle_path, tmp_path):
     e, g = make_engine(lib, oracle_path, tmp_path, "llama_tiny", dtype=0, eos=[2, 999])
     gold = g["ids_fp32"][0]

@@ -109,6 +109,7 @@ GPTOutput GPTEngine::generateSync(const std::vector<std::vector<int32_t>>& promp
   const int B = (int)prompts.size();
   int64_t S = 0;
   std::vector<int64_t> ids = alignPrompts(prompts, padToken, S);
+  if (S == 0) { fail("generateSync: every prompt is empty (nothing to prefill)"); return out; }
   const tgx_sampler_cfg sc = to_c(config_.samplerConfig);
   const int64_t n_new = std::max<int64_t>(1, config_.maxNewTokens);
 
@@ -143,6 +144,7 @@ GPTOutput GPTEngine::generateAsync(const std::vector<int32_t>& prompt, const Gen
   if (!prepared_) { fail("generateAsync: engine not prepared"); return out; }
   int64_t S = 0;
   std::vector<int64_t> ids = alignPrompts({prompt}, 0, S);
+  if (S == 0) { fail("generateAsync: the prompt is empty (nothing to prefill)"); return out; }
   const tgx_sampler_cfg sc = to_c(config_.samplerConfig);
   const auto t0 = std::chrono::steady_clock::now();
   if (be_.forward(model_.ctx, ids.data(), 1, (int)S) != TGX_OK) { fail(std::string("forward: ") + be_.last_error(model_.ctx)); return out; }
