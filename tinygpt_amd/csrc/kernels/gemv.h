@@ -378,14 +378,17 @@ struct QkNormArgs {
   void* k_cache;          // this layer/row: [kv_heads][max_ctx][hd], storage dtype
   const void *q_norm_w, *k_norm_w;     // [hd]
   const float *rope_cos, *rope_sin;
-  const int* pos;
+  const int* pos;         // [rows]
   int heads, kv_heads, hd, max_ctx;
   float eps;
+  long long q_stride, kraw_stride, kv_stride;   // elements between batch rows (blockIdx.y); kv_stride 0 = the rows are positions of one sequence
 };
 template <int DT>
-__global__ __launch_bounds__(64) void qk_norm_rope_kernel(const QkNormArgs a) {
+__global__ __launch_bounds__(64) void qk_norm_rope_kernel(QkNormArgs a) {
   typedef elem_t<DT> E;
   const int hh = blockIdx.x, p = threadIdx.x, half = a.hd >> 1;
+  a.q += blockIdx.y * a.q_stride; a.k_raw += blockIdx.y * a.kraw_stride; a.pos += blockIdx.y;
+  a.k_cache = static_cast<E*>(a.k_cache) + blockIdx.y * a.kv_stride;
   const bool is_q = hh < a.heads;
   const float* src = is_q ? a.q + hh * a.hd : a.k_raw + (hh - a.heads) * a.hd;
   const E* w = static_cast<const E*>(is_q ? a.q_norm_w : a.k_norm_w);

@@ -466,13 +466,13 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
         break;
       }
       launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_QKV_ROPE>(c, a, TGX_KERNEL_QKV, R);
-      if (d.qk_norm) for (int b = 0; b < R; b++) {   // q_norm / k_norm -> RoPE -> cache append (Attention.h:156-163)
-        RowState& rb = rv[b];
+      if (d.qk_norm) {   // q_norm / k_norm -> RoPE -> cache append (Attention.h:156-163); batch rows on blockIdx.y
         tgx::QkNormArgs n{};
-        n.q = rb.q; n.k_raw = rb.k_raw; n.k_cache = rb.kcache + (size_t)l * kv_layer; n.q_norm_w = w.q_norm; n.k_norm_w = w.k_norm;
-        n.rope_cos = c->rope_cos; n.rope_sin = c->rope_sin; n.pos = rb.pos;
+        n.q = r.q; n.k_raw = r.k_raw; n.k_cache = r.kcache + (size_t)l * kv_layer; n.q_norm_w = w.q_norm; n.k_norm_w = w.k_norm;
+        n.rope_cos = c->rope_cos; n.rope_sin = c->rope_sin; n.pos = r.pos;
         n.heads = d.heads; n.kv_heads = d.kv_heads; n.hd = hd; n.max_ctx = d.max_ctx; n.eps = d.norm_eps;
-        TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::qk_norm_rope_kernel<DT>, dim3(d.heads + d.kv_heads), dim3(64), 0, c->stream, n))
+        n.q_stride = qd; n.kraw_stride = kvd; n.kv_stride = kv_stride;
+        TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::qk_norm_rope_kernel<DT>, dim3(d.heads + d.kv_heads, R), dim3(64), 0, c->stream, n))
       }
       break;
     }
