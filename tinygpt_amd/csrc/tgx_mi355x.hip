@@ -382,6 +382,9 @@ void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls, int R) {
   a.dbg = ((c->debug_gemv >> (8 + cls)) & 1) ? (c->debug_gemv & 15) : 0;
   a.ks = gemv_auto_ks(a.K, tn.ks);   // norm-fused launches K-split too (their waves exchange the sums of squares through LDS)
   while (R > 1 && a.ks < 4 && gemv_nx(a.K, a.ks) > 4) a.ks *= 2;   // batch rows: at most 4 slices per row and lane (measured: B = 2 and 4 on the 1B / 3B / 7B shapes)
+  // two rows on the gate_up launch: 2 slices per row and lane leave room for the double-buffered weight registers (R x NX <= 4):
+  // Llama-3.2-1B B = 2: 2394 -> 2506 tok/s; the same split loses 2-6 % at B = 4 and on the other launches (tools/batch_bench.py --opts)
+  if (R == 2 && cls == TGX_KERNEL_GATEUP && a.ks == 1 && gemv_nx(a.K, 1) == 4) a.ks = 2;
   const int grid = (EPI == tgx::EPI_LOGITS) ? c->lm_grid : gemv_grid(c, a.units, a.ks, tn.bpc);
   const int nx = gemv_nx(a.K, a.ks);
   if constexpr (PRO == tgx::PRO_LAYERNORM || EPI == tgx::EPI_GELU) {   // GPT-2 (hidden <= 2048, checked in tgx_create): at most 4 slices per lane

@@ -15,6 +15,7 @@ ap.add_argument("--model", default="llama-3.2-1b")
 ap.add_argument("--prompt", type=int, default=512)
 ap.add_argument("--steps", type=int, default=128)
 ap.add_argument("--batches", default="1,2,4,8")
+ap.add_argument("--opts", default="", help="tgx_set_option pairs applied after finalize, e.g. 'gateup.ks=4;oproj.ks=2'")
 args = ap.parse_args()
 batches = [int(b) for b in args.batches.split(",")]
 desc = dataclasses.replace(known_desc(args.model), max_batch=max(batches), max_ctx=args.prompt + 2 * args.steps + 64)
@@ -22,6 +23,8 @@ m = Model(desc, product_backend())
 for name, bits in synth.synth_checkpoint(desc, 1234, 0.02):
     m.upload(name, bits)
 m.finalize()
+for kv in filter(None, args.opts.split(";")):
+    k, v = kv.split("="); m.set_option(k, int(v))
 for B in batches:
     m.reset_cache()
     ids = np.stack([synth.synth_prompt(desc.vocab, args.prompt, 77 + b) for b in range(B)])
