@@ -308,3 +308,30 @@ def test_direct_attention_equals_split(name, lens, hip):
         np.testing.assert_array_equal(outs[0][0], outs[1][0])
         np.testing.assert_array_equal(outs[0][1], outs[1][1])
         assert rel_err(outs[1][2], outs[0][2]) < 1e-5, (n, rel_err(outs[1][2], outs[0][2]))
+
+
+@pytest.mark.parametrize("hidden,heads,kv,inter", [(5120, 40, 8, 13824), (8192, 64, 8, 16384), (8192, 64, 8, 28672)])
+def test_wide_models_vs_oracle(hidden, heads, kv, inter, hip, oracle_lib):
+    """13B/14B-class widths (Llama-2-13B / Qwen2.5-14B: hidden 5120, intermediate 13824) and the widest shape one launch covers
+    (hidden 8192, intermediate 16384), plus the 70B-class intermediate size 28672 whose down projection is covered by two launches
+    over halves of K: norm-fused launches K-split over 2-4 waves that exchange their sums of squares through LDS.
+    2 layers, small vocabulary; prefill (MFMA) + teacher-forced steps against the oracle."""
+    from oracle.oracle_ffi import OracleModel
+    from tinygpt_amd.desc import ModelDesc
+    from tinygpt_amd.ffi import Model
+    from tinygpt_amd import synth
+    d = ModelDesc(family="llama", hidden=hidden, layers=2, heads=heads, kv_heads=kv, head_dim=128, inter=inter, vocab=2048, max_ctx=128,
+                  qkv_bias=False, tied=False, compute_dtype="bf16", norm_eps=1e-5, rope_theta=1000000.0, max_batch=2)
+    gpu, ref = Model(d, hip), OracleModel(d)
+    for name, bits in synth.synth_checkpoint(d, 1234, 0.02):
+        gpu.upload(name, bits); ref.upload(name, bits)
+    gpu.finalize(); ref.finalize()
+    prompt = np.stack([synth.synth_prompt(d.vocab, 21, 5), synth.synth_prompt(d.vocab, 21, 6)])
+    gpu.forward(prompt); ref.forward(prompt)
+    for step in range(4):
+        assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_ORACLE, step
+        tok = ref.sample(GREEDY); gpu.sample(GREEDY)
+        gpu.forward(tok[:, None]); ref.forward(tok[:, None])
+    assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_ORACLE
+    gpu.reset_cache(); gpu.forward(prompt[:1]); gpu.sample(GREEDY)
+    assert gpu.decode(8, GREEDY).shape == (8, 1)                 # graph-captured decode at this width

@@ -41,6 +41,7 @@ struct GemvArgs {
   const void* norm_b;     // [K] LayerNorm bias (PRO_LAYERNORM)
   float eps;
   int N, K;
+  int ldw;                // elements between weight rows (== K unless the launch covers a K range of wider rows; 0 = K)
   int units;              // number of row pairs
   int ks;                 // waves per unit (1, 2, 4)
   int dbg;                // experiments only ("debug.gemv"): 1 skip the norm arithmetic, 2 skip the weight stream, 4 exit at once, 8 skip the epilogue
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
     const int u = min(ub + slot, a.units - 1);
     int ra, rb; bool v;
     unit_rows<EPI>(a, u, ra, rb, v);
-    const E* pa = W + (size_t)ra * a.K;
-    const E* pb = W + (size_t)rb * a.K;
+    const E* pa = W + (size_t)ra * a.ldw;
+    const E* pb = W + (size_t)rb * a.ldw;
 #pragma unroll
     for (int j = 0; j < NX; j++) { ta[j] = load_slice_nt<DT>(pa, cidx[j]); tb[j] = load_slice_nt<DT>(pb, cidx[j]); }
   };

@@ -380,6 +380,7 @@ template <int PRO, int EPI>
 void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls, int R) {
   const Tune& tn = c->tune[cls];
   a.dbg = ((c->debug_gemv >> (8 + cls)) & 1) ? (c->debug_gemv & 15) : 0;
+  if (!a.ldw) a.ldw = a.K;
   a.ks = gemv_auto_ks(a.K, tn.ks);   // norm-fused launches K-split too (their waves exchange the sums of squares through LDS)
   while (R > 1 && a.ks < 4 && gemv_nx(a.K, a.ks) > 4) a.ks *= 2;   // batch rows: at most 4 slices per row and lane (measured: B = 2 and 4 on the 1B / 3B / 7B shapes)
   // two rows on the gate_up launch: 2 slices per row and lane leave room for the double-buffered weight registers (R x NX <= 4):
@@ -514,6 +515,17 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
       tgx::GemvArgs a{};
       fill_strides(c, a);
       a.W = w.wdown; a.bias = w.bdown; a.x = r.h; a.x_stride = I; a.N = H; a.K = I; a.units = (H + 1) / 2; a.out = resid; a.out_stride = H; a.hd = 2;
+      if (I > 16384) {   // 32B/70B-class intermediate sizes: one launch keeps at most 16384 elements of x in registers — the K range is
+        // covered by 2-4 launches that accumulate into the residual stream in order (x += W[:, k0:k1] . h[k0:k1])
+        const int parts = (I + 16383) / 16384, per = ((I / 8 + parts - 1) / parts) * 8;
+        for (int k0 = 0; k0 < I; k0 += per) {
+          tgx::GemvArgs p = a;
+          p.W = w.wdown + (size_t)k0 * c->esz; p.x = r.h + k0; p.K = std::min(per, I - k0); p.ldw = I;
+          if (k0) p.bias = nullptr;
+          launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, p, TGX_KERNEL_DOWN, R);
+        }
+        break;
+      }
       launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_DOWN, R);
       break;
     }
@@ -830,8 +842,9 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   if (d.heads / d.kv_heads > 16) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "GQA group size %d > 16", d.heads / d.kv_heads);
   if (d.hidden % 8 || d.inter % 8 || (d.heads * d.head_dim) % 8) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "hidden/intermediate sizes must be multiples of 8");
   if (d.hidden <= 0 || d.layers <= 0 || d.inter <= 0 || d.vocab <= 0 || d.max_ctx <= 0) return set_err(nullptr, TGX_ERR_INVALID, "non-positive model dimension");
-  if (d.hidden > 4096) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "hidden_size %d > 4096: the norm-fused GEMV keeps x in one wave's registers", d.hidden);
-  if (d.inter > 16384 || d.heads * d.head_dim > 16384) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "projection input wider than 16384");
+  // a launch keeps its K range in registers: at most 8 slices of 8 elements per lane and 4 waves per row pair = 16384 elements
+  if (d.hidden > 16384) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "hidden_size %d > 16384", d.hidden);
+  if (d.inter > 65536 || d.heads * d.head_dim > 16384) return set_err(nullptr, TGX_ERR_UNSUPPORTED, "projection input wider than 65536 (intermediate) / 16384 (heads * head_dim)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(nullptr, TGX_ERR_DEVICE, "no HIP device visible (--device mi355x needs a GPU; there is no CPU fallback)");
   if (device_ordinal < 0 || device_ordinal >= ndev) return set_err(nullptr, TGX_ERR_INVALID, "device ordinal %d out of range [0,%d)", device_ordinal, ndev);

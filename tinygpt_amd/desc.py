@@ -227,6 +227,23 @@ KNOWN_CONFIGS = {
                         "vocab_size": 32768, "tie_word_embeddings": False, "rms_norm_eps": 1e-5,
                         "rope_theta": 1000000.0, "max_position_embeddings": 32768, "torch_dtype": "bfloat16",
                         "_name_or_path": "Mistral-7B-v0.3"},
+    # the other checkpoints the reference's README names (README.md:50-56), public config.json values
+    "qwen2.5-3b": {"model_type": "qwen2", "hidden_size": 2048, "num_hidden_layers": 36, "num_attention_heads": 16,
+                   "num_key_value_heads": 2, "intermediate_size": 11008, "vocab_size": 151936,
+                   "tie_word_embeddings": True, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0,
+                   "max_position_embeddings": 32768, "torch_dtype": "bfloat16", "_name_or_path": "Qwen2.5-3B"},
+    "qwen3-1.7b": {"model_type": "qwen3", "hidden_size": 2048, "num_hidden_layers": 28, "num_attention_heads": 16,
+                   "num_key_value_heads": 8, "head_dim": 128, "intermediate_size": 6144, "vocab_size": 151936,
+                   "tie_word_embeddings": True, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0,
+                   "max_position_embeddings": 40960, "torch_dtype": "bfloat16", "attention_bias": False,
+                   "_name_or_path": "Qwen3-1.7B"},
+    # 70B-class geometry (Llama-3.1-70B): 141 GB of bf16 parameters — one MI355X holds it in its 288 GB of HBM3E
+    "llama-3.1-70b": {"model_type": "llama", "hidden_size": 8192, "num_hidden_layers": 80, "num_attention_heads": 64,
+                      "num_key_value_heads": 8, "intermediate_size": 28672, "vocab_size": 128256,
+                      "tie_word_embeddings": False, "rms_norm_eps": 1e-5, "rope_theta": 500000.0,
+                      "max_position_embeddings": 131072, "torch_dtype": "bfloat16", "_name_or_path": "Llama-3.1-70B",
+                      "rope_scaling": {"factor": 8.0, "high_freq_factor": 4.0, "low_freq_factor": 1.0,
+                                       "original_max_position_embeddings": 8192, "rope_type": "llama3"}},
     # Qwen3-0.6B (public config.json): per-head q/k RMSNorm, explicit head_dim 128 with q_dim 2048 != hidden 1024
     "qwen3-0.6b": {"model_type": "qwen3", "hidden_size": 1024, "num_hidden_layers": 28, "num_attention_heads": 16,
                    "num_key_value_heads": 8, "head_dim": 128, "intermediate_size": 3072, "vocab_size": 151936,

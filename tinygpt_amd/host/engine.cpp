@@ -293,6 +293,8 @@ bool known_config(const std::string& key, int compute_dtype, int max_batch, Mode
       {"llama-3.2-3b", TGX_FAMILY_LLAMA, 3072, 28, 24, 8, 8192, 128256, 1, 0, 131072, 1e-5f, 500000.f, 1},
       {"qwen2.5-0.5b", TGX_FAMILY_QWEN2, 896, 24, 14, 2, 4864, 151936, 1, 1, 32768, 1e-6f, 1000000.f, 0},
       {"mistral-7b-v0.3", TGX_FAMILY_MISTRAL, 4096, 32, 32, 8, 14336, 32768, 0, 0, 32768, 1e-5f, 1000000.f, 0},
+      {"qwen2.5-3b", TGX_FAMILY_QWEN2, 2048, 36, 16, 2, 11008, 151936, 1, 1, 32768, 1e-6f, 1000000.f, 0},
+      {"llama-3.1-70b", TGX_FAMILY_LLAMA, 8192, 80, 64, 8, 28672, 128256, 0, 0, 131072, 1e-5f, 500000.f, 2},
   };
   if (key == "gpt2") {   // GPT-2 124M (BASELINE.json configs[0]): head = wte, n_ctx = n_positions = 1024
     out = ModelConfig();
@@ -301,6 +303,15 @@ bool known_config(const std::string& key, int compute_dtype, int max_batch, Mode
     d.max_ctx = 1024; d.n_positions = 1024; d.qkv_bias = 1; d.tied = 1; d.compute_dtype = compute_dtype; d.norm_eps = 1e-5f;
     d.max_batch = max_batch < 1 ? 1 : max_batch;
     out.model_type = "gpt2";
+    return true;
+  }
+  if (key == "qwen3-1.7b") {
+    out = ModelConfig();
+    tgx_model_desc& d = out.desc;
+    d.family = TGX_FAMILY_QWEN3; d.hidden = 2048; d.layers = 28; d.heads = 16; d.kv_heads = 8; d.head_dim = 128; d.inter = 6144; d.vocab = 151936;
+    d.max_ctx = 40960; d.tied = 1; d.qk_norm = 1; d.compute_dtype = compute_dtype; d.norm_eps = 1e-6f; d.rope_theta = 1000000.f;
+    d.max_batch = max_batch < 1 ? 1 : max_batch;
+    out.model_type = "qwen3";
     return true;
   }
   if (key == "qwen3-0.6b") {   // explicit head_dim (q_dim 2048 != hidden 1024), per-head q/k RMSNorm (ModelQwen3.h:23-40)
@@ -319,7 +330,7 @@ bool known_config(const std::string& key, int compute_dtype, int max_batch, Mode
     d.family = k.fam; d.hidden = k.H; d.layers = k.L; d.heads = k.nh; d.kv_heads = k.nkv; d.head_dim = k.H / k.nh;
     d.inter = k.I; d.vocab = k.V; d.max_ctx = k.ctx; d.qkv_bias = k.bias; d.tied = k.tied; d.compute_dtype = compute_dtype;
     d.norm_eps = k.eps; d.rope_theta = k.theta; d.max_batch = max_batch < 1 ? 1 : max_batch;
-    if (k.scaled) { d.rope_factor = 32.f; d.rope_high_freq = 4.f; d.rope_low_freq = 1.f; d.rope_orig_ctx = 8192; d.max_ctx = 8192; }
+    if (k.scaled) { d.rope_factor = k.scaled == 2 ? 8.f : 32.f; d.rope_high_freq = 4.f; d.rope_low_freq = 1.f; d.rope_orig_ctx = 8192; d.max_ctx = 8192; }
     out.model_type = k.fam == TGX_FAMILY_LLAMA ? "llama" : k.fam == TGX_FAMILY_QWEN2 ? "qwen2" : "mistral";
     return true;
   }
