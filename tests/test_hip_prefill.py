@@ -52,7 +52,8 @@ def test_fixture_prefill_matches_steps_and_oracle(fam, dtype, oracle_lib):
 
 
 @pytest.mark.parametrize("name,S,dtype", [("llama-3.2-1b", 300, "bf16"), ("mistral-7b-v0.3", 130, "bf16"), ("qwen2.5-0.5b", 257, "bf16"),
-                                          ("llama-3.2-1b", 300, "fp16"), ("mistral-7b-v0.3", 130, "fp16")])
+                                          ("llama-3.2-1b", 300, "fp16"), ("mistral-7b-v0.3", 130, "fp16"),
+                                          ("qwen2.5-3b", 200, "bf16"), ("qwen3-1.7b", 150, "bf16")])   # the README's other checkpoints: 8 query heads per kv head; q/k norm
 def test_real_layer_shapes_prefill_equals_steps(name, S, dtype):
     """Real hidden/intermediate/head geometry (2 layers, 4096-entry vocabulary to keep the upload small)."""
     d = copy.deepcopy(known_desc(name, dtype))
