@@ -200,7 +200,9 @@ def main():
     prefill_tflops = (gemm_flops + attn_flops) / (prefill_ms * 1e-3) / 1e12
 
     line = {
-        "metric": "decode tokens/sec (and % HBM roofline), Llama-3.2-1B bf16 batch=1, 1 GPU",
+        # BASELINE.json's metric string for the headline configuration; other --model / --dtype runs name themselves
+        "metric": ("decode tokens/sec (and % HBM roofline), Llama-3.2-1B bf16 batch=1, 1 GPU" if (args.model == "llama-3.2-1b" and args.dtype == "bf16")
+                   else f"decode tokens/sec (and % HBM roofline), {desc.name} {args.dtype} batch=1, 1 GPU"),
         "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
