@@ -133,6 +133,7 @@ struct tgx_ctx {
   bf16_t *ws_qh = nullptr, *ws_ql = nullptr;          // [S][qd] rotated queries (hi, lo)
   bf16_t *ws_hh = nullptr, *ws_hl = nullptr;          // [S][I] siluMul output (hi, lo): the down product's A operand
   bool prefill_mfma = true;
+  int prefill_min_rows = 4;  // prompts shorter than this go through the decode kernels, 4 positions per pass (set in tgx_create)
   int gemm_tm = 0;           // experiment: force the GEMM row tile (64 / 128); 0 = by the number of tiles
   int debug_attn = 0;        // experiment: AttnArgs.dbg
   int attn_gmax = 0;         // experiment: query heads per attention workgroup (default 2)
@@ -868,6 +869,10 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   // measured crossover of the direct and the split attention (tools/sweep.py --grid attn.direct_max=0,100000): context ~850-1100 at
   // head_dim 64 (Qwen2.5-0.5B, Llama-3.2-1B), ~500 at 128 (Mistral-7B: half the tokens per wave-load)
   c->attn_direct_max = d.head_dim == 64 ? 768 : 384;
+  // short prompts: the tiled GEMMs launch too few workgroups to stream the weights at rate when M is a handful of rows (S <= 96 costs a
+  // flat 4.7 ms on Llama-3.2-1B, 17 ms on Mistral-7B); passes through the batched decode kernels (4 positions each) are faster up to
+  // ~20 tokens (1B, Qwen2.5-0.5B) / ~15 (7B) — tools/prefill_crossover.py
+  c->prefill_min_rows = d.hidden >= 4096 ? 16 : 20;
   c->tune[TGX_KERNEL_DOWN].ks = 4;   // K = intermediate_size: 4 waves split each row pair
   // qkv is the most latency-bound launch (few rows): 4 waves per row pair shorten every wave's load -> reduce chain; measured
   // ks 1 -> 4: Llama-3.2-1B 1395 -> 1411 tok/s, 3B 628 -> 637, Mistral-7B 341 -> 347; hidden 896 (Qwen2.5-0.5B) loses 2 %
@@ -1111,7 +1116,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
   for (int b = 0; b < batch; b++) {
     RowState& r = c->rows[(size_t)b];
     HIP_OK(c, hipMemcpyAsync(r.prompt, ids + (size_t)b * seq, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream));
-    if (seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && !c->gpt2 && prefill_shapes_ok(c->d)) {
+    if (seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && !c->gpt2 && prefill_shapes_ok(c->d)) {
       // batched prefill on the matrix cores; logits for the last position only (== forward + narrow, GPTEngine.cpp:96-97)
       int rc = ensure_prefill_ws(c, seq);
       if (rc) return rc;
@@ -1353,6 +1358,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.gemm_tm")) { c->gemm_tm = value; return TGX_OK; }
   if (!strcmp(key, "debug.gemv")) { c->debug_gemv = value; return TGX_OK; }
   if (!strcmp(key, "prefill.mfma")) { c->prefill_mfma = value != 0; return TGX_OK; }
+  if (!strcmp(key, "prefill.min_rows")) { c->prefill_min_rows = value; return TGX_OK; }
   if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
   if (!strcmp(key, "attn.nsplit")) {
     if (c->finalized) return set_err(c, TGX_ERR_STATE, "attn.nsplit must be set before tgx_finalize");
