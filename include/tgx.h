@@ -208,7 +208,8 @@ TGX_API int tgx_set_logits(tgx_ctx* ctx, const float* logits, int batch);
  *   "attn.nsplit"  KV splits per kv head (<= 32, before tgx_finalize); "attn.gmax" query heads per attention workgroup
  *   "attn.direct_max"  contexts up to this many keys run attention as one workgroup per head group, without the combine launch (default 768 at head_dim 64, 384 at 128; 0 = never)
  *   "graph" 0/1    hipGraph replay vs eager launches; "graph.steps" decode steps per graph for long tgx_decode calls
- *   "prefill.min_rows"  prompts shorter than this take passes through the decode kernels instead of the batched prefill (default 20; 16 at hidden >= 4096)
+ *   "prefill.min_rows"  prompts shorter than this take passes through the decode kernels instead of the batched prefill (default 7)
+ *   "prefill.splitk" 0/1  split K over workgroups when a prompt gives the GEMMs few row tiles (default 1)
  *   "prefill.mfma" 0/1  batched matrix-core prefill vs passes through the decode kernels; "prefill.gemm_tm" 64/128 row tile
  *   "debug.*"      experiment switches (tools/gemv_dissect.py, tools/attn_dissect.py; live only in a -DTGX_DISSECT=1 build) */
 TGX_API int tgx_set_option(tgx_ctx* ctx, const char* key, int value);

