@@ -335,3 +335,31 @@ def test_wide_models_vs_oracle(hidden, heads, kv, inter, hip, oracle_lib):
     assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_ORACLE
     gpu.reset_cache(); gpu.forward(prompt[:1]); gpu.sample(GREEDY)
     assert gpu.decode(8, GREEDY).shape == (8, 1)                 # graph-captured decode at this width
+
+
+def test_streaming_across_the_direct_attention_limit(hip):
+    """One-step-at-a-time streaming (tgx_step_async / tgx_fetch_token) and multi-step decode calls that start on the direct
+    attention form and cross attn.direct_max (768 keys at head_dim 64) mid-generation: the step graphs are re-captured on the
+    split form; ids equal a run that never uses the direct form."""
+    import copy
+    from tinygpt_amd import known_desc, synth
+    from tinygpt_amd.ffi import Model
+    d = copy.deepcopy(known_desc("llama-3.2-1b"))
+    d.layers, d.vocab, d.max_ctx = 2, 4096, 1024
+    m = Model(d, hip).load_synthetic(1234, 0.02).finalize()
+    prompt = synth.synth_prompt(d.vocab, 755, 9)[None, :]
+    m.set_option("attn.direct_max", 0)
+    m.forward(prompt); first = int(m.sample(GREEDY)[0]); want = m.decode(40, GREEDY)[:, 0].copy()
+    m.set_option("attn.direct_max", 768)
+    m.reset_cache(); m.forward(prompt); assert int(m.sample(GREEDY)[0]) == first
+    got = []
+    t_prev = m.step_async(GREEDY)
+    for _ in range(23):                                   # contexts 756 .. 779: crosses 768 while a ticket is outstanding
+        t_next = m.step_async(GREEDY)
+        got.append(m.fetch_token(t_prev)); t_prev = t_next
+    got.append(m.fetch_token(t_prev))
+    np.testing.assert_array_equal(np.array(got), want[:24])
+    np.testing.assert_array_equal(m.decode(16, GREEDY)[:, 0], want[24:40])
+    m.reset_cache(); m.forward(prompt); m.sample(GREEDY)
+    np.testing.assert_array_equal(m.decode(8, GREEDY)[:, 0], want[:8])        # 8 steps stay below the limit: direct form
+    np.testing.assert_array_equal(m.decode(32, GREEDY)[:, 0], want[8:40])     # this call crosses it: split form for the whole call
