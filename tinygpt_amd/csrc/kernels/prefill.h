@@ -308,6 +308,7 @@ struct AttnPrefillArgs {
   bf16_t *o_hi, *o_lo;           // [S][heads*hd]
   int S, heads, kv_heads, max_ctx, past;
   float scale;                   // hd^-1/2
+  int qblk_mirror;               // 1: see the block order in the kernel
 };
 
 // Scores and probabilities never leave the registers (the first version of this round routed them through LDS with four
@@ -333,7 +334,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5, ql = lane & 31;
   const int h = blockIdx.y, G = a.heads / a.kv_heads, kvh = h / G;
   const int qd = a.heads * HD;
-  const int q0 = blockIdx.x * 128 + wv * 32;          // first query of this wave
+  // causal work grows with the query block: the upper half of the heads walks the blocks in reverse, so that workgroups b and b + half
+  // the grid (which tend to share a CU) carry complementary amounts
+  const int qblk = (a.qblk_mirror && h >= a.heads / 2) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const int q0 = qblk * 128 + wv * 32;                 // first query of this wave
   const int qi = q0 + ql;                              // this lane's query
   const bool qvalid = qi < a.S;
   const int qpos = a.past + qi;
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
 
   const bf16_t* kbase = a.k_cache + (size_t)kvh * a.max_ctx * HD;
   const bf16_t* vbase = a.v_cache + (size_t)kvh * a.max_ctx * HD;
-  const int wg_last_pos = a.past + min((int)blockIdx.x * 128 + 127, a.S - 1);   // keys beyond it are never attended by this workgroup
+  const int wg_last_pos = a.past + min(qblk * 128 + 127, a.S - 1);   // keys beyond it are never attended by this workgroup
   const int n_kt = wg_last_pos / 64 + 1;
   const int wave_last_pos = a.past + min(q0 + 31, a.S - 1);
   const bool wave_live = q0 < a.S;

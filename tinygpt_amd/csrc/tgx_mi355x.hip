@@ -134,6 +134,7 @@ struct tgx_ctx {
   bf16_t *ws_hh = nullptr, *ws_hl = nullptr;          // [S][I] siluMul output (hi, lo): the down product's A operand
   float* ws_part = nullptr; size_t ws_part_bytes = 0;   // split-K slabs of the short-prompt GEMMs
   int gemm_splitk = 1;       // experiment: 0 disables split-K
+  int attn_mirror = 1;       // experiment: prefill attention block order
   bool prefill_mfma = true;
   int prefill_min_rows = 4;  // prompts shorter than this go through the decode kernels, 4 positions per pass (set in tgx_create)
   int gemm_tm = 0;           // experiment: force the GEMM row tile (64 / 128); 0 = by the number of tiles
@@ -659,7 +660,7 @@ void launch_prefill(tgx_ctx* c, RowState& r, int S) {
       tgx::AttnPrefillArgs a{};
       a.q_hi = c->ws_qh; a.q_lo = c->ws_ql; a.k_cache = kc + (size_t)l * kv_layer; a.v_cache = vc + (size_t)l * kv_layer;
       a.o_hi = c->ws_ah; a.o_lo = c->ws_al; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
-      a.scale = 1.0f / sqrtf((float)hd);
+      a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = c->attn_mirror;
       const dim3 grid((S + 127) / 128, d.heads), blk(256);
       TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64>), grid, blk, 0, c->stream, a);
                              else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128>), grid, blk, 0, c->stream, a))
@@ -1390,6 +1391,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.mfma")) { c->prefill_mfma = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.min_rows")) { c->prefill_min_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk")) { c->gemm_splitk = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.attn_mirror")) { c->attn_mirror = value; return TGX_OK; }
   if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
   if (!strcmp(key, "attn.nsplit")) {
     if (c->finalized) return set_err(c, TGX_ERR_STATE, "attn.nsplit must be set before tgx_finalize");
