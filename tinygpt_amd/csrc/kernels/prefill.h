@@ -42,8 +42,9 @@ __device__ __forceinline__ void split16(float x, bf16_t& hi, bf16_t& lo) {
 
 // ---- X[s][:] = embed[ids[s]] (fp32) ------------------------------------------------------------------------------
 template <int DT>
-__global__ __launch_bounds__(256) void embed_rows_kernel(const long long* ids, const bf16_t* embed, float* X, int H) {
-  const long long t = ids[blockIdx.x];
+__global__ __launch_bounds__(256) void embed_rows_kernel(const long long* ids, const bf16_t* embed, float* X, int H, int S, long long ids_stride) {
+  // stacked prompts: workspace row blockIdx.x = (batch row, position); the ids of batch row b start at ids + b * ids_stride
+  const long long t = ids[(size_t)(blockIdx.x / S) * ids_stride + blockIdx.x % S];
   const u32x4* src = reinterpret_cast<const u32x4*>(embed + (size_t)t * H);
   f32x4* dst = reinterpret_cast<f32x4*>(X + (size_t)blockIdx.x * H);
   for (int c = threadIdx.x; c < (H >> 3); c += 256) {

@@ -633,44 +633,55 @@ void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float
 
 // All layers for S prompt positions of one row at once; leaves the last position's hidden state in row.x.
 // == CausalLM::forward on [1,S] ids with an empty cache (GPTModel.h:51-56)
-void launch_prefill(tgx_ctx* c, RowState& r, int S) {
+// NB batch rows [row0, row0 + NB) are stacked into ONE [NB*S] row block for the row-wise kernels and the GEMMs (the weights stream
+// once for all of them); RoPE / cache append and attention run per batch row on its slice and its own cache.
+void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
   const tgx_model_desc& d = c->d;
   const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
   const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd;
-  bf16_t* kc = reinterpret_cast<bf16_t*>(r.kcache);
-  bf16_t* vc = reinterpret_cast<bf16_t*>(r.vcache);
-  TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_rows_kernel<DT>, dim3(S), dim3(256), 0, c->stream, (const long long*)r.prompt, (const bf16_t*)c->embed, c->ws_x, H))
+  const int M = NB * S;
+  const size_t wout = (size_t)qd + 2 * kvd;
+  TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_rows_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const long long*)c->rows[(size_t)row0].prompt, (const bf16_t*)c->embed, c->ws_x, H, S, (long long)d.max_ctx))
   for (int l = 0; l < d.layers; l++) {
     const LayerW& w = c->L[(size_t)l];
     // the QKV product feeds a second rounding (the KV cache): bf16 needs three split terms to reproduce the step path's cache
     // entries (two leave 1-8 % of them one ulp off); fp16's two terms already carry 22 bits
     const bool three = c->dt == tgx::DT_BF16;
-    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.in_norm, d.norm_eps, H, c->ws_ah, c->ws_al, three ? c->ws_al2 : (bf16_t*)nullptr))
-    launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, S, qd + 2 * kvd, H, qd + 2 * kvd, /*three_terms=*/three);
-    {
+    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.in_norm, d.norm_eps, H, c->ws_ah, c->ws_al, three ? c->ws_al2 : (bf16_t*)nullptr))
+    launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, M, qd + 2 * kvd, H, qd + 2 * kvd, /*three_terms=*/three);
+    for (int b = 0; b < NB; b++) {
+      RowState& r = c->rows[(size_t)(row0 + b)];
+      bf16_t* kc = reinterpret_cast<bf16_t*>(r.kcache);
+      bf16_t* vc = reinterpret_cast<bf16_t*>(r.vcache);
+      const size_t ro = (size_t)b * S;             // first workspace row of this batch row
       tgx::RopeKvArgs a{};
-      a.QKV = c->ws_out; a.q_hi = c->ws_qh; a.q_lo = c->ws_ql;
+      a.QKV = c->ws_out + ro * wout; a.q_hi = c->ws_qh + ro * qd; a.q_lo = c->ws_ql + ro * qd;
       a.k_cache = kc + (size_t)l * kv_layer; a.v_cache = vc + (size_t)l * kv_layer;
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = (int)c->past;
       a.q_norm_w = d.qk_norm ? (const bf16_t*)w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? (const bf16_t*)w.k_norm : nullptr; a.eps = d.norm_eps;
       TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rope_kv_split_kernel<DT>, dim3(S), dim3(256), 0, c->stream, a))
     }
-    {
+    for (int b = 0; b < NB; b++) {
+      RowState& r = c->rows[(size_t)(row0 + b)];
+      bf16_t* kc = reinterpret_cast<bf16_t*>(r.kcache);
+      bf16_t* vc = reinterpret_cast<bf16_t*>(r.vcache);
+      const size_t ro = (size_t)b * S;
       tgx::AttnPrefillArgs a{};
-      a.q_hi = c->ws_qh; a.q_lo = c->ws_ql; a.k_cache = kc + (size_t)l * kv_layer; a.v_cache = vc + (size_t)l * kv_layer;
-      a.o_hi = c->ws_ah; a.o_lo = c->ws_al; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
+      a.q_hi = c->ws_qh + ro * qd; a.q_lo = c->ws_ql + ro * qd; a.k_cache = kc + (size_t)l * kv_layer; a.v_cache = vc + (size_t)l * kv_layer;
+      a.o_hi = c->ws_ah + ro * qd; a.o_lo = c->ws_al + ro * qd; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
       a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = c->attn_mirror;
       const dim3 grid((S + 127) / 128, d.heads), blk(256);
       TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64>), grid, blk, 0, c->stream, a);
                              else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128>), grid, blk, 0, c->stream, a))
     }
-    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wo, nullptr, c->ws_x, S, H, qd, H);
-    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(S), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al, (bf16_t*)nullptr))
-    launch_gemm(c, tgx::GEMM_SILU, w.wgu, nullptr, nullptr, S, 2 * I, H, 2 * I);      // gate_up + siluMul -> ws_hh / ws_hl
-    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wdown, nullptr, c->ws_x, S, H, I, H, false, c->ws_hh, c->ws_hl);
+    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wo, nullptr, c->ws_x, M, H, qd, H);
+    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al, (bf16_t*)nullptr))
+    launch_gemm(c, tgx::GEMM_SILU, w.wgu, nullptr, nullptr, M, 2 * I, H, 2 * I);      // gate_up + siluMul -> ws_hh / ws_hl
+    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wdown, nullptr, c->ws_x, M, H, I, H, false, c->ws_hh, c->ws_hl);
   }
-  (void)hipMemcpyAsync(r.x, c->ws_x + (size_t)(S - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, c->stream);
+  for (int b = 0; b < NB; b++)     // the last position of every batch row feeds lm_head
+    (void)hipMemcpyAsync(c->rows[(size_t)(row0 + b)].x, c->ws_x + ((size_t)(b + 1) * S - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, c->stream);
 }
 
 // model.norm -> lm_head on the current position + per-workgroup argmax partials   (GPTModel.h:56-57)
@@ -1144,18 +1155,27 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     if (ids[i] < 0 || ids[i] >= c->d.vocab) return set_err(c, TGX_ERR_INVALID, "token id out of range");
   HIP_OK(c, hipSetDevice(c->device));
   c->batch = batch;
-  for (int b = 0; b < batch; b++) {
-    RowState& r = c->rows[(size_t)b];
-    HIP_OK(c, hipMemcpyAsync(r.prompt, ids + (size_t)b * seq, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream));
-    if (seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && !c->gpt2 && prefill_shapes_ok(c->d)) {
-      // batched prefill on the matrix cores; logits for the last position only (== forward + narrow, GPTEngine.cpp:96-97)
-      int rc = ensure_prefill_ws(c, seq);
+  const bool mfma_path = seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && !c->gpt2 && prefill_shapes_ok(c->d);
+  for (int b = 0; b < batch; b++) HIP_OK(c, hipMemcpyAsync(c->rows[(size_t)b].prompt, ids + (size_t)b * seq, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream));
+  if (mfma_path) {
+    // batched prefill on the matrix cores; logits for the last position only (== forward + narrow, GPTEngine.cpp:96-97).  Batch rows are
+    // stacked into one row block while that stays within 8192 workspace rows (the CLI's 4 short prompts cost one pass over the weights)
+    const int per = std::max(1, std::min(batch, 8192 / seq));
+    for (int row0 = 0; row0 < batch; row0 += per) {
+      const int nb = std::min(per, batch - row0);
+      int rc = ensure_prefill_ws(c, nb * seq);
       if (rc) return rc;
-      launch_prefill(c, r, seq);
-      launch_lm_head(c, b, 1);
-      hipLaunchKernelGGL(tgx::add_pos_kernel, dim3(1), dim3(64), 0, c->stream, r.pos, seq);
-      continue;
+      launch_prefill(c, row0, nb, seq);
+      for (int b = row0; b < row0 + nb;) {
+        const int rem = row0 + nb - b, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
+        launch_lm_head(c, b, R);
+        b += R;
+      }
+      for (int b = row0; b < row0 + nb; b++) hipLaunchKernelGGL(tgx::add_pos_kernel, dim3(1), dim3(64), 0, c->stream, c->rows[(size_t)b].pos, seq);
     }
+  }
+  for (int b = 0; b < batch && !mfma_path; b++) {
+    RowState& r = c->rows[(size_t)b];
     // prefill by steps (fp32 storage, GPT-2, prompts shorter than 4 tokens, shapes the GEMM tile does not cover): up to 4 consecutive
     // positions per pass through the decode kernels — the chunk rows share this row's cache (kv_stride 0), each attends the
     // keys up to its own position, so the result equals position-by-position passes at a quarter of the weight traffic
