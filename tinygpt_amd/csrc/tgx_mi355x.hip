@@ -828,7 +828,9 @@ int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int 
   c->attn_direct = c->past + n <= c->attn_direct_max;
   if (c->use_graph) {
     const int K = c->graph_steps;
-    int rc = ensure_step_graph(c, cfg, /*want_multi=*/n >= 2 * K);
+    // any multi-step call captures the K-step graph as well (a short warm-up call then leaves nothing to capture inside a later, longer
+    // call); one-step streaming calls never pay for it
+    int rc = ensure_step_graph(c, cfg, /*want_multi=*/n >= 2);
     if (rc) return rc;
     int i = 0;
     if (c->multi_graph) for (; i + K <= n; i += K) HIP_OK(c, hipGraphLaunch(c->multi_graph, c->stream));
