@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <queue>
@@ -248,7 +249,11 @@ bool Tokenizer::parseSteps(const void* jv, std::vector<Step>& out, const char* w
   else if (type == "ByteLevel") {
     s.type = Step::ByteLevel;
     s.flag_a = j.get_bool("add_prefix_space", false);
-    s.flag_b = j.get_bool("use_regex", false);      // absent == false, as the reference reads it (TokenizerConfig.cpp:70)
+    // absent == false, as the reference reads it (TokenizerConfig.cpp:70).  HF `tokenizers` defaults an absent key to true (gpt2's
+    // tokenizer.json has none): identical ids on ordinary text, different ones on whitespace runs (" \u00a0\u00a0", "a  b"), where the
+    // unsplit text lets BPE merge across what GPT-2's pattern would have separated.  TGX_TOKENIZER_HF_DEFAULTS=1 selects HF's default.
+    const char* hf_defaults = getenv("TGX_TOKENIZER_HF_DEFAULTS");
+    s.flag_b = j.get_bool("use_regex", hf_defaults && hf_defaults[0] == '1');
     if (s.flag_b) s.regex = std::make_shared<Regex>(kGpt2Pattern);
     byteLevelDecode_ = true;
   } else if (type == "Split") {
