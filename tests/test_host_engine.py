@@ -225,3 +225,59 @@ def test_text_entry_points_need_a_tokenizer(lib, oracle_path, tmp_path):
         arr_err = str(ex)
     assert arr_err and "no tokenizer" in arr_err
     e.close()
+
+
+def test_corrupt_model_directories_fail_loudly(lib, oracle_path, tmp_path):
+    """Truncated / malformed config.json, generation_config.json and safetensors files (header length, offsets, shapes, short data):
+    prepare() returns false with a message for every one of them — no crash, no partially loaded model (ModelLoader.cpp:25-89,
+    SafeTensors.cpp:141-229 fail the same way: bool + log)."""
+    import json, os, shutil, struct
+    cfg, g = load_golden("llama_tiny")
+    base = str(tmp_path / "base")
+    write_model_dir(base, cfg, int(g["seed"]), float(g["std"]))
+
+    def attempt(mutate):
+        d = str(tmp_path / "case")
+        shutil.rmtree(d, ignore_errors=True); shutil.copytree(base, d)
+        mutate(d)
+        e = HostEngine(lib, model_dir=d, backend_lib=oracle_path, prefix="tgxo_", dtype=0)
+        ok, err = e.prepare(), e.error()
+        e.close()
+        return ok, err
+
+    def write(path, data, mode="w"):
+        with open(path, mode) as f:
+            f.write(data)
+
+    def edit_header(d, fn):
+        p = os.path.join(d, "model.safetensors"); b = open(p, "rb").read(); n = struct.unpack("<Q", b[:8])[0]
+        h = json.loads(b[8:8 + n]); fn(h, [k for k in h if k != "__metadata__"][0])
+        hb = json.dumps(h).encode(); write(p, struct.pack("<Q", len(hb)) + hb + b[8 + n:], "wb")
+
+    def set_header_len(d, n):
+        p = os.path.join(d, "model.safetensors"); b = bytearray(open(p, "rb").read()); b[:8] = struct.pack("<Q", n); write(p, bytes(b), "wb")
+
+    def truncate(d, keep):
+        p = os.path.join(d, "model.safetensors"); b = open(p, "rb").read(); write(p, b[:keep if keep > 0 else len(b) + keep], "wb")
+
+    assert attempt(lambda d: None) == (True, "")
+    cases = {
+        "config truncated": lambda d: write(os.path.join(d, "config.json"), json.dumps(cfg)[:50]),
+        "config empty": lambda d: write(os.path.join(d, "config.json"), ""),
+        "config is a list": lambda d: write(os.path.join(d, "config.json"), "[1,2,3]"),
+        "config wrong types": lambda d: write(os.path.join(d, "config.json"), json.dumps(dict(cfg, hidden_size="big", num_hidden_layers=None))),
+        "config negative heads": lambda d: write(os.path.join(d, "config.json"), json.dumps(dict(cfg, num_attention_heads=-4))),
+        "config unknown model_type": lambda d: write(os.path.join(d, "config.json"), json.dumps(dict(cfg, model_type="bert"))),
+        "generation_config missing": lambda d: os.remove(os.path.join(d, "generation_config.json")),
+        "safetensors 4 bytes": lambda d: truncate(d, 4),
+        "safetensors header cut": lambda d: truncate(d, 100),
+        "safetensors data cut": lambda d: truncate(d, -1000),
+        "safetensors header length 2^60": lambda d: set_header_len(d, 2 ** 60),
+        "safetensors header length 0": lambda d: set_header_len(d, 0),
+        "safetensors offsets beyond file": lambda d: edit_header(d, lambda h, k: h[k].__setitem__("data_offsets", [0, 2 ** 50])),
+        "safetensors negative shape": lambda d: edit_header(d, lambda h, k: h[k].__setitem__("shape", [-1, 7])),
+        "model dir missing": lambda d: shutil.rmtree(d),
+    }
+    for label, mutate in cases.items():
+        ok, err = attempt(mutate)
+        assert not ok and err, label
