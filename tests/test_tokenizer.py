@@ -58,6 +58,17 @@ def test_pretokenizer_patterns_match_regex_module(lib):
 def test_unsupported_patterns_are_refused(lib):
     assert regex_match_all(lib, r"\p{Han}+", "x") is None      # general categories are built, scripts are not: refuse, never mis-split
     assert regex_match_all(lib, r"a++", "aaa") is None
+    assert regex_match_all(lib, r"(a*)*b", "aaaa") is None       # unbounded repeat of a nullable body: would never terminate
+
+
+def test_exponential_backtracking_is_bounded(lib):
+    """A pattern that backtracks exponentially must not hang the tokenizer: the per-call step budget stops the search (the text is
+    then split more coarsely); ordinary inputs of the same pattern still match."""
+    import time
+    t0 = time.time()
+    assert regex_match_all(lib, r"(a|aa)+b", "a" * 64) == []
+    assert time.time() - t0 < 5.0
+    assert regex_match_all(lib, r"(a|aa)+b", "aaab") == [[0, 4]]
     assert regex_match_all(lib, r"(unclosed", "x") is None
 
 

@@ -132,6 +132,16 @@ struct Regex::Parser {
     }
     return true;
   }
+  static bool nullable(const Node& n) {
+    switch (n.kind) {
+      case Node::Char: case Node::Any: case Node::Class: return false;
+      case Node::Bol: case Node::Eol: case Node::Look: return true;
+      case Node::Cat: for (const Node& k : n.kids) if (!nullable(k)) return false; return true;
+      case Node::Alt: for (const Node& k : n.kids) if (nullable(k)) return true; return false;
+      case Node::Repeat: return n.min == 0 || nullable(n.kids[0]);
+    }
+    return true;
+  }
   bool cat(Node& out, bool icase) {
     out = Node(); out.kind = Node::Cat;
     while (more() && p[i] != '|' && p[i] != ')') {
@@ -152,6 +162,9 @@ struct Regex::Parser {
           i++;
           if (mx >= 0 && mx < mn) return fail("{n,m} with m < n");
         }
+        // an unbounded repeat of something that can match the empty string never terminates in a backtracking matcher (and no
+        // pre-tokenizer pattern needs one): refused at load
+        if (mx < 0 && nullable(a)) return fail("unbounded repeat of an expression that can match the empty string");
         Node r; r.kind = Node::Repeat; r.min = mn; r.max = mx;
         if (more() && p[i] == '?') { r.lazy = true; i++; }
         else if (more() && p[i] == '+') return fail("possessive quantifiers are not supported");
@@ -348,17 +361,17 @@ Regex::Regex(const std::string& pattern) {
 }
 
 // ---------------------------------------------------------------------------------------------- matcher
-long Regex::run(size_t pc0, const std::vector<uint32_t>& cps, size_t i0) const {
+long Regex::run(size_t pc0, const std::vector<uint32_t>& cps, size_t i0, size_t& budget) const {
   struct Thread { uint32_t pc; size_t i; };
   std::vector<Thread> stack;
   stack.push_back({(uint32_t)pc0, i0});
   const size_t n = cps.size();
-  size_t steps = 0;
   while (!stack.empty()) {
     Thread t = stack.back();
     stack.pop_back();
     for (;;) {
-      if (++steps > (size_t)400000000) return -1;   // pathological pattern guard
+      if (budget == 0) return -2;                   // step budget of this matchAll call spent (exponential backtracking): give up
+      budget--;
       const Inst& in = prog_[t.pc];
       bool ok = true;
       switch (in.op) {
@@ -369,7 +382,7 @@ long Regex::run(size_t pc0, const std::vector<uint32_t>& cps, size_t i0) const {
         case EOL: ok = t.i == n; if (ok) t.pc++; break;
         case SPLIT: stack.push_back({in.b, t.i}); t.pc = in.a; break;
         case JMP: t.pc = in.a; break;
-        case LOOK: ok = (run(in.a, cps, t.i) >= 0) != in.flag; if (ok) t.pc = in.b; break;
+        case LOOK: { const long r = run(in.a, cps, t.i, budget); if (r == -2) return -2; ok = (r >= 0) != in.flag; if (ok) t.pc = in.b; break; }
         case MATCH: return (long)t.i;
       }
       if (!ok) break;
@@ -385,9 +398,13 @@ void Regex::matchAll(const std::string& text, std::vector<Range>& out) const {
   cps.reserve(text.size()); off.reserve(text.size() + 1);
   for (size_t k = 0; k < text.size();) { uint32_t cp; off.push_back(k); k += utf8_decode(text.data() + k, text.size() - k, cp); cps.push_back(cp); }
   off.push_back(text.size());
+  // a tokenizer pattern needs a few steps per code point; the budget bounds pathological (exponentially backtracking) patterns: when it
+  // is spent, matching stops and the rest of the text stays unmatched (the Split pre-tokenizer still emits it: a valid, coarser split)
+  size_t budget = 20000000 + 4000 * cps.size();
   size_t i = 0;
   while (i < cps.size()) {
-    const long e = run(0, cps, i);
+    const long e = run(0, cps, i, budget);
+    if (e == -2) break;
     if (e > (long)i) { out.emplace_back(off[i], off[(size_t)e]); i = (size_t)e; }
     else i++;
   }

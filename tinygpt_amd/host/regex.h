@@ -52,7 +52,8 @@ class Regex {
   std::vector<CharClass> classes_;
   std::string err_;
   // runs the program from `pc` at code point index `i`; returns the end index of the match or -1
-  long run(size_t pc, const std::vector<uint32_t>& cps, size_t i) const;
+  // -1: no match here; -2: the call's step budget is spent
+  long run(size_t pc, const std::vector<uint32_t>& cps, size_t i, size_t& budget) const;
 };
 
 }  // namespace tgxh
