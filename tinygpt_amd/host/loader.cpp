@@ -43,6 +43,15 @@ int family_of(const std::string& t) {
 
 }  // namespace
 
+// every dimension the device shim allocates from must be a positive 32-bit integer (a missing key or a value of the wrong JSON type reads as -1)
+static bool check_dims(const tgx_model_desc& d, const std::string& path, std::string& err) {
+  struct { const char* name; int64_t v; } f[] = {{"hidden size", d.hidden}, {"layer count", d.layers}, {"attention heads", d.heads}, {"key/value heads", d.kv_heads},
+                                                 {"head_dim", d.head_dim}, {"intermediate size", d.inter}, {"vocab_size", d.vocab}, {"context size", d.max_ctx}};
+  for (auto& e : f)
+    if (e.v <= 0 || e.v > (int64_t)1 << 30) { err = "config.json: " + std::string(e.name) + " is missing, not an integer or out of range in " + path; return false; }
+  return true;
+}
+
 bool load_model_config(const std::string& path, int compute_dtype, int max_batch, ModelConfig& out, std::string& err) {
   std::string text;
   if (!read_file(path, text) || text.empty()) { err = "Failed to open file: " + path; return false; }
@@ -57,32 +66,34 @@ bool load_model_config(const std::string& path, int compute_dtype, int max_batch
   d.family = fam;
   d.compute_dtype = compute_dtype;
   d.max_batch = max_batch < 1 ? 1 : max_batch;
+  // 64-bit values are range-checked before narrowing (2^32 + 5 must not read as 5)
+  auto dim = [](const Json& j, const char* key, int64_t def) -> int32_t { const int64_t v = j.get_int(key, def); return (v < 0 || v > ((int64_t)1 << 30)) ? -1 : (int32_t)v; };
   out.torch_dtype = doc.get_str("torch_dtype", doc.get_str("dtype", ""));
   out.bos_token_id = doc.get_int("bos_token_id", -1);
   out.eos_token_id = doc.get_int("eos_token_id", -1);
-  d.vocab = (int32_t)doc.get_int("vocab_size", -1);
+  d.vocab = dim(doc, "vocab_size", -1);
   if (fam == TGX_FAMILY_GPT2) {
-    d.hidden = (int32_t)doc.get_int("n_embd", -1);
-    d.layers = (int32_t)doc.get_int("n_layer", -1);
-    d.heads = d.kv_heads = (int32_t)doc.get_int("n_head", -1);
+    d.hidden = dim(doc, "n_embd", -1);
+    d.layers = dim(doc, "n_layer", -1);
+    d.heads = d.kv_heads = dim(doc, "n_head", -1);
     d.head_dim = d.heads > 0 ? d.hidden / d.heads : 0;
     d.inter = 4 * d.hidden;
-    d.n_positions = (int32_t)doc.get_int("n_positions", -1);
-    d.max_ctx = (int32_t)doc.get_int("n_ctx", d.n_positions);      // contextSize = n_ctx (ModelGPT2.h:230)
+    d.n_positions = dim(doc, "n_positions", -1);
+    d.max_ctx = dim(doc, "n_ctx", d.n_positions);      // contextSize = n_ctx (ModelGPT2.h:230)
     d.norm_eps = doc.get_float("layer_norm_epsilon", 1e-5f);
     d.qkv_bias = 1; d.tied = 1;
-    return true;
+    return check_dims(d, path, err);
   }
-  d.hidden = (int32_t)doc.get_int("hidden_size", -1);
-  d.layers = (int32_t)doc.get_int("num_hidden_layers", -1);
-  d.heads = (int32_t)doc.get_int("num_attention_heads", -1);
-  d.kv_heads = (int32_t)doc.get_int("num_key_value_heads", d.heads);
-  d.inter = (int32_t)doc.get_int("intermediate_size", -1);
-  d.max_ctx = (int32_t)doc.get_int("max_position_embeddings", -1);
+  d.hidden = dim(doc, "hidden_size", -1);
+  d.layers = dim(doc, "num_hidden_layers", -1);
+  d.heads = dim(doc, "num_attention_heads", -1);
+  d.kv_heads = dim(doc, "num_key_value_heads", d.heads);
+  d.inter = dim(doc, "intermediate_size", -1);
+  d.max_ctx = dim(doc, "max_position_embeddings", -1);
   d.norm_eps = doc.get_float("rms_norm_eps", 1e-5f);
   d.tied = doc.get_bool("tie_word_embeddings", false) ? 1 : 0;
   d.head_dim = d.heads > 0 ? d.hidden / d.heads : 0;               // ModelLlama.h:37 ignores "head_dim"
-  if (fam == TGX_FAMILY_QWEN3) d.head_dim = (int32_t)doc.get_int("head_dim", d.head_dim);   // ModelQwen3.h:25
+  if (fam == TGX_FAMILY_QWEN3) d.head_dim = dim(doc, "head_dim", d.head_dim);   // ModelQwen3.h:25
   d.qkv_bias = fam == TGX_FAMILY_QWEN2 ? 1 : 0;                    // ModelQwen2.h:26-31
   d.qk_norm = fam == TGX_FAMILY_QWEN3 ? 1 : 0;                     // AttentionWithQKNorm (ModelQwen3.h:29-33)
   // rope: hub-era flat keys (what the reference parses) or the nested rope_parameters newer transformers write
@@ -97,10 +108,10 @@ bool load_model_config(const std::string& path, int compute_dtype, int max_batch
     d.rope_factor = rs->get_float("factor", 1.f);
     d.rope_high_freq = rs->get_float("high_freq_factor", 1.f);
     d.rope_low_freq = rs->get_float("low_freq_factor", 1.f);
-    d.rope_orig_ctx = (int32_t)rs->get_int("original_max_position_embeddings", -1);
+    d.rope_orig_ctx = dim(*rs, "original_max_position_embeddings", -1);
     if (d.rope_orig_ctx > 0) d.max_ctx = d.rope_orig_ctx;           // getContextSize (ModelLlama.h:26-31)
   }
-  return true;
+  return check_dims(d, path, err);
 }
 
 bool load_generation_config(const std::string& path, GenerationConfig& out, std::string& err) {
