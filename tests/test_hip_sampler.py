@@ -94,7 +94,7 @@ def test_sampled_decode_matches_oracle(oracle_lib):
     np.testing.assert_array_equal(gpu.decode(12, sc, seed=42), ref.decode(12, sc, seed=42))
 
 
-@pytest.mark.parametrize("V", [5003, 70001])
+@pytest.mark.parametrize("V", [5003, 70001, 151936])
 def test_staged_sampler_many_workgroups_vs_oracle(V, oracle_lib):
     """Vocabularies that span several workgroups (4096 entries each... 1024 per workgroup), are not a multiple of 4 (the second
     batch row starts unaligned) and need both index digit levels (V > 2048): kept set, probabilities and draws of a
