@@ -34,7 +34,7 @@ struct GPTConfig {       // src/engine/GPTEngine.h:25-32 (+ where to find the de
   int deviceOrdinal = 0;
   int maxBatch = 4;
   uint64_t seed = 0;
-  std::string backendLib;            // default: <dir of this binary/library>/libtgx_mi355x.so
+  std::string backendLib;            // default: <dir of this binary/library>/libtgx_mi355x.so; set only by tests (host logic against the CPU oracle) — never a fallback
   std::string backendPrefix = "tgx_";
   std::string tokenizerDir;          // tokenizer.json + tokenizer_config.json; default: modelDir (lets --synthetic runs take text)
 };

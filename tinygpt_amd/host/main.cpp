@@ -66,6 +66,9 @@ int main(int argc, char** argv) {
     else if (a == "--stream") stream = true;
     else if (a == "--pad-id") pad_id = atol(next());
     else if (a == "--seed") cfg.seed = strtoull(next(), nullptr, 10);
+    // test hooks, not in the usage text: tests/ bind the host engine to a library of their choice that exports the tgx ABI (the CPU oracle) to
+    // check host logic on a machine without a GPU.  Nothing in the product passes them and there is no fallback: if libtgx_mi355x.so cannot be
+    // loaded or finds no GPU, prepare() fails with the loader's / the shim's message.
     else if (a == "--backend-lib") cfg.backendLib = next();
     else if (a == "--backend-prefix") cfg.backendPrefix = next();
     else { fprintf(stderr, "Unknown argument: %s\n", a.c_str()); usage(argv[0]); return 1; }
