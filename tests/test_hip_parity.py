@@ -363,3 +363,42 @@ def test_streaming_across_the_direct_attention_limit(hip):
     m.reset_cache(); m.forward(prompt); m.sample(GREEDY)
     np.testing.assert_array_equal(m.decode(8, GREEDY)[:, 0], want[:8])        # 8 steps stay below the limit: direct form
     np.testing.assert_array_equal(m.decode(32, GREEDY)[:, 0], want[8:40])     # this call crosses it: split form for the whole call
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_qwen3_qk_norm_fused_into_attention(dtype, hip, oracle_lib):
+    """Qwen3 at head_dim 128 (every released size): decode steps apply the per-head q/k RMSNorm + RoPE and the cache append inside
+    the attention launch (`AttnArgs.k_raw`, kernel template QKN) instead of a separate launch.  Both attention forms, 3 batch rows:
+    ids and logits equal the separate-launch path (attn.qk_fuse = 0) and the oracle; the appended keys equal the oracle's."""
+    import copy
+    from oracle.oracle_ffi import OracleModel
+    from tinygpt_amd import known_desc, synth
+    from tinygpt_amd.ffi import Model
+    d = copy.deepcopy(known_desc("qwen3-0.6b", dtype))
+    d.layers, d.vocab, d.max_ctx, d.max_batch = 2, 2048, 1024, 3
+    gpu, ref = Model(d, hip), OracleModel(d)
+    for name, bits in synth.synth_checkpoint(d, 1234, 0.02):
+        gpu.upload(name, bits); ref.upload(name, bits)
+    gpu.finalize(); ref.finalize()
+    prompt = np.stack([synth.synth_prompt(d.vocab, 30, 40 + b) for b in range(3)])
+    ref.forward(prompt); first_ref = ref.sample(GREEDY).copy(); want = ref.decode(12, GREEDY).copy(); lr = ref.logits(rounded=False).copy()
+    tol = 1e-4 if dtype == "fp32" else 2e-3
+    for direct_max in (1 << 20, 0):                       # the one-workgroup-per-head form, then the split + combine form
+        outs = []
+        for fuse in (1, 0):
+            gpu.set_option("attn.direct_max", direct_max); gpu.set_option("attn.qk_fuse", fuse)
+            gpu.reset_cache(); gpu.forward(prompt)
+            first = gpu.sample(GREEDY).copy(); rest = gpu.decode(12, GREEDY).copy()
+            outs.append((first, rest, gpu.logits(rounded=False).copy(), gpu.read_kv(2, 1)))
+        for first, rest, lg, _ in outs:
+            np.testing.assert_array_equal(first, first_ref)
+            np.testing.assert_array_equal(rest, want)
+            assert rel_err(lg, lr) < tol, (direct_max, rel_err(lg, lr))
+        assert rel_err(outs[0][2], outs[1][2]) < tol
+        (k1, v1), (k0, v0) = outs[0][3], outs[1][3]
+        kr, vr = ref.read_kv(2, 1)
+        assert k1.shape == k0.shape == kr.shape and k1.shape[0] == 30 + 12
+        ulp = 2.0 ** -7 if dtype == "bf16" else 1e-5
+        for kk in (k1, k0):
+            assert np.all(np.abs(kk - kr) <= ulp * (np.abs(kr) + 0.1 * np.abs(kr).max()))
+        assert np.all(np.abs(v1 - v0) <= ulp * (np.abs(v0) + 0.1 * np.abs(v0).max()))      # layer 1: downstream of layer 0's (one-ulp) key differences

@@ -34,12 +34,20 @@ struct AttnArgs {
   int gfull;  // query heads per kv head; the G heads of a workgroup are gfull-group blockIdx.z * G .. +G-1 (the last group may be short)
   int direct;  // 1: short context — one workgroup per (kv head, head group) walks every block and writes the normalised output itself
                //    (grid.x = kv_heads, no partials, no combine launch); chosen on the host from pastLength (attn.direct_max)
+  // Qwen3 (kernel template QKN): q arrives un-normalised and this position's k sits in k_raw (fp32) — the kernel applies the per-head
+  // RMSNorm and RoPE to its q heads and to k itself (AttentionWithQKNorm, Attention.h:156-163), uses that k for key `pos`, and the
+  // first head group of a kv head appends it to the cache.  One launch per layer less than a separate norm kernel.
+  const float* k_raw;     // [kv_heads][hd] fp32, rows kraw_stride apart
+  const void *q_norm_w, *k_norm_w;   // [hd], storage dtype
+  const float *rope_cos, *rope_sin;  // [max_ctx][hd/2]
+  float eps;
+  long long kraw_stride;
   int dbg;   // experiments only (tgx_set_option "debug.attn"): 1 skip K/V work, 2 skip the LDS merge, 4 exit at once — results invalid
 };
 
 // NW = waves per workgroup: 4 for the split form; 16 for the direct form (short contexts), where ONE workgroup covers a block of
 // NW * TPW * UNR tokens (512 at head_dim 64, 256 at 128) per pass over the load -> softmax chain.
-template <int DT, int HD, int G, int NW = 4>
+template <int DT, int HD, int G, int NW = 4, bool QKN = false>
 __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) {
   typedef elem_t<DT> E;
   constexpr int LPT = HD / 8;         // lanes per token row
@@ -85,6 +93,49 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
   }
   const int n_keys = a.pos[blockIdx.y] + 1;
   const float qscale = a.scale * LOG2E;     // softmax in base 2: exp(x) = exp2(x * log2 e)
+  float knew[8];                            // QKN: this lane group's slice of the current position's key, as the cache will hold it
+  if constexpr (QKN) {
+    // a head row is spread over LPT lanes (8 dims each): lanes 0..LPT/2-1 hold the first half, their partners (lane ^ LPT/2) the second;
+    // RoPE pairs (p, p + hd/2) therefore meet over one lane exchange
+    constexpr int HL = LPT / 2;
+    const int pos = n_keys - 1, half = HD / 2;
+    const bool second = part_i >= HL;
+    const int p0 = (part_i - (second ? HL : 0)) * 8;         // pair index of this lane's first element
+    float cs[8], sn[8];
+    {
+      const f32x4* cp = reinterpret_cast<const f32x4*>(a.rope_cos + (size_t)pos * half + p0);
+      const f32x4* sp_ = reinterpret_cast<const f32x4*>(a.rope_sin + (size_t)pos * half + p0);
+      const f32x4 c0 = cp[0], c1 = cp[1], s0 = sp_[0], s1 = sp_[1];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { cs[j] = c0[j]; cs[4 + j] = c1[j]; sn[j] = s0[j]; sn[4 + j] = s1[j]; }
+    }
+    auto norm_rope = [&](float* x, const void* wv_) {      // x[8] in place: w * (x * inv_rms), then the rotation
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) ss = fmaf(x[j], x[j], ss);
+      ss = row_group_sum<LPT>(ss);
+      const float inv = 1.0f / sqrtf(ss / (float)HD + a.eps);
+      float w[8];
+      slice_unpack<DT>(load_slice<DT>(static_cast<const E*>(wv_), part_i), w);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const float v = w[j] * (x[j] * inv);
+        const float other = __shfl_xor(v, HL, 64);
+        x[j] = second ? (v * cs[j] + other * sn[j]) : (v * cs[j] - other * sn[j]);
+      }
+    };
+#pragma unroll
+    for (int g = 0; g < G; g++) norm_rope(qf[g], a.q_norm_w);
+    {
+      const f32x4* kp = reinterpret_cast<const f32x4*>(a.k_raw + blockIdx.y * a.kraw_stride + (size_t)kvh * HD + part_i * 8);
+      const f32x4 k0 = kp[0], k1 = kp[1];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { knew[j] = k0[j]; knew[4 + j] = k1[j]; }
+      norm_rope(knew, a.k_norm_w);
+#pragma unroll
+      for (int j = 0; j < 8; j++) knew[j] = elem_to_f32<DT>(f32_to_elem<DT>(knew[j]));     // what the cache holds from now on
+    }
+  }
 
   if (sp * STEP >= n_keys) {   // this split has no keys at the current context length (workgroup-uniform): publish "empty"
     // (the compiler sinks the loads above below this branch; running empty splits through the masked path instead keeps
@@ -117,6 +168,14 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
       float kf[8], vf[8];
       slice_unpack<DT>(kv[r], kf);
       slice_unpack<DT>(vv[r], vf);
+      if constexpr (QKN) {
+        const int tok = t0 + r * TPW + slot;
+        if (tok == n_keys - 1) {            // the key of this step: computed above, not yet in the cache
+#pragma unroll
+          for (int j = 0; j < 8; j++) kf[j] = knew[j];
+          if (g_base == 0) store_slice<DT>(const_cast<E*>(kbase + (size_t)tok * HD), 0, knew);   // KVCacheManager::append, once per kv head
+        }
+      }
 #pragma unroll
       for (int g = 0; g < G; g++) {
         float s = 0.f;

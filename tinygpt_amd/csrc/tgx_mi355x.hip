@@ -135,6 +135,7 @@ struct tgx_ctx {
   float* ws_part = nullptr; size_t ws_part_bytes = 0;   // split-K slabs of the short-prompt GEMMs
   int gemm_splitk = 1;       // experiment: 0 disables split-K
   int attn_mirror = 1;       // experiment: prefill attention block order
+  int qk_fuse = 1;           // experiment: 0 keeps Qwen3's separate q/k norm launch
   bool prefill_mfma = true;
   int prefill_min_rows = 4;  // prompts shorter than this go through the decode kernels, 4 positions per pass (set in tgx_create)
   int gemm_tm = 0;           // experiment: force the GEMM row tile (64 / 128); 0 = by the number of tiles
@@ -413,7 +414,7 @@ void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls, int R) {
   }
 }
 
-template <int DT, int HD>
+template <int DT, int HD, bool QKN = false>
 void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
   // the query heads of a kv group go to workgroups two at a time (blockIdx.z): the per-head state (8 output registers, the
   // merges) is what a workgroup's time grows with, while the K/V tile the groups re-read is small and mostly L2-resident.
@@ -426,20 +427,22 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
   if (a.direct) {   // short context: one 16-wave workgroup per query head, no combine launch.  Measured (tok/s, direct vs split at context
     // ~120 / ~300 / ~430): see DESIGN.md §5; 1 head per workgroup beats 2 and 4 here (the K/V block is L2-resident, the softmax chain is not)
     const dim3 grid(a.kv_heads, R, gfull), blk(1024);
-    if (!(c->debug_skip & 1)) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 16>), grid, blk, 0, c->stream, a);
+    if (!(c->debug_skip & 1)) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 16, QKN>), grid, blk, 0, c->stream, a);
     return;
   }
   const dim3 grid(a.kv_heads * a.nsplit, R, ngroups), blk(256);
   if (!(c->debug_skip & 1)) switch (G) {
-    case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1>), grid, blk, 0, c->stream, a); break;
-    case 2: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2>), grid, blk, 0, c->stream, a); break;
-    case 3: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 3>), grid, blk, 0, c->stream, a); break;
-    default: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4>), grid, blk, 0, c->stream, a); break;
+    case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, QKN>), grid, blk, 0, c->stream, a); break;
+    case 2: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 4, QKN>), grid, blk, 0, c->stream, a); break;
+    case 3: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 3, 4, QKN>), grid, blk, 0, c->stream, a); break;
+    default: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 4, QKN>), grid, blk, 0, c->stream, a); break;
   }
   if (!(c->debug_skip & 2)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
 }
 
 void launch_attn(tgx_ctx* c, const tgx::AttnArgs& a, int R) {
+  // k_raw set: Qwen3's q/k norm + RoPE + cache append happen inside the attention launch (head_dim 128: every released Qwen3 size)
+  if (a.k_raw && c->d.head_dim == 128) { TGX_DT_SWITCH(c->dt, (launch_attn_g<DT, 128, true>(c, a, R))) return; }
   TGX_DT_SWITCH(c->dt, if (c->d.head_dim == 64) launch_attn_g<DT, 64>(c, a, R); else launch_attn_g<DT, 128>(c, a, R))
 }
 
@@ -449,6 +452,10 @@ void fill_strides(const tgx_ctx* c, tgx::GemvArgs& a) {
   a.q_stride = (long long)d.heads * d.head_dim; a.kraw_stride = (long long)d.kv_heads * d.head_dim;
   a.kv_stride = (long long)c->kv_row_elems; a.logits_stride = d.vocab; a.part_stride = c->lm_grid;
 }
+
+// Qwen3: independent batch rows (each its own cache) take the q/k norm inside the attention launch; the positions of one sequence that a
+// prefill-by-steps pass handles together (kv_stride 0) need each other's finished keys, so they keep the separate norm launch
+bool qk_fused(const tgx_ctx* c, long long kv_stride) { return c->d.qk_norm && c->d.head_dim == 128 && kv_stride != 0 && c->qk_fuse; }
 
 // One kernel class of one decoder layer for R rows (batch rows of the slabs, or the chunk rows of a prefill-by-steps pass).  `resid` is the residual stream of row0 that the
 // o_proj/down epilogues update (slab_x in the real pass; a scratch vector when tgx_profile_decode replays a class).
@@ -474,7 +481,7 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
         break;
       }
       launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_QKV_ROPE>(c, a, TGX_KERNEL_QKV, R);
-      if (d.qk_norm) {   // q_norm / k_norm -> RoPE -> cache append (Attention.h:156-163); batch rows on blockIdx.y
+      if (d.qk_norm && !qk_fused(c, kv_stride)) {   // q_norm / k_norm -> RoPE -> cache append (Attention.h:156-163); batch rows on blockIdx.y
         tgx::QkNormArgs n{};
         n.q = r.q; n.k_raw = r.k_raw; n.k_cache = r.kcache + (size_t)l * kv_layer; n.q_norm_w = w.q_norm; n.k_norm_w = w.k_norm;
         n.rope_cos = c->rope_cos; n.rope_sin = c->rope_sin; n.pos = r.pos;
@@ -491,6 +498,10 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
       a.scale = 1.0f / sqrtf((float)hd);
       a.q_stride = qd; a.kv_stride = kv_stride; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
+      if (qk_fused(c, kv_stride)) {
+        a.k_raw = r.k_raw; a.kraw_stride = kvd; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm;
+        a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.eps = d.norm_eps;
+      }
       launch_attn(c, a, R);
       break;
     }
@@ -1414,6 +1425,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.min_rows")) { c->prefill_min_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk")) { c->gemm_splitk = value; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_mirror")) { c->attn_mirror = value; return TGX_OK; }
+  if (!strcmp(key, "attn.qk_fuse")) { c->qk_fuse = value; return TGX_OK; }
   if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
   if (!strcmp(key, "attn.nsplit")) {
     if (c->finalized) return set_err(c, TGX_ERR_STATE, "attn.nsplit must be set before tgx_finalize");
