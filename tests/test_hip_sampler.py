@@ -79,13 +79,15 @@ def test_greedy_tie_break_lowest_index(pair, vec):
     assert int(gpu.sample(SamplerCfg())[0]) == 0
 
 
-def test_sampled_decode_matches_oracle(oracle_lib):
+@pytest.mark.parametrize("fam", ["qwen2_tiny", "gpt2_hd64"])
+def test_sampled_decode_matches_oracle(fam, oracle_lib):
     """Whole sampled decode loop (forward -> sample -> embed) with T=0.8/top-p 0.9, the CLI defaults
-    (examples/inference/main.cpp:36-37): same seed -> same ids as the oracle."""
+    (examples/inference/main.cpp:36-37): same seed -> same ids as the oracle.  GPT-2: the pick kernel also adds the learned
+    position row of the NEXT position to the sampled token's embedding; its fixture prompt is the CLI's batch of 4."""
     from oracle.oracle_ffi import OracleModel
     from tinygpt_amd.ffi import Model, product_backend
-    cfg, g = load_golden("qwen2_tiny")
-    d = desc_from_hf_config(cfg, "bf16")
+    cfg, g = load_golden(fam)
+    d = desc_from_hf_config(cfg, "bf16", max_batch=g["prompt"].shape[0])
     gpu = Model(d, product_backend()).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
     ref = OracleModel(d).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
     sc = SamplerCfg(0.8, 0, 0.9, 0.0)
