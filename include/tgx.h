@@ -112,6 +112,8 @@ TGX_API int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx**
  * the row slices of the merged weights exactly like MergedLinear's LinearRef views
  * (src/layer/Linear.h:64-79).  Shape must match (TGX_ERR_SHAPE); an unknown key is TGX_ERR_NAME
  * (the reference warns "Unexpected key" and continues — callers may ignore that status).
+ * ndim < 0 is a name probe: nothing is copied; TGX_ERR_NAME = unknown key, TGX_OK = a key this path knows and
+ * ignores, TGX_ERR_SHAPE = a parameter the model needs (the loader uses it for tensors whose file dtype it cannot convert).
  * `src_dtype` is the dtype of `host`; conversion to compute_dtype happens on upload
  * (bf16->fp32 exact, fp32->bf16 round-to-nearest-even), == model().to(dtype), ModelLoader.cpp:84. */
 TGX_API int tgx_upload(tgx_ctx* ctx, const char* hf_name, const void* host, const int64_t* shape, int ndim,

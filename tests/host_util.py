@@ -12,8 +12,10 @@ from tinygpt_amd.desc import desc_from_hf_config
 TOKEN_CB = CFUNCTYPE(c_int, c_int32, c_void_p)
 
 
-def host_lib():
-    lib_path, _ = build.build_host()
+def host_lib(test_hooks=False):
+    """The shipped libtgx_host.so (binds libtgx_mi355x.so only) or, for CPU host-logic tests that bind the oracle, the
+    -DTGXH_TEST_HOOKS build under tests/_build."""
+    lib_path, _ = build.build_host(test_hooks=test_hooks)
     lib = ctypes.CDLL(lib_path)
     lib.tgxe_create.restype = c_void_p
     lib.tgxe_create.argtypes = [c_char_p, c_char_p, c_char_p, c_char_p, c_char_p, c_int, c_int, c_int]

@@ -91,7 +91,7 @@ def test_cli_text_prompts_on_gpu(tmp_path, oracle_lib):
     lib = host_lib()
     texts = ["Hello, my name is", "The president of the United States is", "The capital of France is", "The future of AI is"]
     gpu = HostEngine(lib, model_dir=str(tmp_path), tokenizer_dir=tok_dir, max_batch=4)
-    ref = HostEngine(lib, model_dir=str(tmp_path), tokenizer_dir=tok_dir, max_batch=4, backend_lib=oracle_lib.path, prefix="tgxo_")
+    ref = HostEngine(host_lib(test_hooks=True), model_dir=str(tmp_path), tokenizer_dir=tok_dir, max_batch=4, backend_lib=oracle_lib.path, prefix="tgxo_")
     assert gpu.prepare(), gpu.error()
     assert ref.prepare(), ref.error()
     gpu.reconfigure(max_new=8); ref.reconfigure(max_new=8)

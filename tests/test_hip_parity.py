@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import GPU_FAMILIES, load_golden, rel_err
+from tinygpt_amd import synth
 from tinygpt_amd.desc import desc_from_hf_config
 from tinygpt_amd.ffi import GREEDY
 
@@ -206,6 +207,19 @@ def test_errors_are_loud(hip):
     m.forward(g["prompt"])
     with pytest.raises(TgxError):
         m.forward(g["prompt"])                             # seq>1 with pastLength>0
+    with pytest.raises(TgxError, match="gmax"):
+        m.set_option("attn.gmax", 8)                       # the attention kernel is instantiated for 1..4 query heads per workgroup
+    # a tensor uploaded twice must not stand in for a missing one of the same size (k_proj and v_proj have equal shapes)
+    m2 = Model(d, hip)
+    for name, bits in synth.synth_checkpoint(d, int(g["seed"]), float(g["std"])):
+        if name.endswith("layers.1.self_attn.v_proj.weight"):
+            continue
+        m2.upload(name, bits)
+        if name.endswith("layers.1.self_attn.k_proj.weight"):
+            m2.upload(name, bits)
+    with pytest.raises(TgxError, match=r"layers\.1\.self_attn\.v_proj\.weight"):
+        m2.finalize()
+    m2.close()
     import dataclasses
     bad = dataclasses.replace(desc_from_hf_config(cfg, "bf16"), head_dim=48)
     with pytest.raises(TgxError):

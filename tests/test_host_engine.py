@@ -1,5 +1,7 @@
 """The C++ host engine (tinygpt_amd/host: GPTEngine mirror, config + safetensors readers) bound to the CPU oracle
 through the same function table that binds the HIP library — host logic is checked without a GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,7 +12,7 @@ from tinygpt_amd import synth
 
 @pytest.fixture(scope="module")
 def lib():
-    return host_lib()
+    return host_lib(test_hooks=True)      # binds the CPU oracle: only the -DTGXH_TEST_HOOKS build can
 
 
 @pytest.fixture(scope="module")
@@ -274,6 +276,12 @@ def test_corrupt_model_directories_fail_loudly(lib, oracle_path, tmp_path):
         "safetensors data cut": lambda d: truncate(d, -1000),
         "safetensors header length 2^60": lambda d: set_header_len(d, 2 ** 60),
         "safetensors header length 0": lambda d: set_header_len(d, 0),
+        "safetensors header length 2^64-4 (8 + n wraps)": lambda d: set_header_len(d, 2 ** 64 - 4),
+        "safetensors header length 2^64-8": lambda d: set_header_len(d, 2 ** 64 - 8),
+        "safetensors shape product overflows": lambda d: edit_header(d, lambda h, k: h[k].__setitem__("shape", [2 ** 40, 2 ** 40])),
+        "safetensors fractional shape": lambda d: edit_header(d, lambda h, k: h[k].__setitem__("shape", [1.5, 2])),
+        "safetensors needed tensor in an unsupported dtype": lambda d: edit_header(d, lambda h, k: h[k].__setitem__("dtype", "I64")),
+        "config nested 100000 deep": lambda d: write(os.path.join(d, "config.json"), "[" * 100000 + "]" * 100000),
         "safetensors offsets beyond file": lambda d: edit_header(d, lambda h, k: h[k].__setitem__("data_offsets", [0, 2 ** 50])),
         "safetensors negative shape": lambda d: edit_header(d, lambda h, k: h[k].__setitem__("shape", [-1, 7])),
         "model dir missing": lambda d: shutil.rmtree(d),
@@ -281,3 +289,26 @@ def test_corrupt_model_directories_fail_loudly(lib, oracle_path, tmp_path):
     for label, mutate in cases.items():
         ok, err = attempt(mutate)
         assert not ok and err, label
+
+
+def test_extra_non_float_buffers_are_unexpected_keys_not_errors(lib, oracle_path, tmp_path):
+    """A checkpoint that also carries I64 / BOOL / U8 buffers the model has no parameter for (position_ids, mask buffers of old hub
+    checkpoints) loads: the reference looks the name up first and only warns "Unexpected key" (SafeTensors.cpp:176-183); the dtype of a
+    tensor matters only when the model consumes it."""
+    import torch
+    from safetensors.torch import load_file, save_file
+    cfg, g = load_golden("llama_tiny")
+    write_model_dir(str(tmp_path), cfg, int(g["seed"]), float(g["std"]))
+    p = os.path.join(str(tmp_path), "model.safetensors")
+    t = load_file(p)
+    t["model.layers.0.self_attn.rotary_emb.position_ids"] = torch.arange(16, dtype=torch.int64)
+    t["model.causal_mask"] = torch.ones(4, 4, dtype=torch.bool)
+    t["model.byte_buffer"] = torch.zeros(3, dtype=torch.uint8)
+    t["model.scalar"] = torch.tensor(3, dtype=torch.int32)
+    save_file(t, p)
+    e = HostEngine(lib, model_dir=str(tmp_path), backend_lib=oracle_path, prefix="tgxo_", dtype=0)
+    assert e.prepare(), e.error()
+    e.reconfigure(max_new=4)
+    ids, new, fin = e.generate_sync([np.asarray(g["prompt"][0], np.int32)])
+    assert new == 4
+    e.close()

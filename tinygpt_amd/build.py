@@ -44,25 +44,35 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=()):
 HOST = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(LIBDIR, "libtgx_host.so")
 HOST_CLI = os.path.join(LIBDIR, "tgx_cli")
+TEST_BUILD = os.path.join(HERE, "..", "tests", "_build")     # test-hook variants live with the tests, not in the product lib dir
+HOST_TEST_LIB = os.path.join(TEST_BUILD, "libtgx_host_test.so")
+HOST_TEST_CLI = os.path.join(TEST_BUILD, "tgx_cli_test")
 CXX = shutil.which("g++") or "g++"
 CXXFLAGS = ["-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-exceptions", "-Wall", "-Wextra", "-pthread"]
 
 
-def build_host(force: bool = False, verbose: bool = False):
-    """The C++ host engine (no HIP needed: it dlopen()s the device shim): libtgx_host.so + the tgx_cli binary."""
+def build_host(force: bool = False, verbose: bool = False, test_hooks: bool = False):
+    """The C++ host engine (no HIP needed: it dlopen()s the device shim): libtgx_host.so + the tgx_cli binary.
+
+    test_hooks=True builds the TEST variants instead (tests/_build/libtgx_host_test.so, tgx_cli_test, -DTGXH_TEST_HOOKS): the only
+    builds that can bind a library other than libtgx_mi355x.so (the CPU oracle, for host-logic tests without a GPU)."""
     srcs = [os.path.join(HOST, f) for f in ("loader.cpp", "engine.cpp", "regex.cpp", "tokenizer.cpp")]
     deps = [os.path.join(HOST, f) for f in os.listdir(HOST)] + [os.path.join(HERE, "..", "include", "tgx.h")]
-    os.makedirs(LIBDIR, exist_ok=True)
-    for target, extra in ((HOST_LIB, [os.path.join(HOST, "engine_c.cpp"), "-shared"]), (HOST_CLI, [os.path.join(HOST, "main.cpp")])):
+    lib, cli, flags = HOST_LIB, HOST_CLI, []
+    if test_hooks:
+        lib, cli, flags = HOST_TEST_LIB, HOST_TEST_CLI, ["-DTGXH_TEST_HOOKS"]
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    for target, extra in ((lib, [os.path.join(HOST, "engine_c.cpp"), "-shared"]), (cli, [os.path.join(HOST, "main.cpp")])):
         if not force and os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps):
             continue
-        cmd = [CXX] + CXXFLAGS + srcs + extra + ["-o", target, "-ldl"]
+        cmd = [CXX] + CXXFLAGS + flags + srcs + extra + ["-o", target, "-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-    return HOST_LIB, HOST_CLI
+    return lib, cli
 
 
 if __name__ == "__main__":
     print(build_host(force="-f" in sys.argv, verbose=True))
+    print(build_host(force="-f" in sys.argv, verbose=True, test_hooks=True))
     print(build_lib(force="-f" in sys.argv, verbose=True))

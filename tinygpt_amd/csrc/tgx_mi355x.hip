@@ -35,9 +35,10 @@ struct LayerW {
   ebyte *wqkv = nullptr, *bqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wdown = nullptr;
   ebyte *q_norm = nullptr, *k_norm = nullptr;   // Qwen3 [head_dim]
   bool q_norm_ok = false, k_norm_ok = false;
-  int64_t qkv_rows = 0, gu_rows = 0;
+  // one bit per checkpoint tensor that lands in a merged weight: q, k, v, gate, up (bits 0-4) and the q/k/v biases (bits 5-7) — a tensor
+  // uploaded twice must not stand in for a missing one of the same size
+  int merged_filled = 0;
   bool in_norm_ok = false, post_norm_ok = false, wo_ok = false, wdown_ok = false;
-  int64_t bias_rows = 0;
   // GPT-2 (ModelGPT2.h:23-135): LayerNorm biases and a bias on every Conv1D; wgu holds c_fc [inter][hidden]
   ebyte *in_norm_b = nullptr, *post_norm_b = nullptr, *bo = nullptr, *bfc = nullptr, *bdown = nullptr;
   int gpt2_filled = 0;      // bit per GPT-2 tensor of the layer (12 of them)
@@ -119,6 +120,8 @@ struct tgx_ctx {
   int step_graph_batch = 0;
   tgx_sampler_cfg step_graph_cfg{};
   unsigned long long* seed_dev = nullptr;
+  unsigned long long seed_on_dev = 0;         // value last copied to seed_dev: an unchanged seed costs no copy and no stream sync
+  bool seed_valid = false;
   tgx::SampScratch* samp_scratch = nullptr;   // [max_batch] histograms / thresholds / partial sums of the staged sampler
   bool have_probs = false;
   bool use_graph = true;
@@ -829,9 +832,15 @@ int ensure_step_graph(tgx_ctx* c, const tgx_sampler_cfg& cfg, bool want_multi) {
 
 int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int n) {
   if (!is_greedy(&cfg)) {
-    const unsigned long long s = seed;
-    HIP_OK(c, hipMemcpyAsync(c->seed_dev, &s, 8, hipMemcpyHostToDevice, c->stream));
-    HIP_OK(c, hipStreamSynchronize(c->stream));     // `s` is a stack variable
+    // the engine passes one seed for a whole generation (the draw mixes in position and row): only a CHANGED seed is copied — and that
+    // copy must drain the stream, because steps already enqueued still read the old word.  With an unchanged seed tgx_step_async returns
+    // without waiting for the previous step (the one-step lookahead of generateAsync, GPTEngine.cpp:196-217)
+    if (!c->seed_valid || c->seed_on_dev != (unsigned long long)seed) {
+      HIP_OK(c, hipStreamSynchronize(c->stream));
+      const unsigned long long s = seed;
+      HIP_OK(c, hipMemcpy(c->seed_dev, &s, 8, hipMemcpyHostToDevice));
+      c->seed_on_dev = s; c->seed_valid = true;
+    }
     c->have_probs = true;
   }
   // short contexts: attention without the split / combine pair (one launch less per layer); the graphs are re-captured when a
@@ -999,12 +1008,12 @@ int tgx_upload(tgx_ctx* c, const char* name, const void* host, const int64_t* sh
       return upload_param(c, w.post_norm, host, H, src_dtype);
     }
     // MergedLinear row slices (Linear.h:64-79): [q | k | v] and [gate | up]
-    struct Slot { const char* n; ebyte* base; ebyte* bias; int64_t row0, rows, cols; int kind; };
+    struct Slot { const char* n; ebyte* base; ebyte* bias; int64_t row0, rows, cols; int kind; int bit; };
     const Slot slots[] = {
-        {"self_attn.q_proj", w.wqkv, w.bqkv, 0, qd, H, 0},        {"self_attn.k_proj", w.wqkv, w.bqkv, qd, kvd, H, 0},
-        {"self_attn.v_proj", w.wqkv, w.bqkv, qd + kvd, kvd, H, 0}, {"self_attn.o_proj", w.wo, nullptr, 0, H, qd, 1},
-        {"mlp.gate_proj", w.wgu, nullptr, 0, I, H, 2},             {"mlp.up_proj", w.wgu, nullptr, I, I, H, 2},
-        {"mlp.down_proj", w.wdown, nullptr, 0, H, I, 3}};
+        {"self_attn.q_proj", w.wqkv, w.bqkv, 0, qd, H, 0, 0},        {"self_attn.k_proj", w.wqkv, w.bqkv, qd, kvd, H, 0, 1},
+        {"self_attn.v_proj", w.wqkv, w.bqkv, qd + kvd, kvd, H, 0, 2}, {"self_attn.o_proj", w.wo, nullptr, 0, H, qd, 1, -1},
+        {"mlp.gate_proj", w.wgu, nullptr, 0, I, H, 2, 3},             {"mlp.up_proj", w.wgu, nullptr, I, I, H, 2, 4},
+        {"mlp.down_proj", w.wdown, nullptr, 0, H, I, 3, -1}};
     for (const Slot& s : slots) {
       const size_t ln = strlen(s.n);
       if (strncmp(rest, s.n, ln) || rest[ln] != '.') continue;
@@ -1012,15 +1021,14 @@ int tgx_upload(tgx_ctx* c, const char* name, const void* host, const int64_t* sh
         if (!shape_is(shape, nd, s.rows, s.cols)) return bad_shape();
         int rc = upload_param(c, s.base + (size_t)(s.row0 * s.cols) * c->esz, host, s.rows * s.cols, src_dtype);
         if (rc) return rc;
-        if (s.kind == 0) w.qkv_rows += s.rows;
+        if (s.bit >= 0) w.merged_filled |= 1 << s.bit;
         else if (s.kind == 1) w.wo_ok = true;
-        else if (s.kind == 2) w.gu_rows += s.rows;
         else w.wdown_ok = true;
         return TGX_OK;
       }
       if (!strcmp(rest + ln + 1, "bias") && s.bias) {
         if (!shape_is(shape, nd, s.rows, -1)) return bad_shape();
-        w.bias_rows += s.rows;
+        w.merged_filled |= 1 << (5 + s.bit);
         return upload_param(c, s.bias + (size_t)s.row0 * c->esz, host, s.rows, src_dtype);
       }
     }
@@ -1045,9 +1053,12 @@ int tgx_finalize(tgx_ctx* c) {
   if (!c->gpt2 && !c->final_norm_ok) return set_err(c, TGX_ERR_STATE, "Missing key: model.norm.weight");
   for (int l = 0; l < d.layers && !c->gpt2; l++) {
     const LayerW& w = c->L[(size_t)l];
-    if (!w.in_norm_ok || !w.post_norm_ok || w.qkv_rows != qd + 2 * kvd || !w.wo_ok || w.gu_rows != 2 * (int64_t)I || !w.wdown_ok)
-      return set_err(c, TGX_ERR_STATE, "Missing key in model.layers.%d", l);
-    if (d.qkv_bias && w.bias_rows != qd + 2 * kvd) return set_err(c, TGX_ERR_STATE, "Missing qkv bias in model.layers.%d", l);
+    static const char* merged_names[8] = {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight",
+                                          "self_attn.q_proj.bias", "self_attn.k_proj.bias", "self_attn.v_proj.bias"};
+    for (int b = 0; b < (d.qkv_bias ? 8 : 5); b++)
+      if (!(w.merged_filled & (1 << b))) return set_err(c, TGX_ERR_STATE, "Missing key: model.layers.%d.%s", l, merged_names[b]);
+    if (!w.in_norm_ok || !w.post_norm_ok || !w.wo_ok || !w.wdown_ok)
+      return set_err(c, TGX_ERR_STATE, "Missing key: model.layers.%d.%s", l, !w.in_norm_ok ? "input_layernorm.weight" : !w.post_norm_ok ? "post_attention_layernorm.weight" : !w.wo_ok ? "self_attn.o_proj.weight" : "mlp.down_proj.weight");
     if (d.qk_norm && (!w.q_norm_ok || !w.k_norm_ok)) return set_err(c, TGX_ERR_STATE, "Missing key: model.layers.%d.self_attn.{q,k}_norm.weight", l);
   }
   if (c->finalized) return TGX_OK;
@@ -1234,8 +1245,12 @@ int tgx_sample(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* o
   if (!c->have_logits) return set_err(c, TGX_ERR_STATE, "no logits to sample from");
   HIP_OK(c, hipSetDevice(c->device));
   if (!is_greedy(cfg)) {
-    const unsigned long long s = seed;
-    HIP_OK(c, hipMemcpy(c->seed_dev, &s, 8, hipMemcpyHostToDevice));
+    if (!c->seed_valid || c->seed_on_dev != (unsigned long long)seed) {
+      HIP_OK(c, hipStreamSynchronize(c->stream));
+      const unsigned long long s = seed;
+      HIP_OK(c, hipMemcpy(c->seed_dev, &s, 8, hipMemcpyHostToDevice));
+      c->seed_on_dev = s; c->seed_valid = true;
+    }
     c->have_probs = true;
   }
   launch_sample(c, 0, c->batch, *cfg, /*advance_pos=*/false, /*log_step=*/false);
@@ -1417,7 +1432,10 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "debug.nops")) { c->debug_nops = value; return TGX_OK; }
   if (!strcmp(key, "debug.skip")) { c->debug_skip = value; return TGX_OK; }
   if (!strcmp(key, "debug.attn")) { c->debug_attn = value; return TGX_OK; }
-  if (!strcmp(key, "attn.gmax")) { c->attn_gmax = value; return TGX_OK; }
+  if (!strcmp(key, "attn.gmax")) {   // query heads per attention workgroup: the kernel is instantiated for 1..4 (0 = default)
+    if (value < 0 || value > 4) return set_err(c, TGX_ERR_INVALID, "attn.gmax must be 0 (default) or 1..4");
+    c->attn_gmax = value; return TGX_OK;
+  }
   if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_tm")) { c->gemm_tm = value; return TGX_OK; }
   if (!strcmp(key, "debug.gemv")) { c->debug_gemv = value; return TGX_OK; }

@@ -42,10 +42,14 @@ bool GPTEngine::fail(const std::string& what) {
 bool GPTEngine::prepare() {
   // device -> shim.  The reference maps everything that is not "cpu" to CUDA (examples/inference/main.cpp:76-80); here
   // "mi355x" binds the HIP library and any other value is refused — this engine has no CPU execution path of its own.
-  if (config_.device != "mi355x" && config_.backendLib.empty())
+  std::string lib = self_dir() + "/libtgx_mi355x.so", prefix = "tgx_";
+  bool hooked = false;
+#ifdef TGXH_TEST_HOOKS
+  if (!config_.backendLib.empty()) { hooked = true; lib = config_.backendLib; prefix = config_.backendPrefix; }
+#endif
+  if (config_.device != "mi355x" && !hooked)
     return fail("device '" + config_.device + "' is not provided by this engine (only --device mi355x); the reference's cpu path lives in TinyTorch");
-  const std::string lib = config_.backendLib.empty() ? self_dir() + "/libtgx_mi355x.so" : config_.backendLib;
-  if (!be_.open(lib, config_.backendPrefix)) return fail("cannot bind device shim " + lib + ": " + be_.error);
+  if (!be_.open(lib, prefix)) return fail("cannot bind device shim " + lib + ": " + be_.error);
 
   if (!config_.synthetic.empty()) {
     if (!known_config(config_.synthetic, config_.dtype, config_.maxBatch, model_.config)) return fail("unknown synthetic config: " + config_.synthetic);

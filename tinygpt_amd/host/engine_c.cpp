@@ -25,8 +25,13 @@ TGXE_API tgxe_engine* tgxe_create2(const char* model_dir, const char* synthetic,
   c.modelDir = model_dir ? model_dir : "";
   c.synthetic = synthetic ? synthetic : "";
   c.device = device ? device : "mi355x";
+#ifdef TGXH_TEST_HOOKS
   c.backendLib = backend_lib ? backend_lib : "";
   if (prefix && *prefix) c.backendPrefix = prefix;
+#else
+  (void)prefix;
+  if (backend_lib && *backend_lib) return nullptr;     // the shipped library binds libtgx_mi355x.so only
+#endif
   c.deviceOrdinal = device_ordinal;
   c.dtype = dtype;
   c.maxBatch = max_batch;

@@ -50,13 +50,20 @@ class JsonParser {
  private:
   JsonParser(const char* s, size_t n) : s_(s), n_(n) {}
   const char* s_; size_t n_; size_t pos_ = 0;
+  int depth_ = 0;                                  // nesting of the value being parsed; untrusted headers must not overflow the stack
+  static constexpr int kMaxDepth = 64;
   void ws() { while (pos_ < n_ && (s_[pos_] == ' ' || s_[pos_] == '\n' || s_[pos_] == '\t' || s_[pos_] == '\r')) pos_++; }
   bool lit(const char* w) { size_t l = strlen(w); if (pos_ + l <= n_ && !memcmp(s_ + pos_, w, l)) { pos_ += l; return true; } return false; }
   bool value(Json& o) {
     if (pos_ >= n_) return false;
     char c = s_[pos_];
-    if (c == '{') return object(o);
-    if (c == '[') return array(o);
+    if (c == '{' || c == '[') {
+      if (depth_ >= kMaxDepth) return false;
+      depth_++;
+      const bool ok = c == '{' ? object(o) : array(o);
+      depth_--;
+      return ok;
+    }
     if (c == '"') { o.kind = Json::Str; return string(o.str); }
     if (lit("true")) { o.kind = Json::Bool; o.b = true; return true; }
     if (lit("false")) { o.kind = Json::Bool; o.b = false; return true; }

@@ -145,7 +145,8 @@ bool load_one(const Backend& be, tgx_ctx* ctx, const std::string& path, const st
   if (map == MAP_FAILED) { err = "Error mapFileForRead: " + path; return false; }
   bool ok = true;
   const uint64_t header_size = *static_cast<const uint64_t*>(map);
-  if (8 + header_size > (uint64_t)st.st_size) { err = "corrupt safetensors header: " + path; munmap(map, (size_t)st.st_size); return false; }
+  // st_size >= 8 was checked above; written so that a header_size near 2^64 cannot wrap past the check
+  if (header_size > (uint64_t)st.st_size - 8) { err = "corrupt safetensors header: " + path; munmap(map, (size_t)st.st_size); return false; }
   const char* header = static_cast<const char*>(map) + 8;
   const char* data = header + header_size;
   const uint64_t data_size = (uint64_t)st.st_size - 8 - header_size;
@@ -160,13 +161,30 @@ bool load_one(const Backend& be, tgx_ctx* ctx, const std::string& path, const st
     const Json* off = info.get("data_offsets");
     const std::string dt = info.get_str("dtype", "");
     if (!shape || shape->kind != Json::Arr || !off || off->kind != Json::Arr || off->arr.size() != 2) { err = "bad tensor entry: " + name; ok = false; break; }
-    int src;
-    size_t esz;
+    int src = -1;
+    size_t esz = 0;
     if (dt == "BF16") { src = TGX_BF16; esz = 2; } else if (dt == "F16") { src = TGX_F16; esz = 2; } else if (dt == "F32") { src = TGX_F32; esz = 4; }
-    else { err = "dtype not supported for tensor: " + name + " (" + dt + ")"; ok = false; break; }
     std::vector<int64_t> dims;
     uint64_t numel = 1;
-    for (const Json& v : shape->arr) { dims.push_back(v.i); numel *= (uint64_t)v.i; }
+    bool shape_ok = true;
+    for (const Json& v : shape->arr) {      // non-negative integers whose product (times the element size) stays inside 64 bits
+      if (v.kind != Json::Num || !v.is_int || v.i < 0) { shape_ok = false; break; }
+      if (v.i != 0 && numel > (UINT64_MAX / 8) / (uint64_t)v.i) { shape_ok = false; break; }
+      dims.push_back(v.i); numel *= (uint64_t)v.i;
+    }
+    if (!shape_ok || off->arr[0].kind != Json::Num || !off->arr[0].is_int || off->arr[0].i < 0 || off->arr[1].kind != Json::Num || !off->arr[1].is_int || off->arr[1].i < 0) {
+      err = "bad tensor entry: " + name; ok = false; break;
+    }
+    if (src < 0) {
+      // a dtype this path never consumes (I64 position_ids, BOOL / U8 mask buffers of old hub checkpoints): the reference looks the name
+      // up first and only warns about keys it does not know (SafeTensors.cpp:176-183) — ask the shim whether it wants the tensor
+      static const float probe = 0.f;
+      static const int64_t no_dims = 0;
+      const int prc = be.upload(ctx, name.c_str(), &probe, dims.empty() ? &no_dims : dims.data(), -1, TGX_F32);     // nd = -1: name lookup only, nothing is copied
+      if (prc == TGX_ERR_NAME) { fprintf(stderr, "[tgx] Unexpected key: %s\n", name.c_str()); continue; }
+      if (prc == TGX_OK) continue;                                                         // a known non-parameter buffer (GPT-2's attn.bias masks)
+      err = "dtype not supported for tensor: " + name + " (" + dt + ")"; ok = false; break;
+    }
     const uint64_t b0 = (uint64_t)off->arr[0].i, b1 = (uint64_t)off->arr[1].i;
     if (b1 < b0 || b1 > data_size || b1 - b0 != numel * esz) { err = "size not equal for tensor: " + name; ok = false; break; }
     const int rc = be.upload(ctx, name.c_str(), data + b0, dims.data(), (int)dims.size(), src);

@@ -66,11 +66,12 @@ int main(int argc, char** argv) {
     else if (a == "--stream") stream = true;
     else if (a == "--pad-id") pad_id = atol(next());
     else if (a == "--seed") cfg.seed = strtoull(next(), nullptr, 10);
-    // test hooks, not in the usage text: tests/ bind the host engine to a library of their choice that exports the tgx ABI (the CPU oracle) to
-    // check host logic on a machine without a GPU.  Nothing in the product passes them and there is no fallback: if libtgx_mi355x.so cannot be
-    // loaded or finds no GPU, prepare() fails with the loader's / the shim's message.
+#ifdef TGXH_TEST_HOOKS
+    // tgx_cli_test only (tests/_build, -DTGXH_TEST_HOOKS): bind the host engine to a library of the test's choice that exports the tgx ABI
+    // (the CPU oracle), to check host logic on a machine without a GPU.  The shipped tgx_cli has neither flag.
     else if (a == "--backend-lib") cfg.backendLib = next();
     else if (a == "--backend-prefix") cfg.backendPrefix = next();
+#endif
     else { fprintf(stderr, "Unknown argument: %s\n", a.c_str()); usage(argv[0]); return 1; }
   }
   if (cfg.modelDir.empty() && cfg.synthetic.empty()) { fprintf(stderr, "Error: --model (or --synthetic) is required\n"); usage(argv[0]); return 1; }
