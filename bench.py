@@ -21,14 +21,20 @@ Extra objects on the line:
                (2*N*K) / its average duration measured with HIP events on the launch stream
                (tgx_profile_decode: the class launched back-to-back over all layers); HBM peak 8.0 TB/s.
                Also carries the whole-step figure (`step_*`): bytes_per_token(T) * tokens/s.
-  cpu_baseline the CPU oracle (oracle/liboracle.so, a restatement of the reference path — kind "port"),
-               timed on this box's host cores on a bounded sample of the same model (short context).
+  cpu_baseline the CPU oracle (oracle/liboracle.so, a restatement of the reference path — kind "port"), timed on this box's host
+               cores with pinned threads: median of 3 bounded samples at the GPU run's own context (after the same 2048-token
+               prompt) and at a short context; `legs` carries both with min / max.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
+
+# the cpu_baseline leg is OpenMP code: pin its threads to cores, one per core, in order — set before anything loads libgomp
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -54,22 +60,25 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(desc, tensors, seconds):
-    """Oracle decode tok/s on the host cores: 16-token prompt, 1 warm-up token, then a bounded sample."""
+def cpu_baseline(desc, tensors, seconds, prompt_len, prompt_seed, max_prefill_s=90.0):
+    """Oracle decode tok/s on the host cores (rank 0, N = 1 only).  Two legs, each the median of 3 samples:
+      short    16-token prompt (context ~20..) — cheap, always measured;
+      same     the GPU run's own prompt length (2048 for the headline), i.e. the same workload; skipped (and said so) when the
+               oracle's prefill of that prompt would take longer than `max_prefill_s` on this host.
+    `value` is the same-context figure when it was measured, else the short one; `sample` says which."""
     from oracle.oracle_ffi import OracleModel, build_oracle, oracle_backend
     from tinygpt_amd import synth
     from tinygpt_amd.ffi import GREEDY
     build_oracle()
     cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_PROC_BIND", "close")
     be = oracle_backend()
     be.set_threads(min(16, cores))          # before the first parallel region: wide teams are pathologically slow
     m = OracleModel(desc)
     for name, bits in tensors:
         m.upload(name, bits)
     m.finalize()
-    ids = synth.synth_prompt(desc.vocab, 16, 1234)[None, :]
-    m.forward(ids)
+    ids = synth.synth_prompt(desc.vocab, 16, prompt_seed)[None, :]
+    t0 = time.perf_counter(); m.forward(ids); prefill16_s = time.perf_counter() - t0
     m.sample(GREEDY)
     # The port is memory-bound and libgomp's barriers degrade with wide teams (measured on the 2x64-core host:
     # 16 threads 40 tok/s, 64 threads 16, 256 threads 0.1): pick the best team size from a 2-token probe each.
@@ -81,13 +90,45 @@ def cpu_baseline(desc, tensors, seconds):
         if r > best_rate:
             best_n, best_rate = n_thr, r
     be.set_threads(best_n)
-    n = int(max(4, min(256, seconds * best_rate)))
-    t0 = time.perf_counter(); m.decode(n, GREEDY); dt = time.perf_counter() - t0
-    cores_used = best_n
+
+    def three_samples(budget_s, rate_guess):
+        n = int(max(4, min(96, budget_s / 3.0 * rate_guess)))
+        rates = []
+        for _ in range(3):
+            t0 = time.perf_counter(); m.decode(n, GREEDY); rates.append(n / (time.perf_counter() - t0))
+        return n, rates
+
+    n_s, r_short = three_samples(seconds / 2.0, best_rate)
+    ctx_short = (20, 20 + 16 + 3 * n_s)
+    legs = {"short": {"prompt_tokens": 16, "context": list(ctx_short), "tokens_per_sample": n_s, "tok_s_median": round(statistics.median(r_short), 3),
+                      "tok_s_min": round(min(r_short), 3), "tok_s_max": round(max(r_short), 3)}}
+    value, which = statistics.median(r_short), "short"
+    est_prefill = prefill16_s / 16.0 * prompt_len          # measured with 16 threads on 16 tokens; the wider team below only shortens it
+    if prompt_len > 16 and prompt_len + 3 * 96 + 8 <= desc.max_ctx:
+        if est_prefill <= max_prefill_s:
+            be.set_threads(min(32, cores) if cores >= 32 else best_n)     # the prompt's products are compute-bound: a wider team helps there
+            m.reset_cache()
+            t0 = time.perf_counter(); m.forward(synth.synth_prompt(desc.vocab, prompt_len, prompt_seed)[None, :]); pre_s = time.perf_counter() - t0
+            m.sample(GREEDY)
+            be.set_threads(best_n)
+            m.decode(1, GREEDY)
+            n_l, r_same = three_samples(seconds / 2.0, statistics.median(r_short))
+            legs["same"] = {"prompt_tokens": prompt_len, "context": [prompt_len + 2, prompt_len + 2 + 3 * n_l], "tokens_per_sample": n_l,
+                            "tok_s_median": round(statistics.median(r_same), 3), "tok_s_min": round(min(r_same), 3), "tok_s_max": round(max(r_same), 3),
+                            "oracle_prefill_s": round(pre_s, 1)}
+            value, which = statistics.median(r_same), "same"
+        else:
+            legs["same"] = {"skipped": f"oracle prefill of {prompt_len} tokens estimated at {est_prefill:.0f} s > {max_prefill_s:.0f} s on this host"}
     m.close()
-    return {"value": round(n / dt, 3), "unit": "tokens/s", "cores": cores_used, "host_cores": cores, "kind": "port",
-            "sample": f"oracle/liboracle.so (C+OpenMP restatement), same synthetic {desc.name or 'model'} {desc.compute_dtype}, "
-                      f"16-token prompt, {n} greedy decode tokens at the best OpenMP team size ({cores_used} of {cores} host threads), context ~30..{30 + n}"}
+    ctx = legs[which]["context"]
+    return {"value": round(value, 3), "unit": "tokens/s", "cores": best_n, "host_cores": cores, "kind": "port",
+            "omp": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"), "threads": best_n},
+            "legs": legs,
+            "sample": f"oracle/liboracle.so (C+OpenMP restatement), same synthetic {desc.name or 'model'} {desc.compute_dtype}; value = median of 3 samples of "
+                      f"{legs[which]['tokens_per_sample']} greedy decode tokens after a {legs[which]['prompt_tokens']}-token prompt (context {ctx[0]}..{ctx[1]}: "
+                      + ("the GPU run's own context" if which == "same" else "SHORTER than the GPU run's context — the oracle's prefill of the full prompt was over budget")
+                      + f"), {best_n} of {cores} host threads (best team size of a probe), threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores); "
+                      f"spread min/max in legs"}
 
 
 def main():
@@ -154,11 +195,11 @@ def main():
     t0 = time.perf_counter()
     model.decode(args.steps, GREEDY, fetch=False)                   # EXACTLY K steps
     sync()
-    if dist: dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0                              # this rank's K steps; no collective inside the timed region
     if dist:
+        dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                    # MAX over ranks: the job is as slow as its slowest replica
         elapsed = float(t.item())
 
     if rank != 0:
@@ -176,16 +217,25 @@ def main():
     gu_us = ms_gu / n_gu * 1e3
     achieved = gu_bytes / (gu_us * 1e-6) / 1e9
     classes = {k: round(ms / n * 1e3, 3) for k, (n, ms) in prof.items() if n}
+    # HBM traffic of the dominant kernel cannot be read from inside the run (PMC counters need rocprofv3 around the process): it is the
+    # figure a separate `rocprofv3 --pmc FETCH_SIZE` pass of this command gave (x2: the gfx950 correction of MI355X_MICROARCH.md §HBM),
+    # stored per (model, dtype) in profiles/pmc_traffic.json — null for a configuration that has no such pass.
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    traffic = None
-    if os.path.exists(pmc_path) and desc.family == "llama" and desc.hidden == 2048 and desc.inter == 8192 and args.dtype == "bf16":   # measured for this launch only
+    traffic, traffic_source = None, "not measured for this model/dtype (no rocprofv3 --pmc pass on record)"
+    if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get("gateup_bytes_per_launch")
-        except Exception:
-            traffic = None
+            rec = json.load(open(pmc_path))
+            ent = rec.get("by_config", {}).get(f"{args.model}:{args.dtype}")
+            if ent is None and args.model == "llama-3.2-1b" and args.dtype == "bf16" and "gateup_bytes_per_launch" in rec:
+                ent = {"gateup_bytes_per_launch": rec["gateup_bytes_per_launch"], "source": rec.get("source", "profiles/r01_bench_pmc.txt")}
+            if ent:
+                traffic = ent["gateup_bytes_per_launch"]
+                traffic_source = f"static: {ent.get('source', 'profiles/pmc_traffic.json')} (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction), not collected in this run"
+        except Exception as e:
+            traffic_source = f"profiles/pmc_traffic.json unreadable: {e}"
     kname = "gemv_kernel<PRO_LAYERNORM,EPI_GELU> (ln_2 + c_fc + gelu)" if desc.family == "gpt2" else "gemv_kernel<PRO_RMSNORM,EPI_SILU_MUL> (gate_up)"
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "bytes_per_launch": gu_bytes, "avg_launch_us": round(gu_us, 3),
                 "kernel_classes_avg_us": classes,
                 "step_bytes_per_token": bytes_tok, "step_achieved": round(bytes_tok * tok_s / world / 1e9, 1),
@@ -194,7 +244,7 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(desc, tensors, args.cpu_seconds)
+            cpu = cpu_baseline(desc, tensors, args.cpu_seconds, args.prompt, 1234)
         except Exception as e:     # the GPU number stands on its own; say why the baseline is absent
             cpu = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
@@ -203,6 +253,11 @@ def main():
     gemm_flops = 2.0 * args.prompt * L * ((desc.q_dim + 2 * desc.kv_dim) * H + H * desc.q_dim + (2 if desc.family == "gpt2" else 3) * I * H)
     attn_flops = 4.0 * L * desc.heads * desc.head_dim * args.prompt * (args.prompt + 1) / 2.0
     prefill_tflops = (gemm_flops + attn_flops) / (prefill_ms * 1e-3) / 1e12
+    # what the matrix cores execute: fp32 activations enter as exact sums of 16-bit terms — 3 for the bf16 QKV product, 2 elsewhere
+    # (DESIGN.md §5); the attention products (QK^T, PV) take 2 passes each
+    qkv_flops = 2.0 * args.prompt * L * (desc.q_dim + 2 * desc.kv_dim) * H
+    executed_flops = (3.0 if args.dtype == "bf16" else 2.0) * qkv_flops + 2.0 * (gemm_flops - qkv_flops) + 2.0 * attn_flops
+    prefill_exec_tflops = executed_flops / (prefill_ms * 1e-3) / 1e12
 
     line = {
         # BASELINE.json's metric string for the headline configuration; other --model / --dtype runs name themselves
@@ -214,7 +269,8 @@ def main():
         "config": {"workload": f"{desc.name} {args.dtype}, batch 1 per GPU: {args.prompt}-token prefill then greedy decode "
                                f"(one step = one token, context {T0}..{T0 + args.steps - 1})",
                    "replicas": world, "prompt_tokens": args.prompt, "prefill_ms": round(prefill_ms, 1),
-                   "prefill_tflops": round(prefill_tflops, 1), "prefill_mfma_frac_of_2500": round(2 * prefill_tflops / 2500.0, 4),
+                   "prefill_tflops": round(prefill_tflops, 1), "prefill_frac_of_2500_algorithmic": round(prefill_tflops / 2500.0, 4),
+                   "prefill_tflops_executed": round(prefill_exec_tflops, 1), "prefill_frac_of_2500_executed": round(prefill_exec_tflops / 2500.0, 4),
                    "params": desc.param_count(), "graph": not args.no_graph},
         "roofline": roofline,
         "cpu_baseline": cpu,

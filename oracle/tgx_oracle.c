@@ -409,16 +409,20 @@ static inline float dot_row(const tgxo_ctx* c, const mat_t* m, int64_t row, cons
   return acc;
 }
 
-/* y[s][n] = R(x[s] . W[n] + b[n]) for S rows of x; raw != 0 keeps the fp32 accumulator */
+/* y[s][n] = R(x[s] . W[n] + b[n]) for S rows of x; raw != 0 keeps the fp32 accumulator.
+ * Loop order only: blocks of 8 weight rows are walked over all S activation rows, so that a prompt's activations stream from the
+ * cache once per 8 rows instead of once per row (a 2048-token prompt at full model size: minutes -> tens of seconds).  Every dot
+ * product is the same dot_row() in the same element order, i.e. the results are bit-identical to the row-by-row order. */
 static void linear(const tgxo_ctx* c, const mat_t* m, const float* x, int S, float* y, int raw) {
   int64_t N = m->rows, K = m->cols;
 #pragma omp parallel for schedule(static)
-  for (int64_t n = 0; n < N; n++) {
-    float b = m->bias ? m->bias[n] : 0.f;
-    for (int s = 0; s < S; s++) {
-      float a = dot_row(c, m, n, x + (int64_t)s * K) + b;
-      y[(int64_t)s * N + n] = raw ? a : R(c, a);
-    }
+  for (int64_t nb = 0; nb < N; nb += 8) {
+    int64_t ne = nb + 8 < N ? nb + 8 : N;
+    for (int s = 0; s < S; s++)
+      for (int64_t n = nb; n < ne; n++) {
+        float a = dot_row(c, m, n, x + (int64_t)s * K) + (m->bias ? m->bias[n] : 0.f);
+        y[(int64_t)s * N + n] = raw ? a : R(c, a);
+      }
   }
 }
 

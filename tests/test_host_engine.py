@@ -34,7 +34,7 @@ def test_synth_cpp_equals_python(lib):
                          ("model.layers.0.input_layernorm.weight", 64, 0.08), ("lm_head.weight", 1 << 21, 0.08)]:
         out = np.zeros(n, np.uint16)
         lib.tgxe_synth_tensor(1234, name.encode(), n, std, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)))
-        np.testing.assert_array_equal(out, synth.synth_tensor_bf16(1234, name, (n,), std))
+        np.testing.assert_array_equal(out, synth.synth_tensor_bf16(1234, name, (n,), std, force_numpy=True))
 
 
 @pytest.mark.parametrize("fam,shards", [("llama_tiny", 1), ("qwen2_tiny", 2), ("mistral_tiny", 1), ("qwen3_tiny", 1)])

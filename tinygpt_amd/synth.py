@@ -47,9 +47,38 @@ def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
     return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
 
 
-def synth_tensor_bf16(seed: int, name: str, shape, std: float) -> np.ndarray:
+_native = None
+
+
+def _native_fill():
+    """tgxe_synth_tensor of the C++ host library (tinygpt_amd/host/engine.cpp): the same integer hash, ~25x faster than the numpy form
+    below on large tensors (7B parameters: seconds instead of minutes).  Bit-identity of the two is a test
+    (tests/test_host_engine.py::test_synth_cpp_equals_python); TGX_SYNTH_NUMPY=1 forces the numpy form."""
+    global _native
+    if _native is None:
+        _native = False
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtgx_host.so")
+        if os.environ.get("TGX_SYNTH_NUMPY") != "1" and os.path.exists(path):
+            import ctypes
+            try:
+                fn = ctypes.CDLL(path).tgxe_synth_tensor
+                fn.argtypes = [ctypes.c_uint64, ctypes.c_char_p, ctypes.c_int64, ctypes.c_double, ctypes.POINTER(ctypes.c_uint16)]
+                fn.restype = None
+                _native = fn
+            except (OSError, AttributeError):
+                _native = False
+    return _native
+
+
+def synth_tensor_bf16(seed: int, name: str, shape, std: float, force_numpy: bool = False) -> np.ndarray:
     """uint16 (bf16 bits) tensor of `shape` for checkpoint entry `name`."""
     n = int(np.prod(shape))
+    fn = None if force_numpy else _native_fill()
+    if fn and n >= (1 << 16):
+        import ctypes
+        out = np.empty(n, dtype=np.uint16)
+        fn(seed & 0xFFFFFFFFFFFFFFFF, name.encode(), n, float(std), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)))
+        return out.reshape(shape)
     base = np.uint64(_fnv1a64(name) ^ ((seed * 0xD1342543DE82EF95) & 0xFFFFFFFFFFFFFFFF))
     out = np.empty(n, dtype=np.uint16)
     leaf = name.rsplit(".", 2)[-2:]
