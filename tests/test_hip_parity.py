@@ -324,6 +324,59 @@ def test_direct_attention_equals_split(name, lens, hip):
         assert rel_err(outs[1][2], outs[0][2]) < 1e-5, (n, rel_err(outs[1][2], outs[0][2]))
 
 
+@pytest.mark.parametrize("name,lens,batch", [("llama-3.2-1b", (1, 127, 128, 129, 1500, 1536, 2047, 3100), 1), ("llama-3.2-1b", (130, 900), 4),
+                                             ("mistral-7b-v0.3", (63, 64, 65, 700, 2100), 1), ("qwen2.5-0.5b", (300, 1100), 2), ("llama-3.2-3b", (200,), 3)])
+def test_attention_combine_folded_into_o_proj_equals_separate_launch(name, lens, batch, hip):
+    """Split-form attention: the merge of the per-split partials can run in the o_proj launch's prologue (PRO_ATTNCOMB, through LDS) instead
+    of a launch of its own (option attn.fold_combine; off by default: measured slower).  Same records, same fp32 merge in another association order: logits equal to fp32
+    rounding and greedy ids equal, at contexts around the split block size (128 tokens at head_dim 64, 64 at 128), with 1..18+ active
+    splits, more than one round of 12 splits, beyond 32 blocks (round-robin), and for batch rows 2 / 3 (2+1) / 4 that share the launch."""
+    import copy
+    from tinygpt_amd import known_desc, synth
+    from tinygpt_amd.ffi import Model
+    d = copy.deepcopy(known_desc(name))
+    d.layers, d.vocab, d.max_ctx, d.max_batch = 2, 4096, 4224, batch
+    m = Model(d, hip).load_synthetic(1234, 0.02).finalize()
+    m.set_option("attn.direct_max", 0)                  # the split form at every context
+    for n in lens:
+        prompt = np.stack([synth.synth_prompt(d.vocab, n, 100 + n + 7 * b) for b in range(batch)])
+        outs = []
+        for fold in (0, 1):
+            m.set_option("attn.fold_combine", fold)
+            m.reset_cache(); m.forward(prompt)
+            first = m.sample(GREEDY).copy()
+            rest = m.decode(5, GREEDY).copy()
+            outs.append((first, rest, m.logits(rounded=False).copy()))
+        np.testing.assert_array_equal(outs[0][0], outs[1][0])
+        np.testing.assert_array_equal(outs[0][1], outs[1][1])
+        assert rel_err(outs[1][2], outs[0][2]) < 1e-5, (n, rel_err(outs[1][2], outs[0][2]))
+
+
+@pytest.mark.parametrize("fam,batch", [("llama_tiny", 1), ("qwen2_tiny", 3), ("gpt2_hd64", 4)])
+def test_greedy_finalize_fused_into_lm_head_equals_separate_launch(fam, batch, hip, oracle_lib):
+    """Option lmhead.fuse_finalize (off by default: measured no faster): the lm_head launch's last-arriving workgroup reduces the argmax
+    partials and publishes token / position / next embedding row (arrival ticket, agent-scope stores + one acquire).  Ids over a long
+    free-running decode and the final logits must be bit-identical to the separate finalize launch, and equal to the oracle's."""
+    from oracle.oracle_ffi import OracleModel
+    from tinygpt_amd.ffi import Model
+    cfg, g = load_golden(fam)
+    d = desc_from_hf_config(cfg, "bf16", max_batch=batch)
+    m = Model(d, hip).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
+    prompt = np.stack([synth.synth_prompt(d.vocab, 9, 50 + b) for b in range(batch)])
+    outs = []
+    for fuse in (0, 1, 1):
+        m.set_option("lmhead.fuse_finalize", fuse)
+        m.reset_cache(); m.forward(prompt)
+        first = m.sample(GREEDY).copy()
+        rest = m.decode(96, GREEDY).copy()
+        outs.append((first, rest, m.logits(rounded=False).copy()))
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o[0], outs[0][0]); np.testing.assert_array_equal(o[1], outs[0][1]); np.testing.assert_array_equal(o[2], outs[0][2])
+    ref = OracleModel(d).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
+    ref.forward(prompt); ref.sample(GREEDY)
+    np.testing.assert_array_equal(ref.decode(24, GREEDY), outs[1][1][:24])
+
+
 @pytest.mark.parametrize("hidden,heads,kv,inter", [(5120, 40, 8, 13824), (8192, 64, 8, 16384), (8192, 64, 8, 28672)])
 def test_wide_models_vs_oracle(hidden, heads, kv, inter, hip, oracle_lib):
     """13B/14B-class widths (Llama-2-13B / Qwen2.5-14B: hidden 5120, intermediate 13824) and the widest shape one launch covers

@@ -5,6 +5,8 @@
 //   RMSNorm -> MergedLinear qkv -> split -> RoPE(q),RoPE(k)          PRO_RMSNORM + EPI_QKV_ROPE
 //     -> KVCacheManager::append (Attention.h:94-106)                   (K/V land directly in the cache slot)
 //   Linear o_proj -> x + .  (Attention.h:90, DecoderLayer.h:40)      PRO_PLAIN   + EPI_RESIDUAL
+//     ... after split-form attention (long contexts)                 PRO_ATTNCOMB + EPI_RESIDUAL: the merge of the attention
+//                                                                      splits (flash-decode combine) happens in THIS launch's prologue
 //   RMSNorm -> MergedLinear gate_up -> siluMul (GatedMLP.h:37-39)    PRO_RMSNORM + EPI_SILU_MUL
 //   Linear down_proj -> x + .  (GatedMLP.h:40, DecoderLayer.h:41)    PRO_PLAIN   + EPI_RESIDUAL
 //   RMSNorm -> Linear lm_head -> argmax (GPTModel.h:56-57,            PRO_RMSNORM + EPI_LOGITS
@@ -27,8 +29,99 @@
 
 namespace tgx {
 
-enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_LAYERNORM = 2 };   // LAYERNORM: GPT-2's nn::LayerNorm with bias (ModelGPT2.h:120-135)
+enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_LAYERNORM = 2, PRO_ATTNCOMB = 3 };   // LAYERNORM: GPT-2's nn::LayerNorm with bias (ModelGPT2.h:120-135)
+// PRO_ATTNCOMB (the o_proj launch behind split-form attention): the input vector does not exist in memory yet — the workgroup builds it
+// from the attention kernel's per-split partial records (o[hd], m, l per query head and split; attn_decode.h) while its first weight
+// slices are in flight, leaves it in LDS, and every wave takes its slices from there.  One launch (the former attn_combine_kernel: a
+// 1.5 us boundary plus a load -> merge -> store chain that moved a few KB) less per layer.
 enum { EPI_QKV_ROPE = 0, EPI_RESIDUAL = 1, EPI_SILU_MUL = 2, EPI_LOGITS = 3, EPI_GELU = 4 };   // GELU: GPT-2's c_fc -> gelu (ModelGPT2.h:96-107)
+
+// ---- greedy finalize: reduce the lm_head partial argmaxes, publish the token, advance the row ---------
+// == argmax (Sampler.cpp:28) + tokens = concat(tokens, next) + KV pastLength += 1, and it gathers the next
+// step's embedding row (nn::Embedding, GPTModel.h:52) into the residual stream so the decode graph needs
+// no host input between steps.
+// nn::Embedding row gather: table row `t` (storage dtype) -> fp32 residual stream
+// GPT-2 adds the learned position row: wte(ids) + wpe(arange(past, past + S))  (ModelGPT2.h:165-169)
+template <int DT>
+__device__ __forceinline__ void gather_embedding(const void* table, long long t, float* x, int H, const void* wpe = nullptr, int p = 0) {
+  const elem_t<DT>* row = static_cast<const elem_t<DT>*>(table) + (size_t)t * H;
+  const elem_t<DT>* prow = static_cast<const elem_t<DT>*>(wpe) + (size_t)p * H;
+  f32x4* dst = reinterpret_cast<f32x4*>(x);
+  for (int c = threadIdx.x; c < (H >> 3); c += blockDim.x) {
+    float f[8];
+    slice_unpack<DT>(load_slice<DT>(row, c), f);
+    if (wpe) {
+      float g[8];
+      slice_unpack<DT>(load_slice<DT>(prow, c), g);
+#pragma unroll
+      for (int k = 0; k < 8; k++) f[k] += g[k];
+    }
+    dst[2 * c] = f32x4{f[0], f[1], f[2], f[3]};
+    dst[2 * c + 1] = f32x4{f[4], f[5], f[6], f[7]};
+  }
+}
+
+struct FinalizeArgs {
+  const float* part_val;
+  const int* part_idx;
+  int n_part;
+  int* tok;              // this row's current token (device resident)
+  int* pos;              // this row's pastLength
+  int* step;             // decode steps finalized so far (monotonic; index into the token rings)
+  int* tok_log;          // [log_cap][rows] device ring of produced tokens
+  volatile int* host_ring;   // [ring_cap][rows] pinned host mirror (AsyncTokenPipeline read-back); nullptr: not mirrored (multi-step graphs)
+  int log_cap, ring_cap;
+  int row, rows;
+  int log;               // 1: record the token in the rings (decode steps); 0: tgx_sample after a prefill
+  int bump_step;         // 1 on the last row of a step
+  const void* embed;     // [V][H], storage dtype
+  float* x;              // [H] residual stream of this row (fp32)
+  int H, V;
+  int advance_pos;       // 1: pos += 1 (the token just consumed is now in the cache)
+  const void* wpe;       // GPT-2: [n_pos][H] learned positions (nullptr otherwise); the next token sits at the advanced pos
+  int n_pos;
+};
+
+// the body of the greedy finalize for one row, run by all 256 threads of a workgroup: finalize_greedy_kernel (tgx_sample after a
+// prefill, sampled steps' pick kernel) and the lm_head launch's last-arriving workgroup (greedy decode steps) share it
+template <int DT>
+__device__ __forceinline__ void finalize_row(const FinalizeArgs& a) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  __shared__ int s_tok, s_pos;
+  __syncthreads();                 // the shared arrays may still be read by the previous row's call
+  float bv = -INFINITY; int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < a.n_part; i += 256) {
+    const float v = a.part_val[i]; const int ix = a.part_idx[i];
+    if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float v = sv[threadIdx.x + s]; const int ix = si[threadIdx.x + s];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && ix < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = ix; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int t = (unsigned)si[0] < (unsigned)a.V ? si[0] : 0;   // all-NaN logits leave the sentinel index: never gather out of the table
+    s_tok = t;
+    *a.tok = t;
+    const int np = *a.pos + (a.advance_pos ? 1 : 0);
+    if (a.advance_pos) *a.pos = np;
+    s_pos = np < a.n_pos ? np : a.n_pos - 1;    // a full context takes no further step: stay inside wpe
+    if (a.log) {
+      const int st = *a.step;
+      a.tok_log[(st % a.log_cap) * a.rows + a.row] = t;
+      if (a.host_ring) a.host_ring[(st % a.ring_cap) * a.rows + a.row] = t;
+      if (a.bump_step) *a.step = st + 1;
+    }
+  }
+  __syncthreads();
+  gather_embedding<DT>(a.embed, s_tok, a.x, a.H, a.wpe, a.wpe ? s_pos : 0);
+}
+
 
 // Batch rows: R rows (1, 2 or 4) of independent sequences share ONE pass over the weights — every weight slice that
 // lands in a register is multiplied into R activation vectors (the reference runs the whole batch through each
@@ -58,10 +151,20 @@ struct GemvArgs {
   float* k_raw;           // [R][kv_heads*hd] fp32 staging for k when raw_qk
   // EPI_RESIDUAL: out[n] += acc;  EPI_SILU_MUL: out[i] = silu(g) * u;  EPI_GELU: out[n] = gelu_new(acc)      (fp32)
   float* out;
+  // PRO_ATTNCOMB: part = [R][heads][attn_nsplit][attn_hd + 4] records (o[hd], m in the exp2 domain, l, pad), rows part_in_stride apart;
+  // the active splits are the first ceil((pos[r] + 1) / attn_step) (token blocks are dealt round-robin, attn_decode.h); uses `pos`
+  const float* attn_part;
+  long long part_in_stride;
+  int attn_nsplit, attn_step, attn_hd;
   // EPI_LOGITS
   float* logits;          // [R][N] fp32
   float* part_val;        // [R][gridDim.x] best logit of this workgroup
   int* part_idx;
+  // greedy decode steps: the LAST workgroup of the lm_head launch to arrive at `ticket` (a device counter that rests at 0) reduces the
+  // per-workgroup partials and does what finalize_greedy_kernel does for each of the R rows — one launch per token less.  nullptr: off
+  // (sampled steps, tgx_forward: the sampler / tgx_sample finish the step).
+  unsigned int* ticket;
+  FinalizeArgs fin[4];
 };
 
 // HF "gelu_new" (GPT-2's activation_function): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
@@ -133,6 +236,79 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 
   // 2. this wave's slice of every row's activation vector -> registers (zero outside the range)
   float xr[R][NX][8];
+  if constexpr (PRO == PRO_ATTNCOMB) {
+    // Attention's split partials -> the attention output (== attn_combine: out = sum_s o_s 2^(m_s - M) / sum_s l_s 2^(m_s - M)), built by the
+    // whole workgroup: thread = (query head, 8 output dims); the splits of a head arrive as independent 16-byte loads, CH at a time, and
+    // fold into a running (M, L, o[8]) in split order (fixed order: deterministic).  Result -> LDS xs[R][K].
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    constexpr int CH = 18;                                  // splits per round of loads: one round up to 2304 keys at head_dim 64 (18 blocks of 128)
+    const int dgn = a.attn_hd >> 3, rec = a.attn_hd + 4;
+#pragma unroll 1
+    for (int r = 0; r < R; r++) {
+      const int* posp = a.pos + r;
+      const float* prow = a.attn_part + (size_t)r * a.part_in_stride;
+#pragma unroll 1
+      for (int item = threadIdx.x; item < (a.K >> 3); item += 256) {
+        const int h = item / dgn, dg = item - h * dgn;
+        const float* p = prow + (size_t)h * a.attn_nsplit * rec;
+        float M = -INFINITY, L = 0.f, o[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) o[t] = 0.f;
+        // every split slot holds a valid record (a split without keys publishes m = -inf), so the first round needs no position: its loads
+        // leave together with the launch's first weight loads; only contexts beyond CH blocks wait for the position
+        int n_act = min(a.attn_nsplit, CH);
+#pragma unroll 1
+        for (int s0 = 0; s0 < n_act; s0 += CH) {
+          f32x4 d0[CH], d1[CH];
+          float pm[CH], pl[CH];
+#pragma unroll
+          for (int i = 0; i < CH; i++) {                    // every load of the round is issued before the first use
+            const int sidx = min(s0 + i, a.attn_nsplit - 1);   // clamped: a legal record; masked below
+            const float* rp = p + (size_t)sidx * rec;
+            const f32x4* src = reinterpret_cast<const f32x4*>(rp + dg * 8);
+            d0[i] = src[0]; d1[i] = src[1];
+            const float2 ml = *reinterpret_cast<const float2*>(rp + a.attn_hd);
+            pm[i] = (s0 + i < a.attn_nsplit) ? ml.x : -INFINITY; pl[i] = ml.y;
+          }
+          if (s0 == 0 && a.attn_nsplit > CH) n_act = min(a.attn_nsplit, (*posp + a.attn_step) / a.attn_step);   // ceil((pos + 1) / step)
+          float mc = pm[0];
+#pragma unroll
+          for (int i = 1; i < CH; i++) mc = fmaxf(mc, pm[i]);
+          const float Mn = fmaxf(M, mc);
+          if (Mn == -INFINITY) continue;                     // only empty splits so far (m = -inf records hold stale data: select, never multiply)
+          const float sc = (M == -INFINITY) ? 0.f : exp2f(M - Mn);
+          L *= sc;
+#pragma unroll
+          for (int t = 0; t < 8; t++) o[t] *= sc;
+#pragma unroll
+          for (int i = 0; i < CH; i++) {
+            if (pm[i] != -INFINITY) {
+              const float e = exp2f(pm[i] - Mn);
+              L = fmaf(pl[i], e, L);
+#pragma unroll
+              for (int t = 0; t < 4; t++) { o[t] = fmaf(d0[i][t], e, o[t]); o[4 + t] = fmaf(d1[i][t], e, o[4 + t]); }
+            }
+          }
+          M = Mn;
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(xs + (size_t)r * a.K + (size_t)item * 8);
+        dst[0] = f32x4{o[0] / L, o[1] / L, o[2] / L, o[3] / L};
+        dst[1] = f32x4{o[4] / L, o[5] / L, o[6] / L, o[7] / L};
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const f32x4* xl = reinterpret_cast<const f32x4*>(xs + (size_t)r * a.K);
+#pragma unroll
+      for (int j = 0; j < NX; j++) {
+        f32x4 v0 = xl[2 * cidx[j]], v1 = xl[2 * cidx[j] + 1];
+        if (!cok[j]) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+#pragma unroll
+        for (int t = 0; t < 4; t++) { xr[r][j][t] = v0[t]; xr[r][j][4 + t] = v1[t]; }
+      }
+    }
+  } else {
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const f32x4* xg = reinterpret_cast<const f32x4*>(a.x + (size_t)r * a.x_stride);
@@ -143,6 +319,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 #pragma unroll
       for (int t = 0; t < 4; t++) { xr[r][j][t] = v0[t]; xr[r][j][4 + t] = v1[t]; }
     }
+  }
   }
   // sum of one value per batch row over the KS waves that share a unit, in wave order (every wave of the workgroup takes part)
   auto ks_sum = [&](float* v) {
@@ -367,8 +544,35 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       float bv = sv[r][0]; int bi = si[r][0];
       for (int w = 1; w < 4; w++)
         if (sv[r][w] > bv || (sv[r][w] == bv && si[r][w] < bi)) { bv = sv[r][w]; bi = si[r][w]; }
-      a.part_val[(size_t)r * a.part_stride + blockIdx.x] = bv;
-      a.part_idx[(size_t)r * a.part_stride + blockIdx.x] = bi;
+      if (a.ticket) {    // read by another workgroup of THIS launch: agent-scope write-through stores (cdna_hip_programming.md Guideline 16, R1)
+        __hip_atomic_store(reinterpret_cast<int*>(a.part_val) + (size_t)r * a.part_stride + blockIdx.x, __builtin_bit_cast(int, bv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.part_idx + (size_t)r * a.part_stride + blockIdx.x, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        a.part_val[(size_t)r * a.part_stride + blockIdx.x] = bv;
+        a.part_idx[(size_t)r * a.part_stride + blockIdx.x] = bi;
+      }
+    }
+    if (a.ticket) {
+      // arrival ticket: partial stores drained (every storing wave), then one relaxed agent-scope increment; the workgroup that draws the last
+      // ticket is ordered after every other workgroup's partials.  It resets the counter (the next lm_head launch is stream-ordered behind
+      // this one), takes ONE agent-scope acquire (drops its CU's stale lines) and finishes the step for every row.
+      __shared__ int s_last;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == gridDim.x - 1;
+        if (last) {
+          __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        s_last = last;
+      }
+      __syncthreads();
+      if (s_last) {
+#pragma unroll 1
+        for (int r = 0; r < R; r++) finalize_row<DT>(a.fin[r]);
+      }
     }
   }
 }
@@ -412,88 +616,8 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(QkNormArgs a) {
   }
 }
 
-// ---- greedy finalize: reduce the lm_head partial argmaxes, publish the token, advance the row ---------
-// == argmax (Sampler.cpp:28) + tokens = concat(tokens, next) + KV pastLength += 1, and it gathers the next
-// step's embedding row (nn::Embedding, GPTModel.h:52) into the residual stream so the decode graph needs
-// no host input between steps.
-// nn::Embedding row gather: table row `t` (storage dtype) -> fp32 residual stream
-// GPT-2 adds the learned position row: wte(ids) + wpe(arange(past, past + S))  (ModelGPT2.h:165-169)
 template <int DT>
-__device__ __forceinline__ void gather_embedding(const void* table, long long t, float* x, int H, const void* wpe = nullptr, int p = 0) {
-  const elem_t<DT>* row = static_cast<const elem_t<DT>*>(table) + (size_t)t * H;
-  const elem_t<DT>* prow = static_cast<const elem_t<DT>*>(wpe) + (size_t)p * H;
-  f32x4* dst = reinterpret_cast<f32x4*>(x);
-  for (int c = threadIdx.x; c < (H >> 3); c += blockDim.x) {
-    float f[8];
-    slice_unpack<DT>(load_slice<DT>(row, c), f);
-    if (wpe) {
-      float g[8];
-      slice_unpack<DT>(load_slice<DT>(prow, c), g);
-#pragma unroll
-      for (int k = 0; k < 8; k++) f[k] += g[k];
-    }
-    dst[2 * c] = f32x4{f[0], f[1], f[2], f[3]};
-    dst[2 * c + 1] = f32x4{f[4], f[5], f[6], f[7]};
-  }
-}
-
-struct FinalizeArgs {
-  const float* part_val;
-  const int* part_idx;
-  int n_part;
-  int* tok;              // this row's current token (device resident)
-  int* pos;              // this row's pastLength
-  int* step;             // decode steps finalized so far (monotonic; index into the token rings)
-  int* tok_log;          // [log_cap][rows] device ring of produced tokens
-  volatile int* host_ring;   // [ring_cap][rows] pinned host mirror (AsyncTokenPipeline read-back); nullptr: not mirrored (multi-step graphs)
-  int log_cap, ring_cap;
-  int row, rows;
-  int log;               // 1: record the token in the rings (decode steps); 0: tgx_sample after a prefill
-  int bump_step;         // 1 on the last row of a step
-  const void* embed;     // [V][H], storage dtype
-  float* x;              // [H] residual stream of this row (fp32)
-  int H, V;
-  int advance_pos;       // 1: pos += 1 (the token just consumed is now in the cache)
-  const void* wpe;       // GPT-2: [n_pos][H] learned positions (nullptr otherwise); the next token sits at the advanced pos
-  int n_pos;
-};
-
-template <int DT>
-__global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs a) {
-  __shared__ float sv[256];
-  __shared__ int si[256];
-  __shared__ int s_tok, s_pos;
-  float bv = -INFINITY; int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < a.n_part; i += 256) {
-    const float v = a.part_val[i]; const int ix = a.part_idx[i];
-    if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
-  }
-  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      const float v = sv[threadIdx.x + s]; const int ix = si[threadIdx.x + s];
-      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && ix < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = ix; }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const int t = (unsigned)si[0] < (unsigned)a.V ? si[0] : 0;   // all-NaN logits leave the sentinel index: never gather out of the table
-    s_tok = t;
-    *a.tok = t;
-    const int np = *a.pos + (a.advance_pos ? 1 : 0);
-    if (a.advance_pos) *a.pos = np;
-    s_pos = np < a.n_pos ? np : a.n_pos - 1;    // a full context takes no further step: stay inside wpe
-    if (a.log) {
-      const int st = *a.step;
-      a.tok_log[(st % a.log_cap) * a.rows + a.row] = t;
-      if (a.host_ring) a.host_ring[(st % a.ring_cap) * a.rows + a.row] = t;
-      if (a.bump_step) *a.step = st + 1;
-    }
-  }
-  __syncthreads();
-  gather_embedding<DT>(a.embed, s_tok, a.x, a.H, a.wpe, a.wpe ? s_pos : 0);
-}
+__global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs a) { finalize_row<DT>(a); }
 
 // Prefill-by-steps: chunk row r <- embedding of prompt token r, position pos0 + r (one workgroup per chunk row).
 struct EmbedChunkArgs {

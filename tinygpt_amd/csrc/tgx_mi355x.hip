@@ -139,6 +139,15 @@ struct tgx_ctx {
   int gemm_splitk = 1;       // experiment: 0 disables split-K
   int attn_mirror = 1;       // experiment: prefill attention block order
   int qk_fuse = 1;           // experiment: 0 keeps Qwen3's separate q/k norm launch
+  // Two launch folds that are built, parity-tested and OFF by default because they measured slower on MI355X (profiles/r02_launch_folds.txt):
+  // attn.fold_combine = 1 merges the attention splits in the o_proj launch's prologue (98 -> 82 launches per token on Llama-3.2-1B): every one of
+  // the 256 o_proj workgroups then re-reads the same ~150 KB of partial records through L2, which costs 3.3 us against the 2.9 us launch it removes
+  // (context 2.4k: 0.7109 -> 0.7173 ms/token; +1.7 % only on Qwen2.5-0.5B's 14 heads; -20 % at head_dim 128 / context 6k);
+  // lmhead.fuse_finalize = 1 lets the lm_head launch's last-arriving workgroup do the greedy finalize (arrival ticket): the drain + atomic on
+  // all ~1000 workgroups costs what the 1-workgroup finalize launch cost (0.7109 -> 0.7123 ms/token).
+  int attn_fold = 0;
+  int lm_fuse = 0;
+  unsigned int* lm_ticket = nullptr;   // arrival counter of the lm_head launch (rests at 0)
   bool prefill_mfma = true;
   int prefill_min_rows = 4;  // prompts shorter than this go through the decode kernels, 4 positions per pass (set in tgx_create)
   int gemm_tm = 0;           // experiment: force the GEMM row tile (64 / 128); 0 = by the number of tiles
@@ -371,17 +380,21 @@ tgx::GemvArgs gemv_row(const tgx_ctx* c, tgx::GemvArgs a, int r) {
   if (a.logits) a.logits += (size_t)r * a.logits_stride;
   if (a.part_val) a.part_val += (size_t)r * a.part_stride;
   if (a.part_idx) a.part_idx += (size_t)r * a.part_stride;
+  if (a.attn_part) a.attn_part += (size_t)r * a.part_in_stride;
+  if (a.ticket && r) a.fin[0] = a.fin[r];
   return a;
 }
 
 template <int DT, int PRO, int EPI, int NX>
 void launch_gemv_nx(tgx_ctx* c, const tgx::GemvArgs& a, int grid, int R) {
   const dim3 g(grid), b(256);
+  // PRO_ATTNCOMB stages the merged attention output of its rows in LDS: [rows][K] fp32 (attn_fold_ok() keeps it within 64 KB)
+  const size_t smem_row = PRO == tgx::PRO_ATTNCOMB ? (size_t)a.K * 4 : 0;
   // rows share the weight pass; R x NX activation slices of 8 floats stay in registers (4 x 8 x 8 = 256 of the 512 a wave
   // of a 256-thread workgroup may use)
-  if (R == 4) { hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 4>), g, b, 0, c->stream, a); return; }
-  if (R == 2) { hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 2>), g, b, 0, c->stream, a); return; }
-  for (int r = 0; r < R; r++) hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 1>), g, b, 0, c->stream, gemv_row(c, a, r));
+  if (R == 4) { hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 4>), g, b, 4 * smem_row, c->stream, a); return; }
+  if (R == 2) { hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 2>), g, b, 2 * smem_row, c->stream, a); return; }
+  for (int r = 0; r < R; r++) hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 1>), g, b, smem_row, c->stream, gemv_row(c, a, r));
 }
 
 template <int PRO, int EPI>
@@ -417,6 +430,13 @@ void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls, int R) {
   }
 }
 
+// Split-form attention leaves per-split partial records; the o_proj GEMV merges them in its prologue (one launch per layer less) when the
+// merged rows fit its LDS stage: R rows x heads*head_dim fp32 <= 64 KB (every BASELINE geometry at R <= 4).  Option attn.fold_combine = 0
+// keeps the separate attn_combine_kernel launch.
+bool attn_fold_ok(const tgx_ctx* c, int R) {
+  return c->attn_fold && !c->attn_direct && (size_t)R * c->d.heads * c->d.head_dim * 4 <= 65536;
+}
+
 template <int DT, int HD, bool QKN = false>
 void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
   // the query heads of a kv group go to workgroups two at a time (blockIdx.z): the per-head state (8 output registers, the
@@ -440,7 +460,8 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
     case 3: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 3, 4, QKN>), grid, blk, 0, c->stream, a); break;
     default: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 4, QKN>), grid, blk, 0, c->stream, a); break;
   }
-  if (!(c->debug_skip & 2)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
+  // the split partials are merged by the o_proj launch's prologue (PRO_ATTNCOMB) unless that fold is off or its LDS stage would not fit
+  if (!(c->debug_skip & 2) && !attn_fold_ok(c, R)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
 }
 
 void launch_attn(tgx_ctx* c, const tgx::AttnArgs& a, int R) {
@@ -512,6 +533,12 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
       tgx::GemvArgs a{};
       fill_strides(c, a);
       a.W = w.wo; a.bias = w.bo; a.x = r.attn; a.x_stride = qd; a.N = H; a.K = qd; a.units = (H + 1) / 2; a.out = resid; a.out_stride = H; a.hd = 2;
+      if (attn_fold_ok(c, R)) {   // split-form attention: the input vector is built from the split partials inside this launch
+        a.attn_part = r.attn_part; a.part_in_stride = (long long)c->attn_part_row; a.pos = r.pos;
+        a.attn_nsplit = c->attn_nsplit; a.attn_hd = hd; a.attn_step = 4 * (64 / (hd / 8)) * 4;   // attn_decode_kernel: NW waves x TPW tokens x UNR wave-loads per block
+        launch_gemv<tgx::PRO_ATTNCOMB, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_OPROJ, R);
+        break;
+      }
       launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_OPROJ, R);
       break;
     }
@@ -698,8 +725,12 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
     (void)hipMemcpyAsync(c->rows[(size_t)(row0 + b)].x, c->ws_x + ((size_t)(b + 1) * S - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, c->stream);
 }
 
+tgx::FinalizeArgs make_finalize_args(tgx_ctx* c, int row, bool advance_pos, bool log_step);
+
 // model.norm -> lm_head on the current position + per-workgroup argmax partials   (GPTModel.h:56-57)
-void launch_lm_head(tgx_ctx* c, int row0, int R) {
+// fuse_greedy: the launch's last-arriving workgroup also does the greedy finalize of its R rows (argmax over the partials, token publish,
+// pastLength + 1, next embedding row) — decode steps with a greedy sampler; no finalize launch follows.
+void launch_lm_head(tgx_ctx* c, int row0, int R, bool fuse_greedy = false) {
   const tgx_model_desc& d = c->d;
   RowState& r = c->rows[(size_t)row0];
   tgx::GemvArgs a{};
@@ -707,6 +738,10 @@ void launch_lm_head(tgx_ctx* c, int row0, int R) {
   a.W = d.tied ? c->embed : c->lm_head; a.x = r.x; a.x_stride = d.hidden; a.norm_w = c->final_norm; a.eps = d.norm_eps;
   a.N = d.vocab; a.K = d.hidden; a.units = (d.vocab + 1) / 2; a.hd = 2;
   a.logits = r.logits; a.part_val = r.part_val; a.part_idx = r.part_idx;
+  if (fuse_greedy) {
+    a.ticket = c->lm_ticket;
+    for (int k = 0; k < R; k++) a.fin[k] = make_finalize_args(c, row0 + k, /*advance_pos=*/true, /*log_step=*/true);
+  }
   if (c->gpt2) {   // ln_f -> wte^T (tied head, ModelGPT2.h:170-176)
     a.norm_b = c->final_norm_b;
     launch_gemv<tgx::PRO_LAYERNORM, tgx::EPI_LOGITS>(c, a, TGX_KERNEL_LMHEAD, R);
@@ -783,8 +818,9 @@ void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
   for (int row0 = 0; row0 < c->batch;) {
     const int rem = c->batch - row0, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
     launch_layers(c, row0, R);
-    launch_lm_head(c, row0, R);
-    launch_sample(c, row0, R, cfg, /*advance_pos=*/true, /*log_step=*/true);
+    const bool fuse = c->lm_fuse && is_greedy(&cfg);     // greedy: argmax + token publish ride in the lm_head launch (arrival ticket)
+    launch_lm_head(c, row0, R, fuse);
+    if (!fuse) launch_sample(c, row0, R, cfg, /*advance_pos=*/true, /*log_step=*/true);
     row0 += R;
   }
 }
@@ -1131,6 +1167,8 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipMemset(c->samp_scratch, 0, sizeof(tgx::SampScratch) * (size_t)d.max_batch));
   if ((V + tgx::SAMP_TILE - 1) / tgx::SAMP_TILE > tgx::SAMP_MAX_WG) return set_err(c, TGX_ERR_UNSUPPORTED, "vocabulary %d exceeds the sampler's %d entries", V, tgx::SAMP_MAX_WG * tgx::SAMP_TILE);
   if ((rc = dev_alloc(c, &c->nop_word, 1))) return rc;
+  if ((rc = dev_alloc(c, &c->lm_ticket, 1))) return rc;
+  HIP_OK(c, hipMemset(c->lm_ticket, 0, 4));
   if ((rc = dev_alloc(c, &c->scratch_x, (size_t)H))) return rc;
   HIP_OK(c, hipMemset(c->scratch_x, 0, (size_t)H * 4));
   if ((rc = dev_alloc(c, &c->tok_log, (size_t)c->log_cap * d.max_batch))) return rc;
@@ -1156,7 +1194,7 @@ void tgx_destroy(tgx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   drop_step_graphs(c);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->wpe); fr(c->final_norm_b); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
+  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->wpe); fr(c->final_norm_b); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->lm_ticket); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
   fr(c->ch_x); fr(c->ch_q); fr(c->ch_kraw); fr(c->ch_attn); fr(c->ch_h); fr(c->ch_part); fr(c->ch_pos);
   fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl); fr(c->ws_part);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); fr(w.in_norm_b); fr(w.post_norm_b); fr(w.bo); fr(w.bfc); fr(w.bdown); }
@@ -1444,6 +1482,8 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.splitk")) { c->gemm_splitk = value; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_mirror")) { c->attn_mirror = value; return TGX_OK; }
   if (!strcmp(key, "attn.qk_fuse")) { c->qk_fuse = value; return TGX_OK; }
+  if (!strcmp(key, "attn.fold_combine")) { c->attn_fold = value != 0; return TGX_OK; }
+  if (!strcmp(key, "lmhead.fuse_finalize")) { c->lm_fuse = value != 0; return TGX_OK; }
   if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
   if (!strcmp(key, "attn.nsplit")) {
     if (c->finalized) return set_err(c, TGX_ERR_STATE, "attn.nsplit must be set before tgx_finalize");
