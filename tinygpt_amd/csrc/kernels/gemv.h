@@ -619,6 +619,22 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(QkNormArgs a) {
 template <int DT>
 __global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs a) { finalize_row<DT>(a); }
 
+// The greedy finalize of every row of a decode batch in ONE launch (blockIdx.x = row; the batched-MFMA decode step): the step counter is
+// advanced by bump_step_kernel afterwards, because rows running concurrently must all read the same step value.
+struct FinalizeRowsArgs {
+  FinalizeArgs f;          // row 0's view; bump_step is ignored
+  long long part_stride, x_stride;
+};
+template <int DT>
+__global__ __launch_bounds__(256) void finalize_rows_kernel(const FinalizeRowsArgs a) {
+  FinalizeArgs f = a.f;
+  const int r = blockIdx.x;
+  f.part_val += (size_t)r * a.part_stride; f.part_idx += (size_t)r * a.part_stride;
+  f.tok += r; f.pos += r; f.x += (size_t)r * a.x_stride; f.row = a.f.row + r; f.bump_step = 0;
+  finalize_row<DT>(f);
+}
+__global__ void bump_step_kernel(int* step) { if (threadIdx.x == 0) *step = *step + 1; }
+
 // Prefill-by-steps: chunk row r <- embedding of prompt token r, position pos0 + r (one workgroup per chunk row).
 struct EmbedChunkArgs {
   const long long* ids;  // the chunk's first prompt token on the device

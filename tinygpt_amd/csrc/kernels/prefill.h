@@ -142,6 +142,16 @@ struct GemmArgs {
   // gemm_splitk_reduce_kernel sums the slabs in z order and applies the epilogue.  interleave = 1: gate/up column order as for GEMM_SILU
   float* part;
   int k_per, nsplit, interleave;
+  // skinny_gemm_kernel (skinny.h) may take its activations as fp32 rows and split them into 16-bit terms while staging them in LDS
+  // (ASRC 1), optionally applying RMSNorm on the way (ASRC 2: y = norm_w[k] * (x * rsqrt(sum_cb ssq_part[m][cb] / K + eps)), the sums of
+  // squares left by the kernel that produced x): no separate norm / split launch, no 16-bit copy of the activations in memory
+  const float* A_f32;          // [M][lda]
+  int lda;
+  const bf16_t* norm_w;        // [K]
+  const float* ssq_part;       // [M][ssq_ncb]
+  int ssq_ncb;
+  float eps;
+  float* ssq_out;              // reduce_rows_kernel: [M][gridDim.y] partial sums of squares of the rows it writes
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = GBK + 8;

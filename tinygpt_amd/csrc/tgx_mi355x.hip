@@ -21,6 +21,7 @@
 #include "kernels/gemv.h"
 #include "kernels/prefill.h"
 #include "kernels/sampler.h"
+#include "kernels/skinny.h"
 
 using tgx::bf16_t;
 typedef unsigned char ebyte;   // parameter / KV-cache storage in the compute dtype: offsets are elements * ctx.esz
@@ -136,6 +137,7 @@ struct tgx_ctx {
   bf16_t *ws_qh = nullptr, *ws_ql = nullptr;          // [S][qd] rotated queries (hi, lo)
   bf16_t *ws_hh = nullptr, *ws_hl = nullptr;          // [S][I] siluMul output (hi, lo): the down product's A operand
   float* ws_part = nullptr; size_t ws_part_bytes = 0;   // split-K slabs of the short-prompt GEMMs
+  float* ws_ssq = nullptr;                              // [32][SK_NCB] partial sums of squares of the batched step's rows
   int gemm_splitk = 1;       // experiment: 0 disables split-K
   int attn_mirror = 1;       // experiment: prefill attention block order
   int qk_fuse = 1;           // experiment: 0 keeps Qwen3's separate q/k norm launch
@@ -147,6 +149,13 @@ struct tgx_ctx {
   // all ~1000 workgroups costs what the 1-workgroup finalize launch cost (0.7109 -> 0.7123 ms/token).
   int attn_fold = 0;
   int lm_fuse = 0;
+  int skinny_wgs = 256;      // option skinny.wgs: workgroups a skinny product aims for by splitting K
+  int skinny_gu_split = 0;   // option skinny.gu_split: 0 keeps the gate_up product unsplit (siluMul in its epilogue, one launch less)
+  int skinny_cfg_mid = 0;    // option skinny.cfg_mid: tile geometry (kernels/skinny.h SkinnyCfg) of the products that do not oversubscribe the chip
+  int skinny_cfg_force = -1; // option skinny.cfg: force one geometry for every product (experiments)
+  // decode batches of at least this many rows run their Linears as skinny MFMA GEMMs (option decode.mfma_min_batch).  Measured ms/step,
+  // GEMV row groups vs matrix cores: Llama-3.2-1B B = 2 0.794 / 0.991, B = 3 ~1.45 / 1.003, B = 4 1.042 / 1.007; Mistral-7B B = 4 5.04 / 4.01
+  int decode_mfma_min = 3;
   unsigned int* lm_ticket = nullptr;   // arrival counter of the lm_head launch (rests at 0)
   bool prefill_mfma = true;
   int prefill_min_rows = 4;  // prompts shorter than this go through the decode kernels, 4 positions per pass (set in tgx_create)
@@ -593,11 +602,14 @@ bool prefill_shapes_ok(const tgx_model_desc& d) {
   return d.hidden % 64 == 0 && (d.heads * d.head_dim) % 64 == 0 && d.inter % 64 == 0;
 }
 
+void drop_step_graphs(tgx_ctx* c);
+
 int ensure_prefill_ws(tgx_ctx* c, int S) {
   if (S <= c->ws_rows) return TGX_OK;
   const tgx_model_desc& d = c->d;
   const size_t H = (size_t)d.hidden, qd = (size_t)d.heads * d.head_dim, kvd = (size_t)d.kv_heads * d.head_dim, I = (size_t)d.inter;
   const size_t wout = qd + 2 * kvd, wa = std::max(H, qd);   // the gate_up product leaves no fp32 intermediate (GEMM_SILU)
+  drop_step_graphs(c);                                       // a captured batched decode step holds pointers into the old workspace
   HIP_OK(c, hipStreamSynchronize(c->stream));
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl);
@@ -813,7 +825,14 @@ void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool
 
 // One decode step for all active rows: layers at pos, lm_head, then {sample, pos+=1, next embedding}.
 // == nextToken = genNextToken(nextToken)  (GPTEngine.cpp:94-99,165-168)
+void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg& cfg);
+bool decode_mfma_ok(const tgx_ctx* c);
+
 void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
+  if (decode_mfma_ok(c)) {   // more than 4 rows: every Linear is one pass over its weights for up to 32 rows (kernels/skinny.h)
+    for (int row0 = 0; row0 < c->batch; row0 += 32) launch_decode_step_mfma(c, row0, std::min(32, c->batch - row0), cfg);
+    return;
+  }
   // batch rows share each pass over the weights in groups of 4 / 2 / 1 (the batched GEMV's R template)
   for (int row0 = 0; row0 < c->batch;) {
     const int rem = c->batch - row0, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
@@ -822,6 +841,202 @@ void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
     launch_lm_head(c, row0, R, fuse);
     if (!fuse) launch_sample(c, row0, R, cfg, /*advance_pos=*/true, /*log_step=*/true);
     row0 += R;
+  }
+}
+
+
+// ---- batched decode on the matrix cores (kernels/skinny.h) ---------------------------------------------------------------------------
+// the (epilogue, terms, activation source) combinations the batched step uses; every one exists for 2 dtypes x MB 1,2 x NBW 1,2
+#define TGX_SKINNY_COMBOS(X)                                                                                                   \
+  X(tgx::GEMM_PARTIAL, 3, 2) X(tgx::GEMM_STORE, 3, 2) X(tgx::GEMM_PARTIAL, 2, 2) X(tgx::GEMM_STORE, 2, 2) X(tgx::GEMM_SILU, 2, 2) \
+  X(tgx::GEMM_PARTIAL, 2, 1) X(tgx::GEMM_RESIDUAL, 2, 1) X(tgx::GEMM_PARTIAL, 2, 0) X(tgx::GEMM_RESIDUAL, 2, 0)
+
+template <int DT, int EPI, int NT, int ASRC>
+int skinny_set_attr_dt(tgx_ctx* c) {
+#define TGX_SK_A(MB_, CFG_) HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::skinny_gemm_kernel<DT, EPI, MB_, NT, CFG_, ASRC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::skinny_lds_bytes(MB_, NT, CFG_)));
+  TGX_SK_A(1, 0) TGX_SK_A(1, 1) TGX_SK_A(1, 2) TGX_SK_A(2, 0) TGX_SK_A(2, 1) TGX_SK_A(2, 2)
+#undef TGX_SK_A
+  return TGX_OK;
+}
+// the skinny GEMM's LDS image (weight tiles + activation panels) exceeds the 64 KB default for 32 rows
+int skinny_set_attrs(tgx_ctx* c) {
+  int rc;
+#define X(E, N, A) if ((rc = skinny_set_attr_dt<tgx::DT_BF16, E, N, A>(c)) || (rc = skinny_set_attr_dt<tgx::DT_F16, E, N, A>(c))) return rc;
+  TGX_SKINNY_COMBOS(X)
+#undef X
+  return TGX_OK;
+}
+
+template <int EPI, int NT, int ASRC>
+void skinny_dispatch(tgx_ctx* c, dim3 grid, int mb, int cfg, const tgx::GemmArgs& g) {
+  const dim3 blk(256);
+  const size_t lds = tgx::skinny_lds_bytes(mb, NT, cfg);
+#define TGX_SK_L(MB_, CFG_) hipLaunchKernelGGL((tgx::skinny_gemm_kernel<DT, EPI, MB_, NT, CFG_, ASRC>), grid, blk, lds, c->stream, g)
+  TGX_DT16_SWITCH(c->dt,
+    if (mb == 2) { if (cfg == 2) TGX_SK_L(2, 2); else if (cfg == 1) TGX_SK_L(2, 1); else TGX_SK_L(2, 0); }
+    else { if (cfg == 2) TGX_SK_L(1, 2); else if (cfg == 1) TGX_SK_L(1, 1); else TGX_SK_L(1, 0); })
+#undef TGX_SK_L
+}
+
+// One nn::Linear of a batched step: Y[M][N] = X[M][K] . W^T for M <= 32 activation rows, X given as 16-bit terms (asrc 0), fp32 rows
+// (1) or fp32 rows to be RMS-normalised on the way (2).  Wide products (>= ~one 64-row group per CU) run unsplit with their epilogue;
+// narrow ones (N = hidden, the QKV rows) split K over blockIdx.y into fp32 slabs — the return value is the number of slabs the caller's
+// finishing kernel has to sum (1 = the epilogue already ran).
+struct SkinnyCall {
+  int epi = tgx::GEMM_STORE;
+  const ebyte* W = nullptr; const ebyte* bias = nullptr;
+  float* C = nullptr; int ldc = 0;
+  int M = 0, N = 0, K = 0;
+  int nt = 2, asrc = 0;
+  const bf16_t *a_hi = nullptr, *a_lo = nullptr;
+  const float* a_f32 = nullptr; int lda = 0;
+  const ebyte* norm_w = nullptr; const float* ssq_in = nullptr;
+  bool allow_split = true;
+};
+int launch_skinny(tgx_ctx* c, const SkinnyCall& k) {
+  tgx::GemmArgs g{};
+  g.A_hi = k.a_hi; g.A_lo = k.a_lo; g.A_f32 = k.a_f32; g.lda = k.lda;
+  g.norm_w = reinterpret_cast<const bf16_t*>(k.norm_w); g.ssq_part = k.ssq_in; g.ssq_ncb = tgx::SK_NCB; g.eps = c->d.norm_eps;
+  g.inter = k.N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
+  g.B = reinterpret_cast<const bf16_t*>(k.W); g.bias = reinterpret_cast<const bf16_t*>(k.bias); g.C = k.C; g.M = k.M; g.N = k.N; g.K = k.K; g.ldc = k.ldc;
+  const int mb = k.M > 16 ? 2 : 1;
+  // 128-row groups when they alone oversubscribe the chip (the lm_head), else 64-row groups: twice the workgroups for the same bytes
+  int cfg = (k.N + 127) / 128 >= 2 * c->num_cus ? 2 : c->skinny_cfg_mid;
+  if (c->skinny_cfg_force >= 0) cfg = c->skinny_cfg_force;
+  const int kp = tgx::skinny_kp(cfg);
+  const int panels = (k.K + kp - 1) / kp;
+  const int gx = (k.N + tgx::skinny_rows(cfg) - 1) / tgx::skinny_rows(cfg);
+  // split K until ~skinny_wgs workgroups exist (default two per CU: the bytes in flight per CU are what the stream rate follows)
+  int nsplit = 1;
+  if (k.allow_split && c->gemm_splitk && gx < c->skinny_wgs) nsplit = std::max(1, std::min(std::min(16, panels), (c->skinny_wgs + gx / 2) / gx));
+  if (nsplit > 1 && (size_t)nsplit * k.M * k.N * 4 > c->ws_part_bytes) nsplit = 1;      // the slab buffer is sized before capture (ensure_skinny_ws)
+  int epi = k.epi;
+  if (nsplit > 1) {
+    g.part = c->ws_part; g.nsplit = nsplit; g.interleave = k.epi == tgx::GEMM_SILU ? 1 : 0;
+    g.k_per = ((panels + nsplit - 1) / nsplit) * kp;
+    nsplit = (k.K + g.k_per - 1) / g.k_per;      // splits that actually hold a K range
+    g.nsplit = nsplit;
+    epi = tgx::GEMM_PARTIAL;
+  }
+  const dim3 grid(gx, nsplit);
+  bool launched = false;
+#define X(E, N, A) if (!launched && epi == E && k.nt == N && k.asrc == A) { skinny_dispatch<E, N, A>(c, grid, mb, cfg, g); launched = true; }
+  TGX_SKINNY_COMBOS(X)
+#undef X
+  if (!launched) { c->err = "internal: skinny GEMM combination not instantiated"; return -1; }
+  return nsplit;
+}
+
+// finishes a split product into C (store / residual add) and leaves the rows' partial sums of squares for the next RMSNorm-fused product
+void launch_reduce_rows(tgx_ctx* c, int epi, int nsplit, const ebyte* bias, float* C, int ldc, int M, int N, float* ssq_out) {
+  tgx::GemmArgs g{};
+  g.part = c->ws_part; g.nsplit = nsplit; g.bias = reinterpret_cast<const bf16_t*>(bias); g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.ssq_out = ssq_out;
+  const dim3 grid(M, tgx::SK_NCB), blk(256);
+  TGX_DT16_SWITCH(c->dt,
+    if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::reduce_rows_kernel<DT, tgx::GEMM_RESIDUAL>), grid, blk, 0, c->stream, g);
+    else hipLaunchKernelGGL((tgx::reduce_rows_kernel<DT, tgx::GEMM_STORE>), grid, blk, 0, c->stream, g);)
+}
+
+// rows beyond 4 of a decode batch take the matrix-core path when the model has 16-bit storage and tile-friendly shapes
+bool decode_mfma_ok(const tgx_ctx* c) {
+  return c->batch >= c->decode_mfma_min && c->dt != tgx::DT_F32 && !c->gpt2 && prefill_shapes_ok(c->d) && c->d.vocab >= 128;
+}
+
+// workspace of the batched step, sized before the step is captured: qkv rows, siluMul terms, split-K slabs, sums of squares
+int ensure_skinny_ws(tgx_ctx* c, int rows) {
+  int rc = ensure_prefill_ws(c, rows);
+  if (rc) return rc;
+  const tgx_model_desc& d = c->d;
+  const size_t widest = std::max<size_t>((size_t)d.heads * d.head_dim + 2 * (size_t)d.kv_heads * d.head_dim, (size_t)2 * d.inter);
+  const size_t need = (size_t)16 * rows * std::max<size_t>(widest, (size_t)d.hidden) * 4;       // up to 16 K splits
+  if (need > c->ws_part_bytes) {
+    drop_step_graphs(c);
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    if (c->ws_part) (void)hipFree(c->ws_part);
+    c->ws_part = nullptr; c->ws_part_bytes = 0;
+    HIP_OK(c, hipMalloc((void**)&c->ws_part, need));
+    c->ws_part_bytes = need;
+  }
+  if (!c->ws_ssq) HIP_OK(c, hipMalloc((void**)&c->ws_ssq, (size_t)32 * tgx::SK_NCB * 4));
+  return TGX_OK;
+}
+
+// One decode step for rows [row0, row0 + M), M <= 32, with every nn::Linear as ONE pass over its weights (GPTEngine.cpp:154-168: the
+// reference runs the whole [B,1] batch through each Linear).  Same per-row math as the GEMV path in the prefill's arithmetic: fp32
+// activations enter the matrix cores as exact sums of 16-bit terms (three for the QKV product, whose K/V results are rounded into the cache).
+// Per layer: qkv product (RMSNorm applied while staging) -> {sum slabs, bias, RoPE, cache append} -> attention -> o_proj product on the
+// fp32 attention output -> {sum slabs, residual, sums of squares} -> gate_up product (RMSNorm while staging, siluMul epilogue) ->
+// down product -> {sum slabs, residual, sums of squares}: 7 launches (8 with the split-form attention's combine).
+void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg& cfg) {
+  const tgx_model_desc& d = c->d;
+  const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd, V = d.vocab;
+  const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd * c->esz;
+  RowState& r = c->rows[(size_t)row0];
+  const int nt_qkv = c->dt == tgx::DT_BF16 ? 3 : 2;
+  float* ssq = c->ws_ssq;
+  // the rows start as embedding rows (the finalize of the previous step gathered them): their sums of squares for the first RMSNorm
+  hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
+  for (int l = 0; l < d.layers; l++) {
+    const LayerW& w = c->L[(size_t)l];
+    SkinnyCall q;
+    q.epi = tgx::GEMM_STORE; q.W = w.wqkv; q.bias = w.bqkv; q.C = c->ws_out; q.ldc = qd + 2 * kvd; q.M = M; q.N = qd + 2 * kvd; q.K = H;
+    q.nt = nt_qkv; q.asrc = 2; q.a_f32 = r.x; q.lda = H; q.norm_w = w.in_norm; q.ssq_in = ssq;
+    const int qs = launch_skinny(c, q);
+    {
+      tgx::RopeRowsArgs a{};
+      if (qs > 1) { a.part = c->ws_part; a.nsplit = qs; a.bias = w.bqkv; } else a.QKV = c->ws_out;
+      a.rows = M; a.q_out = r.q; a.q_stride = qd; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
+      a.kv_stride = (long long)c->kv_row_elems; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos = r.pos;
+      a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx;
+      a.q_norm_w = d.qk_norm ? w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? w.k_norm : nullptr; a.eps = d.norm_eps;
+      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rope_kv_rows_kernel<DT>, dim3(M, d.heads + 2 * d.kv_heads), dim3(64), 0, c->stream, a))
+    }
+    {
+      tgx::AttnArgs a{};
+      a.q = r.q; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
+      a.pos = r.pos; a.part = r.attn_part; a.out = r.attn;
+      a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
+      a.scale = 1.0f / sqrtf((float)hd);
+      a.q_stride = qd; a.kv_stride = (long long)c->kv_row_elems; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
+      const int fold = c->attn_fold; c->attn_fold = 0;          // the o_proj product here reads the merged output
+      launch_attn(c, a, M);
+      c->attn_fold = fold;
+    }
+    SkinnyCall o;
+    o.epi = tgx::GEMM_RESIDUAL; o.W = w.wo; o.C = r.x; o.ldc = H; o.M = M; o.N = H; o.K = qd; o.nt = 2; o.asrc = 1; o.a_f32 = r.attn; o.lda = qd;
+    const int os = launch_skinny(c, o);
+    if (os > 1) launch_reduce_rows(c, tgx::GEMM_RESIDUAL, os, nullptr, r.x, H, M, H, ssq);
+    else hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
+    SkinnyCall gu;
+    gu.epi = tgx::GEMM_SILU; gu.W = w.wgu; gu.M = M; gu.N = 2 * I; gu.K = H; gu.ldc = 2 * I; gu.nt = 2; gu.asrc = 2; gu.a_f32 = r.x; gu.lda = H;
+    gu.norm_w = w.post_norm; gu.ssq_in = ssq; gu.allow_split = c->skinny_gu_split != 0;
+    const int gs = launch_skinny(c, gu);                                   // -> ws_hh / ws_hl: the down product's activation terms
+    if (gs > 1) {                                                          // slabs -> siluMul -> terms (z-ordered sums)
+      tgx::GemmArgs g{};
+      g.part = c->ws_part; g.nsplit = gs; g.M = M; g.N = 2 * I; g.inter = I; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
+      const dim3 rg((unsigned)(((size_t)M * I + 255) / 256));
+      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_SILU>), rg, dim3(256), 0, c->stream, g))
+    }
+    SkinnyCall dn;
+    dn.epi = tgx::GEMM_RESIDUAL; dn.W = w.wdown; dn.C = r.x; dn.ldc = H; dn.M = M; dn.N = H; dn.K = I; dn.nt = 2; dn.asrc = 0; dn.a_hi = c->ws_hh; dn.a_lo = c->ws_hl;
+    const int ds = launch_skinny(c, dn);
+    if (ds > 1) launch_reduce_rows(c, tgx::GEMM_RESIDUAL, ds, nullptr, r.x, H, M, H, ssq);
+    else hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
+  }
+  SkinnyCall lm;
+  lm.epi = tgx::GEMM_STORE; lm.W = d.tied ? c->embed : c->lm_head; lm.C = r.logits; lm.ldc = V; lm.M = M; lm.N = V; lm.K = H; lm.nt = 2; lm.asrc = 2;
+  lm.a_f32 = r.x; lm.lda = H; lm.norm_w = c->final_norm; lm.ssq_in = ssq; lm.allow_split = false;
+  launch_skinny(c, lm);
+  hipLaunchKernelGGL(tgx::argmax_partials_rows_kernel, dim3(c->lm_grid, M), dim3(256), 0, c->stream, (const float*)r.logits, (long long)V, V, r.part_val, r.part_idx, (long long)c->lm_grid);
+  if (is_greedy(&cfg)) {
+    tgx::FinalizeRowsArgs fa{};
+    fa.f = make_finalize_args(c, row0, /*advance_pos=*/true, /*log_step=*/true);
+    fa.part_stride = c->lm_grid; fa.x_stride = H;
+    // rows are finalized concurrently: the step counter moves afterwards, once, when this group holds the batch's last row
+    TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::finalize_rows_kernel<DT>, dim3(M), dim3(256), 0, c->stream, fa))
+    if (row0 + M == c->batch) hipLaunchKernelGGL(tgx::bump_step_kernel, dim3(1), dim3(64), 0, c->stream, c->step);
+  } else {
+    launch_sample(c, row0, M, cfg, /*advance_pos=*/true, /*log_step=*/true);
   }
 }
 
@@ -882,6 +1097,10 @@ int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int 
   // short contexts: attention without the split / combine pair (one launch less per layer); the graphs are re-captured when a
   // call crosses the limit
   c->attn_direct = c->past + n <= c->attn_direct_max;
+  if (decode_mfma_ok(c)) {   // the batched step's workspace must exist before the step is captured
+    int rc = ensure_skinny_ws(c, std::min(32, c->batch));
+    if (rc) return rc;
+  }
   if (c->use_graph) {
     const int K = c->graph_steps;
     // any multi-step call captures the K-step graph as well (a short warm-up call then leaves nothing to capture inside a later, longer
@@ -1183,6 +1402,7 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_RESIDUAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_PARTIAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_PARTIAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
+  if ((rc = skinny_set_attrs(c))) return rc;
   c->past = 0;
   c->finalized = true;
   return TGX_OK;
@@ -1196,7 +1416,7 @@ void tgx_destroy(tgx_ctx* c) {
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->wpe); fr(c->final_norm_b); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->lm_ticket); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
   fr(c->ch_x); fr(c->ch_q); fr(c->ch_kraw); fr(c->ch_attn); fr(c->ch_h); fr(c->ch_part); fr(c->ch_pos);
-  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl); fr(c->ws_part);
+  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl); fr(c->ws_part); fr(c->ws_ssq);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); fr(w.in_norm_b); fr(w.post_norm_b); fr(w.bo); fr(w.bfc); fr(w.bdown); }
   fr(c->slab_x); fr(c->slab_q); fr(c->slab_kraw); fr(c->slab_attn); fr(c->slab_h); fr(c->slab_logits); fr(c->slab_probs);
   fr(c->slab_part_val); fr(c->slab_part_idx); fr(c->slab_attn_part); fr(c->slab_tok); fr(c->slab_pos); fr(c->slab_prompt); fr(c->slab_k); fr(c->slab_v);
@@ -1484,6 +1704,11 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.qk_fuse")) { c->qk_fuse = value; return TGX_OK; }
   if (!strcmp(key, "attn.fold_combine")) { c->attn_fold = value != 0; return TGX_OK; }
   if (!strcmp(key, "lmhead.fuse_finalize")) { c->lm_fuse = value != 0; return TGX_OK; }
+  if (!strcmp(key, "skinny.wgs")) { if (value < 1) return set_err(c, TGX_ERR_INVALID, "skinny.wgs must be >= 1"); c->skinny_wgs = value; return TGX_OK; }
+  if (!strcmp(key, "skinny.gu_split")) { c->skinny_gu_split = value; return TGX_OK; }
+  if (!strcmp(key, "skinny.cfg_mid")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.cfg_mid is 0..2"); c->skinny_cfg_mid = value; return TGX_OK; }
+  if (!strcmp(key, "skinny.cfg")) { if (value < -1 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.cfg is -1..2"); c->skinny_cfg_force = value; return TGX_OK; }
+  if (!strcmp(key, "decode.mfma_min_batch")) { if (value < 1) return set_err(c, TGX_ERR_INVALID, "decode.mfma_min_batch must be >= 1"); c->decode_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
   if (!strcmp(key, "attn.nsplit")) {
     if (c->finalized) return set_err(c, TGX_ERR_STATE, "attn.nsplit must be set before tgx_finalize");
