@@ -149,6 +149,7 @@ struct tgx_ctx {
   // all ~1000 workgroups costs what the 1-workgroup finalize launch cost (0.7109 -> 0.7123 ms/token).
   int attn_fold = 0;
   int lm_fuse = 0;
+  int prefill_skinny = 1;    // option prefill.skinny: 0 sends prompts of <= 32 rows through the tiled GEMMs as well
   int skinny_wgs = 256;      // option skinny.wgs: workgroups a skinny product aims for by splitting K
   int skinny_gu_split = 0;   // option skinny.gu_split: 0 keeps the gate_up product unsplit (siluMul in its epilogue, one launch less)
   int skinny_cfg_mid = 0;    // option skinny.cfg_mid: tile geometry (kernels/skinny.h SkinnyCfg) of the products that do not oversubscribe the chip
@@ -653,6 +654,7 @@ void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float
   if (nsplit > 1) {
     const size_t need = (size_t)nsplit * M * N * 4;
     if (need > c->ws_part_bytes) {
+      drop_step_graphs(c);              // a captured batched decode step points into the old slab buffer
       (void)hipStreamSynchronize(c->stream);
       if (c->ws_part) (void)hipFree(c->ws_part);
       c->ws_part = nullptr; c->ws_part_bytes = 0;
@@ -1040,6 +1042,74 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
   }
 }
 
+
+// Prompts of a few tokens (NB * S <= 32 workspace rows): the batched prefill with every product as a skinny MFMA GEMM (kernels/skinny.h) —
+// the 128-row tiles of gemm_x2_kernel would stream the weights for 4-25 % useful rows through a two-barrier K loop; here the weight stream
+// is the decode step's, RMSNorm rides in the activation staging and narrow products finish through the row-wise slab reducers.
+void launch_prefill_skinny(tgx_ctx* c, int row0, int NB, int S) {
+  const tgx_model_desc& d = c->d;
+  const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
+  const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd;
+  const int M = NB * S, nq = qd + 2 * kvd;
+  const int nt_qkv = c->dt == tgx::DT_BF16 ? 3 : 2;
+  float* ssq = c->ws_ssq;
+  TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_rows_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const long long*)c->rows[(size_t)row0].prompt, (const bf16_t*)c->embed, c->ws_x, H, S, (long long)d.max_ctx))
+  hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)c->ws_x, (long long)H, H, ssq);
+  for (int l = 0; l < d.layers; l++) {
+    const LayerW& w = c->L[(size_t)l];
+    SkinnyCall q;
+    q.epi = tgx::GEMM_STORE; q.W = w.wqkv; q.bias = w.bqkv; q.C = c->ws_out; q.ldc = nq; q.M = M; q.N = nq; q.K = H;
+    q.nt = nt_qkv; q.asrc = 2; q.a_f32 = c->ws_x; q.lda = H; q.norm_w = w.in_norm; q.ssq_in = ssq;
+    const int qs = launch_skinny(c, q);
+    if (qs > 1) launch_reduce_rows(c, tgx::GEMM_STORE, qs, w.bqkv, c->ws_out, nq, M, nq, nullptr);
+    for (int b = 0; b < NB; b++) {
+      RowState& r = c->rows[(size_t)(row0 + b)];
+      const size_t ro = (size_t)b * S;
+      tgx::RopeKvArgs a{};
+      a.QKV = c->ws_out + ro * nq; a.q_hi = c->ws_qh + ro * qd; a.q_lo = c->ws_ql + ro * qd;
+      a.k_cache = reinterpret_cast<bf16_t*>(r.kcache) + (size_t)l * kv_layer; a.v_cache = reinterpret_cast<bf16_t*>(r.vcache) + (size_t)l * kv_layer;
+      a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
+      a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = (int)c->past;
+      a.q_norm_w = d.qk_norm ? (const bf16_t*)w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? (const bf16_t*)w.k_norm : nullptr; a.eps = d.norm_eps;
+      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rope_kv_split_kernel<DT>, dim3(S), dim3(256), 0, c->stream, a))
+    }
+    for (int b = 0; b < NB; b++) {
+      RowState& r = c->rows[(size_t)(row0 + b)];
+      const size_t ro = (size_t)b * S;
+      tgx::AttnPrefillArgs a{};
+      a.q_hi = c->ws_qh + ro * qd; a.q_lo = c->ws_ql + ro * qd;
+      a.k_cache = reinterpret_cast<bf16_t*>(r.kcache) + (size_t)l * kv_layer; a.v_cache = reinterpret_cast<bf16_t*>(r.vcache) + (size_t)l * kv_layer;
+      a.o_hi = c->ws_ah + ro * qd; a.o_lo = c->ws_al + ro * qd; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
+      a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = c->attn_mirror;
+      const dim3 grid((S + 127) / 128, d.heads), blk(256);
+      TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64>), grid, blk, 0, c->stream, a);
+                             else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128>), grid, blk, 0, c->stream, a))
+    }
+    SkinnyCall o;
+    o.epi = tgx::GEMM_RESIDUAL; o.W = w.wo; o.C = c->ws_x; o.ldc = H; o.M = M; o.N = H; o.K = qd; o.nt = 2; o.asrc = 0; o.a_hi = c->ws_ah; o.a_lo = c->ws_al;
+    const int os = launch_skinny(c, o);
+    if (os > 1) launch_reduce_rows(c, tgx::GEMM_RESIDUAL, os, nullptr, c->ws_x, H, M, H, ssq);
+    else hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)c->ws_x, (long long)H, H, ssq);
+    SkinnyCall gu;
+    gu.epi = tgx::GEMM_SILU; gu.W = w.wgu; gu.M = M; gu.N = 2 * I; gu.K = H; gu.ldc = 2 * I; gu.nt = 2; gu.asrc = 2; gu.a_f32 = c->ws_x; gu.lda = H;
+    gu.norm_w = w.post_norm; gu.ssq_in = ssq; gu.allow_split = c->skinny_gu_split != 0;
+    const int gs = launch_skinny(c, gu);
+    if (gs > 1) {
+      tgx::GemmArgs g{};
+      g.part = c->ws_part; g.nsplit = gs; g.M = M; g.N = 2 * I; g.inter = I; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
+      const dim3 rg((unsigned)(((size_t)M * I + 255) / 256));
+      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_SILU>), rg, dim3(256), 0, c->stream, g))
+    }
+    SkinnyCall dn;
+    dn.epi = tgx::GEMM_RESIDUAL; dn.W = w.wdown; dn.C = c->ws_x; dn.ldc = H; dn.M = M; dn.N = H; dn.K = I; dn.nt = 2; dn.asrc = 0; dn.a_hi = c->ws_hh; dn.a_lo = c->ws_hl;
+    const int ds = launch_skinny(c, dn);
+    if (ds > 1) launch_reduce_rows(c, tgx::GEMM_RESIDUAL, ds, nullptr, c->ws_x, H, M, H, ssq);
+    else hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)c->ws_x, (long long)H, H, ssq);
+  }
+  for (int b = 0; b < NB; b++)     // the last position of every batch row feeds lm_head
+    (void)hipMemcpyAsync(c->rows[(size_t)(row0 + b)].x, c->ws_x + ((size_t)(b + 1) * S - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, c->stream);
+}
+
 bool same_cfg(const tgx_sampler_cfg& a, const tgx_sampler_cfg& b) {
   return a.temperature == b.temperature && a.top_k == b.top_k && a.top_p == b.top_p && a.min_p == b.min_p;
 }
@@ -1188,9 +1258,9 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   // measured crossover of the direct and the split attention (tools/sweep.py --grid attn.direct_max=0,100000): context ~850-1100 at
   // head_dim 64 (Qwen2.5-0.5B, Llama-3.2-1B), ~500 at 128 (Mistral-7B: half the tokens per wave-load)
   c->attn_direct_max = d.head_dim == 64 ? 768 : 384;
-  // very short prompts: one or two passes through the batched decode kernels (4 positions each) beat the split-K GEMMs below ~7 tokens
-  // (Llama-3.2-1B: S = 4 1.03 vs 1.68 ms, S = 8 1.89 vs 1.68; Mistral-7B 4.7 vs 6.5, 9.2 vs 6.6) — tools/prefill_crossover.py
-  c->prefill_min_rows = 7;
+  // very short prompts: ONE pass through the batched decode kernels (4 positions) still beats the skinny MFMA prefill on small models
+  // (Llama-3.2-1B: S = 4 1.00 vs 1.07 ms, S = 5 1.55 vs 1.07; Mistral-7B S = 4 4.65 vs 4.09) — tools/prefill_crossover.py, profiles/r02_prefill_short.txt
+  c->prefill_min_rows = d.hidden > 2048 ? 4 : 5;
   c->tune[TGX_KERNEL_DOWN].ks = 4;   // K = intermediate_size: 4 waves split each row pair
   // qkv is the most latency-bound launch (few rows): 4 waves per row pair shorten every wave's load -> reduce chain; measured
   // ks 1 -> 4: Llama-3.2-1B 1395 -> 1411 tok/s, 3B 628 -> 637, Mistral-7B 341 -> 347; hidden 896 (Qwen2.5-0.5B) loses 2 %
@@ -1445,9 +1515,10 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     const int per = std::max(1, std::min(batch, 8192 / seq));
     for (int row0 = 0; row0 < batch; row0 += per) {
       const int nb = std::min(per, batch - row0);
-      int rc = ensure_prefill_ws(c, nb * seq);
+      const bool skinny = c->prefill_skinny && nb * seq <= 32 && c->d.vocab >= 128;     // a few rows: the weight stream of a decode step
+      int rc = skinny ? ensure_skinny_ws(c, nb * seq) : ensure_prefill_ws(c, nb * seq);
       if (rc) return rc;
-      launch_prefill(c, row0, nb, seq);
+      if (skinny) launch_prefill_skinny(c, row0, nb, seq); else launch_prefill(c, row0, nb, seq);
       for (int b = row0; b < row0 + nb;) {
         const int rem = row0 + nb - b, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
         launch_lm_head(c, b, R);
@@ -1705,6 +1776,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.fold_combine")) { c->attn_fold = value != 0; return TGX_OK; }
   if (!strcmp(key, "lmhead.fuse_finalize")) { c->lm_fuse = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.wgs")) { if (value < 1) return set_err(c, TGX_ERR_INVALID, "skinny.wgs must be >= 1"); c->skinny_wgs = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.skinny")) { c->prefill_skinny = value; return TGX_OK; }
   if (!strcmp(key, "skinny.gu_split")) { c->skinny_gu_split = value; return TGX_OK; }
   if (!strcmp(key, "skinny.cfg_mid")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.cfg_mid is 0..2"); c->skinny_cfg_mid = value; return TGX_OK; }
   if (!strcmp(key, "skinny.cfg")) { if (value < -1 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.cfg is -1..2"); c->skinny_cfg_force = value; return TGX_OK; }
