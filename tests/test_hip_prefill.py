@@ -26,8 +26,11 @@ def run(model, prompt, mfma, n_decode=4):
 
 
 @pytest.mark.parametrize("fam", GPU_FAMILIES)
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
 def test_fixture_prefill_matches_steps_and_oracle(fam, dtype, oracle_lib):
+    """Every family incl. GPT-2 (LayerNorm-split prologue, bias + gelu_new epilogue, learned positions) and every storage dtype: 16-bit
+    storage runs the split-term bf16 / f16 MFMA GEMMs, fp32 storage the f32-input MFMA GEMMs (kernels/gemm_f32.h) with the decode
+    attention kernel over the prompt rows."""
     from oracle.oracle_ffi import OracleModel
     cfg, g = load_golden(fam)
     d = desc_from_hf_config(cfg, dtype)
@@ -44,16 +47,20 @@ def test_fixture_prefill_matches_steps_and_oracle(fam, dtype, oracle_lib):
     np.testing.assert_array_equal(f1, f0)
     np.testing.assert_array_equal(f1, ref.sample(GREEDY))
     np.testing.assert_array_equal(r1, r0)
-    ulp = 8e-3 if dtype == "bf16" else 1e-3
+    ulp = {"bf16": 8e-3, "fp16": 1e-3, "fp32": 1e-5}[dtype]
     for (k1, v1), (k0, v0) in zip(kv1, kv0):
         # cache entries of the two schedules: equal to within one storage ulp of the tensor's magnitude (the split
         # MFMA products are exact to ~2^-17 (bf16 x2) / 2^-22 (fp16 x2) of |x||w|, so near-zero elements may round differently)
         assert rel_err(k1, k0) < ulp and rel_err(v1, v0) < ulp
+    if dtype == "fp32":                      # fp32 storage: both schedules sit on the oracle (and on HF fp32) to fp32 summation order
+        assert rel_err(l1, lr) < 1e-4 and rel_err(l1, l0) < 1e-4
 
 
 @pytest.mark.parametrize("name,S,dtype", [("llama-3.2-1b", 300, "bf16"), ("mistral-7b-v0.3", 130, "bf16"), ("qwen2.5-0.5b", 257, "bf16"),
                                           ("llama-3.2-1b", 300, "fp16"), ("mistral-7b-v0.3", 130, "fp16"),
-                                          ("qwen2.5-3b", 200, "bf16"), ("qwen3-1.7b", 150, "bf16")])   # the README's other checkpoints: 8 query heads per kv head; q/k norm
+                                          ("qwen2.5-3b", 200, "bf16"), ("qwen3-1.7b", 150, "bf16"),   # the README's other checkpoints: 8 query heads per kv head; q/k norm
+                                          ("gpt2", 300, "bf16"), ("gpt2", 300, "fp16"), ("gpt2", 300, "fp32"),           # BASELINE configs[0]'s model
+                                          ("llama-3.2-1b", 300, "fp32"), ("mistral-7b-v0.3", 130, "fp32"), ("qwen2.5-0.5b", 257, "fp32"), ("qwen3-1.7b", 90, "fp32")])
 def test_real_layer_shapes_prefill_equals_steps(name, S, dtype):
     """Real hidden/intermediate/head geometry (2 layers, 4096-entry vocabulary to keep the upload small)."""
     d = copy.deepcopy(known_desc(name, dtype))
@@ -65,6 +72,8 @@ def test_real_layer_shapes_prefill_equals_steps(name, S, dtype):
     assert rel_err(l1, l0) < 1e-3, rel_err(l1, l0)
     np.testing.assert_array_equal(f1, f0)
     np.testing.assert_array_equal(r1, r0)
-    ulp = 8e-3 if dtype == "bf16" else 1e-3
+    ulp = {"bf16": 8e-3, "fp16": 1e-3, "fp32": 1e-5}[dtype]
     for (k1, v1), (k0, v0) in zip(kv1, kv0):
         assert rel_err(k1, k0) < ulp and rel_err(v1, v0) < ulp
+    if dtype == "fp32":
+        assert rel_err(l1, l0) < 1e-4

@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) 
 // 128x128 workgroup tile, BK = 64, 4 waves as 2x2 (each 64x64 = 2x2 MFMA tiles, 64 accumulator VGPRs).  Tiles are
 // staged global -> registers -> LDS with the next K-step's global loads in flight during the MFMAs; LDS rows are
 // padded to 144 B so the 16-byte fragment reads of a 16-lane group fall on 16 distinct bank quads.
-enum { GEMM_STORE = 0, GEMM_RESIDUAL = 1, GEMM_SILU = 2, GEMM_PARTIAL = 3 };   // PARTIAL: split-K slab, finished by gemm_splitk_reduce_kernel
+enum { GEMM_STORE = 0, GEMM_RESIDUAL = 1, GEMM_SILU = 2, GEMM_PARTIAL = 3, GEMM_GELU = 4 };   // PARTIAL: split-K slab, finished by gemm_splitk_reduce_kernel
+// GEMM_GELU (GPT-2's c_fc, ModelGPT2.h:96-107): out_hi / out_lo [M][N] = the 16-bit terms of gelu_new(acc + bias) — the c_proj product's A operand
 struct GemmArgs {
   const bf16_t *A_hi, *A_lo;   // [M][K]
   const bf16_t* A_lo2;         // optional third term (nullptr: two-term product)
@@ -281,8 +282,14 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
       for (int r = 0; r < 16; r++) {
         const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= a.M) continue;
-        float* dst = a.C + (size_t)row * a.ldc + col;
         const float v = acc[i][j][r] + bv;
+        if (EPI == GEMM_GELU) {
+          const float x = v;
+          const size_t o = (size_t)row * a.N + col;
+          split16<DT>(0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))), a.out_hi[o], a.out_lo[o]);
+          continue;
+        }
+        float* dst = a.C + (size_t)row * a.ldc + col;
         *dst = (EPI == GEMM_RESIDUAL) ? (*dst + v) : v;
       }
     }
@@ -308,6 +315,11 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
   float v = 0.f;
   for (int z = 0; z < a.nsplit; z++) v += p[z * slab];
   if (a.bias) v += elem_to_f32<DT>(a.bias[c]);
+  if (EPI == GEMM_GELU) {
+    const size_t o = (size_t)row * a.N + c;
+    split16<DT>(0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v))), a.out_hi[o], a.out_lo[o]);
+    return;
+  }
   float* dst = a.C + (size_t)row * a.ldc + c;
   *dst = (EPI == GEMM_RESIDUAL) ? (*dst + v) : v;
 }

@@ -22,6 +22,7 @@
 #include "kernels/prefill.h"
 #include "kernels/sampler.h"
 #include "kernels/skinny.h"
+#include "kernels/gemm_f32.h"
 
 using tgx::bf16_t;
 typedef unsigned char ebyte;   // parameter / KV-cache storage in the compute dtype: offsets are elements * ctx.esz
@@ -29,6 +30,7 @@ typedef unsigned char ebyte;   // parameter / KV-cache storage in the compute dt
 namespace {
 
 constexpr int MAX_TICKET_EVENTS = 64;
+constexpr int F32_ATTN_ROWS = 64;      // prompt rows per attention launch of the fp32 prefill (bounds the split-partials workspace)
 constexpr int HOST_RING = 256;
 
 struct LayerW {
@@ -137,6 +139,8 @@ struct tgx_ctx {
   bf16_t *ws_qh = nullptr, *ws_ql = nullptr;          // [S][qd] rotated queries (hi, lo)
   bf16_t *ws_hh = nullptr, *ws_hl = nullptr;          // [S][I] siluMul output (hi, lo): the down product's A operand
   float* ws_part = nullptr; size_t ws_part_bytes = 0;   // split-K slabs of the short-prompt GEMMs
+  int* ws_pos = nullptr;                                // fp32 prefill: [rows] positions of the prompt rows
+  float* ws_attn_part = nullptr;                        // fp32 prefill: split-attention partials of one block of rows
   float* ws_ssq = nullptr;                              // [32][SK_NCB] partial sums of squares of the batched step's rows
   int gemm_splitk = 1;       // experiment: 0 disables split-K
   int attn_mirror = 1;       // experiment: prefill attention block order
@@ -160,6 +164,8 @@ struct tgx_ctx {
   unsigned int* lm_ticket = nullptr;   // arrival counter of the lm_head launch (rests at 0)
   bool prefill_mfma = true;
   int prefill_min_rows = 4;  // prompts shorter than this go through the decode kernels, 4 positions per pass (set in tgx_create)
+  int f32_flash = 1;               // option prefill.f32_flash: 0 = attention of the fp32 prefill through the decode attention kernel
+  int prefill_f32_min_rows = 16;   // fp32 storage: prompts from this length on take the f32-input MFMA GEMMs (64-row tiles; option prefill.f32_min_rows)
   int gemm_tm = 0;           // experiment: force the GEMM row tile (64 / 128); 0 = by the number of tiles
   int debug_attn = 0;        // experiment: AttnArgs.dbg
   int attn_gmax = 0;         // experiment: query heads per attention workgroup (default 2)
@@ -617,15 +623,23 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
   c->ws_al2 = nullptr;
   c->ws_x = nullptr; c->ws_out = nullptr; c->ws_ah = c->ws_al = c->ws_qh = c->ws_ql = c->ws_hh = c->ws_hl = nullptr; c->ws_rows = 0;
   const size_t rows = (size_t)S;
+  // fp32 storage: ws_ah / ws_qh / ws_hh hold fp32 rows (the fp32 GEMM's A operands, the rotated queries); the lo terms are unused
+  const size_t te = c->dt == tgx::DT_F32 ? 4 : 2, lo = c->dt == tgx::DT_F32 ? 0 : 1;
   HIP_OK(c, hipMalloc((void**)&c->ws_x, rows * H * 4));
   HIP_OK(c, hipMalloc((void**)&c->ws_out, rows * wout * 4));
-  HIP_OK(c, hipMalloc((void**)&c->ws_ah, rows * wa * 2));
-  HIP_OK(c, hipMalloc((void**)&c->ws_al, rows * wa * 2));
-  HIP_OK(c, hipMalloc((void**)&c->ws_al2, rows * H * 2));
-  HIP_OK(c, hipMalloc((void**)&c->ws_qh, rows * qd * 2));
-  HIP_OK(c, hipMalloc((void**)&c->ws_ql, rows * qd * 2));
-  HIP_OK(c, hipMalloc((void**)&c->ws_hh, rows * I * 2));
-  HIP_OK(c, hipMalloc((void**)&c->ws_hl, rows * I * 2));
+  HIP_OK(c, hipMalloc((void**)&c->ws_ah, rows * wa * te));
+  HIP_OK(c, hipMalloc((void**)&c->ws_al, rows * wa * 2 * lo + 16));
+  HIP_OK(c, hipMalloc((void**)&c->ws_al2, rows * H * 2 * lo + 16));
+  HIP_OK(c, hipMalloc((void**)&c->ws_qh, rows * qd * te));
+  HIP_OK(c, hipMalloc((void**)&c->ws_ql, rows * qd * 2 * lo + 16));
+  HIP_OK(c, hipMalloc((void**)&c->ws_hh, rows * I * te));
+  HIP_OK(c, hipMalloc((void**)&c->ws_hl, rows * I * 2 * lo + 16));
+  if (c->dt == tgx::DT_F32) {
+    if (c->ws_pos) (void)hipFree(c->ws_pos);
+    c->ws_pos = nullptr;
+    HIP_OK(c, hipMalloc((void**)&c->ws_pos, rows * 4));
+    if (!c->ws_attn_part) HIP_OK(c, hipMalloc((void**)&c->ws_attn_part, (size_t)F32_ATTN_ROWS * c->attn_part_row * 4));
+  }
   c->ws_rows = S;
   return TGX_OK;
 }
@@ -642,7 +656,7 @@ void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float
   const bool few = ((N + tgx::GBN - 1) / tgx::GBN) * ((M + tgx::GBM - 1) / tgx::GBM) < 2 * c->num_cus;
   // measured (tools/prefill_bench.py --gemm-tm, Llama-3.2-1B, S = 2048): this policy 15.0 ms, 64-row tiles also for the three-term
   // QKV product 15.3, 128-row tiles everywhere 15.85, 64-row tiles everywhere 15.9
-  const bool small = epi == tgx::GEMM_SILU ? false : (c->gemm_tm ? c->gemm_tm == 64 : (few && !three_terms));
+  const bool small = (epi == tgx::GEMM_SILU || epi == tgx::GEMM_GELU) ? false : (c->gemm_tm ? c->gemm_tm == 64 : (few && !three_terms));
   const int tm = small ? 64 : tgx::GBM;
   const dim3 grid((N + tgx::GBN - 1) / tgx::GBN, (M + tm - 1) / tm), blk(256);
   const size_t dyn = three_terms ? (size_t)tm * tgx::GLD * 2 : 0;      // LDS tile of the third term
@@ -671,12 +685,14 @@ void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float
       if (small) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_PARTIAL, 1>), gz, blk, dyn, c->stream, g);
       else hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_PARTIAL, 2>), gz, blk, dyn, c->stream, g);
       if (epi == tgx::GEMM_SILU) hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_SILU>), rg, blk, 0, c->stream, g);
+      else if (epi == tgx::GEMM_GELU) hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_GELU>), rg, blk, 0, c->stream, g);
       else if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_RESIDUAL>), rg, blk, 0, c->stream, g);
       else hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_STORE>), rg, blk, 0, c->stream, g);)
     return;
   }
   TGX_DT16_SWITCH(c->dt,
     if (epi == tgx::GEMM_SILU) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_SILU, 2>), grid, blk, dyn, c->stream, g);
+    else if (epi == tgx::GEMM_GELU) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_GELU, 2>), grid, blk, dyn, c->stream, g);
     else if (small) {
       if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_RESIDUAL, 1>), grid, blk, dyn, c->stream, g);
       else hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_STORE, 1>), grid, blk, dyn, c->stream, g);
@@ -696,13 +712,16 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
   const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd;
   const int M = NB * S;
   const size_t wout = (size_t)qd + 2 * kvd;
-  TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_rows_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const long long*)c->rows[(size_t)row0].prompt, (const bf16_t*)c->embed, c->ws_x, H, S, (long long)d.max_ctx))
+  // GPT-2 (ModelGPT2.h:23-208): wte + wpe rows, LayerNorm with bias ahead of both products, a bias on every Conv1D, c_fc -> gelu_new;
+  // its rotation tables are the identity, so the RoPE / cache-append kernel and the attention are the Llama family's
+  TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_rows_any_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const long long*)c->rows[(size_t)row0].prompt, (const void*)c->embed, (const void*)(c->gpt2 ? c->wpe : nullptr), c->ws_x, H, S, (long long)d.max_ctx, (int)c->past))
   for (int l = 0; l < d.layers; l++) {
     const LayerW& w = c->L[(size_t)l];
     // the QKV product feeds a second rounding (the KV cache): bf16 needs three split terms to reproduce the step path's cache
     // entries (two leave 1-8 % of them one ulp off); fp16's two terms already carry 22 bits
     const bool three = c->dt == tgx::DT_BF16;
-    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.in_norm, d.norm_eps, H, c->ws_ah, c->ws_al, three ? c->ws_al2 : (bf16_t*)nullptr))
+    if (c->gpt2) { TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::norm_rows_kernel<DT, 1, 1>), dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const void*)w.in_norm, (const void*)w.in_norm_b, d.norm_eps, H, (float*)nullptr, c->ws_ah, c->ws_al, three ? c->ws_al2 : (bf16_t*)nullptr)) }
+    else { TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.in_norm, d.norm_eps, H, c->ws_ah, c->ws_al, three ? c->ws_al2 : (bf16_t*)nullptr)) }
     launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, M, qd + 2 * kvd, H, qd + 2 * kvd, /*three_terms=*/three);
     for (int b = 0; b < NB; b++) {
       RowState& r = c->rows[(size_t)(row0 + b)];
@@ -730,10 +749,15 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
       TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64>), grid, blk, 0, c->stream, a);
                              else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128>), grid, blk, 0, c->stream, a))
     }
-    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wo, nullptr, c->ws_x, M, H, qd, H);
-    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al, (bf16_t*)nullptr))
-    launch_gemm(c, tgx::GEMM_SILU, w.wgu, nullptr, nullptr, M, 2 * I, H, 2 * I);      // gate_up + siluMul -> ws_hh / ws_hl
-    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wdown, nullptr, c->ws_x, M, H, I, H, false, c->ws_hh, c->ws_hl);
+    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wo, w.bo, c->ws_x, M, H, qd, H);
+    if (c->gpt2) {
+      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::norm_rows_kernel<DT, 1, 1>), dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const void*)w.post_norm, (const void*)w.post_norm_b, d.norm_eps, H, (float*)nullptr, c->ws_ah, c->ws_al, (bf16_t*)nullptr))
+      launch_gemm(c, tgx::GEMM_GELU, w.wgu, w.bfc, nullptr, M, I, H, I);             // c_fc + bias + gelu_new -> ws_hh / ws_hl
+    } else {
+      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al, (bf16_t*)nullptr))
+      launch_gemm(c, tgx::GEMM_SILU, w.wgu, nullptr, nullptr, M, 2 * I, H, 2 * I);      // gate_up + siluMul -> ws_hh / ws_hl
+    }
+    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wdown, w.bdown, c->ws_x, M, H, I, H, false, c->ws_hh, c->ws_hl);
   }
   for (int b = 0; b < NB; b++)     // the last position of every batch row feeds lm_head
     (void)hipMemcpyAsync(c->rows[(size_t)(row0 + b)].x, c->ws_x + ((size_t)(b + 1) * S - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, c->stream);
@@ -1107,6 +1131,132 @@ void launch_prefill_skinny(tgx_ctx* c, int row0, int NB, int S) {
     else hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)c->ws_x, (long long)H, H, ssq);
   }
   for (int b = 0; b < NB; b++)     // the last position of every batch row feeds lm_head
+    (void)hipMemcpyAsync(c->rows[(size_t)(row0 + b)].x, c->ws_x + ((size_t)(b + 1) * S - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, c->stream);
+}
+
+
+// ---- batched prefill for fp32 storage (kernels/gemm_f32.h): every product on v_mfma_f32_32x32x2_f32 (exact fp32 products), the
+// row-wise ops in fp32, attention = the decode attention kernel with the prompt positions as its rows (they share the sequence's
+// cache: kv_stride 0, row r attends the keys up to past + r).  All families incl. GPT-2 — BASELINE.json configs[0] is GPT-2 fp32.
+void launch_gemm_f32(tgx_ctx* c, int epi, const ebyte* B, const ebyte* bias, const float* A, float* C, int M, int N, int K, int ldc) {
+  tgx::GemmF32Args g{};
+  g.A = A; g.B = reinterpret_cast<const float*>(B); g.bias = reinterpret_cast<const float*>(bias); g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc; g.inter = N / 2;
+  const bool few = ((N + tgx::FBN - 1) / tgx::FBN) * ((M + 127) / 128) < 2 * c->num_cus;
+  const bool small = epi == tgx::F32_SILU ? false : few;
+  const int tm = small ? 64 : 128;
+  dim3 grid((N + tgx::FBN - 1) / tgx::FBN, (M + tm - 1) / tm), blk(256);
+  // few tiles (a short prompt, or N = hidden): split K over blockIdx.z until ~2 workgroups per CU exist; slabs summed in z order
+  const int ntiles = (int)(grid.x * grid.y), ksteps = (K + tgx::FBK - 1) / tgx::FBK;
+  int nsplit = 1;
+  if (c->gemm_splitk && ntiles < 2 * c->num_cus) nsplit = std::max(1, std::min(std::min(16, ksteps / 4), (2 * c->num_cus + ntiles - 1) / ntiles));
+  if (nsplit > 1 && (size_t)nsplit * M * N * 4 > c->ws_part_bytes) nsplit = 1;      // sized in tgx_forward (ensure_f32_part)
+  if (nsplit > 1) {
+    g.k_per = ((ksteps + nsplit - 1) / nsplit) * tgx::FBK;
+    nsplit = (K + g.k_per - 1) / g.k_per;
+  }
+  g.part = c->ws_part; g.nsplit = nsplit;
+  grid.z = nsplit > 1 ? nsplit : 1;
+  switch (epi) {
+    case tgx::F32_SILU: hipLaunchKernelGGL((tgx::gemm_f32_kernel<tgx::F32_SILU, 2>), grid, blk, 0, c->stream, g); break;
+    case tgx::F32_GELU: if (small) hipLaunchKernelGGL((tgx::gemm_f32_kernel<tgx::F32_GELU, 1>), grid, blk, 0, c->stream, g);
+                        else hipLaunchKernelGGL((tgx::gemm_f32_kernel<tgx::F32_GELU, 2>), grid, blk, 0, c->stream, g); break;
+    case tgx::F32_RESIDUAL: if (small) hipLaunchKernelGGL((tgx::gemm_f32_kernel<tgx::F32_RESIDUAL, 1>), grid, blk, 0, c->stream, g);
+                            else hipLaunchKernelGGL((tgx::gemm_f32_kernel<tgx::F32_RESIDUAL, 2>), grid, blk, 0, c->stream, g); break;
+    default: if (small) hipLaunchKernelGGL((tgx::gemm_f32_kernel<tgx::F32_STORE, 1>), grid, blk, 0, c->stream, g);
+             else hipLaunchKernelGGL((tgx::gemm_f32_kernel<tgx::F32_STORE, 2>), grid, blk, 0, c->stream, g); break;
+  }
+  if (nsplit > 1) {
+    const size_t nout = (size_t)M * (epi == tgx::F32_SILU ? N / 2 : N);
+    const dim3 rg((unsigned)((nout + 255) / 256));
+    switch (epi) {
+      case tgx::F32_SILU: hipLaunchKernelGGL((tgx::gemm_f32_reduce_kernel<tgx::F32_SILU>), rg, blk, 0, c->stream, g); break;
+      case tgx::F32_GELU: hipLaunchKernelGGL((tgx::gemm_f32_reduce_kernel<tgx::F32_GELU>), rg, blk, 0, c->stream, g); break;
+      case tgx::F32_RESIDUAL: hipLaunchKernelGGL((tgx::gemm_f32_reduce_kernel<tgx::F32_RESIDUAL>), rg, blk, 0, c->stream, g); break;
+      default: hipLaunchKernelGGL((tgx::gemm_f32_reduce_kernel<tgx::F32_STORE>), rg, blk, 0, c->stream, g); break;
+    }
+  }
+}
+
+// split-K slabs of the fp32 products: up to 16 splits of the widest [rows][N] output
+int ensure_f32_part(tgx_ctx* c, int rows) {
+  const tgx_model_desc& d = c->d;
+  const size_t widest = std::max<size_t>(std::max<size_t>((size_t)d.heads * d.head_dim + 2 * (size_t)d.kv_heads * d.head_dim, (size_t)(c->gpt2 ? 1 : 2) * d.inter), (size_t)d.hidden);
+  // splits shrink as the tile count grows: nsplit * tiles stays near two per CU, so nsplit * rows * N is bounded by ~2 CUs x one 128 x 128 tile x 16
+  const size_t need = std::min<size_t>((size_t)16 * rows * widest * 4, (size_t)64 << 20);
+  if (need > c->ws_part_bytes) {
+    drop_step_graphs(c);
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    if (c->ws_part) (void)hipFree(c->ws_part);
+    c->ws_part = nullptr; c->ws_part_bytes = 0;
+    HIP_OK(c, hipMalloc((void**)&c->ws_part, need));
+    c->ws_part_bytes = need;
+  }
+  return TGX_OK;
+}
+
+void launch_prefill_f32(tgx_ctx* c, int row0, int NB, int S) {
+  const tgx_model_desc& d = c->d;
+  const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd, nq = qd + 2 * kvd;
+  const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd * c->esz;
+  const int M = NB * S;
+  float* xn = reinterpret_cast<float*>(c->ws_ah);      // [M][max(H, qd)]: normalised rows, later the attention output
+  float* qrows = reinterpret_cast<float*>(c->ws_qh);   // [M][qd] rotated queries
+  float* hrows = reinterpret_cast<float*>(c->ws_hh);   // [M][I]
+  hipLaunchKernelGGL((tgx::embed_rows_any_kernel<tgx::DT_F32>), dim3(M), dim3(256), 0, c->stream, (const long long*)c->rows[(size_t)row0].prompt, (const void*)c->embed, (const void*)(c->gpt2 ? c->wpe : nullptr), c->ws_x, H, S, (long long)d.max_ctx, (int)c->past);
+  hipLaunchKernelGGL(tgx::iota_pos_kernel, dim3((S + 255) / 256), dim3(256), 0, c->stream, c->ws_pos, (int)c->past, S);
+  auto norm = [&](const ebyte* w, const ebyte* b) {
+    if (c->gpt2) hipLaunchKernelGGL((tgx::norm_rows_kernel<tgx::DT_F32, 1, 0>), dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const void*)w, (const void*)b, d.norm_eps, H, xn, (bf16_t*)nullptr, (bf16_t*)nullptr, (bf16_t*)nullptr);
+    else hipLaunchKernelGGL((tgx::norm_rows_kernel<tgx::DT_F32, 0, 0>), dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const void*)w, (const void*)nullptr, d.norm_eps, H, xn, (bf16_t*)nullptr, (bf16_t*)nullptr, (bf16_t*)nullptr);
+  };
+  c->attn_direct = c->past + S <= c->attn_direct_max;
+  for (int l = 0; l < d.layers; l++) {
+    const LayerW& w = c->L[(size_t)l];
+    norm(w.in_norm, w.in_norm_b);
+    launch_gemm_f32(c, tgx::F32_STORE, w.wqkv, w.bqkv, xn, c->ws_out, M, nq, H, nq);
+    for (int b = 0; b < NB; b++) {
+      RowState& r = c->rows[(size_t)(row0 + b)];
+      const size_t ro = (size_t)b * S;
+      tgx::RopeRowsArgs a{};
+      a.QKV = c->ws_out + ro * nq; a.rows = S; a.q_out = qrows + ro * qd; a.q_stride = qd;
+      a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer; a.kv_stride = 0;     // the rows are positions of ONE sequence
+      a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos = c->ws_pos;
+      a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx;
+      a.q_norm_w = d.qk_norm ? w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? w.k_norm : nullptr; a.eps = d.norm_eps;
+      hipLaunchKernelGGL((tgx::rope_kv_rows_kernel<tgx::DT_F32>), dim3(S, d.heads + 2 * d.kv_heads), dim3(64), 0, c->stream, a);
+    }
+    for (int b = 0; b < NB; b++) {
+      RowState& r = c->rows[(size_t)(row0 + b)];
+      const size_t ro = (size_t)b * S;
+      if (c->f32_flash) {        // causal flash attention on the f32-input MFMA (K / V tiles shared by 128 queries)
+        tgx::AttnPrefillF32Args a{};
+        a.q = qrows + ro * qd; a.k_cache = reinterpret_cast<const float*>(r.kcache + (size_t)l * kv_layer); a.v_cache = reinterpret_cast<const float*>(r.vcache + (size_t)l * kv_layer);
+        a.out = xn + ro * qd; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
+        a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = c->attn_mirror;
+        const dim3 grid((S + 127) / 128, d.heads), blk(256);
+        if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_f32_kernel<64>), grid, blk, 0, c->stream, a);
+        else hipLaunchKernelGGL((tgx::attn_prefill_f32_kernel<128>), grid, blk, 0, c->stream, a);
+        continue;
+      }
+      for (int s0 = 0; s0 < S; s0 += F32_ATTN_ROWS) {       // option prefill.f32_flash = 0: the decode attention kernel, blocks of rows
+        const int R = std::min(F32_ATTN_ROWS, S - s0);
+        tgx::AttnArgs a{};
+        a.q = qrows + (ro + s0) * qd; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
+        a.pos = c->ws_pos + s0; a.part = c->ws_attn_part; a.out = xn + (ro + s0) * qd;
+        a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
+        a.scale = 1.0f / sqrtf((float)hd);
+        a.q_stride = qd; a.kv_stride = 0; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
+        const int fold = c->attn_fold; c->attn_fold = 0;
+        launch_attn(c, a, R);
+        c->attn_fold = fold;
+      }
+    }
+    launch_gemm_f32(c, tgx::F32_RESIDUAL, w.wo, w.bo, xn, c->ws_x, M, H, qd, H);
+    norm(w.post_norm, w.post_norm_b);
+    if (c->gpt2) launch_gemm_f32(c, tgx::F32_GELU, w.wgu, w.bfc, xn, hrows, M, I, H, I);
+    else launch_gemm_f32(c, tgx::F32_SILU, w.wgu, nullptr, xn, hrows, M, 2 * I, H, I);
+    launch_gemm_f32(c, tgx::F32_RESIDUAL, w.wdown, w.bdown, hrows, c->ws_x, M, H, I, H);
+  }
+  for (int b = 0; b < NB; b++)
     (void)hipMemcpyAsync(c->rows[(size_t)(row0 + b)].x, c->ws_x + ((size_t)(b + 1) * S - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, c->stream);
 }
 
@@ -1486,7 +1636,7 @@ void tgx_destroy(tgx_ctx* c) {
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->wpe); fr(c->final_norm_b); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->lm_ticket); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
   fr(c->ch_x); fr(c->ch_q); fr(c->ch_kraw); fr(c->ch_attn); fr(c->ch_h); fr(c->ch_part); fr(c->ch_pos);
-  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl); fr(c->ws_part); fr(c->ws_ssq);
+  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl); fr(c->ws_part); fr(c->ws_ssq); fr(c->ws_pos); fr(c->ws_attn_part);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); fr(w.in_norm_b); fr(w.post_norm_b); fr(w.bo); fr(w.bfc); fr(w.bdown); }
   fr(c->slab_x); fr(c->slab_q); fr(c->slab_kraw); fr(c->slab_attn); fr(c->slab_h); fr(c->slab_logits); fr(c->slab_probs);
   fr(c->slab_part_val); fr(c->slab_part_idx); fr(c->slab_attn_part); fr(c->slab_tok); fr(c->slab_pos); fr(c->slab_prompt); fr(c->slab_k); fr(c->slab_v);
@@ -1507,7 +1657,9 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     if (ids[i] < 0 || ids[i] >= c->d.vocab) return set_err(c, TGX_ERR_INVALID, "token id out of range");
   HIP_OK(c, hipSetDevice(c->device));
   c->batch = batch;
-  const bool mfma_path = seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && !c->gpt2 && prefill_shapes_ok(c->d);
+  // matrix-core prefill: 16-bit storage through the split-term GEMMs (every family incl. GPT-2), fp32 storage through the f32-input MFMA
+  const bool f32_path = c->dt == tgx::DT_F32 && seq >= c->prefill_f32_min_rows && c->prefill_mfma;
+  const bool mfma_path = f32_path || (seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && prefill_shapes_ok(c->d));
   for (int b = 0; b < batch; b++) HIP_OK(c, hipMemcpyAsync(c->rows[(size_t)b].prompt, ids + (size_t)b * seq, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream));
   if (mfma_path) {
     // batched prefill on the matrix cores; logits for the last position only (== forward + narrow, GPTEngine.cpp:96-97).  Batch rows are
@@ -1515,10 +1667,12 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     const int per = std::max(1, std::min(batch, 8192 / seq));
     for (int row0 = 0; row0 < batch; row0 += per) {
       const int nb = std::min(per, batch - row0);
-      const bool skinny = c->prefill_skinny && nb * seq <= 32 && c->d.vocab >= 128;     // a few rows: the weight stream of a decode step
+      const bool skinny = !f32_path && !c->gpt2 && c->prefill_skinny && nb * seq <= 32 && c->d.vocab >= 128;     // a few rows: the weight stream of a decode step
       int rc = skinny ? ensure_skinny_ws(c, nb * seq) : ensure_prefill_ws(c, nb * seq);
       if (rc) return rc;
-      if (skinny) launch_prefill_skinny(c, row0, nb, seq); else launch_prefill(c, row0, nb, seq);
+      if (f32_path && (rc = ensure_f32_part(c, nb * seq))) return rc;
+      if (f32_path) launch_prefill_f32(c, row0, nb, seq);
+      else if (skinny) launch_prefill_skinny(c, row0, nb, seq); else launch_prefill(c, row0, nb, seq);
       for (int b = row0; b < row0 + nb;) {
         const int rem = row0 + nb - b, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
         launch_lm_head(c, b, R);
@@ -1770,6 +1924,8 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "debug.gemv")) { c->debug_gemv = value; return TGX_OK; }
   if (!strcmp(key, "prefill.mfma")) { c->prefill_mfma = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.min_rows")) { c->prefill_min_rows = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.f32_flash")) { c->f32_flash = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.f32_min_rows")) { c->prefill_f32_min_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk")) { c->gemm_splitk = value; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_mirror")) { c->attn_mirror = value; return TGX_OK; }
   if (!strcmp(key, "attn.qk_fuse")) { c->qk_fuse = value; return TGX_OK; }
