@@ -153,6 +153,9 @@ struct GemmArgs {
   int ssq_ncb;
   float eps;
   float* ssq_out;              // reduce_rows_kernel: [M][gridDim.y] partial sums of squares of the rows it writes
+  // gemm_x2_kernel with A_lo2: tile columns below three_from take two terms only.  The third term exists for results that are rounded
+  // to 16 bits again — the K / V columns of the QKV product; its Q columns (the first heads*head_dim) stay fp32.
+  int three_from;
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = GBK + 8;
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t sAl[TM * GLD];
   __shared__ __attribute__((aligned(16))) bf16_t sB[GBN * GLD];
   extern __shared__ __attribute__((aligned(16))) bf16_t sAl2[];   // [TM*GLD] only when the launch asks for it
-  const bool three = a.A_lo2 != nullptr;      // wave-uniform
+  const bool three = a.A_lo2 != nullptr && (int)(blockIdx.x + 1) * GBN > a.three_from;      // workgroup-uniform
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * GBN;
