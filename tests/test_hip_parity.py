@@ -542,7 +542,8 @@ def test_qwen3_qk_norm_fused_into_attention(dtype, hip, oracle_lib):
         (k1, v1), (k0, v0) = outs[0][3], outs[1][3]
         kr, vr = ref.read_kv(2, 1)
         assert k1.shape == k0.shape == kr.shape and k1.shape[0] == 30 + 12
-        ulp = 2.0 ** -7 if dtype == "bf16" else 1e-5
+        # fp32 storage: the prompt rows come from the f32-input MFMA GEMMs (another fp32 summation order than the oracle's loops)
+        ulp = 2.0 ** -7 if dtype == "bf16" else 4e-5
         for kk in (k1, k0):
             assert np.all(np.abs(kk - kr) <= ulp * (np.abs(kr) + 0.1 * np.abs(kr).max()))
         assert np.all(np.abs(v1 - v0) <= ulp * (np.abs(v0) + 0.1 * np.abs(v0).max()))      # layer 1: downstream of layer 0's (one-ulp) key differences
