@@ -1,0 +1,297 @@
+// gemm_dma.h — the 16-bit prefill GEMM of prefill.h with its operand tiles delivered by LDS-DMA (global_load_lds_dwordx4: memory ->
+// LDS without passing through registers) into a two-stage ring.
+//
+// Why: in gemm_x2_kernel every operand byte crosses the VGPR file twice (global_load -> ds_write_b128); the ds_write path moves ~79 B/clk
+// per CU, so the 48 KB of tiles per K step keep the LDS pipe as busy as the matrix pipe (MfmaUtil 29-38 %), and the register-staged
+// prefetch forces two workgroup barriers per K step.  Here a K step is: issue the next stage's DMA, MFMAs on the current stage, one
+// counted wait + ONE barrier.
+//
+// LDS image: a tile is rows x 64 elements (128-byte rows, no padding — a DMA piece is 1 KiB of consecutive LDS bytes = 8 rows); the 16-byte
+// chunk c of row r lives in slot c ^ ((r >> 1) & 7): the rows of a ds_read_b128 lane group then fall on distinct bank quads.  The swizzle is
+// applied on the GLOBAL side (each lane fetches the chunk that belongs in its slot) and again in the fragment read address.
+#pragma once
+#include "prefill.h"
+
+namespace tgx {
+
+__host__ __device__ constexpr size_t gemm_dma_lds_bytes(int mi, bool three, int dbk, int ns) {
+  return (size_t)ns * ((three ? 3 : 2) * 64 * mi + 128) * dbk * 2;
+}
+
+// s_waitcnt vmcnt(n) for the piece counts the rings below produce (the count must be an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// one 1-KiB LDS-DMA piece: lane l's 16 bytes land at lds_dst + 16 l (cdna_hip_programming.md §5.7: M0 carries the LDS base and is
+// compiler-reserved, so it is saved, set and restored inside ONE statement)
+__device__ __forceinline__ void dma_1k(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);       // wave-uniform by construction; make it provably scalar for the "s" operand
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// DBK = k per stage: 64 (128-byte rows, 8 chunk slots, swizzle by (row >> 1) & 7) or 32 (64-byte rows, 4 slots, (row >> 2) & 3: half the LDS per
+// stage, so that the 128-row tile keeps three workgroups per CU)
+// NS = ring stages: NS - 1 stages are in flight while one is consumed; the waits are counted (this wave's pieces of the later stages may still fly)
+template <int DT, int EPI, int MI, int DBK, int NS>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs a) {
+  constexpr int TM = 64 * MI;
+  constexpr int CPR = DBK / 8;                 // 16-byte chunks per tile row
+  constexpr int RPP = 64 / CPR;                // tile rows per 1-KiB piece
+  constexpr int SW_SH = DBK == 64 ? 1 : 2, SW_MASK = CPR - 1;
+  extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
+  const bool three = a.A_lo2 != nullptr && (int)(blockIdx.x + 1) * GBN > a.three_from;      // workgroup-uniform
+  const int NA = three ? 3 : 2;
+  const int stage_elems = (NA * TM + GBN) * DBK;                      // A_hi | A_lo | [A_lo2] | B
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv >> 1, wn = wv & 1;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * GBN;
+  const unsigned lds_base = (unsigned)(size_t)dma_lds;                // LDS byte offset of the ring (low 32 bits of the generic address)
+
+  f32x16 acc[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // DMA map: a piece = 8 tile rows; lane l -> row (l >> 3) of the piece, LDS slot (l & 7) -> global chunk slot ^ ((row >> 1) & 7)
+  const int prow = lane / CPR, pslot = lane % CPR;
+  const bool inter = EPI == GEMM_SILU;
+  auto issue_stage = [&](int k0, int stage) {
+    const unsigned sbase = lds_base + (unsigned)(stage * stage_elems * 2);
+    // A tiles: TM / 8 pieces each, dealt to the 4 waves
+#pragma unroll
+    for (int p = 0; p < TM / RPP / 4; p++) {
+      const int piece = wv + 4 * p, row = piece * RPP + prow;
+      const int chunk = pslot ^ ((row >> SW_SH) & SW_MASK);
+      const size_t g = (size_t)min(m0 + row, a.M - 1) * a.K + k0 + chunk * 8;       // rows past M are computed on a clamped row, never stored
+      const unsigned dst = sbase + (unsigned)(piece * 1024);
+      dma_1k(a.A_hi + g, dst);
+      dma_1k(a.A_lo + g, dst + (unsigned)(TM * DBK * 2));
+      if (three) dma_1k(a.A_lo2 + g, dst + (unsigned)(2 * TM * DBK * 2));
+    }
+#pragma unroll
+    for (int p = 0; p < GBN / RPP / 4; p++) {
+      const int piece = wv + 4 * p, row = piece * RPP + prow;
+      const int chunk = pslot ^ ((row >> SW_SH) & SW_MASK);
+      const int nb = min(n0 + row, a.N - 1);
+      const size_t brow = inter ? (size_t)((nb & 1) ? a.inter : 0) + (size_t)(nb >> 1) : (size_t)nb;
+      dma_1k(a.B + brow * a.K + k0 + chunk * 8, sbase + (unsigned)(NA * TM * DBK * 2) + (unsigned)(piece * 1024));
+    }
+  };
+  auto frag = [&](const bf16_t* tile, int row, int kchunk) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(tile + row * DBK + ((kchunk ^ ((row >> SW_SH) & SW_MASK)) << 3));
+  };
+
+  const int nk = a.K / DBK;
+  const int ppw = (NA * TM + GBN) / RPP / 4;                         // pieces per wave and stage
+#pragma unroll
+  for (int sg = 0; sg < NS - 1; sg++)
+    if (sg < nk) issue_stage(sg * DBK, sg);
+  for (int k = 0; k < nk; k++) {
+    // stage k has landed for this wave once only the pieces of the stages issued after it are outstanding (LDS-DMA completes in order)
+    wait_vmcnt(min(NS - 2, nk - 1 - k) * ppw);
+    __builtin_amdgcn_s_barrier();                                    // ... for every wave; and every wave is done reading stage k-1
+    if (k + NS - 1 < nk) issue_stage((k + NS - 1) * DBK, (k + NS - 1) % NS);    // into the buffer stage k-1 occupied
+    const bf16_t* st = dma_lds + (size_t)(k % NS) * stage_elems;
+    const bf16_t *tAh = st, *tAl = st + TM * DBK, *tAl2 = st + 2 * TM * DBK, *tB = st + NA * TM * DBK;
+#pragma unroll
+    for (int kk = 0; kk < DBK / 16; kk++) {
+      const int kchunk = kk * 2 + (lane >> 5);
+      bf16x8 fah[MI], fal[MI], fal2[MI], fb[2];
+#pragma unroll
+      for (int i = 0; i < MI; i++) {
+        const int row = wm * (32 * MI) + i * 32 + (lane & 31);
+        fah[i] = frag(tAh, row, kchunk);
+        fal[i] = frag(tAl, row, kchunk);
+        if (three) fal2[i] = frag(tAl2, row, kchunk);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) fb[j] = frag(tB, wn * 64 + j * 32 + (lane & 31), kchunk);
+#pragma unroll
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          if (three) acc[i][j] = mfma16<DT>(fal2[i], fb[j], acc[i][j]);
+          acc[i][j] = mfma16<DT>(fal[i], fb[j], acc[i][j]);   // small terms first
+          acc[i][j] = mfma16<DT>(fah[i], fb[j], acc[i][j]);
+        }
+    }
+  }
+
+  // epilogue: as gemm_x2_kernel (C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+#pragma unroll
+  for (int i = 0; i < MI; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (EPI == GEMM_SILU) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float v = acc[i][j][r];
+          const float other = dpp_mov<0xB1, 0xf>(v);
+          const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if ((lane & 1) || col >= a.N || row >= a.M) continue;
+          const size_t o = (size_t)row * a.inter + (size_t)(col >> 1);
+          split16<DT>((v / (1.0f + expf(-v))) * other, a.out_hi[o], a.out_lo[o]);
+        }
+        continue;
+      }
+      if (col >= a.N) continue;
+      const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= a.M) continue;
+        const float v = acc[i][j][r] + bv;
+        if (EPI == GEMM_GELU) {
+          const size_t o = (size_t)row * a.N + col;
+          split16<DT>(0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v))), a.out_hi[o], a.out_lo[o]);
+          continue;
+        }
+        float* dst = a.C + (size_t)row * a.ldc + col;
+        *dst = (EPI == GEMM_RESIDUAL) ? (*dst + v) : v;
+      }
+    }
+}
+
+
+// ---- 256 x 256 tile, 8 waves, three-stage LDS-DMA ring (the wide products: gate_up / c_fc) -------------------------------------------
+// Why a bigger tile and a deeper ring: one stage of the 128² kernel holds 0.2-0.4 µs of MFMA work per wave, an LDS-DMA piece takes 1-2 µs
+// to land — the two-stage ring stalls on every stage and only co-resident workgroups hide it.  Here a stage (k = 32) is 48 KB
+// (A_hi | A_lo | B, 256 rows x 64 bytes each) for 32 MFMAs per wave with two waves per SIMD (~0.85 µs of matrix work per SIMD), and TWO
+// stages are in flight while the third is consumed: the waits are counted (vmcnt(6): this wave's six pieces of the NEXT stage may still
+// fly), never a drain.  A wave owns 128 x 64 of the output (4 x 2 MFMA tiles): 10 fragment reads per 16 MFMAs.
+template <int DT, int EPI>
+__global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
+  constexpr int DBK = 32, CPR = 4, RPP = 16, TMN = 256, NS = 3;
+  constexpr int STAGE = 3 * TMN * DBK;                    // 16-bit elements per stage
+  extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv >> 2, wn = wv & 3;
+  const int m0 = blockIdx.y * TMN, n0 = blockIdx.x * TMN;
+  const unsigned lds_base = (unsigned)(size_t)dma_lds;
+  const bool inter = EPI == GEMM_SILU;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int prow = lane / CPR, pslot = lane % CPR;
+  // 48 pieces per stage: wave w takes pieces w, w+8 of each of the three tiles = six DMA instructions, issued ONE AT A TIME between
+  // groups of MFMAs (q = 0..5) so that their issue cost (~100 cycles each) hides under the matrix pipe instead of opening every stage
+  const bf16_t* gsrc[6];
+  unsigned ldst[6];
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const int piece = wv + 8 * p, row = piece * RPP + prow;
+    const int chunk = pslot ^ ((row >> 2) & 3);
+    const size_t g = (size_t)min(m0 + row, a.M - 1) * a.K + chunk * 8;
+    const int nb = min(n0 + row, a.N - 1);
+    const size_t brow = inter ? (size_t)((nb & 1) ? a.inter : 0) + (size_t)(nb >> 1) : (size_t)nb;
+    gsrc[3 * p] = a.A_hi + g; gsrc[3 * p + 1] = a.A_lo + g; gsrc[3 * p + 2] = a.B + brow * a.K + chunk * 8;
+    ldst[3 * p] = (unsigned)(piece * 1024); ldst[3 * p + 1] = ldst[3 * p] + (unsigned)(TMN * DBK * 2); ldst[3 * p + 2] = ldst[3 * p] + (unsigned)(2 * TMN * DBK * 2);
+  }
+  auto issue_piece = [&](int q, int k0, int stage) {
+    dma_1k(gsrc[q] + k0, lds_base + (unsigned)(stage * STAGE * 2) + ldst[q]);
+  };
+  auto issue_stage = [&](int k0, int stage) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) issue_piece(q, k0, stage);
+  };
+  auto frag = [&](const bf16_t* tile, int row, int kchunk) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(tile + row * DBK + ((kchunk ^ ((row >> 2) & 3)) << 3));
+  };
+
+  const int nk = a.K / DBK;
+  issue_stage(0, 0);
+  if (nk > 1) issue_stage(DBK, 1);
+  for (int k = 0; k < nk; k++) {
+    // stage k has landed for this wave once at most the six pieces of stage k+1 are outstanding (LDS-DMA completes in order)
+    if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // ... for every wave; and every wave is done reading stage k-1
+    const bool more = k + 2 < nk;                         // stage k+2 goes into the buffer stage k-1 occupied
+    const int nk0 = (k + 2) * DBK, nst = (k + 2) % NS;
+    const bf16_t* st = dma_lds + (size_t)(k % NS) * STAGE;
+    const bf16_t *tAh = st, *tAl = st + TMN * DBK, *tB = st + 2 * TMN * DBK;
+#pragma unroll
+    for (int kk = 0; kk < DBK / 16; kk++) {
+      const int kchunk = kk * 2 + (lane >> 5);
+      bf16x8 fah[4], fal[4], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) fb[j] = frag(tB, wn * 64 + j * 32 + (lane & 31), kchunk);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int row = wm * 128 + i * 32 + (lane & 31);
+        fah[i] = frag(tAh, row, kchunk);
+        fal[i] = frag(tAl, row, kchunk);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[i][j] = mfma16<DT>(fal[i], fb[j], acc[i][j]);   // small term first
+          acc[i][j] = mfma16<DT>(fah[i], fb[j], acc[i][j]);
+        }
+        if (more && (kk * 4 + i) < 6) issue_piece(kk * 4 + i, nk0, nst);      // one DMA per four MFMAs
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (EPI == GEMM_SILU) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float v = acc[i][j][r];
+          const float other = dpp_mov<0xB1, 0xf>(v);
+          const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if ((lane & 1) || col >= a.N || row >= a.M) continue;
+          const size_t o = (size_t)row * a.inter + (size_t)(col >> 1);
+          split16<DT>((v / (1.0f + expf(-v))) * other, a.out_hi[o], a.out_lo[o]);
+        }
+        continue;
+      }
+      if (col >= a.N) continue;
+      const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= a.M) continue;
+        const float v = acc[i][j][r] + bv;
+        if (EPI == GEMM_GELU) {
+          const size_t o = (size_t)row * a.N + col;
+          split16<DT>(0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v))), a.out_hi[o], a.out_lo[o]);
+          continue;
+        }
+        float* dst = a.C + (size_t)row * a.ldc + col;
+        *dst = (EPI == GEMM_RESIDUAL) ? (*dst + v) : v;
+      }
+    }
+}
+
+}  // namespace tgx

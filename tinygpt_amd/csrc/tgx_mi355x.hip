@@ -23,6 +23,7 @@
 #include "kernels/sampler.h"
 #include "kernels/skinny.h"
 #include "kernels/gemm_f32.h"
+#include "kernels/gemm_dma.h"
 
 using tgx::bf16_t;
 typedef unsigned char ebyte;   // parameter / KV-cache storage in the compute dtype: offsets are elements * ctx.esz
@@ -167,6 +168,10 @@ struct tgx_ctx {
   int f32_flash = 1;               // option prefill.f32_flash: 0 = attention of the fp32 prefill through the decode attention kernel
   int prefill_f32_min_rows = 16;   // fp32 storage: prompts from this length on take the f32-input MFMA GEMMs (64-row tiles; option prefill.f32_min_rows)
   int gemm_tm = 0;           // experiment: force the GEMM row tile (64 / 128); 0 = by the number of tiles
+  // option prefill.gemm_dma: bit 0 / 1 = unsplit prefill GEMMs take their tiles by LDS-DMA (kernels/gemm_dma.h), bit 2 = the wide product (gate_up / c_fc)
+  // on the 8-wave 256 x 256 three-stage kernel; bits 4-7 / 8-11 = ring geometry of the 128-row / 64-row tiles (k per stage, stages).  0 = the register-staged
+  // gemm_x2_kernel everywhere (round 1).  Default 7 | k32x2 << 4 | k64x2 << 8: Llama-3.2-1B 2048 tokens 11.4-11.7 -> 10.0-10.3 ms (tools/dma_sweep.py)
+  int gemm_dma = 7 | (1 << 4) | (2 << 8);
   int debug_attn = 0;        // experiment: AttnArgs.dbg
   int attn_gmax = 0;         // experiment: query heads per attention workgroup (default 2)
   int attn_direct_max = 384; // contexts up to this many keys take the one-workgroup-per-head attention (no split, no combine launch); set in tgx_create
@@ -689,6 +694,37 @@ void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float
       else if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_RESIDUAL>), rg, blk, 0, c->stream, g);
       else hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_STORE>), rg, blk, 0, c->stream, g);)
     return;
+  }
+  if ((c->gemm_dma & 4) && K % 64 == 0 && !three_terms && (epi == tgx::GEMM_SILU || epi == tgx::GEMM_GELU) && ((N + 255) / 256) * ((M + 255) / 256) >= c->num_cus) {
+    // the wide product (gate_up / c_fc) with enough 256 x 256 tiles to fill the chip: 8 waves, three-stage LDS-DMA ring
+    const dim3 g8((N + 255) / 256, (M + 255) / 256), b8(512);
+    const size_t lds8 = (size_t)3 * 3 * 256 * 32 * 2;
+    TGX_DT16_SWITCH(c->dt,
+      if (epi == tgx::GEMM_SILU) hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_SILU>), g8, b8, lds8, c->stream, g);
+      else hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_GELU>), g8, b8, lds8, c->stream, g);)
+    return;
+  }
+  if ((c->gemm_dma & 3) && K % 64 == 0) {     // operand tiles by LDS-DMA into a ring of stages (kernels/gemm_dma.h): one barrier per K step
+    // geometry per tile height (option prefill.gemm_dma bits 4-7 / 8-11 override: value = BK/32 + 4*(stages-2)): 128-row tiles k = 32 x 3 stages,
+    // 64-row tiles k = 64 x 2 stages
+    int sel = small ? ((c->gemm_dma >> 8) & 15) : ((c->gemm_dma >> 4) & 15);
+    if (!sel) sel = small ? 2 : 5;
+    const int dbk = (sel & 3) == 1 ? 32 : 64, ns = 2 + (sel >> 2);
+    const size_t lds = tgx::gemm_dma_lds_bytes(small ? 1 : 2, three_terms, dbk, ns);
+#define TGX_DMA2(EPI_, MI_, BK_) do { if (ns == 2) hipLaunchKernelGGL((tgx::gemm_dma_kernel<DT, EPI_, MI_, BK_, 2>), grid, blk, lds, c->stream, g); \
+                                      else if (ns == 3) hipLaunchKernelGGL((tgx::gemm_dma_kernel<DT, EPI_, MI_, BK_, 3>), grid, blk, lds, c->stream, g); \
+                                      else hipLaunchKernelGGL((tgx::gemm_dma_kernel<DT, EPI_, MI_, BK_, 4>), grid, blk, lds, c->stream, g); } while (0)
+#define TGX_DMA(EPI_, MI_) do { if (dbk == 32) TGX_DMA2(EPI_, MI_, 32); else TGX_DMA2(EPI_, MI_, 64); } while (0)
+    if (lds <= 160 * 1024) {
+      TGX_DT16_SWITCH(c->dt,
+        if (epi == tgx::GEMM_SILU) TGX_DMA(tgx::GEMM_SILU, 2);
+        else if (epi == tgx::GEMM_GELU) TGX_DMA(tgx::GEMM_GELU, 2);
+        else if (epi == tgx::GEMM_RESIDUAL) { if (small) TGX_DMA(tgx::GEMM_RESIDUAL, 1); else TGX_DMA(tgx::GEMM_RESIDUAL, 2); }
+        else { if (small) TGX_DMA(tgx::GEMM_STORE, 1); else TGX_DMA(tgx::GEMM_STORE, 2); })
+      return;
+    }
+#undef TGX_DMA
+#undef TGX_DMA2
   }
   TGX_DT16_SWITCH(c->dt,
     if (epi == tgx::GEMM_SILU) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_SILU, 2>), grid, blk, dyn, c->stream, g);
@@ -1623,6 +1659,17 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_PARTIAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_PARTIAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   if ((rc = skinny_set_attrs(c))) return rc;
+#define TGX_DMA_ATTR1(DT_, EPI_, MI_, BK_, NS_) HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma_kernel<DT_, EPI_, MI_, BK_, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(160 * 1024, tgx::gemm_dma_lds_bytes(MI_, true, BK_, NS_))));
+#define TGX_DMA_ATTR(DT_, EPI_, MI_) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 4) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 4)
+#define TGX_DMA_ATTR_D(DT_) TGX_DMA_ATTR(DT_, tgx::GEMM_SILU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_GELU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 2)
+  TGX_DMA_ATTR_D(tgx::DT_BF16) TGX_DMA_ATTR_D(tgx::DT_F16)
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_BF16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_BF16, tgx::GEMM_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_F16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_F16, tgx::GEMM_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
+#undef TGX_DMA_ATTR_D
+#undef TGX_DMA_ATTR
+#undef TGX_DMA_ATTR1
   c->past = 0;
   c->finalized = true;
   return TGX_OK;
@@ -1921,6 +1968,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   }
   if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_tm")) { c->gemm_tm = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.gemm_dma")) { c->gemm_dma = value; return TGX_OK; }
   if (!strcmp(key, "debug.gemv")) { c->debug_gemv = value; return TGX_OK; }
   if (!strcmp(key, "prefill.mfma")) { c->prefill_mfma = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.min_rows")) { c->prefill_min_rows = value; return TGX_OK; }
