@@ -253,10 +253,12 @@ def main():
     gemm_flops = 2.0 * args.prompt * L * ((desc.q_dim + 2 * desc.kv_dim) * H + H * desc.q_dim + (2 if desc.family == "gpt2" else 3) * I * H)
     attn_flops = 4.0 * L * desc.heads * desc.head_dim * args.prompt * (args.prompt + 1) / 2.0
     prefill_tflops = (gemm_flops + attn_flops) / (prefill_ms * 1e-3) / 1e12
-    # what the matrix cores execute: fp32 activations enter as exact sums of 16-bit terms — 3 for the bf16 QKV product, 2 elsewhere
-    # (DESIGN.md §5); the attention products (QK^T, PV) take 2 passes each
-    qkv_flops = 2.0 * args.prompt * L * (desc.q_dim + 2 * desc.kv_dim) * H
-    executed_flops = (3.0 if args.dtype == "bf16" else 2.0) * qkv_flops + 2.0 * (gemm_flops - qkv_flops) + 2.0 * attn_flops
+    # what the matrix cores execute: fp32 activations enter as exact sums of 16-bit terms — 3 for the K / V columns of the bf16 QKV product
+    # (their results are rounded into the cache), 2 elsewhere; the attention products (QK^T, PV) take 2 passes each
+    kv_flops = 2.0 * args.prompt * L * 2 * desc.kv_dim * H
+    executed_flops = (3.0 if args.dtype == "bf16" else 2.0) * kv_flops + 2.0 * (gemm_flops - kv_flops) + 2.0 * attn_flops
+    if args.dtype == "fp32":
+        executed_flops = gemm_flops + attn_flops          # f32-input MFMA: one pass
     prefill_exec_tflops = executed_flops / (prefill_ms * 1e-3) / 1e12
 
     line = {

@@ -294,4 +294,121 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
     }
 }
 
+
+// ---- 128 x 128 tile, 8 waves with the K step split between wave pairs, three-stage ring (the N = hidden products: o_proj, down) ---------
+// At S = 2048 these products have only 256 tiles of 128 x 128 — one per CU.  Four waves per tile leave one wave per SIMD (nothing hides a
+// wave's fragment-read latency); 64-row tiles double the workgroups but read a fragment per MFMA.  Here the 128 x 128 tile gets EIGHT waves:
+// waves w and w + 4 own the same 64 x 64 quadrant and take alternate halves of every stage's k range (two of its four k16 steps each), so
+// a SIMD holds two waves, a stage is 48 KB with three stages in the ring, and the two partial accumulators meet once, through LDS, after
+// the K loop (fixed order: lower half + upper half).
+template <int DT, int EPI>
+__global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
+  constexpr int DBK = 64, CPR = 8, RPP = 8, TMN = 128, NS = 3;
+  constexpr int STAGE = 3 * TMN * DBK;                    // 16-bit elements per stage (A_hi | A_lo | B)
+  extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = wv >> 2, wm = (wv >> 1) & 1, wn = wv & 1;
+  const int m0 = blockIdx.y * TMN, n0 = blockIdx.x * TMN;
+  const unsigned lds_base = (unsigned)(size_t)dma_lds;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int prow = lane / CPR, pslot = lane % CPR;
+  const bf16_t* gsrc[6];
+  unsigned ldst[6];
+#pragma unroll
+  for (int p = 0; p < 2; p++) {       // 16 pieces per tile: wave w takes pieces w, w + 8 of each of the three tiles
+    const int piece = wv + 8 * p, row = piece * RPP + prow;
+    const int chunk = pslot ^ ((row >> 1) & 7);
+    const size_t g = (size_t)min(m0 + row, a.M - 1) * a.K + chunk * 8;
+    const size_t brow = (size_t)min(n0 + row, a.N - 1);
+    gsrc[3 * p] = a.A_hi + g; gsrc[3 * p + 1] = a.A_lo + g; gsrc[3 * p + 2] = a.B + brow * a.K + chunk * 8;
+    ldst[3 * p] = (unsigned)(piece * 1024); ldst[3 * p + 1] = ldst[3 * p] + (unsigned)(TMN * DBK * 2); ldst[3 * p + 2] = ldst[3 * p] + (unsigned)(2 * TMN * DBK * 2);
+  }
+  auto issue_piece = [&](int q, int k0, int stage) { dma_1k(gsrc[q] + k0, lds_base + (unsigned)(stage * STAGE * 2) + ldst[q]); };
+  auto frag = [&](const bf16_t* tile, int row, int kchunk) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(tile + row * DBK + ((kchunk ^ ((row >> 1) & 7)) << 3));
+  };
+
+  const int nk = a.K / DBK;
+#pragma unroll
+  for (int q = 0; q < 6; q++) issue_piece(q, 0, 0);
+  if (nk > 1) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) issue_piece(q, DBK, 1);
+  }
+  for (int k = 0; k < nk; k++) {
+    if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool more = k + 2 < nk;
+    const int nk0 = (k + 2) * DBK, nst = (k + 2) % NS;
+    const bf16_t* st = dma_lds + (size_t)(k % NS) * STAGE;
+    const bf16_t *tAh = st, *tAl = st + TMN * DBK, *tB = st + 2 * TMN * DBK;
+#pragma unroll
+    for (int kl = 0; kl < 2; kl++) {                       // this wave's two k16 steps of the stage
+      const int kchunk = (2 * kh + kl) * 2 + (lane >> 5);
+      bf16x8 fah[2], fal[2], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) fb[j] = frag(tB, wn * 64 + j * 32 + (lane & 31), kchunk);
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int row = wm * 64 + i * 32 + (lane & 31);
+        fah[i] = frag(tAh, row, kchunk);
+        fal[i] = frag(tAl, row, kchunk);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[i][j] = mfma16<DT>(fal[i], fb[j], acc[i][j]);   // small term first
+          acc[i][j] = mfma16<DT>(fah[i], fb[j], acc[i][j]);
+          if (more && (kl * 4 + i * 2 + j) < 6) issue_piece(kl * 4 + i * 2 + j, nk0, nst);     // one DMA per two MFMAs
+        }
+    }
+  }
+
+  // the upper k-half's accumulators -> LDS -> added by the lower half's wave of the same quadrant
+  __builtin_amdgcn_s_barrier();
+  float* red = reinterpret_cast<float*>(dma_lds) + (size_t)(wv & 3) * 4 * 16 * 64;
+  if (kh == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[((i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (kh == 1) return;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] += red[((i * 2 + j) * 16 + r) * 64 + lane];
+
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (col >= a.N) continue;
+      const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= a.M) continue;
+        const float v = acc[i][j][r] + bv;
+        float* dst = a.C + (size_t)row * a.ldc + col;
+        *dst = (EPI == GEMM_RESIDUAL) ? (*dst + v) : v;
+      }
+    }
+}
+
 }  // namespace tgx

@@ -171,7 +171,8 @@ struct tgx_ctx {
   // option prefill.gemm_dma: bit 0 / 1 = unsplit prefill GEMMs take their tiles by LDS-DMA (kernels/gemm_dma.h), bit 2 = the wide product (gate_up / c_fc)
   // on the 8-wave 256 x 256 three-stage kernel; bits 4-7 / 8-11 = ring geometry of the 128-row / 64-row tiles (k per stage, stages).  0 = the register-staged
   // gemm_x2_kernel everywhere (round 1).  Default 7 | k32x2 << 4 | k64x2 << 8: Llama-3.2-1B 2048 tokens 11.4-11.7 -> 10.0-10.3 ms (tools/dma_sweep.py)
-  int gemm_dma = 7 | (1 << 4) | (2 << 8);
+  // bit 3 = the N = hidden products (o_proj, down) on the 8-wave 128 x 128 kernel with the K step split between wave pairs when their tiles number ~one per CU
+  int gemm_dma = 15 | (1 << 4) | (2 << 8);
   int debug_attn = 0;        // experiment: AttnArgs.dbg
   int attn_gmax = 0;         // experiment: query heads per attention workgroup (default 2)
   int attn_direct_max = 384; // contexts up to this many keys take the one-workgroup-per-head attention (no split, no combine launch); set in tgx_create
@@ -703,6 +704,18 @@ void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float
       if (epi == tgx::GEMM_SILU) hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_SILU>), g8, b8, lds8, c->stream, g);
       else hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_GELU>), g8, b8, lds8, c->stream, g);)
     return;
+  }
+  if ((c->gemm_dma & 8) && K % 64 == 0 && !three_terms && (epi == tgx::GEMM_RESIDUAL || epi == tgx::GEMM_STORE)) {
+    // N = hidden products whose 128 x 128 tiles number between half a chip and a chip and a half: eight waves per tile, K step split between wave pairs
+    const int t128 = ((N + 127) / 128) * ((M + 127) / 128);
+    if (2 * t128 >= c->num_cus && 2 * t128 <= 3 * c->num_cus) {
+      const dim3 g8((N + 127) / 128, (M + 127) / 128), b8(512);
+      const size_t lds8 = (size_t)3 * 3 * 128 * 64 * 2;
+      TGX_DT16_SWITCH(c->dt,
+        if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_RESIDUAL>), g8, b8, lds8, c->stream, g);
+        else hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_STORE>), g8, b8, lds8, c->stream, g);)
+      return;
+    }
   }
   if ((c->gemm_dma & 3) && K % 64 == 0) {     // operand tiles by LDS-DMA into a ring of stages (kernels/gemm_dma.h): one barrier per K step
     // geometry per tile height (option prefill.gemm_dma bits 4-7 / 8-11 override: value = BK/32 + 4*(stages-2)): 128-row tiles k = 32 x 3 stages,
@@ -1663,6 +1676,10 @@ int tgx_finalize(tgx_ctx* c) {
 #define TGX_DMA_ATTR(DT_, EPI_, MI_) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 4) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 4)
 #define TGX_DMA_ATTR_D(DT_) TGX_DMA_ATTR(DT_, tgx::GEMM_SILU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_GELU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 2)
   TGX_DMA_ATTR_D(tgx::DT_BF16) TGX_DMA_ATTR_D(tgx::DT_F16)
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_F16, tgx::GEMM_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_F16, tgx::GEMM_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_BF16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_BF16, tgx::GEMM_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_F16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
