@@ -454,6 +454,29 @@ def test_greedy_finalize_fused_into_lm_head_equals_separate_launch(fam, batch, h
     np.testing.assert_array_equal(ref.decode(24, GREEDY), outs[1][1][:24])
 
 
+@pytest.mark.parametrize("name,ctx,dtype", [("llama-3.2-1b", 3000, "bf16"), ("mistral-7b-v0.3", 2100, "bf16"), ("qwen2.5-0.5b", 2500, "fp16")])
+def test_mfma_decode_attention_equals_valu_kernel(name, ctx, dtype, hip):
+    """Option attn.mfma_min (off by default: measured no faster, kernels/attn_decode_mfma.h): QK^T and PV of the decode attention on the
+    matrix cores with the kv group's query heads as the narrow operand.  Logits within 1e-4 of the VALU split kernel, greedy ids equal,
+    at contexts that end inside a 64-key block, with G = 4 / 7, head_dim 64 / 128, bf16 / fp16, two batch rows of different lengths."""
+    import copy
+    from tinygpt_amd import known_desc
+    from tinygpt_amd.ffi import Model
+    d = copy.deepcopy(known_desc(name, dtype))
+    d.layers, d.vocab, d.max_ctx, d.max_batch = 2, 4096, ctx + 64, 2
+    m = Model(d, hip).load_synthetic(1234, 0.02).finalize()
+    prompt = np.stack([synth.synth_prompt(d.vocab, ctx, 5 + b) for b in range(2)])
+    outs = []
+    for mf in (1 << 30, 1):
+        m.set_option("attn.mfma_min", mf)
+        m.reset_cache(); m.forward(prompt)
+        first = m.sample(GREEDY).copy(); rest = m.decode(9, GREEDY).copy()
+        outs.append((first, rest, m.logits(rounded=False).copy()))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    assert rel_err(outs[1][2], outs[0][2]) < 1e-4, rel_err(outs[1][2], outs[0][2])
+
+
 @pytest.mark.parametrize("hidden,heads,kv,inter", [(5120, 40, 8, 13824), (8192, 64, 8, 16384), (8192, 64, 8, 28672)])
 def test_wide_models_vs_oracle(hidden, heads, kv, inter, hip, oracle_lib):
     """13B/14B-class widths (Llama-2-13B / Qwen2.5-14B: hidden 5120, intermediate 13824) and the widest shape one launch covers

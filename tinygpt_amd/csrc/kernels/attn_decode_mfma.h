@@ -1,0 +1,234 @@
+// attn_decode_mfma.h — single-query GQA attention over long contexts on the matrix cores.
+//
+// The VALU kernel of attn_decode.h spends ~120 instructions per 2 KB of K+V and wave (dot product, two exp2, P.V update per query head):
+// from a few thousand keys on it is bound by that arithmetic, not by HBM (Mistral-7B at 24k keys: 3.0 TB/s).  Here the G query heads of a kv
+// group are the narrow operand of the prefill attention's MFMA scheme (prefill.h attn_prefill_kernel): a wave computes S^T = K . Q^T for 64
+// keys x 32 "query columns" (the G heads of the group, zero-padded), keeps the online softmax in registers (lane = query column) and
+// accumulates O^T += V^T . P^T.  What differs from the prefill kernel: every wave walks its OWN key blocks (blocks of 64 keys are dealt
+// round-robin to splits x waves), so K fragments come straight from global memory (a fragment row is 16 contiguous bytes of a key row) and
+// the V^T tile is wave-private in LDS — the main loop has no workgroup barrier.  The four waves' partials meet once in LDS and leave as one
+// (o[hd], m, l) record per query head and split, merged by attn_combine_kernel exactly like the VALU kernel's.
+//
+// STATUS (round 2): correct (logits within 3e-5 of the VALU kernel, ids equal: tools/attn_long.py, tests) but NOT faster — per 64-key block
+// the V^T staging through LDS, the hi/lo splitting of the probabilities and the half-used K fragment loads cost what the VALU kernel's
+// arithmetic costs at G = 4 (Mistral-7B at 24k keys: 40 vs 33 us per layer; Qwen2.5-0.5B, G = 7, at 30k: 20.6 vs 18.1).  Option attn.mfma_min
+// enables it from that many keys on; the default leaves it off (profiles/r02_attn_long.txt).
+//
+// Roofline: HBM — 2 * kv_heads * (T+1) * hd * 2 bytes per launch.  MFMA work: 2 x (QK^T + PV) x 32 / G of the useful flops — negligible.
+#pragma once
+#include "attn_decode.h"
+#include "prefill.h"
+
+namespace tgx {
+
+template <int HD>
+__host__ __device__ constexpr size_t attn_mfma_lds_bytes() { return (size_t)4 * HD * (64 + 4) * 2; }
+
+template <int DT, int HD>
+__global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnArgs a) {
+  typedef elem_t<DT> E;
+  constexpr int LV = 64 + 4;                  // 16-bit row stride of the V^T tile
+  constexpr int KS = HD / 16;                 // MFMA k-steps over the head dimension
+  constexpr int NB = HD / 32;                 // 32-row output-dim blocks
+  constexpr int CH = HD / 8;                  // 16-byte chunks per key row
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) bf16_t amf_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5, ql = lane & 31;
+  bf16_t* sVt = amf_lds + (size_t)wv * HD * LV;        // this wave's V^T tile [HD][LV]
+  const int nsp = a.nsplit;
+  const int kvh = blockIdx.x / nsp, sp = blockIdx.x - kvh * nsp;
+  const int G = a.gfull;
+  const float* q_row = a.q + blockIdx.y * a.q_stride;
+  const E* kbase = static_cast<const E*>(a.k_cache) + blockIdx.y * a.kv_stride + (size_t)kvh * a.max_ctx * HD;
+  const E* vbase = static_cast<const E*>(a.v_cache) + blockIdx.y * a.kv_stride + (size_t)kvh * a.max_ctx * HD;
+  float* part_row = a.part + blockIdx.y * a.part_stride;
+  const int n_keys = a.pos[blockIdx.y] + 1;
+  const bool qvalid = ql < G;
+
+  // Q^T fragments (B operand: column = query head ql, 8 consecutive d at 16 kk + 8 hh), fp32 -> hi / lo terms
+  bf16x8 qh[KS], qlo[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) {
+    unsigned int wh[4] = {0u, 0u, 0u, 0u}, wl[4] = {0u, 0u, 0u, 0u};
+    if (qvalid) {
+      const f32x4* qp = reinterpret_cast<const f32x4*>(q_row + (size_t)(kvh * G + ql) * HD + kk * 16 + 8 * hh);
+      const f32x4 q0 = qp[0], q1 = qp[1];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        bf16_t h, l;
+        split16<DT>(j < 4 ? q0[j] : q1[j - 4], h, l);
+        if (j & 1) { wh[j >> 1] |= (unsigned int)h << 16; wl[j >> 1] |= (unsigned int)l << 16; }
+        else { wh[j >> 1] = h; wl[j >> 1] = l; }
+      }
+    }
+    qh[kk] = __builtin_bit_cast(bf16x8, u32x4{wh[0], wh[1], wh[2], wh[3]});
+    qlo[kk] = __builtin_bit_cast(bf16x8, u32x4{wl[0], wl[1], wl[2], wl[3]});
+  }
+  f32x16 oacc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) oacc[b][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float qs = a.scale * LOG2E;
+
+  const int nblk = (n_keys + 63) >> 6;
+  // register sets of one block's loads: V rows (chunk c = lane + 64 i -> key row c / CH, 16-byte column c % CH) and the K fragments
+  // (row = key 32 sub + ql, 8 d at 16 kk + 8 hh); the NEXT block's loads are issued before the current block's arithmetic
+  constexpr bool PREF = HD == 64;            // head_dim 128: a second register set spills (measured 40 -> 68 us per layer at 24k keys)
+  u32x4 vvr[CH], kfr[2][KS], vnx[PREF ? CH : 1], knx[2][PREF ? KS : 1];
+  auto load_block = [&](int blk, u32x4* vdst, u32x4 (*kdst)[KS]) {
+    const int key0 = blk * 64;
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+      const int c = lane + 64 * i, row = c / CH, kc = c - row * CH;
+      vdst[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)min(key0 + row, n_keys - 1) * HD + kc * 8);     // clamped inside the context; masked by P = 0
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      const E* krow = kbase + (size_t)min(key0 + 32 * sub + ql, n_keys - 1) * HD + 8 * hh;
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++) kdst[sub][kk] = *reinterpret_cast<const u32x4*>(krow + kk * 16);
+    }
+  };
+  const int blk0 = sp * 4 + wv, bstep = nsp * 4;
+  if (PREF && blk0 < nblk) load_block(blk0, vvr, kfr);
+  for (int blk = blk0; blk < nblk; blk += bstep) {     // wave-uniform trip count
+    const int key0 = blk * 64;
+    const bool has_next = PREF && blk + bstep < nblk;
+    if constexpr (PREF) { if (has_next) load_block(blk + bstep, vnx, knx); }
+    else load_block(blk, vvr, kfr);
+    f32x16 sacc[2];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) sacc[sub][r] = 0.f;
+      const int kb = key0 + 32 * sub;
+      if (kb < n_keys) {
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) {
+          const bf16x8 fk = __builtin_bit_cast(bf16x8, kfr[sub][kk]);
+          sacc[sub] = mfma16<DT>(fk, qlo[kk], sacc[sub]);
+          sacc[sub] = mfma16<DT>(fk, qh[kk], sacc[sub]);
+        }
+      }
+      if (kb + 32 > n_keys) {      // the context ends inside (or before) this sub-tile
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= n_keys) sacc[sub][r] = -INFINITY;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[sub][r]);
+    }
+    // V^T into the wave's LDS tile: {even key, odd key} dwords (the lane CH away holds the neighbouring key), as attn_prefill_kernel
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+      const int c = lane + 64 * i, row = c / CH, kc = c - row * CH;
+      const u32x4 vv = vvr[i];
+      u32x4 ov;
+#pragma unroll
+      for (int t = 0; t < 4; t++) ov[t] = (unsigned int)__shfl_xor((int)vv[t], CH, 64);
+      const bool odd = row & 1;
+      const int rk = row & ~1;
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const unsigned int mine = odd ? vv[2 + t] : vv[t], other = odd ? ov[2 + t] : ov[t];
+        const unsigned int ev = odd ? other : mine, od = odd ? mine : other;
+        const int d0 = kc * 8 + (odd ? 4 : 0) + 2 * t;
+        *reinterpret_cast<unsigned int*>(&sVt[d0 * LV + rk]) = (ev & 0xffffu) | (od << 16);
+        *reinterpret_cast<unsigned int*>(&sVt[(d0 + 1) * LV + rk]) = (ev >> 16) | (od & 0xffff0000u);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * qs;
+    const float m_new = fmaxf(m_run, mx);                 // finite: every block holds at least one key of the context
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float sum = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[sub][r], qs, -m_new));   // exp2(-inf) = 0 for masked keys
+        sacc[sub][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    l_run = l_run * alpha + sum;
+    m_run = m_new;
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) oacc[b][r] *= alpha;
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      if (key0 + 32 * sub >= n_keys) continue;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        unsigned int wh[4], wl[4];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          bf16_t ph, pl;
+          split16<DT>(sacc[sub][8 * s2 + j], ph, pl);
+          if (j & 1) { wh[j >> 1] |= (unsigned int)ph << 16; wl[j >> 1] |= (unsigned int)pl << 16; }
+          else { wh[j >> 1] = ph; wl[j >> 1] = pl; }
+        }
+        const bf16x8 fph = __builtin_bit_cast(bf16x8, u32x4{wh[0], wh[1], wh[2], wh[3]});
+        const bf16x8 fpl = __builtin_bit_cast(bf16x8, u32x4{wl[0], wl[1], wl[2], wl[3]});
+        const int kloc = 32 * sub + 16 * s2 + 4 * hh;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          const bf16_t* vrow = &sVt[(32 * b + ql) * LV + kloc];
+          const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
+          const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 8);
+          const bf16x8 fv = __builtin_bit_cast(bf16x8, u32x4{v0[0], v0[1], v1[0], v1[1]});
+          oacc[b] = mfma16<DT>(fv, fpl, oacc[b]);
+          oacc[b] = mfma16<DT>(fv, fph, oacc[b]);
+        }
+      }
+    }
+    if constexpr (PREF) {
+      if (has_next) {
+#pragma unroll
+        for (int i = 0; i < CH; i++) vvr[i] = vnx[i];
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+          for (int kk = 0; kk < KS; kk++) kfr[sub][kk] = knx[sub][kk];
+      }
+    }
+  }
+
+  // the four waves meet in LDS (one (o[HD], m, l) record per wave and query head), merged in wave order — the VALU kernel's step 2
+  __syncthreads();                                       // every wave is done with its V^T tile: the space is reused
+  float* red = reinterpret_cast<float*>(amf_lds);        // [4][G][HD + 4]
+  if (qvalid) {
+    float* dst = red + ((size_t)wv * G + ql) * (HD + 4);
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) dst[32 * b + (r & 3) + 8 * (r >> 2) + 4 * hh] = oacc[b][r];
+    if (hh == 0) { dst[HD] = m_run; dst[HD + 1] = l_run; }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G * HD; idx += 256) {
+    const int g = idx / HD, d = idx - g * HD;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; w++) M = fmaxf(M, red[((size_t)w * G + g) * (HD + 4) + HD]);
+    float acc = 0.f, L = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const float* rec = red + ((size_t)w * G + g) * (HD + 4);
+      const float sw = (rec[HD] == -INFINITY) ? 0.f : exp2f(rec[HD] - M);
+      acc = fmaf(rec[d], sw, acc);
+      L = fmaf(rec[HD + 1], sw, L);
+    }
+    float* out = part_row + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
+    out[d] = acc;
+    if (d == 0) { out[HD] = M; out[HD + 1] = L; }       // a split without keys publishes m = -inf, l = 0
+  }
+}
+
+}  // namespace tgx

@@ -17,6 +17,7 @@
 
 #include "../../include/tgx.h"
 #include "kernels/attn_decode.h"
+#include "kernels/attn_decode_mfma.h"
 #include "kernels/common.h"
 #include "kernels/gemv.h"
 #include "kernels/prefill.h"
@@ -178,6 +179,10 @@ struct tgx_ctx {
   int attn_direct_max = 384; // contexts up to this many keys take the one-workgroup-per-head attention (no split, no combine launch); set in tgx_create
   bool attn_direct = false;  // mode of the launches being issued / captured
   bool step_graph_direct = false;
+  // contexts from attn_mfma_min keys on take the MFMA decode attention (kernels/attn_decode_mfma.h); like the direct form it is a mode of the
+  // captured step: the graphs are re-captured when a decode call crosses the limit.  Not for Qwen3's fused q/k norm, not for fp32 storage.
+  int attn_mfma_min = 1 << 30;
+  bool attn_mfma = false, step_graph_mfma = false;
   int debug_gemv = 0;        // experiment: GemvArgs.dbg = value & 15 for the kernel classes selected by bits 8.. (1 << (8 + class))
   int debug_skip = 0;        // experiment: bit0 skip attn decode kernel, bit1 skip combine (results invalid)
   int prof_same_layer = 0;   // experiment: tgx_profile_decode replays ONE layer's weights (Infinity-Cache resident)
@@ -473,6 +478,14 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
     // ~120 / ~300 / ~430): see DESIGN.md §5; 1 head per workgroup beats 2 and 4 here (the K/V block is L2-resident, the softmax chain is not)
     const dim3 grid(a.kv_heads, R, gfull), blk(1024);
     if (!(c->debug_skip & 1)) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 16, QKN>), grid, blk, 0, c->stream, a);
+    return;
+  }
+  if (c->attn_mfma && !QKN && DT != tgx::DT_F32) {   // long context: QK^T and PV on the matrix cores, the kv group's query heads as the narrow operand
+    if constexpr (!QKN && DT != tgx::DT_F32) {
+      const dim3 gm(a.kv_heads * a.nsplit, R), bm(256);
+      hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD>), gm, bm, tgx::attn_mfma_lds_bytes<HD>(), c->stream, a);
+    }
+    if (!(c->debug_skip & 2) && !attn_fold_ok(c, R)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
     return;
   }
   const dim3 grid(a.kv_heads * a.nsplit, R, ngroups), blk(256);
@@ -1338,13 +1351,14 @@ void drop_step_graphs(tgx_ctx* c) {
 
 int ensure_step_graph(tgx_ctx* c, const tgx_sampler_cfg& cfg, bool want_multi) {
   if (!c->use_graph) return TGX_OK;
-  if (!(c->step_graph && c->step_graph_batch == c->batch && same_cfg(c->step_graph_cfg, cfg) && c->step_graph_direct == c->attn_direct)) {
+  if (!(c->step_graph && c->step_graph_batch == c->batch && same_cfg(c->step_graph_cfg, cfg) && c->step_graph_direct == c->attn_direct && c->step_graph_mfma == c->attn_mfma)) {
     drop_step_graphs(c);
     int rc = capture_steps(c, cfg, 1, &c->step_graph);
     if (rc) return rc;
     c->step_graph_batch = c->batch;
     c->step_graph_cfg = cfg;
     c->step_graph_direct = c->attn_direct;
+    c->step_graph_mfma = c->attn_mfma;
   }
   if (want_multi && !c->multi_graph && c->graph_steps > 1) return capture_steps(c, cfg, c->graph_steps, &c->multi_graph);
   return TGX_OK;
@@ -1366,6 +1380,7 @@ int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int 
   // short contexts: attention without the split / combine pair (one launch less per layer); the graphs are re-captured when a
   // call crosses the limit
   c->attn_direct = c->past + n <= c->attn_direct_max;
+  c->attn_mfma = !c->attn_direct && c->past >= c->attn_mfma_min && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
   if (decode_mfma_ok(c)) {   // the batched step's workspace must exist before the step is captured
     int rc = ensure_skinny_ws(c, std::min(32, c->batch));
     if (rc) return rc;
@@ -1672,6 +1687,8 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_PARTIAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_PARTIAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   if ((rc = skinny_set_attrs(c))) return rc;
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_lds_bytes<128>()));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_F16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_lds_bytes<128>()));
 #define TGX_DMA_ATTR1(DT_, EPI_, MI_, BK_, NS_) HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma_kernel<DT_, EPI_, MI_, BK_, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(160 * 1024, tgx::gemm_dma_lds_bytes(MI_, true, BK_, NS_))));
 #define TGX_DMA_ATTR(DT_, EPI_, MI_) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 4) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 4)
 #define TGX_DMA_ATTR_D(DT_) TGX_DMA_ATTR(DT_, tgx::GEMM_SILU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_GELU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 2)
@@ -1918,6 +1935,7 @@ int tgx_profile_decode(tgx_ctx* c, int n_reps, int64_t* launches, double* total_
   HIP_OK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < TGX_KERNEL_COUNT; i++) { launches[i] = 0; total_ms[i] = 0.0; }
   c->attn_direct = c->past + 1 <= c->attn_direct_max;
+  c->attn_mfma = !c->attn_direct && c->past >= c->attn_mfma_min && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
   // Each class is launched back-to-back over all layers (every launch streams a different layer's weights, so
   // nothing is served from the Infinity Cache) between two events on the launch stream.  The residual
   // epilogues write to a scratch vector: the model state (x, KV cache up to pastLength, token) is untouched.
@@ -1984,6 +2002,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
     c->attn_gmax = value; return TGX_OK;
   }
   if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
+  if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_tm")) { c->gemm_tm = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_dma")) { c->gemm_dma = value; return TGX_OK; }
   if (!strcmp(key, "debug.gemv")) { c->debug_gemv = value; return TGX_OK; }
