@@ -16,7 +16,10 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtgx_mi355x.so")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-         "-Wall", "-Wno-unused-function", "-DNDEBUG"]
+         "-Wall", "-Wno-unused-function", "-DNDEBUG",
+         # MFMA accumulators in the (unified) VGPR file instead of AGPRs: the softmax / epilogue arithmetic reads them without
+         # v_accvgpr_read/write copies (attention prefill: 127 of ~700 loop instructions) and most MFMA kernels need fewer registers
+         ] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("TGX_VGPR_FORM", "1") == "1" else [])
 
 
 def sources():

@@ -143,15 +143,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs a) {
     for (int j = 0; j < 2; j++) {
       const int col = n0 + wn * 64 + j * 32 + (lane & 31);
       if (EPI == GEMM_SILU) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const float v = acc[i][j][r];
-          const float other = dpp_mov<0xB1, 0xf>(v);
-          const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if ((lane & 1) || col >= a.N || row >= a.M) continue;
-          const size_t o = (size_t)row * a.inter + (size_t)(col >> 1);
-          split16<DT>((v / (1.0f + expf(-v))) * other, a.out_hi[o], a.out_lo[o]);
-        }
+        silu_block_store<DT>(acc[i][j], lane, col, m0 + wm * (32 * MI) + i * 32, a);
         continue;
       }
       if (col >= a.N) continue;
@@ -163,7 +155,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs a) {
         const float v = acc[i][j][r] + bv;
         if (EPI == GEMM_GELU) {
           const size_t o = (size_t)row * a.N + col;
-          split16<DT>(0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v))), a.out_hi[o], a.out_lo[o]);
+          split16<DT>(gelu_new_fast(v), a.out_hi[o], a.out_lo[o]);
           continue;
         }
         float* dst = a.C + (size_t)row * a.ldc + col;
@@ -178,7 +170,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs a) {
 // to land — the two-stage ring stalls on every stage and only co-resident workgroups hide it.  Here a stage (k = 32) is 48 KB
 // (A_hi | A_lo | B, 256 rows x 64 bytes each) for 32 MFMAs per wave with two waves per SIMD (~0.85 µs of matrix work per SIMD), and TWO
 // stages are in flight while the third is consumed: the waits are counted (vmcnt(6): this wave's six pieces of the NEXT stage may still
-// fly), never a drain.  A wave owns 128 x 64 of the output (4 x 2 MFMA tiles): 10 fragment reads per 16 MFMAs.
+// fly), never a drain.  A wave owns 128 x 64 of the output (4 x 2 MFMA tiles): 10 fragment reads per 16 MFMAs, double-buffered in
+// registers (see the pipeline note at the loop).
 template <int DT, int EPI>
 __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
   constexpr int DBK = 32, CPR = 4, RPP = 16, TMN = 256, NS = 3;
@@ -213,51 +206,73 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
     gsrc[3 * p] = a.A_hi + g; gsrc[3 * p + 1] = a.A_lo + g; gsrc[3 * p + 2] = a.B + brow * a.K + chunk * 8;
     ldst[3 * p] = (unsigned)(piece * 1024); ldst[3 * p + 1] = ldst[3 * p] + (unsigned)(TMN * DBK * 2); ldst[3 * p + 2] = ldst[3 * p] + (unsigned)(2 * TMN * DBK * 2);
   }
-  auto issue_piece = [&](int q, int k0, int stage) {
-    dma_1k(gsrc[q] + k0, lds_base + (unsigned)(stage * STAGE * 2) + ldst[q]);
+  const int nk = a.K / DBK;
+  const int klast = (nk - 1) * DBK;
+  // stage s (stages past the end reload the last real one into a free buffer: every wait below then counts the same six pieces)
+  auto issue_piece = [&](int q, int s) {
+    dma_1k(gsrc[q] + min(s * DBK, klast), lds_base + (unsigned)((s % NS) * STAGE * 2) + ldst[q]);
   };
-  auto issue_stage = [&](int k0, int stage) {
+  // fragment addresses: the swizzle term depends on the lane only (tile rows are 32-aligned per MFMA block)
+  const int swz = ((lane & 31) >> 2) & 3;
+  const int arow = (wm * 128 + (lane & 31)) * DBK, brow_l = (wn * 64 + (lane & 31)) * DBK;
+  // one k16 step of stage s: 4 x (A_hi, A_lo) + 2 B fragments
+  auto read_frags = [&](int s, int kk, bf16x8* fa, bf16x8* fb) {
+    const bf16_t* st = dma_lds + (size_t)(s % NS) * STAGE;
+    const int ko = ((kk * 2 + (lane >> 5)) ^ swz) << 3;
 #pragma unroll
-    for (int q = 0; q < 6; q++) issue_piece(q, k0, stage);
-  };
-  auto frag = [&](const bf16_t* tile, int row, int kchunk) -> bf16x8 {
-    return *reinterpret_cast<const bf16x8*>(tile + row * DBK + ((kchunk ^ ((row >> 2) & 3)) << 3));
+    for (int j = 0; j < 2; j++) fb[j] = *reinterpret_cast<const bf16x8*>(st + 2 * TMN * DBK + brow_l + j * 32 * DBK + ko);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      fa[2 * i] = *reinterpret_cast<const bf16x8*>(st + arow + i * 32 * DBK + ko);
+      fa[2 * i + 1] = *reinterpret_cast<const bf16x8*>(st + TMN * DBK + arow + i * 32 * DBK + ko);
+    }
   };
 
-  const int nk = a.K / DBK;
-  issue_stage(0, 0);
-  if (nk > 1) issue_stage(DBK, 1);
+  // Software pipeline (one barrier per K step): the fragments of the NEXT k16 step are read into a second register set while the MFMAs of
+  // the current one run, also across the stage boundary — so the barrier that opens stage k+1 sits between the two k16 steps of stage k:
+  //   step k:   read F1 <- (k, kk 1) | MFMA(F0) + DMA pieces 3..5 of stage k+2 | wait: stage k+1 landed, own reads of stage k done | barrier
+  //             read F0 <- (k+1, kk 0) | MFMA(F1) + DMA pieces 0..2 of stage k+3 (into the buffer stage k just left)
+  // Without it both waves of a SIMD read, wait and multiply in lockstep after every barrier (LDS burst, then matrix burst): 4600 cycles per
+  // step against 2048 of MFMA work.
+#pragma unroll
+  for (int q = 0; q < 6; q++) issue_piece(q, 0);
+#pragma unroll
+  for (int q = 0; q < 6; q++) issue_piece(q, 1);
+#pragma unroll
+  for (int q = 0; q < 3; q++) issue_piece(q, 2);
+  bf16x8 fa0[8], fb0[2], fa1[8], fb1[2];
+  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // stage 0 landed (this wave's pieces); stage 1 and half of stage 2 may fly
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, 0, fa0, fb0);
   for (int k = 0; k < nk; k++) {
-    // stage k has landed for this wave once at most the six pieces of stage k+1 are outstanding (LDS-DMA completes in order)
-    if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                         // ... for every wave; and every wave is done reading stage k-1
-    const bool more = k + 2 < nk;                         // stage k+2 goes into the buffer stage k-1 occupied
-    const int nk0 = (k + 2) * DBK, nst = (k + 2) % NS;
-    const bf16_t* st = dma_lds + (size_t)(k % NS) * STAGE;
-    const bf16_t *tAh = st, *tAl = st + TMN * DBK, *tB = st + 2 * TMN * DBK;
+    read_frags(k, 1, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);                        // the reads leave first: the scheduler would sink them next to their uses
 #pragma unroll
-    for (int kk = 0; kk < DBK / 16; kk++) {
-      const int kchunk = kk * 2 + (lane >> 5);
-      bf16x8 fah[4], fal[4], fb[2];
+    for (int i = 0; i < 4; i++) {
 #pragma unroll
-      for (int j = 0; j < 2; j++) fb[j] = frag(tB, wn * 64 + j * 32 + (lane & 31), kchunk);
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int row = wm * 128 + i * 32 + (lane & 31);
-        fah[i] = frag(tAh, row, kchunk);
-        fal[i] = frag(tAl, row, kchunk);
+      for (int j = 0; j < 2; j++) {
+        acc[i][j] = mfma16<DT>(fa0[2 * i + 1], fb0[j], acc[i][j]);   // small term first
+        acc[i][j] = mfma16<DT>(fa0[2 * i], fb0[j], acc[i][j]);
       }
+      if (i < 3) issue_piece(3 + i, k + 2);                           // one DMA per four MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // stage k+1 landed; this wave's reads of stage k are complete
+    __builtin_amdgcn_s_barrier();                             // ... for every wave: the buffer of stage k is free
+    read_frags(k + 1, 0, fa0, fb0);                           // (after the last step: a harmless read of a reloaded stage)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 4; i++) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-          acc[i][j] = mfma16<DT>(fal[i], fb[j], acc[i][j]);   // small term first
-          acc[i][j] = mfma16<DT>(fah[i], fb[j], acc[i][j]);
-        }
-        if (more && (kk * 4 + i) < 6) issue_piece(kk * 4 + i, nk0, nst);      // one DMA per four MFMAs
+      for (int j = 0; j < 2; j++) {
+        acc[i][j] = mfma16<DT>(fa1[2 * i + 1], fb1[j], acc[i][j]);
+        acc[i][j] = mfma16<DT>(fa1[2 * i], fb1[j], acc[i][j]);
       }
+      if (i < 3) issue_piece(i, k + 3);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no DMA may land in this CU's LDS after the workgroup has gone
 
 #pragma unroll
   for (int i = 0; i < 4; i++)
@@ -265,15 +280,7 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
     for (int j = 0; j < 2; j++) {
       const int col = n0 + wn * 64 + j * 32 + (lane & 31);
       if (EPI == GEMM_SILU) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const float v = acc[i][j][r];
-          const float other = dpp_mov<0xB1, 0xf>(v);
-          const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if ((lane & 1) || col >= a.N || row >= a.M) continue;
-          const size_t o = (size_t)row * a.inter + (size_t)(col >> 1);
-          split16<DT>((v / (1.0f + expf(-v))) * other, a.out_hi[o], a.out_lo[o]);
-        }
+        silu_block_store<DT>(acc[i][j], lane, col, m0 + wm * 128 + i * 32, a);
         continue;
       }
       if (col >= a.N) continue;
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
         const float v = acc[i][j][r] + bv;
         if (EPI == GEMM_GELU) {
           const size_t o = (size_t)row * a.N + col;
-          split16<DT>(0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v))), a.out_hi[o], a.out_lo[o]);
+          split16<DT>(gelu_new_fast(v), a.out_hi[o], a.out_lo[o]);
           continue;
         }
         float* dst = a.C + (size_t)row * a.ldc + col;

@@ -40,6 +40,17 @@ __device__ __forceinline__ void split16(float x, bf16_t& hi, bf16_t& lo) {
   lo = f32_to_elem<DT>(x - elem_to_f32<DT>(hi));
 }
 
+// silu(g) * u and gelu_new(v) = v * sigmoid(2 y) with the hardware exp2 / rcp (1 ulp each, ~2e-7 relative).  The MFMA prefill epilogues run them
+// for every output element — with expf + an IEEE division (~35 instructions) the epilogue of a 256 x 256 tile issued as many instructions as
+// its whole K loop; the value is rounded to two 16-bit terms (2^-17) right after.
+__device__ __forceinline__ float silu_mul_fast(float g, float u) {
+  return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g)) * u;
+}
+__device__ __forceinline__ float gelu_new_fast(float v) {
+  const float y = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * y));     // 0.5 v (1 + tanh y) = v / (1 + e^(-2y))
+}
+
 // ---- X[s][:] = embed[ids[s]] (fp32) ------------------------------------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(256) void embed_rows_kernel(const long long* ids, const bf16_t* embed, float* X, int H, int S, long long ids_stride) {
@@ -158,6 +169,26 @@ struct GemmArgs {
   int three_from;
 };
 
+// GEMM_SILU epilogue of one 32 x 32 accumulator block (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)): even lanes hold
+// gate_i, odd lanes up_i (column parity).  The lane pair shares the block's 16 registers: the even lane finishes r = 0, 2, ..., the odd lane
+// r + 1 (one DPP exchange per register pair), so every lane computes and stores a result.  row_base = the block's first row.
+template <int DT>
+__device__ __forceinline__ void silu_block_store(const f32x16& acc, int lane, int col, int row_base, const GemmArgs& a) {
+  const bool odd = lane & 1;
+  const bool col_ok = col < a.N;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const float a0 = acc[r], a1 = acc[r + 1];
+    const float recv = dpp_mov<0xB1, 0xf>(odd ? a0 : a1);        // quad_perm [1,0,3,2]: what the neighbour lane needs from this one
+    const float g = odd ? recv : a0, u = odd ? a1 : recv;
+    const int row = row_base + (r & 3) + (odd ? 1 : 0) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (col_ok && row < a.M) {
+      const size_t o = (size_t)row * a.inter + (size_t)(col >> 1);
+      split16<DT>(silu_mul_fast(g, u), a.out_hi[o], a.out_lo[o]);
+    }
+  }
+}
+
 constexpr int GBM = 128, GBN = 128, GBK = 64, GLD = GBK + 8;
 
 // MI = 32-row blocks per wave along M: 2 -> the 128x128 tile; 1 -> a 64x128 tile for the products with few column tiles
@@ -259,16 +290,8 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-      if (EPI == GEMM_SILU) {      // even lanes hold gate_i, odd lanes up_i (i = col / 2): the pair meets over the DPP crossbar
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const float v = acc[i][j][r];
-          const float other = dpp_mov<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]: the neighbour lane's value
-          const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if ((lane & 1) || col >= a.N || row >= a.M) continue;
-          const size_t o = (size_t)row * a.inter + (size_t)(col >> 1);
-          split16<DT>((v / (1.0f + expf(-v))) * other, a.out_hi[o], a.out_lo[o]);
-        }
+      if (EPI == GEMM_SILU) {
+        silu_block_store<DT>(acc[i][j], lane, col, m0 + wm * (32 * MI) + i * 32, a);
         continue;
       }
       if (col >= a.N) continue;
@@ -287,9 +310,8 @@ __global__ __launch_bounds__(256) void gemm_x2_kernel(const GemmArgs a) {
         if (row >= a.M) continue;
         const float v = acc[i][j][r] + bv;
         if (EPI == GEMM_GELU) {
-          const float x = v;
           const size_t o = (size_t)row * a.N + col;
-          split16<DT>(0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))), a.out_hi[o], a.out_lo[o]);
+          split16<DT>(gelu_new_fast(v), a.out_hi[o], a.out_lo[o]);
           continue;
         }
         float* dst = a.C + (size_t)row * a.ldc + col;
@@ -345,8 +367,12 @@ struct AttnPrefillArgs {
 // plus one exchange with lane^32, the running maximum / sum / rescale are per-lane scalars, and the probabilities are already
 // in the B-operand order of the next MFMA: O^T += V^T.P^T, where the V^T fragment is read in the SAME key permutation
 // (keys 4hh..4hh+3 and 8+4hh..8+4hh+3 of every 16: two 8-byte LDS reads).  Q (hi, lo) lives in registers for the whole kernel.
+#ifndef TGX_ATTN_DIS
+#define TGX_ATTN_DIS 0      // experiments only (tools/probes/attn_prefill_probe.hip): 1 no LDS staging, 2 no softmax arithmetic, 4 no PV, 8 no QK^T, 16 no tile fetch
+#endif
 template <int DT, int HD>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs a) {
+  constexpr int DIS = TGX_ATTN_DIS;
   constexpr int LQ = HD + 8;                  // 16-bit row stride of the K tile (144 / 272 B: conflict-free 16-byte fragment reads)
   constexpr int LV = 64 + 4;                  // 16-bit row stride of the V^T tile (136 B: 34 dwords, odd/2 -> the 32 rows of a fragment read hit 64 distinct banks)
   constexpr int KS = HD / 16;                 // MFMA k-steps over the head dimension
@@ -354,8 +380,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
   constexpr int CH = HD / 8;                  // 16-byte chunks per head row
   constexpr int NCH = 64 * CH / 256;          // chunks per thread and tile
   constexpr float LOG2E = 1.4426950408889634f;
-  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * LQ];
-  __shared__ __attribute__((aligned(16))) bf16_t sVt[HD * LV];
+  __shared__ __attribute__((aligned(16))) bf16_t smem[64 * LQ + HD * LV];     // K tile | V^T tile; the output rows pass through it at the end
+  bf16_t* const sK = smem;
+  bf16_t* const sVt = smem + 64 * LQ;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5, ql = lane & 31;
   const int h = blockIdx.y, G = a.heads / a.kv_heads, kvh = h / G;
@@ -395,27 +422,26 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
   const bool wave_live = q0 < a.S;
   const float qs = a.scale * LOG2E;
 
-  u32x4 kvr[NCH], vvr[NCH];
-  auto fetch_tile = [&](int kt) {
+  // K / V tiles travel global -> registers -> LDS, TWO tiles ahead of the one being multiplied (two register sets, static roles): with one
+  // tile of look-ahead a workgroup's tile time was the load latency itself (~2.4 µs per tile, MfmaUtil 16 %) whatever the arithmetic cost.
+  // Keys past the workgroup's range are clamped to its last key (a written cache row: finite values, masked by index below).
+  u32x4 kvA[NCH], vvA[NCH], kvB[NCH], vvB[NCH];
+  auto fetch_tile = [&](int kt, u32x4* kr, u32x4* vr) {
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
       const int c = tid + 256 * i, row = c / CH, kc = c - row * CH;
-      const int key = kt * 64 + row;
-      kvr[i] = u32x4{0u, 0u, 0u, 0u}; vvr[i] = kvr[i];
-      if (key <= wg_last_pos) {
-        kvr[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * HD + kc * 8);
-        vvr[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * HD + kc * 8);
-      }
+      const int key = min(kt * 64 + row, wg_last_pos);
+      kr[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * HD + kc * 8);
+      __builtin_amdgcn_sched_barrier(0);       // the same issue order at every call site: the counted vmcnt waits rely on it
+      vr[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * HD + kc * 8);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
-  fetch_tile(0);
-  for (int kt = 0; kt < n_kt; kt++) {
-    const int key0 = kt * 64;
-    __syncthreads();                           // the previous tile is consumed by every wave
+  auto stage_tile = [&](const u32x4* kr, const u32x4* vr) {
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
       const int c = tid + 256 * i, row = c / CH, kc = c - row * CH;
-      const u32x4 kv = kvr[i], vv = vvr[i];
+      const u32x4 kv = kr[i], vv = vr[i];
       *reinterpret_cast<u32x4*>(&sK[row * LQ + kc * 8]) = kv;
       u32x4 ov;                                // the lane CH away holds the neighbouring key: write {even key, odd key} dwords
 #pragma unroll
@@ -431,9 +457,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
         *reinterpret_cast<unsigned int*>(&sVt[(d0 + 1) * LV + rk]) = (ev >> 16) | (od & 0xffff0000u);
       }
     }
-    __syncthreads();
-    if (kt + 1 < n_kt) fetch_tile(kt + 1);     // in flight during this tile's MFMAs
-    if (!wave_live || key0 > wave_last_pos) continue;    // wave-uniform: nothing of this tile is visible to the wave's queries
+  };
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; r++) zero16[r] = 0.f;
+
+  auto compute_tile = [&](int kt) {
+    const int key0 = kt * 64;
+    if (!wave_live || key0 > wave_last_pos) return;      // wave-uniform: nothing of this tile is visible to the wave's queries
 
     // S^T sub-tiles: sacc[sub][r] = raw score (q.k) of key key0 + 32 sub + (r&3) + 8 (r>>2) + 4 hh for this lane's query
     f32x16 sacc[2];
@@ -441,16 +472,15 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
     const bool diag = key0 + 63 > a.past + q0;           // wave-uniform: some (key, query) pair of this tile needs the causal mask
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) sacc[sub][r] = 0.f;
       const int kb = key0 + 32 * sub;
-      if (kb <= wave_last_pos) {
+      // both sub-tiles always (keys past the workgroup's range are zero rows in LDS and masked below): a skip for the half-masked diagonal
+      // tile costs register copies at the join on every tile
+      if (DIS & 8) sacc[sub] = zero16;
 #pragma unroll
-        for (int kk = 0; kk < KS; kk++) {
-          const bf16x8 fk = *reinterpret_cast<const bf16x8*>(&sK[(32 * sub + ql) * LQ + kk * 16 + 8 * hh]);
-          sacc[sub] = mfma16<DT>(fk, qlo[kk], sacc[sub]);
-          sacc[sub] = mfma16<DT>(fk, qh[kk], sacc[sub]);
-        }
+      for (int kk = 0; kk < ((DIS & 8) ? 0 : KS); kk++) {
+        const bf16x8 fk = *reinterpret_cast<const bf16x8*>(&sK[(32 * sub + ql) * LQ + kk * 16 + 8 * hh]);
+        sacc[sub] = mfma16<DT>(fk, qlo[kk], kk == 0 ? zero16 : sacc[sub]);      // the chain starts from the constant 0: no register clearing
+        sacc[sub] = mfma16<DT>(fk, qh[kk], sacc[sub]);
       }
       if (diag || !qvalid || kb > wave_last_pos) {
 #pragma unroll
@@ -462,6 +492,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
 #pragma unroll
       for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[sub][r]);
     }
+    if (DIS & 2) {                                        // experiment: scores go to PV as they are
+      l_run += 1.f;
+    } else {
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * qs;          // qs > 0: scaling commutes with the maximum
     const float m_new = fmaxf(m_run, mx);
     const bool dead = m_new == -INFINITY;               // padded query: nothing attended yet
@@ -479,24 +512,35 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
     sum += __shfl_xor(sum, 32, 64);
     l_run = l_run * alpha + sum;
     m_run = m_new;
+    if (__any(alpha != 1.f)) {                   // the running maximum settles after the first tiles: most steps leave O as it is
 #pragma unroll
-    for (int b = 0; b < NB; b++)
+      for (int b = 0; b < NB; b++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) oacc[b][r] *= alpha;
+        for (int r = 0; r < 16; r++) oacc[b][r] *= alpha;
+    }
 
+    }
     // O^T += V^T . P^T over the four 16-key steps of the tile; B-operand element j of step s is register 8 s' + j of its sub-tile
 #pragma unroll
-    for (int sub = 0; sub < 2; sub++) {
-      if (key0 + 32 * sub > wave_last_pos) continue;
+    for (int sub = 0; sub < ((DIS & 4) ? 0 : 2); sub++) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; s2++) {
         unsigned int wh[4], wl[4];
+        if constexpr (DT == DT_BF16) {          // pairs: one packed convert per term, the residual from the packed hi word itself
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          bf16_t ph, pl;
-          split16<DT>(sacc[sub][8 * s2 + j], ph, pl);
-          if (j & 1) { wh[j >> 1] |= (unsigned int)ph << 16; wl[j >> 1] |= (unsigned int)pl << 16; }
-          else { wh[j >> 1] = ph; wl[j >> 1] = pl; }
+          for (int j = 0; j < 4; j++) {
+            const float p0 = sacc[sub][8 * s2 + 2 * j], p1 = sacc[sub][8 * s2 + 2 * j + 1];
+            wh[j] = pack_bf16(p0, p1);
+            wl[j] = pack_bf16(p0 - bf16_lo(wh[j]), p1 - bf16_hi(wh[j]));
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            bf16_t ph, pl;
+            split16<DT>(sacc[sub][8 * s2 + j], ph, pl);
+            if (j & 1) { wh[j >> 1] |= (unsigned int)ph << 16; wl[j >> 1] |= (unsigned int)pl << 16; }
+            else { wh[j >> 1] = ph; wl[j >> 1] = pl; }
+          }
         }
         const bf16x8 fph = __builtin_bit_cast(bf16x8, u32x4{wh[0], wh[1], wh[2], wh[3]});
         const bf16x8 fpl = __builtin_bit_cast(bf16x8, u32x4{wl[0], wl[1], wl[2], wl[3]});
@@ -512,19 +556,66 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
         }
       }
     }
+  };
+
+  __builtin_amdgcn_sched_barrier(0);           // the loop's counted waits assume the issue order: set A, then set B (older loads retire first)
+  fetch_tile(0, kvA, vvA);
+  __builtin_amdgcn_sched_barrier(0);
+  fetch_tile(1, kvB, vvB);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 0; kt < n_kt; kt += 2) {
+    __syncthreads();                           // the previous tile is consumed by every wave
+    if (!(DIS & 1)) stage_tile(kvA, vvA);
+    __syncthreads();
+    if (!(DIS & 16)) fetch_tile(kt + 2, kvA, vvA);              // in flight during two tiles of MFMAs
+    compute_tile(kt);
+    // no early exit for an odd tile count: a break here gives the loop a second back edge on which set A is the youngest, and every wait
+    // above becomes a drain; the extra tile is a clamped reload that compute_tile skips (key0 > wave_last_pos)
+    __syncthreads();
+    if (!(DIS & 1)) stage_tile(kvB, vvB);
+    __syncthreads();
+    if (!(DIS & 16)) fetch_tile(kt + 3, kvB, vvB);
+    compute_tile(kt + 1);
   }
 
-  // normalise and emit as hi / lo 16-bit pairs (the o_proj GEMM's A operand): lane = query, registers = output dims
-  if (qvalid) {
+  // normalise and emit as hi / lo 16-bit pairs (the o_proj GEMM's A operand).  A lane holds ONE query's output dims, so direct stores would be
+  // 2-byte writes 4 KB apart (64 cache lines per instruction: ~20 µs of the kernel at S = 2048); instead each wave transposes its 32 x HD block
+  // through LDS (rows of 2 HD + 8 bytes: conflict-free 4-byte column writes) and stores whole rows, 16 bytes per lane.
+  __syncthreads();                              // every wave is done with the last K / V tile
+  constexpr int RS = HD + 4;                    // staged row stride in 16-bit elements
+  static_assert(4 * 32 * RS <= 64 * LQ + HD * LV, "output staging exceeds the K / V tiles");
+  bf16_t* const wrow = smem + wv * 32 * RS;
+  const float inv_l = qvalid ? 1.0f / l_run : 0.f;
+  unsigned int whi[NB * 8], wlo[NB * 8];
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float v0 = oacc[b][r] * inv_l, v1 = oacc[b][r + 1] * inv_l;
+      bf16_t h0, l0, h1, l1;
+      split16<DT>(v0, h0, l0);
+      split16<DT>(v1, h1, l1);
+      whi[b * 8 + (r >> 1)] = (unsigned int)h0 | ((unsigned int)h1 << 16);
+      wlo[b * 8 + (r >> 1)] = (unsigned int)l0 | ((unsigned int)l1 << 16);
+    }
+#pragma unroll
+  for (int term = 0; term < 2; term++) {
 #pragma unroll
     for (int b = 0; b < NB; b++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int d = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const float v = oacc[b][r] / l_run;
-        const size_t o = (size_t)qi * qd + (size_t)h * HD + d;
-        split16<DT>(v, a.o_hi[o], a.o_lo[o]);
+      for (int r = 0; r < 16; r += 2) {
+        const int d = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * hh;                 // dims d, d + 1
+        *reinterpret_cast<unsigned int*>(wrow + ql * RS + d) = term ? wlo[b * 8 + (r >> 1)] : whi[b * 8 + (r >> 1)];
       }
+    bf16_t* const dst = term ? a.o_lo : a.o_hi;
+#pragma unroll
+    for (int i = 0; i < HD / 16; i++) {          // 32 rows x HD / 8 chunks of 16 bytes over 64 lanes
+      const int c = lane + 64 * i, row = c / CH, cc = c - row * CH;
+      const u32x2 p0 = *reinterpret_cast<const u32x2*>(wrow + row * RS + cc * 8);
+      const u32x2 p1 = *reinterpret_cast<const u32x2*>(wrow + row * RS + cc * 8 + 4);
+      if (q0 + row < a.S)
+        *reinterpret_cast<u32x4*>(dst + (size_t)(q0 + row) * qd + (size_t)h * HD + cc * 8) = u32x4{p0[0], p0[1], p1[0], p1[1]};
+    }
   }
 }
 

@@ -1,0 +1,10 @@
+set -x
+R=$PWD; O=gpurun_out/r02y; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+for m in llama-3.2-1b llama-3.2-3b qwen2.5-0.5b qwen3-1.7b; do
+rocprofv3 --kernel-trace --stats -d $R/$O/prof_$m -o p -- python $R/tools/prefill_bench.py --model $m --seq 2048 --reps 3 > $R/$O/prof_$m.log 2>&1
+tail -1 $R/$O/prof_$m.log
+python $R/tools/rocpd_stats.py $(find $R/$O/prof_$m -name "*.db" | head -1) 2>&1 | head -7 | cut -c1-170 > $R/$O/sum_$m.txt
+cat $R/$O/sum_$m.txt
+rm -rf $R/$O/prof_$m
+done
