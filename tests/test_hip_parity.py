@@ -191,7 +191,10 @@ def test_batches_beyond_four_rows_run_on_the_matrix_cores(family, dtype, rows, h
         for layer in (0, 1):
             for g_, r_ in zip(gpu.read_kv(row, layer), ref.read_kv(row, layer)):
                 tol = (1 if layer == 0 or dtype == "bf16" else 4) * ulp
-                bad = np.abs(g_ - r_) > tol * (np.abs(r_) + floor * np.abs(r_).max())
+                # one ulp of the LARGER of the two (a flip across a power of two is one ulp of the upper binade).  Layer 1's inputs differ by
+                # layer 0's flips, an ABSOLUTE difference of ~1e-4 of the largest entry: entries near zero get the wider floor there
+                fl = floor if layer == 0 else max(floor, 2e-2)
+                bad = np.abs(g_ - r_) > tol * (np.maximum(np.abs(g_), np.abs(r_)) + fl * np.abs(r_).max())
                 assert not bad.any(), (row, layer, int(bad.sum()), float(np.abs(g_ - r_).max()))
     # a free-running multi-step graph replay (8-step graphs + single steps) stays consistent with single-step replays of the same path
     gpu.reset_cache(); gpu.forward(ids); t0 = gpu.sample(GREEDY).copy(); a = gpu.decode(11, GREEDY).copy()

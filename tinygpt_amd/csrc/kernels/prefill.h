@@ -71,18 +71,58 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const long long* ids, c
 // per cent of the cache entries round differently from the single-position path, with three the schedules agree.
 template <int DT>
 __global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* X, const bf16_t* w, float eps, int H, bf16_t* hi, bf16_t* lo, bf16_t* lo2) {
+  // one workgroup per row; a thread owns 8-element slices (two 16-byte loads, one 16-byte store per term), kept in registers between the
+  // sum of squares and the scaling for rows up to 8192 elements (H % 8 == 0: checked by the caller)
   __shared__ float sc[4];
+  constexpr int NV = 4;
   const float* x = X + (size_t)blockIdx.x * H;
+  const int nch = H >> 3;
+  f32x4 xr[NV][2];
   float ss = 0.f;
-  for (int i = threadIdx.x; i < H; i += 256) ss = fmaf(x[i], x[i], ss);
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const int c = threadIdx.x + 256 * j;
+    xr[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; xr[j][1] = xr[j][0];
+    if (c < nch) { xr[j][0] = *reinterpret_cast<const f32x4*>(x + 8 * c); xr[j][1] = *reinterpret_cast<const f32x4*>(x + 8 * c + 4); }
+#pragma unroll
+    for (int t = 0; t < 4; t++) { ss = fmaf(xr[j][0][t], xr[j][0][t], ss); ss = fmaf(xr[j][1][t], xr[j][1][t], ss); }
+  }
+  for (int c = threadIdx.x + 256 * NV; c < nch; c += 256) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + 8 * c), v1 = *reinterpret_cast<const f32x4*>(x + 8 * c + 4);
+#pragma unroll
+    for (int t = 0; t < 4; t++) { ss = fmaf(v0[t], v0[t], ss); ss = fmaf(v1[t], v1[t], ss); }
+  }
   ss = block_sum_256(ss, sc);
   const float inv = 1.0f / sqrtf(ss / (float)H + eps);
-  for (int i = threadIdx.x; i < H; i += 256) {
-    const float y = elem_to_f32<DT>(w[i]) * (x[i] * inv);
-    const size_t o = (size_t)blockIdx.x * H + i;
-    split16<DT>(y, hi[o], lo[o]);
-    if (lo2) lo2[o] = f32_to_elem<DT>(y - elem_to_f32<DT>(hi[o]) - elem_to_f32<DT>(lo[o]));
+  auto emit = [&](int c, const f32x4& v0, const f32x4& v1) {
+    const u32x4 wv = *reinterpret_cast<const u32x4*>(w + 8 * c);
+    unsigned int h[4], l[4], l2[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const float xa = t < 2 ? v0[2 * t] : v1[2 * t - 4], xb = t < 2 ? v0[2 * t + 1] : v1[2 * t - 3];
+      const float ya = pair_lo<DT>(wv[t]) * (xa * inv), yb = pair_hi<DT>(wv[t]) * (xb * inv);
+      bf16_t ha, la, hb, lb;
+      split16<DT>(ya, ha, la);
+      split16<DT>(yb, hb, lb);
+      h[t] = (unsigned int)ha | ((unsigned int)hb << 16);
+      l[t] = (unsigned int)la | ((unsigned int)lb << 16);
+      if (lo2) {
+        const bf16_t ta = f32_to_elem<DT>(ya - elem_to_f32<DT>(ha) - elem_to_f32<DT>(la)), tb = f32_to_elem<DT>(yb - elem_to_f32<DT>(hb) - elem_to_f32<DT>(lb));
+        l2[t] = (unsigned int)ta | ((unsigned int)tb << 16);
+      }
+    }
+    const size_t o = (size_t)blockIdx.x * H + 8 * c;
+    *reinterpret_cast<u32x4*>(hi + o) = u32x4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u32x4*>(lo + o) = u32x4{l[0], l[1], l[2], l[3]};
+    if (lo2) *reinterpret_cast<u32x4*>(lo2 + o) = u32x4{l2[0], l2[1], l2[2], l2[3]};
+  };
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const int c = threadIdx.x + 256 * j;
+    if (c < nch) emit(c, xr[j][0], xr[j][1]);
   }
+  for (int c = threadIdx.x + 256 * NV; c < nch; c += 256)
+    emit(c, *reinterpret_cast<const f32x4*>(x + 8 * c), *reinterpret_cast<const f32x4*>(x + 8 * c + 4));
 }
 
 // ---- split -> RoPE(q), RoPE(k) at pastLength+s -> cache append; q as bf16 hi/lo ------------------------------------
@@ -97,37 +137,53 @@ struct RopeKvArgs {
 };
 template <int DT>
 __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) {
-  const int s = blockIdx.x, pos = a.past + s, half = a.hd >> 1;
+  // one workgroup per position; a thread owns FOUR adjacent RoPE pairs (p..p+3, p+half..p+half+3) of one head: 16-byte loads, 8-byte stores
+  const int s = blockIdx.x, pos = a.past + s, half = a.hd >> 1, q4 = half >> 2;
   const int qd = a.heads * a.hd, kvd = a.kv_heads * a.hd;
   const float* row = a.QKV + (size_t)s * (qd + 2 * kvd);
-  const int pairs = (a.heads + 2 * a.kv_heads) * half;
-  for (int u = threadIdx.x; u < pairs; u += 256) {
-    const int hh = u / half, p = u - hh * half;
-    float x0 = row[hh * a.hd + p], x1 = row[hh * a.hd + p + half];
+  const int units = (a.heads + 2 * a.kv_heads) * q4;
+  auto pack4 = [](const bf16_t* e) { return u32x2{(unsigned int)e[0] | ((unsigned int)e[1] << 16), (unsigned int)e[2] | ((unsigned int)e[3] << 16)}; };
+  for (int u = threadIdx.x; u < units; u += 256) {
+    const int hh = u / q4, p = 4 * (u - hh * q4);
+    f32x4 x0 = *reinterpret_cast<const f32x4*>(row + hh * a.hd + p), x1 = *reinterpret_cast<const f32x4*>(row + hh * a.hd + p + half);
     if (a.q_norm_w != nullptr && hh < a.heads + a.kv_heads) {
-      // AttentionWithQKNorm (Attention.h:156-163): RMSNorm over head_dim; the hd/2 lanes of one head are adjacent and
-      // aligned (hd/2 = 32 or 64), so the mean of squares is a sub-wave butterfly
-      float ss = x0 * x0 + x1 * x1;
-      for (int o = half >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      // AttentionWithQKNorm (Attention.h:156-163): RMSNorm over head_dim; the hd/8 lanes of one head are adjacent and
+      // aligned (8 or 16), so the mean of squares is a sub-wave butterfly
+      float ss = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; t++) ss += x0[t] * x0[t] + x1[t] * x1[t];
+      for (int o = q4 >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
       const float inv = 1.0f / sqrtf(ss / (float)a.hd + a.eps);
       const bf16_t* w = hh < a.heads ? a.q_norm_w : a.k_norm_w;
-      x0 = elem_to_f32<DT>(w[p]) * (x0 * inv);
-      x1 = elem_to_f32<DT>(w[p + half]) * (x1 * inv);
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        x0[t] = elem_to_f32<DT>(w[p + t]) * (x0[t] * inv);
+        x1[t] = elem_to_f32<DT>(w[p + t + half]) * (x1[t] * inv);
+      }
     }
     if (hh < a.heads + a.kv_heads) {
-      const float cs = a.rope_cos[(size_t)pos * half + p], sn = a.rope_sin[(size_t)pos * half + p];
-      const float r0 = x0 * cs - x1 * sn, r1 = x1 * cs + x0 * sn;
-      x0 = r0; x1 = r1;
+      const f32x4 cs = *reinterpret_cast<const f32x4*>(a.rope_cos + (size_t)pos * half + p), sn = *reinterpret_cast<const f32x4*>(a.rope_sin + (size_t)pos * half + p);
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const float r0 = x0[t] * cs[t] - x1[t] * sn[t], r1 = x1[t] * cs[t] + x0[t] * sn[t];
+        x0[t] = r0; x1[t] = r1;
+      }
     }
     if (hh < a.heads) {
+      bf16_t h0[4], l0[4], h1[4], l1[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) { split16<DT>(x0[t], h0[t], l0[t]); split16<DT>(x1[t], h1[t], l1[t]); }
       const size_t o = (size_t)s * qd + hh * a.hd + p;
-      split16<DT>(x0, a.q_hi[o], a.q_lo[o]);
-      split16<DT>(x1, a.q_hi[o + half], a.q_lo[o + half]);
+      *reinterpret_cast<u32x2*>(a.q_hi + o) = pack4(h0); *reinterpret_cast<u32x2*>(a.q_lo + o) = pack4(l0);
+      *reinterpret_cast<u32x2*>(a.q_hi + o + half) = pack4(h1); *reinterpret_cast<u32x2*>(a.q_lo + o + half) = pack4(l1);
     } else {
       bf16_t* dst = (hh < a.heads + a.kv_heads) ? a.k_cache + ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd
                                                 : a.v_cache + ((size_t)(hh - a.heads - a.kv_heads) * a.max_ctx + pos) * a.hd;
-      dst[p] = f32_to_elem<DT>(x0);
-      dst[p + half] = f32_to_elem<DT>(x1);
+      bf16_t e0[4], e1[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) { e0[t] = f32_to_elem<DT>(x0[t]); e1[t] = f32_to_elem<DT>(x1[t]); }
+      *reinterpret_cast<u32x2*>(dst + p) = pack4(e0);
+      *reinterpret_cast<u32x2*>(dst + p + half) = pack4(e1);
     }
   }
 }
