@@ -499,14 +499,16 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
       const int c = tid + 256 * i, row = c / CH, kc = c - row * CH;
       const u32x4 kv = kr[i], vv = vr[i];
       *reinterpret_cast<u32x4*>(&sK[row * LQ + kc * 8]) = kv;
-      u32x4 ov;                                // the lane CH away holds the neighbouring key: write {even key, odd key} dwords
-#pragma unroll
-      for (int t = 0; t < 4; t++) ov[t] = (unsigned int)__shfl_xor((int)vv[t], CH, 64);
+      // the lane CH away holds the neighbouring key: each lane keeps half of its own row and receives the matching half of the
+      // neighbour's, then writes {even key, odd key} dwords.  CH == 8: lane ^ 8 is a rotation by 8 inside the DPP row — no LDS trip
       const bool odd = row & 1;
       const int rk = row & ~1;
 #pragma unroll
       for (int t = 0; t < 2; t++) {
-        const unsigned int mine = odd ? vv[2 + t] : vv[t], other = odd ? ov[2 + t] : ov[t];
+        const unsigned int mine = odd ? vv[2 + t] : vv[t], send = odd ? vv[t] : vv[2 + t];
+        unsigned int other;
+        if constexpr (CH == 8) other = (unsigned int)__builtin_amdgcn_update_dpp((int)send, (int)send, 0x128 /* row_ror:8 */, 0xf, 0xf, true);
+        else other = (unsigned int)__shfl_xor((int)send, CH, 64);
         const unsigned int ev = odd ? other : mine, od = odd ? mine : other;
         const int d0 = kc * 8 + (odd ? 4 : 0) + 2 * t;
         *reinterpret_cast<unsigned int*>(&sVt[d0 * LV + rk]) = (ev & 0xffffu) | (od << 16);

@@ -1,11 +1,6 @@
 set -x
 R=$PWD; O=gpurun_out/r02z; mkdir -p $O
-python -m pytest tests/test_hip_prefill.py tests/test_hip_parity.py -m gpu -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
-cd /tmp && export TMPDIR=/tmp
-for m in llama-3.2-1b qwen3-1.7b; do
-rocprofv3 --kernel-trace --stats -d $R/$O/prof_$m -o p -- python $R/tools/prefill_bench.py --model $m --seq 2048 --reps 3 > $R/$O/prof_$m.log 2>&1
-tail -2 $R/$O/prof_$m.log
-python $R/tools/rocpd_stats.py $(find $R/$O/prof_$m -name "*.db" | head -1) 2>&1 | head -8 | cut -c1-170 > $R/$O/sum_$m.txt
-cat $R/$O/sum_$m.txt
-rm -rf $R/$O/prof_$m
-done
+python -m pytest tests/test_hip_prefill.py -m gpu -x -q > $O/tests.log 2>&1; tail -2 $O/tests.log
+python tools/prefill_bench.py --reps 6 2>&1 | tail -3
+python tools/prefill_bench.py --reps 3 --model mistral-7b-v0.3 2>&1 | tail -2
+python tools/prefill_bench.py --reps 3 --seq 8192 2>&1 | tail -2
