@@ -189,8 +189,9 @@ __global__ __launch_bounds__(256) void attn_prefill_f32_kernel(const AttnPrefill
   constexpr int NSUB = KT / 32;
   constexpr int NCH = KT * CH / 256;          // chunks per thread and tile
   constexpr float LOG2E = 1.4426950408889634f;
-  __shared__ float sK[KT * LK];
-  __shared__ __attribute__((aligned(16))) float sV[KT * LV];
+  __shared__ __attribute__((aligned(16))) float smem[KT * LV + KT * LK];     // V tile | K tile; the output rows pass through it at the end
+  float* const sV = smem;
+  float* const sK = smem + KT * LV;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5, ql = lane & 31;
   const int h = blockIdx.y, G = a.heads / a.kv_heads, kvh = h / G;
@@ -303,14 +304,21 @@ __global__ __launch_bounds__(256) void attn_prefill_f32_kernel(const AttnPrefill
     }
   }
 
-  if (qvalid) {
+  // A lane holds one query's output dims: direct stores would be 4-byte writes a whole row apart (64 cache lines per instruction).  Each wave
+  // passes its 32 x 32 blocks through LDS (row stride 33 floats: conflict-free column writes) and stores 128-byte row segments.
+  __syncthreads();                              // every wave is done with the last K / V tile
+  static_assert(4 * 32 * 33 <= KT * LV + KT * LK, "output staging exceeds the K / V tiles");
+  float* const wblk = smem + wv * 32 * 33;
+  const float inv_l = qvalid ? 1.0f / l_run : 0.f;
 #pragma unroll
-    for (int b = 0; b < NB; b++)
+  for (int b = 0; b < NB; b++) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int dd = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        a.out[(size_t)qi * qd + (size_t)h * HD + dd] = oacc[b][r] / l_run;
-      }
+    for (int r = 0; r < 16; r++) wblk[ql * 33 + (r & 3) + 8 * (r >> 2) + 4 * hh] = oacc[b][r] * inv_l;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {               // 32 rows x 32 floats over 64 lanes: lane -> (row = 2 i + hh, column ql)
+      const int row = 2 * i + hh;
+      if (q0 + row < a.S) a.out[(size_t)(q0 + row) * qd + (size_t)h * HD + 32 * b + ql] = wblk[row * 33 + ql];
+    }
   }
 }
 

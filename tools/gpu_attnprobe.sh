@@ -1,5 +1,5 @@
 cd /root/repo; mkdir -p gpurun_out
-for d in 0 1 31; do timeout 60 tools/probes/build/attn_probe_$d; done > gpurun_out/attn_probe.txt 2>&1
-cat gpurun_out/attn_probe.txt
-python -m pytest tests/test_hip_prefill.py -m gpu -x -q 2>&1 | tail -3
-python tools/prefill_bench.py --reps 4 2>&1 | tail -2
+python -m pytest tests/test_hip_prefill.py -m gpu -x -q 2>&1 | tail -2
+python tools/prefill_bench.py --dtype fp32 --seq 256 --reps 3 2>&1 | tail -1
+python tools/prefill_bench.py --dtype fp32 --seq 1000 --model gpt2 --reps 3 2>&1 | tail -1
+python tools/prefill_bench.py --dtype fp32 --seq 2048 --reps 3 2>&1 | tail -1
