@@ -430,15 +430,15 @@ template <int DT, int HD>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs a) {
   constexpr int DIS = TGX_ATTN_DIS;
   constexpr int LQ = HD + 8;                  // 16-bit row stride of the K tile (144 / 272 B: conflict-free 16-byte fragment reads)
-  constexpr int LV = 64 + 4;                  // 16-bit row stride of the V^T tile (136 B: 34 dwords, odd/2 -> the 32 rows of a fragment read hit 64 distinct banks)
+  constexpr int LV = HD + 32;                 // 16-bit row stride of the V tile ([key][d], 64 B more than a row: the four key rows of a transposing read fall on four bank quarters)
   constexpr int KS = HD / 16;                 // MFMA k-steps over the head dimension
   constexpr int NB = HD / 32;                 // 32-row output-dim blocks
   constexpr int CH = HD / 8;                  // 16-byte chunks per head row
   constexpr int NCH = 64 * CH / 256;          // chunks per thread and tile
   constexpr float LOG2E = 1.4426950408889634f;
-  __shared__ __attribute__((aligned(16))) bf16_t smem[64 * LQ + HD * LV];     // K tile | V^T tile; the output rows pass through it at the end
+  __shared__ __attribute__((aligned(16))) bf16_t smem[64 * LQ + 64 * LV];     // K tile | V tile; the output rows pass through it at the end
   bf16_t* const sK = smem;
-  bf16_t* const sVt = smem + 64 * LQ;
+  bf16_t* const sV = smem + 64 * LQ;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5, ql = lane & 31;
   const int h = blockIdx.y, G = a.heads / a.kv_heads, kvh = h / G;
@@ -499,21 +499,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
       const int c = tid + 256 * i, row = c / CH, kc = c - row * CH;
       const u32x4 kv = kr[i], vv = vr[i];
       *reinterpret_cast<u32x4*>(&sK[row * LQ + kc * 8]) = kv;
-      // the lane CH away holds the neighbouring key: each lane keeps half of its own row and receives the matching half of the
-      // neighbour's, then writes {even key, odd key} dwords.  CH == 8: lane ^ 8 is a rotation by 8 inside the DPP row — no LDS trip
-      const bool odd = row & 1;
-      const int rk = row & ~1;
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const unsigned int mine = odd ? vv[2 + t] : vv[t], send = odd ? vv[t] : vv[2 + t];
-        unsigned int other;
-        if constexpr (CH == 8) other = (unsigned int)__builtin_amdgcn_update_dpp((int)send, (int)send, 0x128 /* row_ror:8 */, 0xf, 0xf, true);
-        else other = (unsigned int)__shfl_xor((int)send, CH, 64);
-        const unsigned int ev = odd ? other : mine, od = odd ? mine : other;
-        const int d0 = kc * 8 + (odd ? 4 : 0) + 2 * t;
-        *reinterpret_cast<unsigned int*>(&sVt[d0 * LV + rk]) = (ev & 0xffffu) | (od << 16);
-        *reinterpret_cast<unsigned int*>(&sVt[(d0 + 1) * LV + rk]) = (ev >> 16) | (od & 0xffff0000u);
-      }
+      *reinterpret_cast<u32x4*>(&sV[row * LV + kc * 8]) = vv;       // V stays [key][d]: the PV step reads it with the transposing LDS read
     }
   };
   f32x16 zero16;
@@ -605,9 +591,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
         const int kloc = 32 * sub + 16 * s2 + 4 * hh;     // tile-local key of element 0; elements 4..7 are 8 keys further
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-          const bf16_t* vrow = &sVt[(32 * b + ql) * LV + kloc];
-          const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
-          const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 8);
+          // ds_read_b64_tr_b16: the 16 lanes of a group point at the [4 keys][16 dims] block (lane i: key i >> 2, dims 4 (i & 3)..+3) and
+          // lane i receives column i — the four consecutive keys of ITS dim (tools/probes/tr_read_probe.hip)
+          const bf16_t* vblk = &sV[(kloc + ((lane & 15) >> 2)) * LV + 32 * b + (lane & 16) + 4 * (lane & 3)];
+          const u32x2 v0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk)));
+          const u32x2 v1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk + 8 * LV)));
           const bf16x8 fv = __builtin_bit_cast(bf16x8, u32x4{v0[0], v0[1], v1[0], v1[1]});
           oacc[b] = mfma16<DT>(fv, fpl, oacc[b]);
           oacc[b] = mfma16<DT>(fv, fph, oacc[b]);
@@ -641,7 +629,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
   // through LDS (rows of 2 HD + 8 bytes: conflict-free 4-byte column writes) and stores whole rows, 16 bytes per lane.
   __syncthreads();                              // every wave is done with the last K / V tile
   constexpr int RS = HD + 4;                    // staged row stride in 16-bit elements
-  static_assert(4 * 32 * RS <= 64 * LQ + HD * LV, "output staging exceeds the K / V tiles");
+  static_assert(4 * 32 * RS <= 64 * LQ + 64 * LV, "output staging exceeds the K / V tiles");
   bf16_t* const wrow = smem + wv * 32 * RS;
   const float inv_l = qvalid ? 1.0f / l_run : 0.f;
   unsigned int whi[NB * 8], wlo[NB * 8];

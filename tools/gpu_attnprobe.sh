@@ -1,5 +1,4 @@
 cd /root/repo; mkdir -p gpurun_out
-python -m pytest tests/test_hip_prefill.py -m gpu -x -q 2>&1 | tail -2
-python tools/prefill_bench.py --dtype fp32 --seq 256 --reps 3 2>&1 | tail -1
-python tools/prefill_bench.py --dtype fp32 --seq 1000 --model gpt2 --reps 3 2>&1 | tail -1
-python tools/prefill_bench.py --dtype fp32 --seq 2048 --reps 3 2>&1 | tail -1
+for i in 1 2 3; do echo old; tools/probes/build/attn_probe_old; echo new; tools/probes/build/attn_probe_0; done
+for i in 1 2; do echo old; tools/probes/build/attn_probe_old128; echo new; tools/probes/build/attn_probe_new128; done
+for i in 1 2; do echo old; tools/probes/build/attn_probe_old 8192; echo new; tools/probes/build/attn_probe_0 8192; done
