@@ -459,7 +459,7 @@ def test_greedy_finalize_fused_into_lm_head_equals_separate_launch(fam, batch, h
 
 @pytest.mark.parametrize("name,ctx,dtype", [("llama-3.2-1b", 3000, "bf16"), ("mistral-7b-v0.3", 2100, "bf16"), ("qwen2.5-0.5b", 2500, "fp16")])
 def test_mfma_decode_attention_equals_valu_kernel(name, ctx, dtype, hip):
-    """Option attn.mfma_min (off by default: measured no faster, kernels/attn_decode_mfma.h): QK^T and PV of the decode attention on the
+    """Option attn.mfma_min (default: the measured crossover, 6k / 14k keys — kernels/attn_decode_mfma.h; forced on here): QK^T and PV of the decode attention on the
     matrix cores with the kv group's query heads as the narrow operand.  Logits within 1e-4 of the VALU split kernel, greedy ids equal,
     at contexts that end inside a 64-key block, with G = 4 / 7, head_dim 64 / 128, bf16 / fp16, two batch rows of different lengths."""
     import copy

@@ -9,10 +9,12 @@
 // the V^T tile is wave-private in LDS — the main loop has no workgroup barrier.  The four waves' partials meet once in LDS and leave as one
 // (o[hd], m, l) record per query head and split, merged by attn_combine_kernel exactly like the VALU kernel's.
 //
-// STATUS (round 2): correct (logits within 3e-5 of the VALU kernel, ids equal: tools/attn_long.py, tests) but NOT faster — per 64-key block
-// the V^T staging through LDS, the hi/lo splitting of the probabilities and the half-used K fragment loads cost what the VALU kernel's
-// arithmetic costs at G = 4 (Mistral-7B at 24k keys: 40 vs 33 us per layer; Qwen2.5-0.5B, G = 7, at 30k: 20.6 vs 18.1).  Option attn.mfma_min
-// enables it from that many keys on; the default leaves it off (profiles/r02_attn_long.txt).
+// STATUS (round 2): the first version (V^T staged through LDS with lane exchanges and 4-byte stores) was correct but slower than the VALU
+// kernel (Mistral-7B at 24k keys: 40 vs 33 us per layer).  With V left [key][d] in the wave's tile and read by ds_read_b64_tr_b16, paired
+// probability packing, chains started from a constant zero and O rescaled only when a maximum moved, it wins from ~6k keys at head_dim 64 with
+// 8 kv heads (Llama-3.2-1B: 23.3 -> 18.3 us per layer at 30k) and from ~14k at head_dim 128 or 2 kv heads (Mistral-7B 39.5 -> 31.4 at 30k,
+// Qwen2.5-0.5B 18.1 -> 14.4): the shim switches at those contexts (attn_mfma_threshold; option attn.mfma_min overrides;
+// profiles/r02_attn_long.txt).  Logits within 3e-5 of the VALU kernel, ids equal (tools/attn_long.py, tests).
 //
 // Roofline: HBM — 2 * kv_heads * (T+1) * hd * 2 bytes per launch.  MFMA work: 2 x (QK^T + PV) x 32 / G of the useful flops — negligible.
 #pragma once
@@ -22,19 +24,19 @@
 namespace tgx {
 
 template <int HD>
-__host__ __device__ constexpr size_t attn_mfma_lds_bytes() { return (size_t)4 * HD * (64 + 4) * 2; }
+__host__ __device__ constexpr size_t attn_mfma_lds_bytes() { return (size_t)4 * 64 * (HD + 32) * 2; }
 
 template <int DT, int HD>
 __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnArgs a) {
   typedef elem_t<DT> E;
-  constexpr int LV = 64 + 4;                  // 16-bit row stride of the V^T tile
+  constexpr int LV = HD + 32;                 // 16-bit row stride of the wave's V tile ([key][d]; read with the transposing LDS read, as attn_prefill_kernel)
   constexpr int KS = HD / 16;                 // MFMA k-steps over the head dimension
   constexpr int NB = HD / 32;                 // 32-row output-dim blocks
   constexpr int CH = HD / 8;                  // 16-byte chunks per key row
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) bf16_t amf_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5, ql = lane & 31;
-  bf16_t* sVt = amf_lds + (size_t)wv * HD * LV;        // this wave's V^T tile [HD][LV]
+  bf16_t* sV = amf_lds + (size_t)wv * 64 * LV;         // this wave's V tile [64 keys][LV]
   const int nsp = a.nsplit;
   const int kvh = blockIdx.x / nsp, sp = blockIdx.x - kvh * nsp;
   const int G = a.gfull;
@@ -72,6 +74,9 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnArgs a)
   float m_run = -INFINITY, l_run = 0.f;
   const float qs = a.scale * LOG2E;
 
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; r++) zero16[r] = 0.f;
   const int nblk = (n_keys + 63) >> 6;
   // register sets of one block's loads: V rows (chunk c = lane + 64 i -> key row c / CH, 16-byte column c % CH) and the K fragments
   // (row = key 32 sub + ql, 8 d at 16 kk + 8 hh); the NEXT block's loads are issued before the current block's arithmetic
@@ -102,16 +107,12 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnArgs a)
     float mx = -INFINITY;
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) sacc[sub][r] = 0.f;
       const int kb = key0 + 32 * sub;
-      if (kb < n_keys) {
 #pragma unroll
-        for (int kk = 0; kk < KS; kk++) {
-          const bf16x8 fk = __builtin_bit_cast(bf16x8, kfr[sub][kk]);
-          sacc[sub] = mfma16<DT>(fk, qlo[kk], sacc[sub]);
-          sacc[sub] = mfma16<DT>(fk, qh[kk], sacc[sub]);
-        }
+      for (int kk = 0; kk < KS; kk++) {        // always both sub-tiles (rows past the context are clamped loads, masked below)
+        const bf16x8 fk = __builtin_bit_cast(bf16x8, kfr[sub][kk]);
+        sacc[sub] = mfma16<DT>(fk, qlo[kk], kk == 0 ? zero16 : sacc[sub]);
+        sacc[sub] = mfma16<DT>(fk, qh[kk], sacc[sub]);
       }
       if (kb + 32 > n_keys) {      // the context ends inside (or before) this sub-tile
 #pragma unroll
@@ -123,24 +124,11 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnArgs a)
 #pragma unroll
       for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[sub][r]);
     }
-    // V^T into the wave's LDS tile: {even key, odd key} dwords (the lane CH away holds the neighbouring key), as attn_prefill_kernel
+    // V into the wave's LDS tile as it is ([key][d]); the PV step reads it transposed (ds_read_b64_tr_b16)
 #pragma unroll
     for (int i = 0; i < CH; i++) {
       const int c = lane + 64 * i, row = c / CH, kc = c - row * CH;
-      const u32x4 vv = vvr[i];
-      u32x4 ov;
-#pragma unroll
-      for (int t = 0; t < 4; t++) ov[t] = (unsigned int)__shfl_xor((int)vv[t], CH, 64);
-      const bool odd = row & 1;
-      const int rk = row & ~1;
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const unsigned int mine = odd ? vv[2 + t] : vv[t], other = odd ? ov[2 + t] : ov[t];
-        const unsigned int ev = odd ? other : mine, od = odd ? mine : other;
-        const int d0 = kc * 8 + (odd ? 4 : 0) + 2 * t;
-        *reinterpret_cast<unsigned int*>(&sVt[d0 * LV + rk]) = (ev & 0xffffu) | (od << 16);
-        *reinterpret_cast<unsigned int*>(&sVt[(d0 + 1) * LV + rk]) = (ev >> 16) | (od & 0xffff0000u);
-      }
+      *reinterpret_cast<u32x4*>(&sV[row * LV + kc * 8]) = vvr[i];
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * qs;
     const float m_new = fmaxf(m_run, mx);                 // finite: every block holds at least one key of the context
@@ -157,31 +145,41 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnArgs a)
     sum += __shfl_xor(sum, 32, 64);
     l_run = l_run * alpha + sum;
     m_run = m_new;
+    if (__any(alpha != 1.f)) {
 #pragma unroll
-    for (int b = 0; b < NB; b++)
+      for (int b = 0; b < NB; b++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) oacc[b][r] *= alpha;
+        for (int r = 0; r < 16; r++) oacc[b][r] *= alpha;
+    }
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
-      if (key0 + 32 * sub >= n_keys) continue;
 #pragma unroll
       for (int s2 = 0; s2 < 2; s2++) {
         unsigned int wh[4], wl[4];
+        if constexpr (DT == DT_BF16) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          bf16_t ph, pl;
-          split16<DT>(sacc[sub][8 * s2 + j], ph, pl);
-          if (j & 1) { wh[j >> 1] |= (unsigned int)ph << 16; wl[j >> 1] |= (unsigned int)pl << 16; }
-          else { wh[j >> 1] = ph; wl[j >> 1] = pl; }
+          for (int j = 0; j < 4; j++) {
+            const float p0 = sacc[sub][8 * s2 + 2 * j], p1 = sacc[sub][8 * s2 + 2 * j + 1];
+            wh[j] = pack_bf16(p0, p1);
+            wl[j] = pack_bf16(p0 - bf16_lo(wh[j]), p1 - bf16_hi(wh[j]));
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            bf16_t ph, pl;
+            split16<DT>(sacc[sub][8 * s2 + j], ph, pl);
+            if (j & 1) { wh[j >> 1] |= (unsigned int)ph << 16; wl[j >> 1] |= (unsigned int)pl << 16; }
+            else { wh[j >> 1] = ph; wl[j >> 1] = pl; }
+          }
         }
         const bf16x8 fph = __builtin_bit_cast(bf16x8, u32x4{wh[0], wh[1], wh[2], wh[3]});
         const bf16x8 fpl = __builtin_bit_cast(bf16x8, u32x4{wl[0], wl[1], wl[2], wl[3]});
         const int kloc = 32 * sub + 16 * s2 + 4 * hh;
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-          const bf16_t* vrow = &sVt[(32 * b + ql) * LV + kloc];
-          const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
-          const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 8);
+          const bf16_t* vblk = &sV[(kloc + ((lane & 15) >> 2)) * LV + 32 * b + (lane & 16) + 4 * (lane & 3)];
+          const u32x2 v0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk)));
+          const u32x2 v1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk + 8 * LV)));
           const bf16x8 fv = __builtin_bit_cast(bf16x8, u32x4{v0[0], v0[1], v1[0], v1[1]});
           oacc[b] = mfma16<DT>(fv, fpl, oacc[b]);
           oacc[b] = mfma16<DT>(fv, fph, oacc[b]);
@@ -201,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnArgs a)
   }
 
   // the four waves meet in LDS (one (o[HD], m, l) record per wave and query head), merged in wave order — the VALU kernel's step 2
-  __syncthreads();                                       // every wave is done with its V^T tile: the space is reused
+  __syncthreads();                                       // every wave is done with its V tile: the space is reused
   float* red = reinterpret_cast<float*>(amf_lds);        // [4][G][HD + 4]
   if (qvalid) {
     float* dst = red + ((size_t)wv * G + ql) * (HD + 4);

@@ -181,7 +181,7 @@ struct tgx_ctx {
   bool step_graph_direct = false;
   // contexts from attn_mfma_min keys on take the MFMA decode attention (kernels/attn_decode_mfma.h); like the direct form it is a mode of the
   // captured step: the graphs are re-captured when a decode call crosses the limit.  Not for Qwen3's fused q/k norm, not for fp32 storage.
-  int attn_mfma_min = 1 << 30;
+  int attn_mfma_min = -1;          // -1: the measured crossover of the geometry (attn_mfma_threshold); option attn.mfma_min overrides
   bool attn_mfma = false, step_graph_mfma = false;
   int debug_gemv = 0;        // experiment: GemvArgs.dbg = value & 15 for the kernel classes selected by bits 8.. (1 << (8 + class))
   int debug_skip = 0;        // experiment: bit0 skip attn decode kernel, bit1 skip combine (results invalid)
@@ -914,6 +914,13 @@ void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool
 // One decode step for all active rows: layers at pos, lm_head, then {sample, pos+=1, next embedding}.
 // == nextToken = genNextToken(nextToken)  (GPTEngine.cpp:94-99,165-168)
 void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg& cfg);
+// Context from which the MFMA decode attention (kernels/attn_decode_mfma.h) beats the VALU kernel, measured per geometry class
+// (profiles/r02_attn_long.txt): head_dim 64 with 8 kv heads from ~6k keys (Llama-3.2-1B: 11.0 -> 9.9 µs per layer at 6k, 23.3 -> 18.3 at 30k);
+// two kv heads (Qwen2.5-0.5B: few workgroups) and head_dim 128 (Mistral-7B, Llama-3.2-3B) from ~14k (Mistral-7B: 25.3 -> 21.4 at 16k, 39.5 -> 31.4 at 30k).
+static int attn_mfma_threshold(const tgx_ctx* c) {
+  if (c->attn_mfma_min >= 0) return c->attn_mfma_min;
+  return (c->d.head_dim == 64 && c->d.kv_heads >= 8) ? 6000 : 14000;
+}
 bool decode_mfma_ok(const tgx_ctx* c);
 
 void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
@@ -1380,7 +1387,7 @@ int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int 
   // short contexts: attention without the split / combine pair (one launch less per layer); the graphs are re-captured when a
   // call crosses the limit
   c->attn_direct = c->past + n <= c->attn_direct_max;
-  c->attn_mfma = !c->attn_direct && c->past >= c->attn_mfma_min && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
+  c->attn_mfma = !c->attn_direct && c->past >= attn_mfma_threshold(c) && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
   if (decode_mfma_ok(c)) {   // the batched step's workspace must exist before the step is captured
     int rc = ensure_skinny_ws(c, std::min(32, c->batch));
     if (rc) return rc;
@@ -1935,7 +1942,7 @@ int tgx_profile_decode(tgx_ctx* c, int n_reps, int64_t* launches, double* total_
   HIP_OK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < TGX_KERNEL_COUNT; i++) { launches[i] = 0; total_ms[i] = 0.0; }
   c->attn_direct = c->past + 1 <= c->attn_direct_max;
-  c->attn_mfma = !c->attn_direct && c->past >= c->attn_mfma_min && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
+  c->attn_mfma = !c->attn_direct && c->past >= attn_mfma_threshold(c) && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
   // Each class is launched back-to-back over all layers (every launch streams a different layer's weights, so
   // nothing is served from the Infinity Cache) between two events on the launch stream.  The residual
   // epilogues write to a scratch vector: the model state (x, KV cache up to pastLength, token) is untouched.
