@@ -169,6 +169,29 @@ def test_other_baseline_geometries_decode_properties(name, full):
     np.testing.assert_array_equal(m.decode(3, GREEDY)[:, 0], r0[:3, 0])
 
 
+@pytest.mark.parametrize("name,prompt_len", [("llama-3.2-1b", 5990), ("mistral-7b-v0.3", 13990)])
+def test_decode_crosses_the_matrix_core_attention_threshold(name, prompt_len):
+    """Long contexts switch the decode attention to the matrix-core kernel at a measured context (6000 keys at head_dim 64 with 8 kv heads, 14000
+    at head_dim 128: attn_mfma_threshold in the shim).  Real head geometry, 2 layers, 8k vocabulary: a decode run that STARTS below the limit and
+    crosses it (graph re-captured on the way) must give the ids and logits of the same run with the switch disabled (VALU kernel throughout)."""
+    d = copy.deepcopy(known_desc(name))
+    d.layers, d.vocab, d.max_ctx, d.max_batch = 2, 8192, prompt_len + 64, 1
+    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    p = synth.synth_prompt(d.vocab, prompt_len, 3)[None, :]
+    out = {}
+    for mode, mf in (("auto", -1), ("valu", 1 << 30)):
+        m.set_option("attn.mfma_min", mf)
+        m.reset_cache(); m.forward(p)
+        t0 = m.sample(GREEDY).copy()
+        ids = m.decode(24, GREEDY).copy()            # contexts prompt_len + 1 .. prompt_len + 24: the limit is crossed after ~10 steps
+        out[mode] = (t0, ids, m.logits(False).copy())
+    np.testing.assert_array_equal(out["auto"][0], out["valu"][0])
+    assert rel_err(out["auto"][2], out["valu"][2]) < 1e-3
+    # random weights: ids may only differ where the top-2 gap is inside the comparison tolerance; with 2 layers the runs agree in practice
+    same = (out["auto"][1] == out["valu"][1]).mean()
+    assert same >= 0.9, same
+
+
 def test_full_size_sharded_checkpoint_through_cpp_engine(tmp_path):
     """a full-size (Llama-3.2-1B geometry, 2.5 GB) checkpoint written as 3 safetensors shards +
     index by the `safetensors` package, read by the C++ loader (mmap -> tgx_upload by HF name) and run by the C++ engine

@@ -1,0 +1,2 @@
+cd /root/repo
+python -m pytest tests/test_hip_fullsize.py -m gpu -x -q -k "crosses" 2>&1 | tail -5
