@@ -50,8 +50,12 @@ __host__ __device__ constexpr size_t skinny_lds_bytes(int mb, int nt, int cfg) {
 // MB = 16-row blocks of activation rows (1: M <= 16, 2: M <= 32); NT = 16-bit terms per activation (2, or 3 for a product whose result is
 // rounded to 16 bits again: the K/V rows of the QKV product); NBW = 16-row weight blocks per wave; ASRC: see above.
 // Uses GemmArgs (prefill.h).
+#ifndef TGX_SKINNY_DIS
+#define TGX_SKINNY_DIS 0    // experiments only (tools/probes/skinny_probe.hip): 1 activation panel staged once, 2 no fragment reads / MFMAs, 8 no W refills, 16 no panel barriers
+#endif
 template <int DT, int EPI, int MB, int NT, int CFG, int ASRC>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmArgs a) {
+  constexpr int DIS = TGX_SKINNY_DIS;
   constexpr int NBW = SkinnyCfg<CFG>::NBW, KT = SkinnyCfg<CFG>::KT, SLOTS = SkinnyCfg<CFG>::SLOTS, SK_KP = SkinnyCfg<CFG>::KP;
   constexpr int SK_LDX = SK_KP + 8;                    // 16-bit elements per LDS row of an activation panel
   constexpr int LPT = 16 * NBW * KT * 2 / 1024;        // 16-byte loads per lane and weight tile (4 or 8)
@@ -174,9 +178,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmArgs a) {
   auto tile = [&](u32x4* ws, int kt, int xoff) {
 #pragma unroll
     for (int i = 0; i < LPT; i++) *reinterpret_cast<u32x4*>(&sW[(RPL * i + lrow) * LDW + chunk * 8]) = ws[i];
-    load_w(kt + SLOTS * KT, ws);
+    if (!(DIS & 8)) load_w(kt + SLOTS * KT, ws);
 #pragma unroll
-    for (int ks = 0; ks < KT / 32; ks++) {
+    for (int ks = 0; ks < ((DIS & 2) ? 0 : KT / 32); ks++) {
       const int kcol = ks * 32 + 8 * (lane >> 4);
       bf16x8 fb[NBW], fa[MB][NT];
 #pragma unroll
@@ -200,9 +204,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmArgs a) {
   // (with a run-time slot index the compiler's vmcnt bookkeeping merges "slot 0 is the youngest load" with "slot 1 is", and every tile
   // then waits for ALL outstanding loads — the prefetch depth collapses to one tile: measured 3.0 vs 5 TB/s).
   auto panel_head = [&](int kp) {
-    __syncthreads();                 // every wave is done with the previous panel
+    if ((DIS & 1) && kp != k_begin) return;
+    if (!(DIS & 16)) __syncthreads();                 // every wave is done with the previous panel
     store_x();
-    __syncthreads();
+    if (!(DIS & 16)) __syncthreads();
     load_x(kp + SK_KP);
   };
   if (k_begin < k_end) {
