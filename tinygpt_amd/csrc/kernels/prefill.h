@@ -69,26 +69,50 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const long long* ids, c
 // `lo2` (optional) receives a third term: x = hi + lo + lo2 carries ~24 mantissa bits.  The QKV projection uses it,
 // because its output is the only one that is rounded to bf16 again (the KV cache): with two terms (2^-18) a few
 // per cent of the cache entries round differently from the single-position path, with three the schedules agree.
+// `part` (optional): the row first takes a pending split-K residual — x += sum_z part[z][row][:] (+ bias), slabs `slab` floats apart, summed in z
+// order exactly as gemm_splitk_reduce_kernel<GEMM_RESIDUAL> does — and is written back: the reduce launch and its pass over x disappear.
 template <int DT>
-__global__ __launch_bounds__(256) void rmsnorm_split_kernel(const float* X, const bf16_t* w, float eps, int H, bf16_t* hi, bf16_t* lo, bf16_t* lo2) {
+__global__ __launch_bounds__(256) void rmsnorm_split_kernel(float* X, const bf16_t* w, float eps, int H, bf16_t* hi, bf16_t* lo, bf16_t* lo2,
+                                                            const float* part = nullptr, int nsplit = 0, long long slab = 0, const bf16_t* bias = nullptr) {
   // one workgroup per row; a thread owns 8-element slices (two 16-byte loads, one 16-byte store per term), kept in registers between the
   // sum of squares and the scaling for rows up to 8192 elements (H % 8 == 0: checked by the caller)
   __shared__ float sc[4];
   constexpr int NV = 4;
-  const float* x = X + (size_t)blockIdx.x * H;
+  float* x = X + (size_t)blockIdx.x * H;
   const int nch = H >> 3;
+  auto fetch = [&](int c, f32x4& v0, f32x4& v1) {
+    v0 = *reinterpret_cast<const f32x4*>(x + 8 * c); v1 = *reinterpret_cast<const f32x4*>(x + 8 * c + 4);
+    if (part) {
+      const float* p = part + (size_t)blockIdx.x * H + 8 * c;
+      f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+      for (int z = 0; z < nsplit; z++) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (size_t)z * slab), a1 = *reinterpret_cast<const f32x4*>(p + (size_t)z * slab + 4);
+#pragma unroll
+        for (int t = 0; t < 4; t++) { s0[t] += a0[t]; s1[t] += a1[t]; }
+      }
+      if (bias) {
+        const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + 8 * c);
+#pragma unroll
+        for (int t = 0; t < 2; t++) { s0[2 * t] += pair_lo<DT>(bv[t]); s0[2 * t + 1] += pair_hi<DT>(bv[t]); s1[2 * t] += pair_lo<DT>(bv[2 + t]); s1[2 * t + 1] += pair_hi<DT>(bv[2 + t]); }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++) { v0[t] += s0[t]; v1[t] += s1[t]; }
+      *reinterpret_cast<f32x4*>(x + 8 * c) = v0; *reinterpret_cast<f32x4*>(x + 8 * c + 4) = v1;
+    }
+  };
   f32x4 xr[NV][2];
   float ss = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; j++) {
     const int c = threadIdx.x + 256 * j;
     xr[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; xr[j][1] = xr[j][0];
-    if (c < nch) { xr[j][0] = *reinterpret_cast<const f32x4*>(x + 8 * c); xr[j][1] = *reinterpret_cast<const f32x4*>(x + 8 * c + 4); }
+    if (c < nch) fetch(c, xr[j][0], xr[j][1]);
 #pragma unroll
     for (int t = 0; t < 4; t++) { ss = fmaf(xr[j][0][t], xr[j][0][t], ss); ss = fmaf(xr[j][1][t], xr[j][1][t], ss); }
   }
   for (int c = threadIdx.x + 256 * NV; c < nch; c += 256) {
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + 8 * c), v1 = *reinterpret_cast<const f32x4*>(x + 8 * c + 4);
+    f32x4 v0, v1;
+    fetch(c, v0, v1);                 // (rows wider than 8192: the residual lands in memory here and is re-read below)
 #pragma unroll
     for (int t = 0; t < 4; t++) { ss = fmaf(v0[t], v0[t], ss); ss = fmaf(v1[t], v1[t], ss); }
   }
@@ -134,18 +158,34 @@ struct RopeKvArgs {
   int heads, kv_heads, hd, max_ctx, past;
   const bf16_t *q_norm_w, *k_norm_w;   // Qwen3 per-head RMSNorm weights [hd] (nullptr: no QK-norm)
   float eps;
+  // the QKV product left as split-K slabs (QKV == nullptr): row s = sum_z part[z][s][:] + bias, z order as gemm_splitk_reduce_kernel<GEMM_STORE>
+  const float* part; int nsplit; long long slab; const bf16_t* bias;
 };
 template <int DT>
 __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) {
   // one workgroup per position; a thread owns FOUR adjacent RoPE pairs (p..p+3, p+half..p+half+3) of one head: 16-byte loads, 8-byte stores
   const int s = blockIdx.x, pos = a.past + s, half = a.hd >> 1, q4 = half >> 2;
   const int qd = a.heads * a.hd, kvd = a.kv_heads * a.hd;
-  const float* row = a.QKV + (size_t)s * (qd + 2 * kvd);
+  const float* row = (a.QKV ? a.QKV : a.part) + (size_t)s * (qd + 2 * kvd);
   const int units = (a.heads + 2 * a.kv_heads) * q4;
+  auto fetch4 = [&](int col) {
+    if (a.QKV) return *reinterpret_cast<const f32x4*>(row + col);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < a.nsplit; z++) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(row + (size_t)z * a.slab + col);
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] += t[e];
+    }
+    if (a.bias) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] += elem_to_f32<DT>(a.bias[col + e]);
+    }
+    return v;
+  };
   auto pack4 = [](const bf16_t* e) { return u32x2{(unsigned int)e[0] | ((unsigned int)e[1] << 16), (unsigned int)e[2] | ((unsigned int)e[3] << 16)}; };
   for (int u = threadIdx.x; u < units; u += 256) {
     const int hh = u / q4, p = 4 * (u - hh * q4);
-    f32x4 x0 = *reinterpret_cast<const f32x4*>(row + hh * a.hd + p), x1 = *reinterpret_cast<const f32x4*>(row + hh * a.hd + p + half);
+    f32x4 x0 = fetch4(hh * a.hd + p), x1 = fetch4(hh * a.hd + p + half);
     if (a.q_norm_w != nullptr && hh < a.heads + a.kv_heads) {
       // AttentionWithQKNorm (Attention.h:156-163): RMSNorm over head_dim; the hd/8 lanes of one head are adjacent and
       // aligned (8 or 16), so the mean of squares is a sub-wave butterfly

@@ -181,6 +181,7 @@ struct tgx_ctx {
   bool step_graph_direct = false;
   // contexts from attn_mfma_min keys on take the MFMA decode attention (kernels/attn_decode_mfma.h); like the direct form it is a mode of the
   // captured step: the graphs are re-captured when a decode call crosses the limit.  Not for Qwen3's fused q/k norm, not for fp32 storage.
+  int defer_reduce = 1;            // split-K slabs of the prefill's N = hidden / QKV products are summed by the next row-wise kernel (option prefill.defer_reduce)
   int attn_mfma_min = -1;          // -1: the measured crossover of the geometry (attn_mfma_threshold); option attn.mfma_min overrides
   bool attn_mfma = false, step_graph_mfma = false;
   int debug_gemv = 0;        // experiment: GemvArgs.dbg = value & 15 for the kernel classes selected by bits 8.. (1 << (8 + class))
@@ -663,8 +664,11 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
   return TGX_OK;
 }
 
+// defer (optional, RESIDUAL / STORE products): when the product is split over K, leave the slabs in ws_part for the consumer kernel to sum
+// (rmsnorm_split_kernel / rope_kv_split_kernel: same z order, one launch and one pass over the rows less) and report the slab count; 1 = done here.
 void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float* C, int M, int N, int K, int ldc, bool three_terms = false,
-                 const bf16_t* a_hi = nullptr, const bf16_t* a_lo = nullptr, int three_from = 0) {
+                 const bf16_t* a_hi = nullptr, const bf16_t* a_lo = nullptr, int three_from = 0, int* defer = nullptr) {
+  if (defer) *defer = 1;
   const bf16_t* B = reinterpret_cast<const bf16_t*>(B_);   // 16-bit storage (bf16 or fp16 bit patterns); fp32 storage never gets here
   const bf16_t* bias = reinterpret_cast<const bf16_t*>(bias_);
   tgx::GemmArgs g{};
@@ -703,7 +707,8 @@ void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float
     TGX_DT16_SWITCH(c->dt,
       if (small) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_PARTIAL, 1>), gz, blk, dyn, c->stream, g);
       else hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_PARTIAL, 2>), gz, blk, dyn, c->stream, g);
-      if (epi == tgx::GEMM_SILU) hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_SILU>), rg, blk, 0, c->stream, g);
+      if (defer && c->defer_reduce && M >= 192 && (epi == tgx::GEMM_RESIDUAL || epi == tgx::GEMM_STORE)) { *defer = nsplit; }   // below ~192 rows the row-wise consumers are too few workgroups to sum 16 slabs quickly (S = 64: 1.82 -> 1.87 ms; S = 256: 2.80 -> 2.70)
+      else if (epi == tgx::GEMM_SILU) hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_SILU>), rg, blk, 0, c->stream, g);
       else if (epi == tgx::GEMM_GELU) hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_GELU>), rg, blk, 0, c->stream, g);
       else if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_RESIDUAL>), rg, blk, 0, c->stream, g);
       else hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_STORE>), rg, blk, 0, c->stream, g);)
@@ -777,14 +782,19 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
   // GPT-2 (ModelGPT2.h:23-208): wte + wpe rows, LayerNorm with bias ahead of both products, a bias on every Conv1D, c_fc -> gelu_new;
   // its rotation tables are the identity, so the RoPE / cache-append kernel and the attention are the Llama family's
   TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_rows_any_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const long long*)c->rows[(size_t)row0].prompt, (const void*)c->embed, (const void*)(c->gpt2 ? c->wpe : nullptr), c->ws_x, H, S, (long long)d.max_ctx, (int)c->past))
+  int pend = 1;                     // slabs of the previous layer's down product still to be added to ws_x (1: none)
+  const bf16_t* pend_bias = nullptr;
   for (int l = 0; l < d.layers; l++) {
     const LayerW& w = c->L[(size_t)l];
     // the QKV product feeds a second rounding (the KV cache): bf16 needs three split terms to reproduce the step path's cache
     // entries (two leave 1-8 % of them one ulp off); fp16's two terms already carry 22 bits
     const bool three = c->dt == tgx::DT_BF16;
     if (c->gpt2) { TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::norm_rows_kernel<DT, 1, 1>), dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const void*)w.in_norm, (const void*)w.in_norm_b, d.norm_eps, H, (float*)nullptr, c->ws_ah, c->ws_al, three ? c->ws_al2 : (bf16_t*)nullptr)) }
-    else { TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.in_norm, d.norm_eps, H, c->ws_ah, c->ws_al, three ? c->ws_al2 : (bf16_t*)nullptr)) }
-    launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, M, qd + 2 * kvd, H, qd + 2 * kvd, /*three_terms=*/three, nullptr, nullptr, /*three_from=*/qd);   // Q columns: two terms
+    else { TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, c->ws_x, (const bf16_t*)w.in_norm, d.norm_eps, H, c->ws_ah, c->ws_al, three ? c->ws_al2 : (bf16_t*)nullptr,
+                                                  (const float*)(pend > 1 ? c->ws_part : nullptr), pend, (long long)M * H, pend_bias)) }
+    pend = 1;
+    int qsl = 1;
+    launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, M, qd + 2 * kvd, H, qd + 2 * kvd, /*three_terms=*/three, nullptr, nullptr, /*three_from=*/qd, &qsl);   // Q columns: two terms
     for (int b = 0; b < NB; b++) {
       RowState& r = c->rows[(size_t)(row0 + b)];
       bf16_t* kc = reinterpret_cast<bf16_t*>(r.kcache);
@@ -792,6 +802,7 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
       const size_t ro = (size_t)b * S;             // first workspace row of this batch row
       tgx::RopeKvArgs a{};
       a.QKV = c->ws_out + ro * wout; a.q_hi = c->ws_qh + ro * qd; a.q_lo = c->ws_ql + ro * qd;
+      if (qsl > 1) { a.QKV = nullptr; a.part = c->ws_part + ro * wout; a.nsplit = qsl; a.slab = (long long)M * (long long)wout; a.bias = reinterpret_cast<const bf16_t*>(w.bqkv); }
       a.k_cache = kc + (size_t)l * kv_layer; a.v_cache = vc + (size_t)l * kv_layer;
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = (int)c->past;
@@ -811,15 +822,20 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
       TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64>), grid, blk, 0, c->stream, a);
                              else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128>), grid, blk, 0, c->stream, a))
     }
-    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wo, w.bo, c->ws_x, M, H, qd, H);
+    int osl = 1;
+    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wo, w.bo, c->ws_x, M, H, qd, H, false, nullptr, nullptr, 0, c->gpt2 ? nullptr : &osl);
     if (c->gpt2) {
       TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::norm_rows_kernel<DT, 1, 1>), dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const void*)w.post_norm, (const void*)w.post_norm_b, d.norm_eps, H, (float*)nullptr, c->ws_ah, c->ws_al, (bf16_t*)nullptr))
       launch_gemm(c, tgx::GEMM_GELU, w.wgu, w.bfc, nullptr, M, I, H, I);             // c_fc + bias + gelu_new -> ws_hh / ws_hl
     } else {
-      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al, (bf16_t*)nullptr))
+      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al, (bf16_t*)nullptr,
+                                                (const float*)(osl > 1 ? c->ws_part : nullptr), osl, (long long)M * H, reinterpret_cast<const bf16_t*>(w.bo)))
       launch_gemm(c, tgx::GEMM_SILU, w.wgu, nullptr, nullptr, M, 2 * I, H, 2 * I);      // gate_up + siluMul -> ws_hh / ws_hl
     }
-    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wdown, w.bdown, c->ws_x, M, H, I, H, false, c->ws_hh, c->ws_hl);
+    // the down product's slabs wait for the next layer's input norm (the last layer, and GPT-2's LayerNorm path, finish them here)
+    const bool can_defer = !c->gpt2 && l + 1 < d.layers;
+    launch_gemm(c, tgx::GEMM_RESIDUAL, w.wdown, w.bdown, c->ws_x, M, H, I, H, false, c->ws_hh, c->ws_hl, 0, can_defer ? &pend : nullptr);
+    pend_bias = reinterpret_cast<const bf16_t*>(w.bdown);
   }
   for (int b = 0; b < NB; b++)     // the last position of every batch row feeds lm_head
     (void)hipMemcpyAsync(c->rows[(size_t)(row0 + b)].x, c->ws_x + ((size_t)(b + 1) * S - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, c->stream);
@@ -2010,6 +2026,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   }
   if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
   if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.defer_reduce")) { c->defer_reduce = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_tm")) { c->gemm_tm = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_dma")) { c->gemm_dma = value; return TGX_OK; }
   if (!strcmp(key, "debug.gemv")) { c->debug_gemv = value; return TGX_OK; }

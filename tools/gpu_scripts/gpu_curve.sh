@@ -1,6 +1,3 @@
-R=/root/repo; cd /tmp; export TMPDIR=/tmp; O=$R/gpurun_out/curve; mkdir -p $O
-for s in 64 128 256 512; do
-rocprofv3 --kernel-trace --stats -d $O/p$s -o p -- python $R/tools/prefill_bench.py --seq $s --reps 3 > $O/p$s.log 2>&1
-echo "S=$s"; python $R/tools/rocpd_stats.py $(find $O/p$s -name "*.db" | head -1) 2>&1 | head -10 | cut -c1-150
-rm -rf $O/p$s
-done
+cd /root/repo
+python -m pytest tests/test_hip_prefill.py tests/test_hip_parity.py -m gpu -x -q 2>&1 | tail -3
+for s in 64 128 256 512 1024; do python tools/prefill_bench.py --seq $s --reps 4 2>&1 | tail -1; python tools/prefill_bench.py --seq $s --reps 4 --opts "prefill.defer_reduce=0" 2>&1 | tail -1 | sed 's/^/   no defer: /'; done

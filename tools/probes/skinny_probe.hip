@@ -13,7 +13,11 @@ static void run(int M, int N, int K, const tgx::bf16_t* W, const float* X, const
   tgx::GemmArgs g{};
   g.A_f32 = X; g.lda = K; g.norm_w = nw; g.ssq_part = ssq; g.ssq_ncb = tgx::SK_NCB; g.eps = 1e-5f;
   g.inter = N / 2; g.out_hi = oh; g.out_lo = ol; g.B = W; g.M = M; g.N = N; g.K = K; g.ldc = N;
-  auto kern = tgx::skinny_gemm_kernel<tgx::DT_BF16, tgx::GEMM_SILU, MB, 2, 0, 2>;
+#ifndef PROBE_ASRC
+#define PROBE_ASRC 2      // 2: fp32 rows, RMSNorm + split while staging (the product's gate_up call); 0: the 16-bit terms precomputed in memory
+#endif
+  g.A_hi = oh + (size_t)32 * N / 2; g.A_lo = oh + (size_t)32 * N / 2 + 32 * K;      // any initialised memory will do for timing
+  auto kern = tgx::skinny_gemm_kernel<tgx::DT_BF16, tgx::GEMM_SILU, MB, 2, 0, PROBE_ASRC>;
   const size_t lds = tgx::skinny_lds_bytes(MB, 2, 0);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -24,7 +28,7 @@ static void run(int M, int N, int K, const tgx::bf16_t* W, const float* X, const
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r >= 3 && ms < best) best = ms;
   }
-  printf("DIS=%2d  M %2d  N %d K %d: %.1f us  (%.2f TB/s of weights)\n", TGX_SKINNY_DIS, M, N, K, best * 1e3, (double)N * K * 2 / (best * 1e-3) / 1e12);
+  printf("ASRC=%d DIS=%2d  M %2d  N %d K %d: %.1f us  (%.2f TB/s of weights)\n", PROBE_ASRC, TGX_SKINNY_DIS, M, N, K, best * 1e3, (double)N * K * 2 / (best * 1e-3) / 1e12);
 }
 int main() {
   const int N = 16384, K = 2048;
@@ -40,7 +44,7 @@ int main() {
   CK(hipMalloc(&X, hx.size() * 4)); CK(hipMemcpy(X, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&ssq, hs.size() * 4)); CK(hipMemcpy(ssq, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&nw, K * 2)); CK(hipMemcpy(nw, hw.data(), K * 2, hipMemcpyHostToDevice));
-  CK(hipMalloc(&oh, (size_t)32 * N)); CK(hipMalloc(&ol, (size_t)32 * N));
+  CK(hipMalloc(&oh, (size_t)32 * N * 2)); CK(hipMemset(oh, 0, (size_t)32 * N * 2)); CK(hipMalloc(&ol, (size_t)32 * N));
   static int rot = 0;
   for (int rep = 0; rep < 2; rep++) {
     run<1>(8, N, K, W[(rot++) % NC], X, nw, ssq, oh, ol);
