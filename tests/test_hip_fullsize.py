@@ -192,6 +192,38 @@ def test_decode_crosses_the_matrix_core_attention_threshold(name, prompt_len):
     assert same >= 0.9, same
 
 
+@pytest.mark.parametrize("name,dtype,rows", [("llama-3.2-1b", "bf16", 8), ("llama-3.2-1b", "fp16", 5), ("llama-3.2-3b", "bf16", 16), ("mistral-7b-v0.3", "bf16", 3),
+                                             ("llama-3.2-1b", "bf16", 24)])
+def test_batched_step_wide_products_on_the_k_split_kernel(name, dtype, rows, oracle_lib):
+    """Batches of <= 16 rows run gate_up and lm_head on the barrier-free K-split kernel (kernels/skinny_ksplit.h: hidden sizes 2048 / 3072 /
+    4096 with a compile-time K loop); the tiny fixtures' hidden sizes never reach it, so this runs REAL layer geometry (2 layers, 8k vocabulary)
+    against the oracle, teacher-forced, and against the same batch with the kernel switched off.  24 rows = the panel kernel (control)."""
+    from oracle.oracle_ffi import OracleModel
+    d = copy.deepcopy(known_desc(name, dtype))
+    d.layers, d.vocab, d.max_ctx, d.max_batch = 2, 8192, 96, rows
+    gpu = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    ref = OracleModel(d).load_synthetic(1234, 0.02).finalize()
+    ids = np.stack([synth.synth_prompt(d.vocab, 11, 5 + b) for b in range(rows)])
+    V = d.vocab
+    runs = {}
+    for mode, ks in (("ksplit", 1), ("panel", 0)):
+        gpu.set_option("skinny.ksplit", ks)
+        gpu.reset_cache(); ref.reset_cache()
+        gpu.forward(ids); ref.forward(ids)
+        tok = ref.sample(GREEDY); gpu.sample(GREEDY)
+        logs = []
+        for step in range(4):
+            onehot = np.full((rows, V), -1.0, np.float32); onehot[np.arange(rows), tok] = 1.0
+            gpu.set_logits(onehot); np.testing.assert_array_equal(gpu.sample(GREEDY), tok)
+            gpu.decode(1, GREEDY); tr = ref.decode(1, GREEDY)[0]
+            lg, lr = gpu.logits(False).copy(), ref.logits(False)
+            assert rel_err(lg, lr) < 1e-3, (mode, step, rel_err(lg, lr))
+            logs.append(lg); tok = tr
+        runs[mode] = logs
+    for a, b in zip(runs["ksplit"], runs["panel"]):
+        assert rel_err(a, b) < 5e-4
+
+
 def test_full_size_sharded_checkpoint_through_cpp_engine(tmp_path):
     """a full-size (Llama-3.2-1B geometry, 2.5 GB) checkpoint written as 3 safetensors shards +
     index by the `safetensors` package, read by the C++ loader (mmap -> tgx_upload by HF name) and run by the C++ engine

@@ -23,6 +23,7 @@
 #include "kernels/prefill.h"
 #include "kernels/sampler.h"
 #include "kernels/skinny.h"
+#include "kernels/skinny_ksplit.h"
 #include "kernels/gemm_f32.h"
 #include "kernels/gemm_dma.h"
 
@@ -181,6 +182,7 @@ struct tgx_ctx {
   bool step_graph_direct = false;
   // contexts from attn_mfma_min keys on take the MFMA decode attention (kernels/attn_decode_mfma.h); like the direct form it is a mode of the
   // captured step: the graphs are re-captured when a decode call crosses the limit.  Not for Qwen3's fused q/k norm, not for fp32 storage.
+  int skinny_ksplit = 1;           // wide products (gate_up, lm_head) of batches of <= 16 rows on the barrier-free K-split kernel (option skinny.ksplit)
   int defer_reduce = 1;            // split-K slabs of the prefill's N = hidden / QKV products are summed by the next row-wise kernel (option prefill.defer_reduce)
   int attn_mfma_min = -1;          // -1: the measured crossover of the geometry (attn_mfma_threshold); option attn.mfma_min overrides
   bool attn_mfma = false, step_graph_mfma = false;
@@ -1072,6 +1074,28 @@ int ensure_skinny_ws(tgx_ctx* c, int rows) {
   return TGX_OK;
 }
 
+// The wide products of a batch of <= 16 rows on the barrier-free K-split kernel (kernels/skinny_ksplit.h); activations = the 16-bit terms
+// rmsnorm_split_kernel left in ws_ah / ws_al.  false: shape not covered (the caller takes the panel kernel).
+bool ksplit_ok(const tgx_ctx* c, int M, int N, int K) {
+  return c->skinny_ksplit && M <= 16 && K % 256 == 0 && K >= 768 && N >= 64 * c->num_cus;
+}
+void launch_ksplit(tgx_ctx* c, int epi, const ebyte* W, float* C, int ldc, int M, int N, int K) {
+  tgx::GemmArgs g{};
+  g.A_hi = c->ws_ah; g.A_lo = c->ws_al; g.B = reinterpret_cast<const bf16_t*>(W); g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.inter = N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
+  const dim3 grid((N + 63) / 64), blk(256);
+#define TGX_KS(E_, K_) hipLaunchKernelGGL((tgx::skinny_ksplit_kernel<DT, E_, K_>), grid, blk, 0, c->stream, g)
+#define TGX_KS_K(E_) do { if (K == 2048) TGX_KS(E_, 2048); else if (K == 3072) TGX_KS(E_, 3072); else if (K == 4096) TGX_KS(E_, 4096); else TGX_KS(E_, 0); } while (0)
+  TGX_DT16_SWITCH(c->dt, if (epi == tgx::GEMM_SILU) TGX_KS_K(tgx::GEMM_SILU); else TGX_KS_K(tgx::GEMM_STORE);)
+#undef TGX_KS_K
+#undef TGX_KS
+}
+// RMSNorm of the rows of x into 16-bit terms (ws_ah / ws_al), first adding a pending split-K residual (nsplit > 1: the slabs in ws_part)
+void launch_norm_terms(tgx_ctx* c, float* x, const ebyte* norm_w, int M, int H, int nsplit) {
+  TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, x, reinterpret_cast<const bf16_t*>(norm_w), c->d.norm_eps, H,
+                                          c->ws_ah, c->ws_al, (bf16_t*)nullptr, (const float*)(nsplit > 1 ? c->ws_part : nullptr), nsplit, (long long)M * H, (const bf16_t*)nullptr))
+}
+
 // One decode step for rows [row0, row0 + M), M <= 32, with every nn::Linear as ONE pass over its weights (GPTEngine.cpp:154-168: the
 // reference runs the whole [B,1] batch through each Linear).  Same per-row math as the GEMV path in the prefill's arithmetic: fp32
 // activations enter the matrix cores as exact sums of 16-bit terms (three for the QKV product, whose K/V results are rounded into the cache).
@@ -1085,6 +1109,7 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
   RowState& r = c->rows[(size_t)row0];
   const int nt_qkv = c->dt == tgx::DT_BF16 ? 3 : 2;
   float* ssq = c->ws_ssq;
+  const bool lm_ks = ksplit_ok(c, M, V, H);
   // the rows start as embedding rows (the finalize of the previous step gathered them): their sums of squares for the first RMSNorm
   hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
   for (int l = 0; l < d.layers; l++) {
@@ -1116,12 +1141,19 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
     SkinnyCall o;
     o.epi = tgx::GEMM_RESIDUAL; o.W = w.wo; o.C = r.x; o.ldc = H; o.M = M; o.N = H; o.K = qd; o.nt = 2; o.asrc = 1; o.a_f32 = r.attn; o.lda = qd;
     const int os = launch_skinny(c, o);
+    const bool gu_ks = ksplit_ok(c, M, 2 * I, H);
+    int gs = 1;
+    if (gu_ks) {     // {sum slabs, residual, RMSNorm, 16-bit terms} in one row-wise launch, then the barrier-free wide product
+      launch_norm_terms(c, r.x, w.post_norm, M, H, os);
+      launch_ksplit(c, tgx::GEMM_SILU, w.wgu, nullptr, 2 * I, M, 2 * I, H);
+    } else {
     if (os > 1) launch_reduce_rows(c, tgx::GEMM_RESIDUAL, os, nullptr, r.x, H, M, H, ssq);
     else hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
     SkinnyCall gu;
     gu.epi = tgx::GEMM_SILU; gu.W = w.wgu; gu.M = M; gu.N = 2 * I; gu.K = H; gu.ldc = 2 * I; gu.nt = 2; gu.asrc = 2; gu.a_f32 = r.x; gu.lda = H;
     gu.norm_w = w.post_norm; gu.ssq_in = ssq; gu.allow_split = c->skinny_gu_split != 0;
-    const int gs = launch_skinny(c, gu);                                   // -> ws_hh / ws_hl: the down product's activation terms
+    gs = launch_skinny(c, gu);                                             // -> ws_hh / ws_hl: the down product's activation terms
+    }
     if (gs > 1) {                                                          // slabs -> siluMul -> terms (z-ordered sums)
       tgx::GemmArgs g{};
       g.part = c->ws_part; g.nsplit = gs; g.M = M; g.N = 2 * I; g.inter = I; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
@@ -1131,13 +1163,18 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
     SkinnyCall dn;
     dn.epi = tgx::GEMM_RESIDUAL; dn.W = w.wdown; dn.C = r.x; dn.ldc = H; dn.M = M; dn.N = H; dn.K = I; dn.nt = 2; dn.asrc = 0; dn.a_hi = c->ws_hh; dn.a_lo = c->ws_hl;
     const int ds = launch_skinny(c, dn);
-    if (ds > 1) launch_reduce_rows(c, tgx::GEMM_RESIDUAL, ds, nullptr, r.x, H, M, H, ssq);
+    if (l + 1 == d.layers && lm_ks) launch_norm_terms(c, r.x, c->final_norm, M, H, ds);      // the last residual goes straight into model.norm's terms
+    else if (ds > 1) launch_reduce_rows(c, tgx::GEMM_RESIDUAL, ds, nullptr, r.x, H, M, H, ssq);
     else hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
   }
+  if (lm_ks) {
+    launch_ksplit(c, tgx::GEMM_STORE, d.tied ? c->embed : c->lm_head, r.logits, V, M, V, H);
+  } else {
   SkinnyCall lm;
   lm.epi = tgx::GEMM_STORE; lm.W = d.tied ? c->embed : c->lm_head; lm.C = r.logits; lm.ldc = V; lm.M = M; lm.N = V; lm.K = H; lm.nt = 2; lm.asrc = 2;
   lm.a_f32 = r.x; lm.lda = H; lm.norm_w = c->final_norm; lm.ssq_in = ssq; lm.allow_split = false;
   launch_skinny(c, lm);
+  }
   hipLaunchKernelGGL(tgx::argmax_partials_rows_kernel, dim3(c->lm_grid, M), dim3(256), 0, c->stream, (const float*)r.logits, (long long)V, V, r.part_val, r.part_idx, (long long)c->lm_grid);
   if (is_greedy(&cfg)) {
     tgx::FinalizeRowsArgs fa{};
@@ -2027,6 +2064,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
   if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "prefill.defer_reduce")) { c->defer_reduce = value != 0; return TGX_OK; }
+  if (!strcmp(key, "skinny.ksplit")) { c->skinny_ksplit = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_tm")) { c->gemm_tm = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_dma")) { c->gemm_dma = value; return TGX_OK; }
   if (!strcmp(key, "debug.gemv")) { c->debug_gemv = value; return TGX_OK; }

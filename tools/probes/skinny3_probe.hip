@@ -1,0 +1,173 @@
+// skinny3_probe.hip — prototype of a barrier-free skinny GEMM: does the weight stream reach the GEMV's rate once the activation-panel chain is gone?
+//
+// kernels/skinny.h stages an activation panel in LDS for the four waves of a workgroup (two barriers per 256 k) and is bound by that chain
+// (profiles/r02_skinny_probe.txt).  Here the four waves of a workgroup split K instead: every wave owns all 64 weight rows of the workgroup for a
+// quarter of K, reads its activation fragments straight from memory (16-bit terms prepared once per layer: lane (m, g) -> 16 bytes of row m),
+// passes its weight tiles through a wave-private LDS tile (transposition only), and the four partial accumulators meet once at the end.
+// No barrier in the K loop.  Timing prototype: bf16, two terms, plain fp32 store; Y[M][N] = X[M][K] . W[N][K]^T checked against a host reference.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "kernels/common.h"
+#include "kernels/skinny.h"
+#include "kernels/skinny_ksplit.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+using namespace tgx;
+
+template <int MB, int K>
+__global__ __launch_bounds__(256) void skinny3_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ Ahi, const bf16_t* __restrict__ Alo, float* __restrict__ C, int M, int N) {
+  constexpr int KT = 64, LDW = KT + 8, KW = K / 4, TILES = KW / KT, SLOTS = 3;      // 4 slots need > 256 VGPRs: the refills then bounce through AGPRs, a drain each
+  __shared__ __attribute__((aligned(16))) bf16_t lds[4 * 64 * LDW];            // wave-private weight tiles; reused for the final reduction
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  bf16_t* sW = lds + wv * 64 * LDW;
+  const int n0 = blockIdx.x * 64;
+  const int kw0 = wv * KW;
+  // weight tile loads: instruction i covers rows 8 i .. 8 i + 7 (8 lanes x 16 B = one 128-byte line per row)
+  const int lrow = lane >> 3, chunk = lane & 7;
+  const bf16_t* wbase = W + (size_t)(n0 + lrow) * K + kw0 + 8 * chunk;
+  u32x4 w[SLOTS][8];
+  auto load_w = [&](int t, u32x4* r) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = load_nt(reinterpret_cast<const u32x4*>(wbase + (size_t)(8 * i) * K + t * KT));
+  };
+  // activation fragments of one tile: 2 k-steps x MB row blocks x 2 terms, straight from memory (row m = 16 mb + (lane & 15), k = ... + 8 (lane >> 4))
+  const int am = lane & 15, ag = lane >> 4;
+  u32x4 fa[SLOTS][2][MB][2];     // as deep as the weight slots: loads retire in order, so a fragment fetched later than a weight tile would drain that tile with it
+  auto load_a = [&](int t, u32x4 (*dst)[MB][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int mb = 0; mb < MB; mb++) {
+        const size_t off = (size_t)min(16 * mb + am, M - 1) * K + kw0 + t * KT + ks * 32 + 8 * ag;
+        dst[ks][mb][0] = *reinterpret_cast<const u32x4*>(Ahi + off);
+        dst[ks][mb][1] = *reinterpret_cast<const u32x4*>(Alo + off);
+      }
+  };
+  f32x4 acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; sl++) { load_a(sl, fa[sl]); load_w(sl, w[sl]); }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {                  // fully unrolled: every register slot is a compile-time constant
+    u32x4* ws = w[t % SLOTS];
+#pragma unroll
+    for (int i = 0; i < 8; i++) *reinterpret_cast<u32x4*>(&sW[(8 * i + lrow) * LDW + chunk * 8]) = ws[i];
+    u32x4 fc[2][MB][2];                              // this tile's fragments leave their slot before it is refilled
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int mb = 0; mb < MB; mb++) { fc[ks][mb][0] = fa[t % SLOTS][ks][mb][0]; fc[ks][mb][1] = fa[t % SLOTS][ks][mb][1]; }
+    if (t + SLOTS < TILES) { load_a(t + SLOTS, fa[t % SLOTS]); load_w(t + SLOTS, ws); }
+    __builtin_amdgcn_sched_barrier(0);               // the refill is issued HERE: the scheduler would sink it towards its use and shrink the bytes in flight
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf16x8 fb[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; nb++) fb[nb] = *reinterpret_cast<const bf16x8*>(&sW[(16 * nb + am) * LDW + ks * 32 + 8 * ag]);
+#pragma unroll
+      for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+        for (int nb = 0; nb < 4; nb++) {
+          acc[mb][nb] = mfma16x16<DT_BF16>(__builtin_bit_cast(bf16x8, fc[ks][mb][1]), fb[nb], acc[mb][nb]);     // small term first
+          acc[mb][nb] = mfma16x16<DT_BF16>(__builtin_bit_cast(bf16x8, fc[ks][mb][0]), fb[nb], acc[mb][nb]);
+        }
+    }
+  }
+  // the four k-quarters meet in LDS; wave w finishes weight-row block w (fixed order: deterministic)
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds);          // [wave][mb][nb][r][lane]
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) red[(((wv * MB + mb) * 4 + nb) * 4 + r) * 64 + lane] = acc[mb][nb][r];
+  __syncthreads();
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float v = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 4; w2++) v += red[(((w2 * MB + mb) * 4 + wv) * 4 + r) * 64 + lane];
+      const int row = 16 * mb + 4 * ag + r, col = n0 + 16 * wv + am;
+      if (row < M && col < N) C[(size_t)row * N + col] = v;
+    }
+}
+
+template <int MB>
+static void run(int M, int N, const bf16_t* W, const bf16_t* Ahi, const bf16_t* Alo, float* C, const std::vector<float>& ref) {
+  constexpr int K = 2048;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int r = 0; r < 20; r++) {
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((skinny3_kernel<MB, K>), dim3(N / 64), dim3(256), 0, 0, W, Ahi, Alo, C, M, N);
+    CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r >= 3 && ms < best) best = ms;
+  }
+  std::vector<float> h((size_t)M * N);
+  CK(hipMemcpy(h.data(), C, h.size() * 4, hipMemcpyDeviceToHost));
+  double err = 0, mx = 0;
+  for (int m = 0; m < M; m++) for (int n = 0; n < N; n += 97) { const size_t i = (size_t)m * N + n; err = fmax(err, fabs(h[i] - ref[i])); mx = fmax(mx, fabs(ref[i])); }   // the host reference fills every 97th column
+  printf("skinny3  M %2d  N %d K %d: %.1f us  (%.2f TB/s of weights)   max err %.3g of %.3g\n", M, N, K, best * 1e3, (double)N * K * 2 / (best * 1e-3) / 1e12, err, mx);
+}
+
+static void run_product(bool fixed, int M, int N, int K, const bf16_t* W, const bf16_t* Ahi, const bf16_t* Alo, float* C, const std::vector<float>& ref) {
+  GemmArgs g{};
+  g.A_hi = Ahi; g.A_lo = Alo; g.B = W; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int r = 0; r < 20; r++) {
+    CK(hipEventRecord(e0, 0));
+    if (fixed) hipLaunchKernelGGL((skinny_ksplit_kernel<DT_BF16, GEMM_STORE, 2048>), dim3(N / 64), dim3(256), 0, 0, g); else hipLaunchKernelGGL((skinny_ksplit_kernel<DT_BF16, GEMM_STORE, 0>), dim3(N / 64), dim3(256), 0, 0, g);
+    CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r >= 3 && ms < best) best = ms;
+  }
+  std::vector<float> h((size_t)M * N);
+  CK(hipMemcpy(h.data(), C, h.size() * 4, hipMemcpyDeviceToHost));
+  double err = 0, mx = 0;
+  for (int m = 0; m < M; m++) for (int n = 0; n < N; n += 97) { const size_t i = (size_t)m * N + n; err = fmax(err, fabs(h[i] - ref[i])); mx = fmax(mx, fabs(ref[i])); }
+  printf("skinny_ksplit_kernel (product, %s K)  M %2d  N %d K %d: %.1f us  (%.2f TB/s of weights)   max err %.3g of %.3g\n", fixed ? "compile-time" : "run-time", M, N, K, best * 1e3, (double)N * K * 2 / (best * 1e-3) / 1e12, err, mx);
+}
+
+static float bf2f(unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
+static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
+
+int main() {
+  const int N = 16384, K = 2048;
+  std::vector<unsigned short> hw((size_t)N * K), hh((size_t)32 * K), hl((size_t)32 * K);
+  std::vector<float> hx((size_t)32 * K);
+  unsigned s = 12345;
+  for (auto& v : hw) { s = s * 1664525u + 1013904223u; v = f2bf((((s >> 8) & 0xffff) / 65536.0f - 0.5f) * 0.05f); }
+  for (size_t i = 0; i < hx.size(); i++) { s = s * 1664525u + 1013904223u; hx[i] = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; hh[i] = f2bf(hx[i]); hl[i] = f2bf(hx[i] - bf2f(hh[i])); }
+  std::vector<float> ref((size_t)32 * N);
+  for (int m = 0; m < 32; m++)
+    for (int n = 0; n < N; n += 97) { double a = 0; for (int k = 0; k < K; k++) a += (double)(bf2f(hh[(size_t)m * K + k]) + bf2f(hl[(size_t)m * K + k])) * bf2f(hw[(size_t)n * K + k]); ref[(size_t)m * N + n] = (float)a; }
+  constexpr int NC = 12;
+  bf16_t* W[NC]; bf16_t *Ahi, *Alo; float* C;
+  for (int i = 0; i < NC; i++) { CK(hipMalloc(&W[i], (size_t)N * K * 2)); CK(hipMemcpy(W[i], hw.data(), (size_t)N * K * 2, hipMemcpyHostToDevice)); }
+  CK(hipMalloc(&Ahi, hh.size() * 2)); CK(hipMemcpy(Ahi, hh.data(), hh.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc(&Alo, hl.size() * 2)); CK(hipMemcpy(Alo, hl.data(), hl.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMalloc(&C, (size_t)32 * N * 4));
+  // compare only the sampled columns (the host reference fills every 97th)
+  auto sampled = [&](int M) { std::vector<float> r((size_t)M * N, 0.f); for (int m = 0; m < M; m++) for (int n = 0; n < N; n += 97) r[(size_t)m * N + n] = ref[(size_t)m * N + n]; return r; };
+  for (int rep = 0; rep < 2; rep++) {
+    for (int M : {8, 32}) {
+      std::vector<float> r = sampled(M);
+      // zero the unsampled columns of the device result on the host side by comparing only sampled entries
+      if (M <= 16) run<1>(M, N, W[(2 * rep) % NC], Ahi, Alo, C, r); else run<2>(M, N, W[(2 * rep + 1) % NC], Ahi, Alo, C, r);
+    }
+  }
+  { std::vector<float> r = sampled(8); run_product(false, 8, N, K, W[5], Ahi, Alo, C, r); run_product(true, 8, N, K, W[6], Ahi, Alo, C, r); }
+  { std::vector<float> r = sampled(16); run_product(true, 16, N, K, W[7], Ahi, Alo, C, r); }
+  return 0;
+}
