@@ -222,6 +222,12 @@ def test_batched_step_wide_products_on_the_k_split_kernel(name, dtype, rows, ora
         runs[mode] = logs
     for a, b in zip(runs["ksplit"], runs["panel"]):
         assert rel_err(a, b) < 5e-4
+    # a prompt of 11 tokens of ONE row takes the same kernels in the short-prompt prefill (11 activation rows)
+    ref.reset_cache(); ref.forward(ids[:1]); lr = ref.logits(False)[:1]
+    for ks in (1, 0):
+        gpu.set_option("skinny.ksplit", ks)
+        gpu.reset_cache(); gpu.forward(ids[:1])
+        assert rel_err(gpu.logits(False)[:1], lr) < 1e-3, ks
 
 
 def test_full_size_sharded_checkpoint_through_cpp_engine(tmp_path):

@@ -1234,12 +1234,18 @@ void launch_prefill_skinny(tgx_ctx* c, int row0, int NB, int S) {
     SkinnyCall o;
     o.epi = tgx::GEMM_RESIDUAL; o.W = w.wo; o.C = c->ws_x; o.ldc = H; o.M = M; o.N = H; o.K = qd; o.nt = 2; o.asrc = 0; o.a_hi = c->ws_ah; o.a_lo = c->ws_al;
     const int os = launch_skinny(c, o);
+    int gs = 1;
+    if (ksplit_ok(c, M, 2 * I, H)) {       // prompts of <= 16 rows: as the batched decode step (the o_proj product has consumed ws_ah / ws_al by now)
+      launch_norm_terms(c, c->ws_x, w.post_norm, M, H, os);
+      launch_ksplit(c, tgx::GEMM_SILU, w.wgu, nullptr, 2 * I, M, 2 * I, H);
+    } else {
     if (os > 1) launch_reduce_rows(c, tgx::GEMM_RESIDUAL, os, nullptr, c->ws_x, H, M, H, ssq);
     else hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)c->ws_x, (long long)H, H, ssq);
     SkinnyCall gu;
     gu.epi = tgx::GEMM_SILU; gu.W = w.wgu; gu.M = M; gu.N = 2 * I; gu.K = H; gu.ldc = 2 * I; gu.nt = 2; gu.asrc = 2; gu.a_f32 = c->ws_x; gu.lda = H;
     gu.norm_w = w.post_norm; gu.ssq_in = ssq; gu.allow_split = c->skinny_gu_split != 0;
-    const int gs = launch_skinny(c, gu);
+    gs = launch_skinny(c, gu);
+    }
     if (gs > 1) {
       tgx::GemmArgs g{};
       g.part = c->ws_part; g.nsplit = gs; g.M = M; g.N = 2 * I; g.inter = I; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
