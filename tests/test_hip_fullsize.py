@@ -193,11 +193,11 @@ def test_decode_crosses_the_matrix_core_attention_threshold(name, prompt_len):
 
 
 @pytest.mark.parametrize("name,dtype,rows", [("llama-3.2-1b", "bf16", 8), ("llama-3.2-1b", "fp16", 5), ("llama-3.2-3b", "bf16", 16), ("mistral-7b-v0.3", "bf16", 3),
-                                             ("llama-3.2-1b", "bf16", 24)])
+                                             ("llama-3.2-1b", "bf16", 24), ("llama-3.2-1b", "fp16", 32)])
 def test_batched_step_wide_products_on_the_k_split_kernel(name, dtype, rows, oracle_lib):
-    """Batches of <= 16 rows run gate_up and lm_head on the barrier-free K-split kernel (kernels/skinny_ksplit.h: hidden sizes 2048 / 3072 /
-    4096 with a compile-time K loop); the tiny fixtures' hidden sizes never reach it, so this runs REAL layer geometry (2 layers, 8k vocabulary)
-    against the oracle, teacher-forced, and against the same batch with the kernel switched off.  24 rows = the panel kernel (control)."""
+    """The batched step runs gate_up and lm_head on the barrier-free K-split kernel (kernels/skinny_ksplit.h: one 16-row block with three weight
+    slots, two blocks with two; hidden sizes 2048 / 3072 / 4096 with a compile-time K loop); the tiny fixtures' hidden sizes never reach it, so
+    this runs REAL layer geometry (2 layers, 8k vocabulary) against the oracle, teacher-forced, and against the same batch with the kernel off."""
     from oracle.oracle_ffi import OracleModel
     d = copy.deepcopy(known_desc(name, dtype))
     d.layers, d.vocab, d.max_ctx, d.max_batch = 2, 8192, 96, rows
@@ -206,7 +206,7 @@ def test_batched_step_wide_products_on_the_k_split_kernel(name, dtype, rows, ora
     ids = np.stack([synth.synth_prompt(d.vocab, 11, 5 + b) for b in range(rows)])
     V = d.vocab
     runs = {}
-    for mode, ks in (("ksplit", 1), ("panel", 0)):
+    for mode, ks in (("ksplit", 2), ("panel", 0)):        # 2: also the two-block form (17-32 rows), which the default leaves to the panel kernel
         gpu.set_option("skinny.ksplit", ks)
         gpu.reset_cache(); ref.reset_cache()
         gpu.forward(ids); ref.forward(ids)
@@ -224,7 +224,7 @@ def test_batched_step_wide_products_on_the_k_split_kernel(name, dtype, rows, ora
         assert rel_err(a, b) < 5e-4
     # a prompt of 11 tokens of ONE row takes the same kernels in the short-prompt prefill (11 activation rows)
     ref.reset_cache(); ref.forward(ids[:1]); lr = ref.logits(False)[:1]
-    for ks in (1, 0):
+    for ks in (2, 0):
         gpu.set_option("skinny.ksplit", ks)
         gpu.reset_cache(); gpu.forward(ids[:1])
         assert rel_err(gpu.logits(False)[:1], lr) < 1e-3, ks

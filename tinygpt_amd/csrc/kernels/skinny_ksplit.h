@@ -14,7 +14,7 @@
 // Every load of the K loop is unconditional from a clamped address and every register slot a compile-time constant (the loop body covers the
 // three slots; a trailing partial trip multiplies by zeroed activation fragments), so the compiler's vmcnt waits stay counted.
 //
-// Needs K % 256 == 0 (a whole number of 64-k tiles per wave) and M <= 16; the launcher falls back to skinny.h otherwise.
+// Needs K % 256 == 0 (a whole number of 64-k tiles per wave) and M <= 32; the launcher falls back to skinny.h otherwise.
 #pragma once
 #include "skinny.h"
 
@@ -22,9 +22,11 @@ namespace tgx {
 
 // KFIX: K known at compile time (2048 / 3072 / 4096: the hidden sizes of the benchmark configs) — the K loop is then fully unrolled, no refill
 // is issued past the range and no trailing dead tile exists (prototype rate: 12.8 µs); 0 = run-time K (14.9 µs on the same product).
-template <int DT, int EPI, int KFIX>
+// MB = 16-row blocks of activation rows (1: M <= 16 with three weight slots in flight per wave; 2: M <= 32 with two — a third slot next to
+// the second block's fragments exceeds 256 VGPRs, and the refills would then bounce through AGPRs with a full drain each).
+template <int DT, int EPI, int KFIX, int MB>
 __global__ __launch_bounds__(256) void skinny_ksplit_kernel(const GemmArgs a) {
-  constexpr int KT = 64, LDW = KT + 8, SLOTS = 3;
+  constexpr int KT = 64, LDW = KT + 8, SLOTS = MB == 1 ? 3 : 2;
   __shared__ __attribute__((aligned(16))) bf16_t lds[4 * 64 * LDW];          // wave-private weight tiles; reused for the final reduction
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   bf16_t* sW = lds + wv * 64 * LDW;
@@ -49,32 +51,40 @@ __global__ __launch_bounds__(256) void skinny_ksplit_kernel(const GemmArgs a) {
   };
   // activation fragments of one tile: 2 k-steps x 2 terms (row m = lane & 15 clamped to M - 1, masked at the store; k = ... + 8 (lane >> 4))
   const int am = lane & 15, ag = lane >> 4;
-  const size_t aoff = (size_t)min(am, a.M - 1) * a.K + kw0 + 8 * ag;
-  auto load_a = [&](int t, u32x4 (*dst)[2]) {
+  size_t aoff[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++) aoff[mb] = (size_t)min(16 * mb + am, a.M - 1) * a.K + kw0 + 8 * ag;
+  auto load_a = [&](int t, u32x4 (*dst)[MB][2]) {
     const bool real = t < tiles;
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      dst[ks][0] = *reinterpret_cast<const u32x4*>(real ? a.A_hi + aoff + t * KT + ks * 32 : a.A_hi);
-      dst[ks][1] = *reinterpret_cast<const u32x4*>(real ? a.A_lo + aoff + t * KT + ks * 32 : a.A_lo);
-    }
-  };
-  f32x4 acc[4];
+    for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-  for (int nb = 0; nb < 4; nb++) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int mb = 0; mb < MB; mb++) {
+        dst[ks][mb][0] = *reinterpret_cast<const u32x4*>(real ? a.A_hi + aoff[mb] + t * KT + ks * 32 : a.A_hi);
+        dst[ks][mb][1] = *reinterpret_cast<const u32x4*>(real ? a.A_lo + aoff[mb] + t * KT + ks * 32 : a.A_lo);
+      }
+  };
+  f32x4 acc[MB][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+    for (int nb = 0; nb < 4; nb++) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 w[SLOTS][8], fa[SLOTS][2][2];
+  u32x4 w[SLOTS][8], fa[SLOTS][2][MB][2];
 #pragma unroll
   for (int sl = 0; sl < SLOTS; sl++) { load_a(sl, fa[sl]); load_w(sl, w[sl]); }
   __builtin_amdgcn_sched_barrier(0);
 
-  auto tile = [&](int t, u32x4* ws, u32x4 (*fs)[2], bool refill) {
+  auto tile = [&](int t, u32x4* ws, u32x4 (*fs)[MB][2], bool refill) {
     const bool live = t < tiles;                                // a trailing partial trip: the tile is a reload, its activations count as zero
 #pragma unroll
     for (int i = 0; i < 8; i++) *reinterpret_cast<u32x4*>(&sW[(8 * i + lrow) * LDW + chunk * 8]) = ws[i];
-    u32x4 fc[2][2];                                              // this tile's fragments leave their slot before it is refilled
+    u32x4 fc[2][MB][2];                                          // this tile's fragments leave their slot before it is refilled
     const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) { fc[ks][0] = live ? fs[ks][0] : zero; fc[ks][1] = live ? fs[ks][1] : zero; }
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int mb = 0; mb < MB; mb++) { fc[ks][mb][0] = live ? fs[ks][mb][0] : zero; fc[ks][mb][1] = live ? fs[ks][mb][1] : zero; }
     if (refill) { load_a(t + SLOTS, fs); load_w(t + SLOTS, ws); }
     __builtin_amdgcn_sched_barrier(0);                           // the refill is issued HERE: the scheduler would sink it towards its use
 #pragma unroll
@@ -83,10 +93,12 @@ __global__ __launch_bounds__(256) void skinny_ksplit_kernel(const GemmArgs a) {
 #pragma unroll
       for (int nb = 0; nb < 4; nb++) fb[nb] = *reinterpret_cast<const bf16x8*>(&sW[(16 * nb + am) * LDW + ks * 32 + 8 * ag]);
 #pragma unroll
-      for (int nb = 0; nb < 4; nb++) {
-        acc[nb] = mfma16x16<DT>(__builtin_bit_cast(bf16x8, fc[ks][1]), fb[nb], acc[nb]);      // small term first
-        acc[nb] = mfma16x16<DT>(__builtin_bit_cast(bf16x8, fc[ks][0]), fb[nb], acc[nb]);
-      }
+      for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+        for (int nb = 0; nb < 4; nb++) {
+          acc[mb][nb] = mfma16x16<DT>(__builtin_bit_cast(bf16x8, fc[ks][mb][1]), fb[nb], acc[mb][nb]);      // small term first
+          acc[mb][nb] = mfma16x16<DT>(__builtin_bit_cast(bf16x8, fc[ks][mb][0]), fb[nb], acc[mb][nb]);
+        }
     }
   };
   if constexpr (KFIX > 0) {
@@ -97,35 +109,39 @@ __global__ __launch_bounds__(256) void skinny_ksplit_kernel(const GemmArgs a) {
     for (int t0 = 0; t0 < tiles; t0 += SLOTS) {
       tile(t0, w[0], fa[0], true);
       tile(t0 + 1, w[1], fa[1], true);
-      tile(t0 + 2, w[2], fa[2], true);
+      if constexpr (SLOTS == 3) tile(t0 + 2, w[2], fa[2], true);
     }
   }
 
   // the four k-quarters meet in LDS; wave w finishes weight-row block w (sum in wave order: deterministic)
   __syncthreads();
-  float* red = reinterpret_cast<float*>(lds);                    // [wave][nb][r][lane]
+  float* red = reinterpret_cast<float*>(lds);                    // [wave][mb][nb][r][lane]
 #pragma unroll
-  for (int nb = 0; nb < 4; nb++)
+  for (int mb = 0; mb < MB; mb++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) red[((wv * 4 + nb) * 4 + r) * 64 + lane] = acc[nb][r];
+    for (int nb = 0; nb < 4; nb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) red[(((wv * MB + mb) * 4 + nb) * 4 + r) * 64 + lane] = acc[mb][nb][r];
   __syncthreads();
   const int col = n0 + 16 * wv + am;
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    float v = 0.f;
+  for (int mb = 0; mb < MB; mb++)
 #pragma unroll
-    for (int w2 = 0; w2 < 4; w2++) v += red[((w2 * 4 + wv) * 4 + r) * 64 + lane];
-    const int row = 4 * ag + r;
-    if (EPI == GEMM_SILU) {        // even lanes hold gate_i, odd lanes up_i (i = col / 2): the pair meets over the DPP crossbar
-      const float other = dpp_mov<0xB1, 0xf>(v);
-      if ((lane & 1) || col >= a.N || row >= a.M) continue;
-      const size_t o = (size_t)row * a.inter + (size_t)(col >> 1);
-      split16<DT>((v / (1.0f + expf(-v))) * other, a.out_hi[o], a.out_lo[o]);
-      continue;
+    for (int r = 0; r < 4; r++) {
+      float v = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 4; w2++) v += red[(((w2 * MB + mb) * 4 + wv) * 4 + r) * 64 + lane];
+      const int row = 16 * mb + 4 * ag + r;
+      if (EPI == GEMM_SILU) {        // even lanes hold gate_i, odd lanes up_i (i = col / 2): the pair meets over the DPP crossbar
+        const float other = dpp_mov<0xB1, 0xf>(v);
+        if ((lane & 1) || col >= a.N || row >= a.M) continue;
+        const size_t o = (size_t)row * a.inter + (size_t)(col >> 1);
+        split16<DT>((v / (1.0f + expf(-v))) * other, a.out_hi[o], a.out_lo[o]);
+        continue;
+      }
+      if (col >= a.N || row >= a.M) continue;
+      a.C[(size_t)row * a.ldc + col] = v + (a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f);
     }
-    if (col >= a.N || row >= a.M) continue;
-    a.C[(size_t)row * a.ldc + col] = v + (a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f);
-  }
 }
 
 }  // namespace tgx

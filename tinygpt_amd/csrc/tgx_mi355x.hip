@@ -182,7 +182,7 @@ struct tgx_ctx {
   bool step_graph_direct = false;
   // contexts from attn_mfma_min keys on take the MFMA decode attention (kernels/attn_decode_mfma.h); like the direct form it is a mode of the
   // captured step: the graphs are re-captured when a decode call crosses the limit.  Not for Qwen3's fused q/k norm, not for fp32 storage.
-  int skinny_ksplit = 1;           // wide products (gate_up, lm_head) of batches of <= 16 rows on the barrier-free K-split kernel (option skinny.ksplit)
+  int skinny_ksplit = 1;           // wide products (gate_up, lm_head) of the batched step on the barrier-free K-split kernel (option skinny.ksplit)
   int defer_reduce = 1;            // split-K slabs of the prefill's N = hidden / QKV products are summed by the next row-wise kernel (option prefill.defer_reduce)
   int attn_mfma_min = -1;          // -1: the measured crossover of the geometry (attn_mfma_threshold); option attn.mfma_min overrides
   bool attn_mfma = false, step_graph_mfma = false;
@@ -1074,17 +1074,19 @@ int ensure_skinny_ws(tgx_ctx* c, int rows) {
   return TGX_OK;
 }
 
-// The wide products of a batch of <= 16 rows on the barrier-free K-split kernel (kernels/skinny_ksplit.h); activations = the 16-bit terms
+// The wide products of a batch of <= 32 rows on the barrier-free K-split kernel (kernels/skinny_ksplit.h); activations = the 16-bit terms
 // rmsnorm_split_kernel left in ws_ah / ws_al.  false: shape not covered (the caller takes the panel kernel).
 bool ksplit_ok(const tgx_ctx* c, int M, int N, int K) {
-  return c->skinny_ksplit && M <= 16 && K % 256 == 0 && K >= 768 && N >= 64 * c->num_cus;
+  // 17-32 rows (two activation blocks, two weight slots) measured level with the panel kernel on Llama-3.2-1B and 3 % behind on Mistral-7B: option value 2 only
+  return c->skinny_ksplit && M <= (c->skinny_ksplit >= 2 ? 32 : 16) && K % 256 == 0 && K >= 768 && N >= 64 * c->num_cus;
 }
 void launch_ksplit(tgx_ctx* c, int epi, const ebyte* W, float* C, int ldc, int M, int N, int K) {
   tgx::GemmArgs g{};
   g.A_hi = c->ws_ah; g.A_lo = c->ws_al; g.B = reinterpret_cast<const bf16_t*>(W); g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.inter = N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
   const dim3 grid((N + 63) / 64), blk(256);
-#define TGX_KS(E_, K_) hipLaunchKernelGGL((tgx::skinny_ksplit_kernel<DT, E_, K_>), grid, blk, 0, c->stream, g)
+#define TGX_KS(E_, K_) do { if (M > 16) hipLaunchKernelGGL((tgx::skinny_ksplit_kernel<DT, E_, K_, 2>), grid, blk, 0, c->stream, g); \
+                            else hipLaunchKernelGGL((tgx::skinny_ksplit_kernel<DT, E_, K_, 1>), grid, blk, 0, c->stream, g); } while (0)
 #define TGX_KS_K(E_) do { if (K == 2048) TGX_KS(E_, 2048); else if (K == 3072) TGX_KS(E_, 3072); else if (K == 4096) TGX_KS(E_, 4096); else TGX_KS(E_, 0); } while (0)
   TGX_DT16_SWITCH(c->dt, if (epi == tgx::GEMM_SILU) TGX_KS_K(tgx::GEMM_SILU); else TGX_KS_K(tgx::GEMM_STORE);)
 #undef TGX_KS_K
@@ -2070,7 +2072,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
   if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "prefill.defer_reduce")) { c->defer_reduce = value != 0; return TGX_OK; }
-  if (!strcmp(key, "skinny.ksplit")) { c->skinny_ksplit = value != 0; return TGX_OK; }
+  if (!strcmp(key, "skinny.ksplit")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.ksplit must be 0, 1 (<= 16 rows) or 2 (<= 32 rows)"); c->skinny_ksplit = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_tm")) { c->gemm_tm = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_dma")) { c->gemm_dma = value; return TGX_OK; }
   if (!strcmp(key, "debug.gemv")) { c->debug_gemv = value; return TGX_OK; }

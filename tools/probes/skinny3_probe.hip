@@ -128,7 +128,8 @@ static void run_product(bool fixed, int M, int N, int K, const bf16_t* W, const 
   float best = 1e30f;
   for (int r = 0; r < 20; r++) {
     CK(hipEventRecord(e0, 0));
-    if (fixed) hipLaunchKernelGGL((skinny_ksplit_kernel<DT_BF16, GEMM_STORE, 2048>), dim3(N / 64), dim3(256), 0, 0, g); else hipLaunchKernelGGL((skinny_ksplit_kernel<DT_BF16, GEMM_STORE, 0>), dim3(N / 64), dim3(256), 0, 0, g);
+    if (M > 16) { if (fixed) hipLaunchKernelGGL((skinny_ksplit_kernel<DT_BF16, GEMM_STORE, 2048, 2>), dim3(N / 64), dim3(256), 0, 0, g); else hipLaunchKernelGGL((skinny_ksplit_kernel<DT_BF16, GEMM_STORE, 0, 2>), dim3(N / 64), dim3(256), 0, 0, g); }
+    else if (fixed) hipLaunchKernelGGL((skinny_ksplit_kernel<DT_BF16, GEMM_STORE, 2048, 1>), dim3(N / 64), dim3(256), 0, 0, g); else hipLaunchKernelGGL((skinny_ksplit_kernel<DT_BF16, GEMM_STORE, 0, 1>), dim3(N / 64), dim3(256), 0, 0, g);
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r >= 3 && ms < best) best = ms;
   }
@@ -169,5 +170,6 @@ int main() {
   }
   { std::vector<float> r = sampled(8); run_product(false, 8, N, K, W[5], Ahi, Alo, C, r); run_product(true, 8, N, K, W[6], Ahi, Alo, C, r); }
   { std::vector<float> r = sampled(16); run_product(true, 16, N, K, W[7], Ahi, Alo, C, r); }
+  { std::vector<float> r = sampled(32); run_product(true, 32, N, K, W[8], Ahi, Alo, C, r); run_product(false, 32, N, K, W[9], Ahi, Alo, C, r); run_product(true, 24, N, K, W[10], Ahi, Alo, C, sampled(24)); }
   return 0;
 }
