@@ -230,6 +230,22 @@ def test_batched_step_wide_products_on_the_k_split_kernel(name, dtype, rows, ora
         assert rel_err(gpu.logits(False)[:1], lr) < 1e-3, ks
 
 
+def test_long_prompt_attention_form_matches_the_other_schedules():
+    """Prompts that give every CU three or more attention workgroups (head_dim 64: from ~3k tokens at 32 heads) take the one-tile look-ahead form of
+    attn_prefill_kernel (three waves per SIMD).  Real head geometry, 2 layers: the logits of a 3200-token prefill equal those of (a) a 3199-token
+    prefill followed by the last token as a decode pass over the cache that prefill wrote and (b) the decode kernels walking the whole prompt."""
+    d = copy.deepcopy(known_desc("llama-3.2-1b"))
+    d.layers, d.vocab, d.max_ctx, d.max_batch = 2, 8192, 3300, 1
+    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    p = synth.synth_prompt(d.vocab, 3200, 3)[None, :]
+    m.forward(p); a = m.logits(False).copy(); ta = m.sample(GREEDY).copy()
+    m.reset_cache(); m.forward(p[:, :3199]); m.forward(p[:, 3199:]); b = m.logits(False).copy()
+    assert rel_err(b, a) < 1e-3
+    m.reset_cache(); m.set_option("prefill.mfma", 0); m.forward(p); c_ = m.logits(False).copy(); m.set_option("prefill.mfma", 1)
+    assert rel_err(c_, a) < 1e-3
+    np.testing.assert_array_equal(m.sample(GREEDY), ta)
+
+
 def test_full_size_sharded_checkpoint_through_cpp_engine(tmp_path):
     """a full-size (Llama-3.2-1B geometry, 2.5 GB) checkpoint written as 3 safetensors shards +
     index by the `safetensors` package, read by the C++ loader (mmap -> tgx_upload by HF name) and run by the C++ engine

@@ -466,8 +466,10 @@ struct AttnPrefillArgs {
 #ifndef TGX_ATTN_DIS
 #define TGX_ATTN_DIS 0      // experiments only (tools/probes/attn_prefill_probe.hip): 1 no LDS staging, 2 no softmax arithmetic, 4 no PV, 8 no QK^T, 16 no tile fetch
 #endif
-template <int DT, int HD>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs a) {
+// LA = K / V tiles of look-ahead.  2 (two register sets) is the faster form while a CU holds two workgroups (S <= ~2k: 61 vs 65 µs per layer at 2048);
+// long prompts give every CU three or more, and the leaner LA = 1 form (162 VGPRs) then runs three waves per SIMD: 251 -> 203 µs per layer at S = 4096, 820 -> 720 at 8192.
+template <int DT, int HD, int LA = 2>
+__global__ __launch_bounds__(256, LA == 1 ? 3 : 1) void attn_prefill_kernel(const AttnPrefillArgs a) {      // LA = 1 is instantiated for head_dim 64 only (128 would spill at three waves)
   constexpr int DIS = TGX_ATTN_DIS;
   constexpr int LQ = HD + 8;                  // 16-bit row stride of the K tile (144 / 272 B: conflict-free 16-byte fragment reads)
   constexpr int LV = HD + 32;                 // 16-bit row stride of the V tile ([key][d], 64 B more than a row: the four key rows of a transposing read fall on four bank quarters)
@@ -644,6 +646,16 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
     }
   };
 
+  if constexpr (LA == 1) {
+    fetch_tile(0, kvA, vvA);
+    for (int kt = 0; kt < n_kt; kt++) {
+      __syncthreads();
+      if (!(DIS & 1)) stage_tile(kvA, vvA);
+      __syncthreads();
+      if (!(DIS & 16)) fetch_tile(kt + 1, kvA, vvA);            // (past the range: a clamped reload)
+      compute_tile(kt);
+    }
+  } else {
   __builtin_amdgcn_sched_barrier(0);           // the loop's counted waits assume the issue order: set A, then set B (older loads retire first)
   fetch_tile(0, kvA, vvA);
   __builtin_amdgcn_sched_barrier(0);
@@ -662,6 +674,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnPrefillArgs
     __syncthreads();
     if (!(DIS & 16)) fetch_tile(kt + 3, kvB, vvB);
     compute_tile(kt + 1);
+  }
   }
 
   // normalise and emit as hi / lo 16-bit pairs (the o_proj GEMM's A operand).  A lane holds ONE query's output dims, so direct stores would be

@@ -821,7 +821,10 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
       a.o_hi = c->ws_ah + ro * qd; a.o_lo = c->ws_al + ro * qd; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
       a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = c->attn_mirror;
       const dim3 grid((S + 127) / 128, d.heads), blk(256);
-      TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64>), grid, blk, 0, c->stream, a);
+      // head_dim 64 with three or more workgroups per CU: the one-tile look-ahead form at three waves per SIMD (prefill.h)
+      const bool lean = hd == 64 && (int)(grid.x * grid.y) >= 3 * c->num_cus;
+      TGX_DT16_SWITCH(c->dt, if (lean) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64, 1>), grid, blk, 0, c->stream, a);
+                             else if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64>), grid, blk, 0, c->stream, a);
                              else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128>), grid, blk, 0, c->stream, a))
     }
     int osl = 1;

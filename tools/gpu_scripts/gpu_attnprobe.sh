@@ -1,4 +1,3 @@
-cd /root/repo; mkdir -p gpurun_out
-for i in 1 2 3; do echo old; tools/probes/build/attn_probe_old; echo new; tools/probes/build/attn_probe_0; done
-for i in 1 2; do echo old; tools/probes/build/attn_probe_old128; echo new; tools/probes/build/attn_probe_new128; done
-for i in 1 2; do echo old; tools/probes/build/attn_probe_old 8192; echo new; tools/probes/build/attn_probe_0 8192; done
+cd /root/repo
+for i in 1 2; do for s in 2048 3072 4096 8192; do for la in 2 1; do tools/probes/build/attn_probe_la$la $s; done; done; done
+for s in 2048 4096 8192; do for la in 2 1; do tools/probes/build/attn_probe_la${la}_128 $s; done; done

@@ -9,6 +9,9 @@
 #include "kernels/common.h"
 #include "kernels/prefill.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+#ifndef PROBE_LA
+#define PROBE_LA 2
+#endif
 #ifndef PROBE_HD
 #define PROBE_HD 64
 #endif
@@ -31,10 +34,10 @@ int main(int argc, char** argv) {
   float best = 1e30f;
   for (int r = 0; r < 12; r++) {
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((tgx::attn_prefill_kernel<tgx::DT_BF16, PROBE_HD>), grid, blk, 0, 0, a);
+    hipLaunchKernelGGL((tgx::attn_prefill_kernel<tgx::DT_BF16, PROBE_HD, PROBE_LA>), grid, blk, 0, 0, a);
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r >= 2 && ms < best) best = ms;
   }
-  printf("DIS=%2d  hd %3d  S %d: %.1f us\n", TGX_ATTN_DIS, HD, S, best * 1e3);
+  printf("DIS=%2d  LA %d  hd %3d  S %d: %.1f us\n", TGX_ATTN_DIS, PROBE_LA, HD, S, best * 1e3);
   return 0;
 }
