@@ -469,7 +469,7 @@ struct AttnPrefillArgs {
 // LA = K / V tiles of look-ahead.  2 (two register sets) is the faster form while a CU holds two workgroups (S <= ~2k: 61 vs 65 µs per layer at 2048);
 // long prompts give every CU three or more, and the leaner LA = 1 form (162 VGPRs) then runs three waves per SIMD: 251 -> 203 µs per layer at S = 4096, 820 -> 720 at 8192.
 template <int DT, int HD, int LA = 2>
-__global__ __launch_bounds__(256, LA == 1 ? 3 : 1) void attn_prefill_kernel(const AttnPrefillArgs a) {      // LA = 1 is instantiated for head_dim 64 only (128 would spill at three waves)
+__global__ __launch_bounds__(256, LA == 1 ? (HD == 64 ? 3 : 2) : 1) void attn_prefill_kernel(const AttnPrefillArgs a) {      // head_dim 128: LA = 1 fits two waves per SIMD (LA = 2 needs 292 registers: one)
   constexpr int DIS = TGX_ATTN_DIS;
   constexpr int LQ = HD + 8;                  // 16-bit row stride of the K tile (144 / 272 B: conflict-free 16-byte fragment reads)
   constexpr int LV = HD + 32;                 // 16-bit row stride of the V tile ([key][d], 64 B more than a row: the four key rows of a transposing read fall on four bank quarters)
