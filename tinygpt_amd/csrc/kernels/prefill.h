@@ -458,11 +458,12 @@ struct AttnPrefillArgs {
 // Scores and probabilities never leave the registers (the first version of this round routed them through LDS with four
 // barriers per tile: 262 us per layer at S = 2048 against 165 us for this one).
 // One workgroup = 128 queries of one query head (4 waves x 32 queries); K / V tiles of 64 keys go global -> registers -> LDS
-// (V transposed), shared by the four waves.  Each wave computes S^T = K.Q^T — the MFMA's output layout then gives every lane
-// ONE query column (16 keys per 32-key sub-tile; the other half-wave holds the other 16), so the online softmax is lane-local
+// as they are ([key][d], padded rows), shared by the four waves.  Each wave computes S^T = K.Q^T — the MFMA's output layout then gives
+// every lane ONE query column (16 keys per 32-key sub-tile; the other half-wave holds the other 16), so the online softmax is lane-local
 // plus one exchange with lane^32, the running maximum / sum / rescale are per-lane scalars, and the probabilities are already
-// in the B-operand order of the next MFMA: O^T += V^T.P^T, where the V^T fragment is read in the SAME key permutation
-// (keys 4hh..4hh+3 and 8+4hh..8+4hh+3 of every 16: two 8-byte LDS reads).  Q (hi, lo) lives in registers for the whole kernel.
+// in the B-operand order of the next MFMA: O^T += V^T.P^T, where the V^T fragment comes out of the [key][d] tile through the transposing
+// LDS read (ds_read_b64_tr_b16) in the SAME key permutation (keys 4hh..4hh+3 and 8+4hh..8+4hh+3 of every 16: two 8-byte reads).
+// Q (hi, lo) lives in registers for the whole kernel; the output rows leave through an LDS transpose as whole rows.
 #ifndef TGX_ATTN_DIS
 #define TGX_ATTN_DIS 0      // experiments only (tools/probes/attn_prefill_probe.hip): 1 no LDS staging, 2 no softmax arithmetic, 4 no PV, 8 no QK^T, 16 no tile fetch
 #endif
