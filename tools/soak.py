@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Determinism soak: the same work repeated many times must give bit-identical results (a race in an LDS-DMA ring, a counted wait one short or a
+missing barrier shows up as a rare mismatch long before it shows up in a parity test).  Prefill of 2048 / 3200 / 300 tokens x N, batched decode x 2."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from tinygpt_amd import known_desc, synth
+from tinygpt_amd.ffi import GREEDY, Model
+import copy
+name = sys.argv[1] if len(sys.argv) > 1 else "llama-3.2-1b"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+d = copy.deepcopy(known_desc(name)); d.max_ctx = 4096; d.max_batch = 16
+m = Model(d).load_synthetic(1234, 0.02).finalize()
+bad = 0
+for S in (2048, 3200, 300, 40, 12):
+    ids = synth.synth_prompt(d.vocab, S, 7)[None, :]
+    ref = None
+    t0 = time.time()
+    for r in range(reps if S >= 300 else 3 * reps):
+        m.reset_cache(); m.forward(ids)
+        lg = m.logits(False).copy()
+        if ref is None: ref = lg
+        elif not np.array_equal(ref, lg): bad += 1; print(f"MISMATCH prefill S={S} rep {r}: max diff {np.abs(ref - lg).max():.3e}", flush=True)
+    print(f"prefill S={S}: {reps if S >= 300 else 3 * reps} repetitions, {time.time() - t0:.1f} s", flush=True)
+for B in (3, 8, 16):
+    ids = np.stack([synth.synth_prompt(d.vocab, 64, 11 + b) for b in range(B)])
+    outs = []
+    for r in range(3):
+        m.reset_cache(); m.forward(ids); m.sample(GREEDY)
+        outs.append(m.decode(300, GREEDY).copy())
+    for r in (1, 2):
+        if not np.array_equal(outs[0], outs[r]): bad += 1; print(f"MISMATCH decode B={B} run {r}", flush=True)
+    print(f"decode B={B}: 3 x 300 steps equal: {all(np.array_equal(outs[0], o) for o in outs)}", flush=True)
+print("SOAK", "FAILED" if bad else "OK", bad)
+sys.exit(1 if bad else 0)
