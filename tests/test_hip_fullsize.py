@@ -246,6 +246,21 @@ def test_long_prompt_attention_form_matches_the_other_schedules():
     np.testing.assert_array_equal(m.sample(GREEDY), ta)
 
 
+@pytest.mark.parametrize("name,S", [("llama-3.2-1b", 256), ("qwen2.5-0.5b", 300), ("mistral-7b-v0.3", 200)])
+def test_deferred_split_k_reduce_is_bit_identical(name, S):
+    """Prompts of a few hundred tokens split the N = hidden and QKV products over K; the slabs are summed either by a reduce launch or (default, from
+    192 rows) by the next row-wise kernel — RMSNorm / RoPE — in the same z order.  Same sums, same order: the logits must be EQUAL, not close."""
+    d = copy.deepcopy(known_desc(name))
+    d.layers, d.vocab, d.max_ctx, d.max_batch = 3, 8192, 512, 1
+    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    p = synth.synth_prompt(d.vocab, S, 3)[None, :]
+    out = []
+    for v in (1, 0):
+        m.set_option("prefill.defer_reduce", v)
+        m.reset_cache(); m.forward(p); out.append(m.logits(False).copy())
+    np.testing.assert_array_equal(out[0], out[1])
+
+
 def test_full_size_sharded_checkpoint_through_cpp_engine(tmp_path):
     """a full-size (Llama-3.2-1B geometry, 2.5 GB) checkpoint written as 3 safetensors shards +
     index by the `safetensors` package, read by the C++ loader (mmap -> tgx_upload by HF name) and run by the C++ engine
