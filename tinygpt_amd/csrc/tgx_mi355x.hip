@@ -26,6 +26,7 @@
 #include "kernels/skinny_ksplit.h"
 #include "kernels/gemm_f32.h"
 #include "kernels/gemm_dma.h"
+#include "kernels/engine.h"
 
 using tgx::bf16_t;
 typedef unsigned char ebyte;   // parameter / KV-cache storage in the compute dtype: offsets are elements * ctx.esz
@@ -190,6 +191,17 @@ struct tgx_ctx {
   int debug_skip = 0;        // experiment: bit0 skip attn decode kernel, bit1 skip combine (results invalid)
   int prof_same_layer = 0;   // experiment: tgx_profile_decode replays ONE layer's weights (Infinity-Cache resident)
   int debug_nops = 0;     // extra no-op launches per layer (launch-overhead experiments only)
+  // The persistent weight-streaming engine (kernels/engine.h), batch-1 decode steps of the RMSNorm families in 16-bit storage.  Option
+  // engine.mode: 0 = off (default: the GEMV launches measured faster on MI355X, profiles/r03_engine.txt), 1 = gate_up + down in one launch,
+  // 2 = o_proj + gate_up + down + the next layer's qkv in one launch (3 launches per layer instead of 6).
+  int engine_mode = 0;
+  int engine_ns = 0;         // ring slots (0: as many as LDS holds)
+  int engine_depth = 3;      // fills in flight per CU
+  int engine_thin = 0;
+  int engine_stats = 0;      // 1: the STATS instantiation records its timeline per layer (tgx_engine_read_stats)
+  tgx::u64 *eng_gx1 = nullptr, *eng_gh = nullptr, *eng_gx2 = nullptr;   // granule buffers of the three in-launch edges
+  unsigned *eng_epoch = nullptr, *eng_err = nullptr;
+  unsigned long long* eng_stats = nullptr;   // [layers][num_cus][ENG_NSTAT]
   int* nop_word = nullptr;
   float* scratch_x = nullptr;   // [hidden] residual sink for tgx_profile_decode
   Profiler prof;
@@ -464,7 +476,7 @@ void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls, int R) {
 // merged rows fit its LDS stage: R rows x heads*head_dim fp32 <= 64 KB (every BASELINE geometry at R <= 4).  Option attn.fold_combine = 0
 // keeps the separate attn_combine_kernel launch.
 bool attn_fold_ok(const tgx_ctx* c, int R) {
-  return c->attn_fold && !c->attn_direct && (size_t)R * c->d.heads * c->d.head_dim * 4 <= 65536;
+  return c->attn_fold && c->engine_mode < 2 && !c->attn_direct && (size_t)R * c->d.heads * c->d.head_dim * 4 <= 65536;
 }
 
 template <int DT, int HD, bool QKN = false>
@@ -618,7 +630,87 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
 
 // All decoder layers for rows [row0, row0+R): their current tokens' embeddings sit in slab_x, positions in slab_pos.
 // == for (auto& layer : layers_) x = layer->forward(x)  (GPTModel.h:53-55)
+// ---- persistent engine (kernels/engine.h) ----------------------------------------------------------------------------------------
+int engine_ring_slots(const tgx_ctx* c, int xb0, int xb1) {
+  int ns = (int)((160 * 1024 - (size_t)xb0 - (size_t)xb1 - tgx::ENG_RGS * tgx::ENG_KCMAX * 32 - 1024) / tgx::ENG_SLOT);
+  if (ns > 15) ns = 15;
+  if (c->engine_ns > 0 && c->engine_ns < ns) ns = c->engine_ns;
+  return ns;
+}
+// Geometries the engine's tiles cover: every K a multiple of 1024 (8 rows x 1024 k tiles), row counts multiples of 8, head_dim 64 / 128,
+// a normed input of at most 4096 values, and at least 4 ring slots next to the staged inputs.
+bool engine_ok(const tgx_ctx* c, int R, long long kv_stride) {
+  const tgx_model_desc& d = c->d;
+  if (!c->engine_mode || R != 1 || kv_stride == 0 || c->gpt2 || d.qk_norm || c->dt == tgx::DT_F32 || !c->eng_gh) return false;
+  const int H = d.hidden, I = d.inter, qd = d.heads * d.head_dim, kvd = d.kv_heads * d.head_dim;
+  if (H % 1024 || I % 1024 || qd % 1024 || (qd + 2 * kvd) % 8 || H > 4096 || I > 1024 * tgx::ENG_KCMAX || qd > 8192) return false;
+  if (d.head_dim != 64 && d.head_dim != 128) return false;
+  if ((H / 8 + c->num_cus - 1) / c->num_cus * 8 > tgx::ENG_RES_MAX) return false;
+  return engine_ring_slots(c, std::max(qd, I) * 4, H * 4) >= 4;
+}
+
+// One engine launch for layer l of row r: mode 1 = {gate_up, down}; mode 2 = {o_proj, gate_up, down, qkv of layer l + 1 (if any)}
+void launch_engine(tgx_ctx* c, RowState& r, int l) {
+  const tgx_model_desc& d = c->d;
+  const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
+  const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd * c->esz;
+  const LayerW& w = c->L[(size_t)l];
+  tgx::EngArgs a{};
+  a.thin = c->engine_thin; a.depth = c->engine_depth;
+  a.x_in = r.x; a.pos = r.pos; a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.eps = d.norm_eps;
+  a.epoch = c->eng_epoch; a.err = c->eng_err;
+  a.stats = (c->engine_stats && c->eng_stats) ? c->eng_stats + (size_t)l * c->num_cus * tgx::ENG_NSTAT : nullptr;
+  int n = 0, edge = 0;
+  if (c->engine_mode >= 2) {
+    tgx::EngOp& o = a.op[n++];
+    o.W = w.wo; o.bias = w.bo; o.N = H; o.K = qd; o.epi = tgx::EOP_RESID; o.in_plain = r.attn; o.out_gran = c->eng_gx1; o.out_tag = edge;
+  }
+  {
+    tgx::EngOp& o = a.op[n++];
+    o.W = w.wgu; o.norm_w = w.post_norm; o.N = 2 * I; o.K = H; o.epi = tgx::EOP_SILU;
+    if (c->engine_mode >= 2) { o.in_gran = c->eng_gx1; o.in_tag = edge++; } else o.in_plain = r.x;
+    o.out_gran = c->eng_gh; o.out_tag = edge;
+  }
+  {
+    tgx::EngOp& o = a.op[n++];
+    o.W = w.wdown; o.bias = w.bdown; o.N = H; o.K = I; o.epi = tgx::EOP_RESID; o.in_gran = c->eng_gh; o.in_tag = edge++; o.out_plain = r.x;
+  }
+  if (c->engine_mode >= 2 && l + 1 < d.layers) {
+    const LayerW& nw = c->L[(size_t)l + 1];
+    a.op[n - 1].out_gran = c->eng_gx2; a.op[n - 1].out_tag = edge;
+    tgx::EngOp& o = a.op[n++];
+    o.W = nw.wqkv; o.bias = nw.bqkv; o.norm_w = nw.in_norm; o.N = qd + 2 * kvd; o.K = H; o.epi = tgx::EOP_QKV; o.in_gran = c->eng_gx2; o.in_tag = edge++;
+    a.q_out = r.q; a.k_cache = r.kcache + (size_t)(l + 1) * kv_layer; a.v_cache = r.vcache + (size_t)(l + 1) * kv_layer;
+    a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
+  }
+  a.nops = n;
+  // the ops' inputs alternate between two LDS staging buffers: sizes by the widest input of each parity
+  int xb[2] = {0, 0};
+  for (int k = 0; k < n; k++) { xb[k & 1] = std::max(xb[k & 1], a.op[k].K * 4); tgx::eng_plan_op(a.op[k], c->num_cus); }
+  a.xb_bytes[0] = xb[0]; a.xb_bytes[1] = xb[1];
+  a.ns = engine_ring_slots(c, xb[0], xb[1]);
+  const size_t lds = tgx::eng_lds_bytes(a.ns, xb[0], xb[1]);
+  const dim3 g(c->num_cus), b(tgx::ENG_THREADS);
+  if (c->dt == tgx::DT_F16) {
+    if (a.stats) hipLaunchKernelGGL((tgx::engine_kernel<tgx::DT_F16, true>), g, b, lds, c->stream, a);
+    else hipLaunchKernelGGL((tgx::engine_kernel<tgx::DT_F16, false>), g, b, lds, c->stream, a);
+  } else {
+    if (a.stats) hipLaunchKernelGGL((tgx::engine_kernel<tgx::DT_BF16, true>), g, b, lds, c->stream, a);
+    else hipLaunchKernelGGL((tgx::engine_kernel<tgx::DT_BF16, false>), g, b, lds, c->stream, a);
+  }
+}
+
 void launch_layers(tgx_ctx* c, RowState* rv, int R, long long kv_stride) {
+  if (engine_ok(c, R, kv_stride)) {
+    // == the same layer sequence (GPTModel.h:53-55) with the Linears between two attentions in ONE persistent launch
+    for (int l = 0; l < c->d.layers; l++) {
+      if (c->engine_mode == 1 || l == 0) launch_layer_kernel(c, rv, R, l, TGX_KERNEL_QKV, rv[0].x, kv_stride);
+      launch_layer_kernel(c, rv, R, l, TGX_KERNEL_ATTN, rv[0].x, kv_stride);
+      if (c->engine_mode == 1) launch_layer_kernel(c, rv, R, l, TGX_KERNEL_OPROJ, rv[0].x, kv_stride);
+      launch_engine(c, rv[0], l);
+    }
+    return;
+  }
   for (int l = 0; l < c->d.layers; l++) {
     for (int cls = TGX_KERNEL_QKV; cls <= TGX_KERNEL_DOWN; cls++) launch_layer_kernel(c, rv, R, l, cls, rv[0].x, kv_stride);
     for (int i = 0; i < c->debug_nops; i++) hipLaunchKernelGGL(tgx::nop_kernel, dim3(1), dim3(64), 0, c->stream, c->nop_word);
@@ -1775,6 +1867,21 @@ int tgx_finalize(tgx_ctx* c) {
 #undef TGX_DMA_ATTR_D
 #undef TGX_DMA_ATTR
 #undef TGX_DMA_ATTR1
+  // persistent engine (option engine.mode): granule buffers of its in-launch edges, the tag epoch, the give-up word
+  if (!c->gpt2 && c->dt != tgx::DT_F32) {
+    if ((rc = dev_alloc(c, &c->eng_gx1, (size_t)H))) return rc;
+    if ((rc = dev_alloc(c, &c->eng_gh, (size_t)I))) return rc;
+    if ((rc = dev_alloc(c, &c->eng_gx2, (size_t)H))) return rc;
+    if ((rc = dev_alloc(c, &c->eng_epoch, 1))) return rc;
+    if ((rc = dev_alloc(c, &c->eng_err, 1))) return rc;
+    HIP_OK(c, hipMemset(c->eng_gx1, 0, (size_t)H * 8)); HIP_OK(c, hipMemset(c->eng_gh, 0, (size_t)I * 8)); HIP_OK(c, hipMemset(c->eng_gx2, 0, (size_t)H * 8));
+    const unsigned one = 1, zero = 0;
+    HIP_OK(c, hipMemcpy(c->eng_epoch, &one, 4, hipMemcpyHostToDevice)); HIP_OK(c, hipMemcpy(c->eng_err, &zero, 4, hipMemcpyHostToDevice));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::engine_kernel<tgx::DT_BF16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::engine_kernel<tgx::DT_BF16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::engine_kernel<tgx::DT_F16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::engine_kernel<tgx::DT_F16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
   c->past = 0;
   c->finalized = true;
   return TGX_OK;
@@ -1787,6 +1894,7 @@ void tgx_destroy(tgx_ctx* c) {
   drop_step_graphs(c);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->wpe); fr(c->final_norm_b); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->lm_ticket); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
+  fr(c->eng_gx1); fr(c->eng_gh); fr(c->eng_gx2); fr(c->eng_epoch); fr(c->eng_err); fr(c->eng_stats);
   fr(c->ch_x); fr(c->ch_q); fr(c->ch_kraw); fr(c->ch_attn); fr(c->ch_h); fr(c->ch_part); fr(c->ch_pos);
   fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl); fr(c->ws_part); fr(c->ws_ssq); fr(c->ws_pos); fr(c->ws_attn_part);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); fr(w.in_norm_b); fr(w.post_norm_b); fr(w.bo); fr(w.bfc); fr(w.bdown); }
@@ -1969,6 +2077,26 @@ int tgx_synchronize(tgx_ctx* c) {
   if (!c) return TGX_ERR_INVALID;
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipStreamSynchronize(c->stream));
+  if (c->engine_mode && c->eng_err) {   // a bounded spin of the persistent engine gave up (kernels/engine.h): the step's results are invalid
+    unsigned e = 0;
+    HIP_OK(c, hipMemcpy(&e, c->eng_err, 4, hipMemcpyDeviceToHost));
+    if (e) { const unsigned z = 0; (void)hipMemcpy(c->eng_err, &z, 4, hipMemcpyHostToDevice); return set_err(c, TGX_ERR_DEVICE, "decode engine gave up a wait (code 0x%x)", e); }
+  }
+  return TGX_OK;
+}
+
+int tgx_engine_read_stats(tgx_ctx* c, uint64_t* out, int64_t capacity, int32_t* out_layers, int32_t* out_cus, int32_t* out_fields) {
+  if (!c || !c->finalized) return TGX_ERR_INVALID;
+  if (out_layers) *out_layers = c->d.layers;
+  if (out_cus) *out_cus = c->num_cus;
+  if (out_fields) *out_fields = tgx::ENG_NSTAT;
+  if (!out) return TGX_OK;
+  if (!c->eng_stats) return set_err(c, TGX_ERR_STATE, "no engine statistics: set option engine.stats = 1 first");
+  const int64_t n = (int64_t)c->d.layers * c->num_cus * tgx::ENG_NSTAT;
+  if (capacity < n) return set_err(c, TGX_ERR_INVALID, "engine statistics need %lld words", (long long)n);
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  HIP_OK(c, hipMemcpy(out, c->eng_stats, (size_t)n * 8, hipMemcpyDeviceToHost));
   return TGX_OK;
 }
 
@@ -2095,6 +2223,23 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "skinny.cfg")) { if (value < -1 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.cfg is -1..2"); c->skinny_cfg_force = value; return TGX_OK; }
   if (!strcmp(key, "decode.mfma_min_batch")) { if (value < 1) return set_err(c, TGX_ERR_INVALID, "decode.mfma_min_batch must be >= 1"); c->decode_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
+  if (!strncmp(key, "engine.", 7)) {   // the persistent decode engine (kernels/engine.h); captured step graphs hold the old launch sequence
+    if (!strcmp(key, "engine.mode")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "engine.mode is 0 (off), 1 (gate_up + down) or 2 (o_proj .. next qkv)"); drop_step_graphs(c); c->engine_mode = value; return TGX_OK; }
+    if (!strcmp(key, "engine.ns")) { if (value < 0 || value > 15) return set_err(c, TGX_ERR_INVALID, "engine.ns is 0 (auto) .. 15"); drop_step_graphs(c); c->engine_ns = value; return TGX_OK; }
+    if (!strcmp(key, "engine.depth")) { if (value < 2 || value > 4) return set_err(c, TGX_ERR_INVALID, "engine.depth is 2 .. 4"); drop_step_graphs(c); c->engine_depth = value; return TGX_OK; }
+    if (!strcmp(key, "engine.thin")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "engine.thin is 0 .. 2"); drop_step_graphs(c); c->engine_thin = value; return TGX_OK; }
+    if (!strcmp(key, "engine.stats")) {
+      drop_step_graphs(c);
+      if (value && !c->eng_stats) {
+        if (!c->finalized) return set_err(c, TGX_ERR_STATE, "engine.stats needs a finalized context");
+        int rc;
+        if ((rc = dev_alloc(c, &c->eng_stats, (size_t)c->d.layers * c->num_cus * tgx::ENG_NSTAT))) return rc;
+        HIP_OK(c, hipMemset(c->eng_stats, 0, (size_t)c->d.layers * c->num_cus * tgx::ENG_NSTAT * 8));
+      }
+      c->engine_stats = value != 0;
+      return TGX_OK;
+    }
+  }
   if (!strcmp(key, "attn.nsplit")) {
     if (c->finalized) return set_err(c, TGX_ERR_STATE, "attn.nsplit must be set before tgx_finalize");
     if (value < 1 || value > 32) return set_err(c, TGX_ERR_INVALID, "attn.nsplit out of range");

@@ -16,6 +16,7 @@ ap.add_argument("--model", default="llama-3.2-1b")
 ap.add_argument("--prompt", type=int, default=64)
 ap.add_argument("--steps", type=int, default=128)
 ap.add_argument("--ctx", type=int, default=0)
+ap.add_argument("--opt", action="append", default=[], help="key=value for tgx_set_option (after finalize), e.g. engine.mode=2")
 args = ap.parse_args()
 
 d = known_desc(args.model)
@@ -23,6 +24,9 @@ if args.ctx:
     d.max_ctx = args.ctx
 t0 = time.time()
 m = Model(d).load_synthetic(1234, 0.02).finalize()
+for kv in args.opt:
+    k, v = kv.split("=")
+    m.set_option(k, int(v))
 print(f"load {time.time() - t0:.1f}s  params {d.param_count() / 1e9:.3f}B", flush=True)
 ids = synth.synth_prompt(d.vocab, args.prompt, 1234)[None, :]
 t0 = time.time(); m.forward(ids); m.synchronize(); tp = time.time() - t0
