@@ -42,19 +42,26 @@ def test_engine_matches_oracle_and_launches(oracle_lib, mode, geom):
     prompt = synth.synth_prompt(d.vocab, 9, 5)[None, :]
     for m in (ref, eng, base):
         m.forward(prompt)
+
+    def force_step(m, tok):
+        """one teacher-forced step through the CAPTURED DECODE GRAPH (where the engine runs): make `tok` the current token, replay one step"""
+        onehot = np.full((1, d.vocab), -1.0, np.float32); onehot[0, int(tok[0])] = 1.0
+        m.set_logits(onehot)
+        assert int(m.sample(GREEDY)[0]) == int(tok[0])
+        m.decode(1, GREEDY)
+
     for step in range(6):
         lr, le, lb = ref.logits(rounded=False), eng.logits(rounded=False), base.logits(rounded=False)
         assert rel_err(le, lr) < 1e-3, (step, rel_err(le, lr))            # north_star's bar against the CPU path
         assert rel_err(le, lb) < 2e-5, (step, rel_err(le, lb))            # the launches' result to rounding (another summation order)
+        if step:
+            assert not np.array_equal(le, lb) or mode == 0                # another summation order: the engine really ran
         tok = ref.sample(GREEDY)
         top2 = np.sort(lr[0])[-2:]
         if (top2[1] - top2[0]) > 1e-3 * np.abs(lr).max():
-            np.testing.assert_array_equal(eng.sample(GREEDY), tok)
-        else:
-            eng.sample(GREEDY)
-        base.sample(GREEDY)
-        for m in (ref, eng, base):
-            m.forward(tok[None, :])                                        # teacher forcing: single-position passes through the engine
+            assert int(np.argmax(le[0])) == int(tok[0])
+        ref.forward(tok[None, :])
+        force_step(eng, tok); force_step(base, tok)
     # cache rows written by the engine's qkv epilogue (mode 2) / the qkv launch (mode 1) equal the oracle's to one bf16 ulp
     for layer in (0, d.layers - 1):
         ke, ve = eng.read_kv(0, layer)
@@ -111,12 +118,16 @@ def test_engine_full_size_llama_3_2_1b_vs_launches():
     eng.forward(prompt); base.forward(prompt)
     t0, t1 = eng.sample(GREEDY), base.sample(GREEDY)
     np.testing.assert_array_equal(t0, t1)
-    for step in range(3):
-        eng.forward(t1[None, :]); base.forward(t1[None, :])
+    for step in range(3):                                  # free-running through the captured decode graph of each context
+        te, tb = eng.decode(1, GREEDY), base.decode(1, GREEDY)
         le, lb = eng.logits(rounded=False), base.logits(rounded=False)
         assert rel_err(le, lb) < 2e-5, (step, rel_err(le, lb))
-        eng.sample(GREEDY)
-        t1 = base.sample(GREEDY)
+        assert not np.array_equal(le, lb)                  # the engine's own summation order
+        top2 = np.sort(lb[0])[-2:]
+        if (top2[1] - top2[0]) > 1e-4 * np.abs(lb).max():
+            np.testing.assert_array_equal(te, tb)
+        else:
+            break
     eng.set_option("engine.stats", 1)
     eng.decode(2, GREEDY)
     st = eng.engine_stats()

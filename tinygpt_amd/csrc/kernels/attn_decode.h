@@ -17,6 +17,7 @@
 // one (m, l, o[HD]) partial per query head per split).  attn_combine_kernel merges the splits.
 #pragma once
 #include "common.h"
+#include "l2_prefetch.h"
 
 namespace tgx {
 
@@ -43,11 +44,13 @@ struct AttnArgs {
   float eps;
   long long kraw_stride;
   int dbg;   // experiments only (tgx_set_option "debug.attn"): 1 skip K/V work, 2 skip the LDS merge, 4 exit at once — results invalid
+  // L2 prefetch chaining (l2_prefetch.h; split form only): workgroups with blockIdx.x >= pf.n_compute touch the next launches' weights
+  PfArgs pf;
 };
 
 // NW = waves per workgroup: 4 for the split form; 16 for the direct form (short contexts), where ONE workgroup covers a block of
 // NW * TPW * UNR tokens (512 at head_dim 64, 256 at 128) per pass over the load -> softmax chain.
-template <int DT, int HD, int G, int NW = 4, bool QKN = false>
+template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool PF = false>
 __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) {
   typedef elem_t<DT> E;
   constexpr int LPT = HD / 8;         // lanes per token row
@@ -58,6 +61,11 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
   __shared__ __attribute__((aligned(16))) float red[NW][G][HD + 4];
 
   if (TGX_DBG(a, 4)) return;
+  if (PF && (int)blockIdx.x >= a.pf.n_compute) {      // prefetch workgroup: the attention pair leaves the fabric idle
+    const unsigned v = pf_run(a.pf);
+    if (v == 0x9e3779b9u && threadIdx.x == 1023) *a.pf.sink = v;
+    return;
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* q_row = a.q + blockIdx.y * a.q_stride;
   const E* k_row = static_cast<const E*>(a.k_cache) + blockIdx.y * a.kv_stride;

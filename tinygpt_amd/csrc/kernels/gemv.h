@@ -26,6 +26,7 @@
 // hidden sizes whose R x NX slices would not fit one wave) exchange their partial sums of squares through LDS once.
 #pragma once
 #include "common.h"
+#include "l2_prefetch.h"
 
 namespace tgx {
 
@@ -165,6 +166,8 @@ struct GemvArgs {
   // (sampled steps, tgx_forward: the sampler / tgx_sample finish the step).
   unsigned int* ticket;
   FinalizeArgs fin[4];
+  // L2 prefetch chaining (l2_prefetch.h): workgroups with blockIdx.x >= pf.n_compute touch the next launches' weights and exit
+  PfArgs pf;
 };
 
 // HF "gelu_new" (GPT-2's activation_function): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
@@ -190,10 +193,18 @@ __device__ __forceinline__ void unit_rows(const GemvArgs& a, int u, int& ra, int
   }
 }
 
-template <int DT, int PRO, int EPI, int NX, int R>
+// PF: the launch carries prefetch workgroups behind its a.pf.n_compute compute workgroups (a separate instantiation: the plain one keeps
+// its first weight load free of any test on a kernel argument)
+template <int DT, int PRO, int EPI, int NX, int R, bool PF = false>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   typedef elem_t<DT> E;
   if (TGX_DBG(a, 4)) return;
+  if (PF && (int)blockIdx.x >= a.pf.n_compute) {      // prefetch workgroup: hints only, no result
+    const unsigned v = pf_run(a.pf);
+    if (v == 0x9e3779b9u && threadIdx.x == 1023) *a.pf.sink = v;    // never true: keeps the touches alive
+    return;
+  }
+  const int n_wg = PF ? a.pf.n_compute : (int)gridDim.x;         // compute workgroups of this launch
   // double-buffer the weight registers when the activations leave room; with 4 rows also at up to 4 slices per lane (~250 VGPRs, two
   // waves per SIMD): B = 4 Llama-3.2-3B 1577 -> 1621 tok/s, Mistral-7B 821 -> 845, 1B unchanged; two rows at 3 slices lose 5 % with it
   constexpr bool PIPE = NX * R <= 4 || (R == 4 && NX <= 4);
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   const int per = ((nchunk + KS * 64 - 1) / (KS * 64)) * 64;           // slices per k-part (multiple of 64)
   const int c_begin = min(kpart * per, nchunk), c_end = min(c_begin + per, nchunk);
   const E* W = static_cast<const E*>(a.W);
-  const int stride = gridDim.x * UPB;
+  const int stride = n_wg * UPB;
 
   int cidx[NX];
   bool cok[NX];

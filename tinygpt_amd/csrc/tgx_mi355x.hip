@@ -191,6 +191,15 @@ struct tgx_ctx {
   int debug_skip = 0;        // experiment: bit0 skip attn decode kernel, bit1 skip combine (results invalid)
   int prof_same_layer = 0;   // experiment: tgx_profile_decode replays ONE layer's weights (Infinity-Cache resident)
   int debug_nops = 0;     // extra no-op launches per layer (launch-overhead experiments only)
+  // L2 prefetch chaining (kernels/l2_prefetch.h): batch-1 decode launches carry prefetch workgroups that pull the next launches' weights into
+  // the L2 of the XCD that will read them.  Option pf.mode: 0 off, 1 on.  Budgets are KB per XCD (L2 = 4 MB per XCD).
+  int pf_mode = 0;
+  int pf_wgs = 64;            // prefetch workgroups appended to a launch (256 threads each)
+  int pf_stride = 128;        // bytes between touches
+  int pf_oproj_kb = 4096;     // qkv(l)     -> o_proj(l)      (whole matrix: 1 MB per XCD on Llama-3.2-1B)
+  int pf_gu_kb = 2048;        // attn(l)    -> gate_up(l) head
+  int pf_dn_kb = 0;           // gate_up(l) -> down(l) head
+  int pf_qkv_kb = 4096;       // down(l)    -> qkv(l + 1)     (whole matrix: 1.6 MB per XCD)
   // The persistent weight-streaming engine (kernels/engine.h), batch-1 decode steps of the RMSNorm families in 16-bit storage.  Option
   // engine.mode: 0 = off (default: the GEMV launches measured faster on MI355X, profiles/r03_engine.txt), 1 = gate_up + down in one launch,
   // 2 = o_proj + gate_up + down + the next layer's qkv in one launch (3 launches per layer instead of 6).
@@ -436,6 +445,9 @@ void launch_gemv_nx(tgx_ctx* c, const tgx::GemvArgs& a, int grid, int R) {
   // of a 256-thread workgroup may use)
   if (R == 4) { hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 4>), g, b, 4 * smem_row, c->stream, a); return; }
   if (R == 2) { hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 2>), g, b, 2 * smem_row, c->stream, a); return; }
+  if constexpr (PRO != tgx::PRO_ATTNCOMB && PRO != tgx::PRO_LAYERNORM && EPI != tgx::EPI_LOGITS && EPI != tgx::EPI_GELU && DT != tgx::DT_F32) {
+    if (R == 1 && a.pf.n_compute) { hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 1, true>), g, b, smem_row, c->stream, a); return; }   // with prefetch workgroups
+  }
   for (int r = 0; r < R; r++) hipLaunchKernelGGL((tgx::gemv_kernel<DT, PRO, EPI, NX, 1>), g, b, smem_row, c->stream, gemv_row(c, a, r));
 }
 
@@ -449,7 +461,11 @@ void launch_gemv(tgx_ctx* c, tgx::GemvArgs a, int cls, int R) {
   // two rows on the gate_up launch: 2 slices per row and lane leave room for the double-buffered weight registers (R x NX <= 4):
   // Llama-3.2-1B B = 2: 2394 -> 2506 tok/s; the same split loses 2-6 % at B = 4 and on the other launches (tools/batch_bench.py --opts)
   if (R == 2 && cls == TGX_KERNEL_GATEUP && a.ks == 1 && gemv_nx(a.K, 1) == 4) a.ks = 2;
-  const int grid = (EPI == tgx::EPI_LOGITS) ? c->lm_grid : gemv_grid(c, a.units, a.ks, tn.bpc);
+  int grid = (EPI == tgx::EPI_LOGITS) ? c->lm_grid : gemv_grid(c, a.units, a.ks, tn.bpc);
+  a.pf.n_compute = 0;
+  if (R == 1 && (a.pf.t[0].W || a.pf.t[1].W) && PRO != tgx::PRO_ATTNCOMB && PRO != tgx::PRO_LAYERNORM && EPI != tgx::EPI_LOGITS && EPI != tgx::EPI_GELU && c->dt != tgx::DT_F32) {
+    a.pf.n_compute = grid; a.pf.stride = c->pf_stride; a.pf.sink = reinterpret_cast<unsigned*>(c->nop_word); grid += c->pf_wgs;
+  }
   const int nx = gemv_nx(a.K, a.ks);
   if constexpr (PRO == tgx::PRO_LAYERNORM || EPI == tgx::EPI_GELU) {   // GPT-2 (hidden <= 2048, checked in tgx_create): at most 4 slices per lane
     TGX_DT_SWITCH(c->dt, switch (nx) {
@@ -489,6 +505,8 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
   const int gfull = a.heads / a.kv_heads, ngroups = gfull > gmax ? (gfull + gmax - 1) / gmax : 1, G = (gfull + ngroups - 1) / ngroups;
   a.gfull = gfull;
   a.direct = c->attn_direct ? 1 : 0;
+  if (a.direct || (c->attn_mfma && !QKN && DT != tgx::DT_F32)) a.pf.t[0].W = nullptr;   // prefetch workgroups ride in the VALU split form only
+  a.pf.n_compute = 0;
   if (a.direct) {   // short context: one 16-wave workgroup per query head, no combine launch.  Measured (tok/s, direct vs split at context
     // ~120 / ~300 / ~430): see DESIGN.md §5; 1 head per workgroup beats 2 and 4 here (the K/V block is L2-resident, the softmax chain is not)
     const dim3 grid(a.kv_heads, R, gfull), blk(1024);
@@ -503,7 +521,24 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
     if (!(c->debug_skip & 2) && !attn_fold_ok(c, R)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
     return;
   }
-  const dim3 grid(a.kv_heads * a.nsplit, R, ngroups), blk(256);
+  int gx = a.kv_heads * a.nsplit;
+  if (a.pf.t[0].W && R == 1 && !QKN && DT != tgx::DT_F32) {   // prefetch workgroups behind the split workgroups; the x extent a multiple of 8 (block x -> XCD x % 8 in every z slab)
+    a.pf.n_compute = gx; a.pf.stride = c->pf_stride; a.pf.sink = reinterpret_cast<unsigned*>(c->nop_word);
+    gx += std::max(8, c->pf_wgs / ngroups); gx = (gx + 7) / 8 * 8;
+    const dim3 gridp(gx, R, ngroups), blkp(256);
+    if constexpr (!QKN && DT != tgx::DT_F32) {
+      if (!(c->debug_skip & 1)) switch (G) {
+        case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, false, true>), gridp, blkp, 0, c->stream, a); break;
+        case 2: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 4, false, true>), gridp, blkp, 0, c->stream, a); break;
+        case 3: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 3, 4, false, true>), gridp, blkp, 0, c->stream, a); break;
+        default: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 4, false, true>), gridp, blkp, 0, c->stream, a); break;
+      }
+    }
+    if (!(c->debug_skip & 2) && !attn_fold_ok(c, R)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
+    return;
+  }
+  a.pf.n_compute = 0;
+  const dim3 grid(gx, R, ngroups), blk(256);
   if (!(c->debug_skip & 1)) switch (G) {
     case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, QKN>), grid, blk, 0, c->stream, a); break;
     case 2: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 4, QKN>), grid, blk, 0, c->stream, a); break;
@@ -531,6 +566,33 @@ void fill_strides(const tgx_ctx* c, tgx::GemvArgs& a) {
 // prefill-by-steps pass handles together (kv_stride 0) need each other's finished keys, so they keep the separate norm launch
 bool qk_fused(const tgx_ctx* c, long long kv_stride) { return c->d.qk_norm && c->d.head_dim == 128 && kv_stride != 0 && c->qk_fuse; }
 
+// ---- L2 prefetch chaining (kernels/l2_prefetch.h) ---------------------------------------------------------------------------------
+// The consumer launch of class `cls` at layer `l` (batch 1) as a prefetch target: its weight matrix, unit -> rows map and workgroup -> units
+// map exactly as launch_gemv will set them, cut at `kb` KB per XCD.
+tgx::PfTarget pf_target(const tgx_ctx* c, int l, int cls, int kb) {
+  tgx::PfTarget t{};
+  const tgx_model_desc& d = c->d;
+  if (!c->pf_mode || kb <= 0 || l < 0 || l >= d.layers) return t;
+  const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
+  const LayerW& w = c->L[(size_t)l];
+  int N = 0, K = 0, units = 0;
+  switch (cls) {
+    case TGX_KERNEL_QKV: t.W = w.wqkv; N = qd + 2 * kvd; K = H; units = N / 2; t.rows_map = tgx::PF_ROWS_ROPE; break;
+    case TGX_KERNEL_OPROJ: t.W = w.wo; N = H; K = qd; units = (H + 1) / 2; t.rows_map = tgx::PF_ROWS_PAIR; break;
+    case TGX_KERNEL_GATEUP: t.W = w.wgu; N = 2 * I; K = H; units = I; t.rows_map = tgx::PF_ROWS_SILU; break;
+    case TGX_KERNEL_DOWN: if (I > 16384) return t; t.W = w.wdown; N = H; K = I; units = (H + 1) / 2; t.rows_map = tgx::PF_ROWS_PAIR; break;
+    default: return t;
+  }
+  const int ks = gemv_auto_ks(K, c->tune[cls].ks);
+  t.grid = gemv_grid(c, units, ks, c->tune[cls].bpc); t.upb = 4 / ks; t.units = units; t.N = N; t.hd = hd;
+  t.row_bytes = (int)(K * c->esz);
+  const long long wp_bytes = 2LL * t.upb * t.row_bytes;                                     // one consumer workgroup, one pass
+  const long long all = ((long long)units + 8LL * t.upb - 1) / (8LL * t.upb);              // passes x workgroups of one XCD
+  t.budget_wp = (int)std::max<long long>(1, std::min(all, (long long)kb * 1024 / wp_bytes));
+  return t;
+}
+bool pf_active(const tgx_ctx* c, int R, const float* resid, const RowState* rv) { return c->pf_mode && R == 1 && resid == rv[0].x && !c->gpt2 && c->dt != tgx::DT_F32; }
+
 // One kernel class of one decoder layer for R rows (batch rows of the slabs, or the chunk rows of a prefill-by-steps pass).  `resid` is the residual stream of row0 that the
 // o_proj/down epilogues update (slab_x in the real pass; a scratch vector when tgx_profile_decode replays a class).
 void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float* resid, long long kv_stride) {
@@ -549,6 +611,7 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos = r.pos;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx;
       a.raw_qk = d.qk_norm ? 1 : 0; a.k_raw = r.k_raw;
+      if (pf_active(c, R, resid, rv)) a.pf.t[0] = pf_target(c, l, TGX_KERNEL_OPROJ, c->pf_oproj_kb);
       if (c->gpt2) {   // ln_1 -> c_attn (+bias) -> split into heads -> cache append; no rotation: the tables hold cos = 1, sin = 0 (ModelGPT2.h:60-75)
         a.norm_b = w.in_norm_b;
         launch_gemv<tgx::PRO_LAYERNORM, tgx::EPI_QKV_ROPE>(c, a, TGX_KERNEL_QKV, R);
@@ -572,6 +635,7 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
       a.scale = 1.0f / sqrtf((float)hd);
       a.q_stride = qd; a.kv_stride = kv_stride; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
+      if (pf_active(c, R, resid, rv)) a.pf.t[0] = pf_target(c, l, TGX_KERNEL_GATEUP, c->pf_gu_kb);
       if (qk_fused(c, kv_stride)) {
         a.k_raw = r.k_raw; a.kraw_stride = kvd; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm;
         a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.eps = d.norm_eps;
@@ -603,6 +667,7 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
         break;
       }
       a.N = 2 * I; a.K = H; a.units = I; a.out = r.h; a.out_stride = I; a.hd = 2;
+      if (pf_active(c, R, resid, rv)) a.pf.t[0] = pf_target(c, l, TGX_KERNEL_DOWN, c->pf_dn_kb);
       launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_SILU_MUL>(c, a, TGX_KERNEL_GATEUP, R);
       break;
     }
@@ -621,6 +686,7 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
         }
         break;
       }
+      if (pf_active(c, R, resid, rv)) a.pf.t[0] = pf_target(c, l + 1, TGX_KERNEL_QKV, c->pf_qkv_kb);
       launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_DOWN, R);
       break;
     }
@@ -1035,6 +1101,13 @@ static int attn_mfma_threshold(const tgx_ctx* c) {
   return (c->d.head_dim == 64 && c->d.kv_heads >= 8) ? 6000 : 14000;
 }
 bool decode_mfma_ok(const tgx_ctx* c);
+// The attention form of the launches about to be issued / captured, from the context the call ends at: direct (one workgroup per head, no
+// combine) for short contexts, the MFMA decode attention for long ones, the VALU split form in between.  One place for all callers
+// (the prefill-by-steps branch used to leave attn_mfma at whatever the previous decode call had chosen).
+void update_attn_modes(tgx_ctx* c, int n_positions) {
+  c->attn_direct = c->past + n_positions <= c->attn_direct_max;
+  c->attn_mfma = !c->attn_direct && c->past >= attn_mfma_threshold(c) && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
+}
 
 void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
   if (decode_mfma_ok(c)) {   // more than 4 rows: every Linear is one pass over its weights for up to 32 rows (kernels/skinny.h)
@@ -1542,8 +1615,7 @@ int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int 
   }
   // short contexts: attention without the split / combine pair (one launch less per layer); the graphs are re-captured when a
   // call crosses the limit
-  c->attn_direct = c->past + n <= c->attn_direct_max;
-  c->attn_mfma = !c->attn_direct && c->past >= attn_mfma_threshold(c) && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
+  update_attn_modes(c, n);
   if (decode_mfma_ok(c)) {   // the batched step's workspace must exist before the step is captured
     int rc = ensure_skinny_ws(c, std::min(32, c->batch));
     if (rc) return rc;
@@ -1946,7 +2018,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     // prefill by steps (fp32 storage, GPT-2, prompts shorter than 4 tokens, shapes the GEMM tile does not cover): up to 4 consecutive
     // positions per pass through the decode kernels — the chunk rows share this row's cache (kv_stride 0), each attends the
     // keys up to its own position, so the result equals position-by-position passes at a quarter of the weight traffic
-    c->attn_direct = c->past + seq <= c->attn_direct_max;
+    update_attn_modes(c, seq);
     for (int s0 = 0; s0 < seq;) {
       const int rem = seq - s0, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
       tgx::EmbedChunkArgs e{};
@@ -2133,8 +2205,7 @@ int tgx_profile_decode(tgx_ctx* c, int n_reps, int64_t* launches, double* total_
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < TGX_KERNEL_COUNT; i++) { launches[i] = 0; total_ms[i] = 0.0; }
-  c->attn_direct = c->past + 1 <= c->attn_direct_max;
-  c->attn_mfma = !c->attn_direct && c->past >= attn_mfma_threshold(c) && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
+  update_attn_modes(c, 1);
   // Each class is launched back-to-back over all layers (every launch streams a different layer's weights, so
   // nothing is served from the Infinity Cache) between two events on the launch stream.  The residual
   // epilogues write to a scratch vector: the model state (x, KV cache up to pastLength, token) is untouched.
@@ -2223,6 +2294,15 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "skinny.cfg")) { if (value < -1 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.cfg is -1..2"); c->skinny_cfg_force = value; return TGX_OK; }
   if (!strcmp(key, "decode.mfma_min_batch")) { if (value < 1) return set_err(c, TGX_ERR_INVALID, "decode.mfma_min_batch must be >= 1"); c->decode_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
+  if (!strncmp(key, "pf.", 3)) {   // L2 prefetch chaining (kernels/l2_prefetch.h); the captured step graphs hold the old launch geometry
+    int* dst = !strcmp(key, "pf.mode") ? &c->pf_mode : !strcmp(key, "pf.wgs") ? &c->pf_wgs : !strcmp(key, "pf.stride") ? &c->pf_stride : !strcmp(key, "pf.oproj_kb") ? &c->pf_oproj_kb
+             : !strcmp(key, "pf.gu_kb") ? &c->pf_gu_kb : !strcmp(key, "pf.dn_kb") ? &c->pf_dn_kb : !strcmp(key, "pf.qkv_kb") ? &c->pf_qkv_kb : nullptr;
+    if (!dst) return set_err(c, TGX_ERR_INVALID, "unknown option %s", key);
+    if (value < 0 || (dst == &c->pf_wgs && (value < 8 || value > 1024)) || (dst == &c->pf_stride && value != 64 && value != 128 && value != 256)) return set_err(c, TGX_ERR_INVALID, "%s out of range", key);
+    drop_step_graphs(c);
+    *dst = value;
+    return TGX_OK;
+  }
   if (!strncmp(key, "engine.", 7)) {   // the persistent decode engine (kernels/engine.h); captured step graphs hold the old launch sequence
     if (!strcmp(key, "engine.mode")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "engine.mode is 0 (off), 1 (gate_up + down) or 2 (o_proj .. next qkv)"); drop_step_graphs(c); c->engine_mode = value; return TGX_OK; }
     if (!strcmp(key, "engine.ns")) { if (value < 0 || value > 15) return set_err(c, TGX_ERR_INVALID, "engine.ns is 0 (auto) .. 15"); drop_step_graphs(c); c->engine_ns = value; return TGX_OK; }
