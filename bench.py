@@ -131,6 +131,32 @@ def cpu_baseline(desc, tensors, seconds, prompt_len, prompt_seed, max_prefill_s=
                       f"spread min/max in legs"}
 
 
+def timed_region(run_steps, sync, dist=None, torch=None):
+    """The contract's timed region, used by the real run below and (with a stand-in `run_steps`) by tests/test_replicas_gloo.py:
+    barrier + synchronize | EXACTLY the K steps of this rank | synchronize; then barrier + MAX over ranks.  No collective sits inside the
+    timed region — the replicas never exchange data.  Returns (elapsed of the job = slowest replica, this rank's own)."""
+    sync()
+    if dist:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    run_steps()
+    sync()
+    mine = time.perf_counter() - t0
+    job = mine
+    if dist:
+        dist.barrier()
+        t = torch.tensor([mine], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                    # MAX over ranks: the job is as slow as its slowest replica
+        job = float(t.item())
+    return job, mine
+
+
+def aggregate_tokens_per_s(world, steps, job_elapsed):
+    """whole-job throughput of N replicas that each decoded `steps` tokens"""
+    return world * steps / job_elapsed
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -191,18 +217,7 @@ def main():
             torch.cuda.synchronize()
 
     model.decode(args.warmup, GREEDY, fetch=False)                  # untimed warm-up (instantiates the graph)
-    sync()
-    if dist: dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    model.decode(args.steps, GREEDY, fetch=False)                   # EXACTLY K steps
-    sync()
-    elapsed = time.perf_counter() - t0                              # this rank's K steps; no collective inside the timed region
-    if dist:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)                    # MAX over ranks: the job is as slow as its slowest replica
-        elapsed = float(t.item())
+    elapsed, _mine = timed_region(lambda: model.decode(args.steps, GREEDY, fetch=False), sync, dist, torch)   # EXACTLY K steps per rank
 
     if rank != 0:
         if dist: dist.barrier(); dist.destroy_process_group()
@@ -210,7 +225,7 @@ def main():
 
     T0 = args.prompt + 1 + args.warmup                              # tokens in the cache at the first timed step
     T_mean = T0 + (args.steps - 1) / 2.0
-    tok_s = world * args.steps / elapsed
+    tok_s = aggregate_tokens_per_s(world, args.steps, elapsed)
     bytes_tok = model.bytes_per_token(int(round(T_mean)))
 
     prof = model.profile_decode(args.profile_reps)

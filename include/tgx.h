@@ -181,6 +181,12 @@ TGX_API int tgx_synchronize(tgx_ctx* ctx);
  * (the BSHD view KVCacheManager::append returns, Attention.h:106).  Test/diagnostic use. */
 TGX_API int tgx_read_kv(tgx_ctx* ctx, int row, int layer, float* k_out, float* v_out);
 
+/* The inverse of tgx_read_kv: overwrites cache rows [0, n_rows) of (row, layer), n_rows <= pastLength, from fp32 k_in / v_in
+ * [n_rows][kv_heads][head_dim] (either may be NULL), rounded once to the cache's storage dtype.  Test/diagnostic use: with the CPU path's
+ * cache rows injected, a decode step is compared free of the bf16 KV-rounding floor (the reference's KVCacheManager holds the tensors
+ * it was given, CacheManager.h:24-51 — there is nothing to overwrite there). */
+TGX_API int tgx_write_kv(tgx_ctx* ctx, int row, int layer, const float* k_in, const float* v_in, int64_t n_rows);
+
 /* Per-kernel-class timing with HIP events on the context's stream (bench.py's roofline leg).  For each
  * class (TGX_KERNEL_*) the kernels of ALL layers are launched back-to-back between two events, n_reps times,
  * at the current context length; returns launch counts and summed milliseconds.  Every launch streams a

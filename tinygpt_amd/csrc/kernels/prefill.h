@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
     float g = 0.f, u = 0.f;
     for (int z = 0; z < a.nsplit; z++) { g += p[z * slab]; u += p[z * slab + 1]; }
     const size_t o = (size_t)row * a.inter + c;
-    split16<DT>((g / (1.0f + expf(-g))) * u, a.out_hi[o], a.out_lo[o]);
+    split16<DT>(silu_mul_fast(g, u), a.out_hi[o], a.out_lo[o]);      // the same formulation as the unsplit epilogues: a prompt's activations do not depend on whether split-K was chosen
     return;
   }
   const float* p = a.part + (size_t)row * a.N + c;
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmArgs 
   if (a.bias) v += elem_to_f32<DT>(a.bias[c]);
   if (EPI == GEMM_GELU) {
     const size_t o = (size_t)row * a.N + c;
-    split16<DT>(0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v))), a.out_hi[o], a.out_lo[o]);
+    split16<DT>(gelu_new_fast(v), a.out_hi[o], a.out_lo[o]);
     return;
   }
   float* dst = a.C + (size_t)row * a.ldc + c;

@@ -2198,6 +2198,31 @@ int tgx_read_kv(tgx_ctx* c, int row, int layer, float* k_out, float* v_out) {
   return TGX_OK;
 }
 
+int tgx_write_kv(tgx_ctx* c, int row, int layer, const float* k_in, const float* v_in, int64_t n_rows) {
+  if (!c || !c->finalized || row < 0 || row >= c->d.max_batch || layer < 0 || layer >= c->d.layers || n_rows < 0 || n_rows > c->past) return c ? set_err(c, TGX_ERR_INVALID, "write_kv: row / layer / n_rows out of range") : TGX_ERR_INVALID;
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  const tgx_model_desc& d = c->d;
+  const size_t hd = (size_t)d.head_dim, per_head = (size_t)d.max_ctx * hd, T = (size_t)n_rows;
+  std::vector<unsigned char> tmp(T * hd * c->esz);
+  for (int which = 0; which < 2; which++) {
+    const float* in = which ? v_in : k_in;
+    if (!in || !T) continue;
+    ebyte* base = (which ? c->rows[(size_t)row].vcache : c->rows[(size_t)row].kcache) + (size_t)layer * d.kv_heads * per_head * c->esz;
+    for (int h = 0; h < d.kv_heads; h++) {
+      for (size_t t = 0; t < T; t++)
+        for (size_t k = 0; k < hd; k++) {   // BSHD view in, head-major cache out; one round-to-nearest-even into the storage dtype
+          const float v = in[(t * d.kv_heads + h) * hd + k];
+          const size_t i = t * hd + k;
+          if (c->dt == tgx::DT_F32) memcpy(tmp.data() + 4 * i, &v, 4);
+          else { const uint16_t u = c->dt == tgx::DT_BF16 ? host_f32_to_bf16(v) : host_f32_to_half(v); memcpy(tmp.data() + 2 * i, &u, 2); }
+        }
+      HIP_OK(c, hipMemcpy(base + (size_t)h * per_head * c->esz, tmp.data(), T * hd * c->esz, hipMemcpyHostToDevice));
+    }
+  }
+  return TGX_OK;
+}
+
 int tgx_profile_decode(tgx_ctx* c, int n_reps, int64_t* launches, double* total_ms) {
   if (!c || !launches || !total_ms || n_reps < 0) return TGX_ERR_INVALID;
   if (!c->have_token) return set_err(c, TGX_ERR_STATE, "profile needs a current token: call tgx_sample after tgx_forward");

@@ -70,6 +70,7 @@ ABI = {
     "last_error": (c_char_p, [c_void_p]),
     "synchronize": (c_int, [c_void_p]),
     "read_kv": (c_int, [c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float)]),
+    "write_kv": (c_int, [c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float), c_int64]),
     "profile_decode": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_double)]),
     "set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "read_probs": (c_int, [c_void_p, POINTER(c_float)]),
@@ -239,6 +240,12 @@ class Model:
         v = np.empty(shape, dtype=np.float32)
         self._check(self.be.read_kv(self._ctx, row, layer, k.ctypes.data_as(POINTER(c_float)), v.ctypes.data_as(POINTER(c_float))))
         return k, v
+
+    def write_kv(self, row: int, layer: int, k: np.ndarray, v: np.ndarray):
+        """overwrite cache rows [0, len(k)) of (row, layer) from fp32 [T][kv_heads][head_dim] arrays (the layout read_kv returns)"""
+        k = np.ascontiguousarray(k, dtype=np.float32); v = np.ascontiguousarray(v, dtype=np.float32)
+        assert k.shape == v.shape and k.shape[1:] == (self.desc.kv_heads, self.desc.head_dim)
+        self._check(self.be.write_kv(self._ctx, row, layer, k.ctypes.data_as(POINTER(c_float)), v.ctypes.data_as(POINTER(c_float)), k.shape[0]))
 
     def profile_decode(self, n_steps: int):
         n = len(KERNEL_CLASSES)
