@@ -124,7 +124,8 @@ def cpu_baseline(desc, tensors, seconds, prompt_len, prompt_seed, max_prefill_s=
     return {"value": round(value, 3), "unit": "tokens/s", "cores": best_n, "host_cores": cores, "kind": "port",
             "omp": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"), "threads": best_n},
             "legs": legs,
-            "sample": f"oracle/liboracle.so (C+OpenMP restatement), same synthetic {desc.name or 'model'} {desc.compute_dtype}; value = median of 3 samples of "
+            "sample": f"oracle/liboracle.so (C+OpenMP restatement: an UNTUNED loop nest — plain fp32 loops, no blocking, no SIMD intrinsics; a stated baseline, not a tuned CPU "
+                      f"implementation, so the GPU/CPU ratio says nothing about kernel quality), same synthetic {desc.name or 'model'} {desc.compute_dtype}; value = median of 3 samples of "
                       f"{legs[which]['tokens_per_sample']} greedy decode tokens after a {legs[which]['prompt_tokens']}-token prompt (context {ctx[0]}..{ctx[1]}: "
                       + ("the GPU run's own context" if which == "same" else "SHORTER than the GPU run's context — the oracle's prefill of the full prompt was over budget")
                       + f"), {best_n} of {cores} host threads (best team size of a probe), threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores); "
