@@ -465,6 +465,37 @@ def test_attention_combine_folded_into_o_proj_equals_separate_launch(name, lens,
         assert rel_err(outs[1][2], outs[0][2]) < 1e-5, (n, rel_err(outs[1][2], outs[0][2]))
 
 
+@pytest.mark.parametrize("name,lens,batch", [("llama-3.2-1b", (1, 127, 128, 129, 1500, 2047, 3100), 1), ("llama-3.2-1b", (130, 900), 2),
+                                             ("mistral-7b-v0.3", (63, 65, 700, 2100), 1), ("qwen2.5-0.5b", (300, 1100), 2)])
+def test_attention_combine_by_the_last_arriving_split_equals_separate_launch(name, lens, batch, hip):
+    """Option attn.fold_ticket (round 3; off by default, numbers in profiles/r03_attn_fold.txt): the last split workgroup of each (row, kv
+    head, head group) to arrive at the group's ticket merges the group's records inside the attention launch — the SAME merge code as
+    attn_combine_kernel over the same records (only the active splits are read), so logits and ids must be bit-identical to the two-launch
+    form, at contexts around the block size, with 1..25 active splits, beyond 32 blocks (round-robin) and for batch rows sharing the launch;
+    run twice so that a ticket left non-zero would show."""
+    import copy
+    from tinygpt_amd import known_desc, synth
+    from tinygpt_amd.ffi import Model
+    d = copy.deepcopy(known_desc(name))
+    d.layers, d.vocab, d.max_ctx, d.max_batch = 2, 4096, 4224, batch
+    m = Model(d, hip).load_synthetic(1234, 0.02).finalize()
+    m.set_option("attn.direct_max", 0)                  # the split form at every context
+    for n in lens:
+        prompt = np.stack([synth.synth_prompt(d.vocab, n, 100 + n + 7 * b) for b in range(batch)])
+        outs = []
+        for fold in (0, 1, 1):
+            m.set_option("attn.fold_ticket", fold)
+            m.reset_cache(); m.forward(prompt)
+            first = m.sample(GREEDY).copy()
+            rest = m.decode(5, GREEDY).copy()
+            outs.append((first, rest, m.logits(rounded=False).copy()))
+        for k in (1, 2):
+            np.testing.assert_array_equal(outs[0][0], outs[k][0])
+            np.testing.assert_array_equal(outs[0][1], outs[k][1])
+            np.testing.assert_array_equal(outs[0][2], outs[k][2])
+    m.set_option("attn.fold_ticket", 0)
+
+
 @pytest.mark.parametrize("fam,batch", [("llama_tiny", 1), ("qwen2_tiny", 3), ("gpt2_hd64", 4)])
 def test_greedy_finalize_fused_into_lm_head_equals_separate_launch(fam, batch, hip, oracle_lib):
     """Option lmhead.fuse_finalize (off by default: measured no faster): the lm_head launch's last-arriving workgroup reduces the argmax

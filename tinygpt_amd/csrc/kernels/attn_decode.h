@@ -44,13 +44,19 @@ struct AttnArgs {
   float eps;
   long long kraw_stride;
   int dbg;   // experiments only (tgx_set_option "debug.attn"): 1 skip K/V work, 2 skip the LDS merge, 4 exit at once — results invalid
+  // in-kernel combine (template FOLD, split form): the LAST split workgroup of a (row, kv head, head group) to arrive at this counter merges
+  // the group's records itself and writes a.out — no attn_combine launch.  [rows][kv_heads][groups] counters that rest at 0.
+  unsigned* fold_ticket;
   // L2 prefetch chaining (l2_prefetch.h; split form only): workgroups with blockIdx.x >= pf.n_compute touch the next launches' weights
   PfArgs pf;
 };
 
+template <int HD>
+__device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, float* out_head, float (*sm_o)[HD + 4]);   // below
+
 // NW = waves per workgroup: 4 for the split form; 16 for the direct form (short contexts), where ONE workgroup covers a block of
 // NW * TPW * UNR tokens (512 at head_dim 64, 256 at 128) per pass over the load -> softmax chain.
-template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool PF = false>
+template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool PF = false, bool FOLD = false>
 __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) {
   typedef elem_t<DT> E;
   constexpr int LPT = HD / 8;         // lanes per token row
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
   if (sp * STEP >= n_keys) {   // this split has no keys at the current context length (workgroup-uniform): publish "empty"
     // (the compiler sinks the loads above below this branch; running empty splits through the masked path instead keeps
     //  them ahead of the position load but measured 1262 vs 1260 tok/s at context 2.3k and 1267 vs 1289 at 300 — rejected)
+    if (FOLD) return;            // the in-kernel merge reads the active splits only: nothing to publish, no ticket to take
     for (int g = threadIdx.x; g < G; g += 64 * NW) {
       if (!head_live(g)) continue;
       float* dst = part_row + ((size_t)head_of(g) * nsp + sp) * (HD + 4);
@@ -270,8 +277,42 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
       continue;
     }
     float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);
+    if (FOLD) {   // read by another workgroup of THIS launch: agent-scope write-through stores (cdna_hip_programming.md Guideline 16, R1)
+      __hip_atomic_store(dst + d, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d == 0) { __hip_atomic_store(dst + HD, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(dst + HD + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      continue;
+    }
     dst[d] = acc;
     if (d == 0) { dst[HD] = M; dst[HD + 1] = L; }
+  }
+  if constexpr (FOLD && NW == 4) {
+    // arrival ticket of this (row, kv head, head group): records drained by every storing wave, one relaxed agent-scope increment; the workgroup
+    // that draws the last ticket of the ACTIVE splits resets the counter, takes one agent-scope acquire and merges the group's heads
+    __shared__ int s_last;
+    const int n_act = min(nsp, (n_keys + STEP - 1) / STEP);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned* tk = a.fold_ticket + ((size_t)blockIdx.y * a.kv_heads + kvh) * gridDim.z + blockIdx.z;
+      const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == (unsigned)(n_act - 1);
+      if (last) {
+        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (s_last) {
+#pragma unroll 1
+      for (int g = 0; g < G; g++) {
+        if (!head_live(g)) continue;
+        const int h = head_of(g);
+        __syncthreads();                     // red (the LDS scratch) is reused per head
+        attn_combine_head<HD>(part_row + (size_t)h * a.nsplit * (HD + 4), n_act, a.out + blockIdx.y * a.q_stride + (size_t)h * HD,
+                              reinterpret_cast<float (*)[HD + 4]>(&red[0][0][0]));
+      }
+    }
   }
 }
 
@@ -280,23 +321,23 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
 // One workgroup per query head; thread (s, dg) owns 8 dims of one split, so all partials arrive with one round of
 // independent 16-byte loads.  Each wave folds its splits in registers (butterfly over the lane bits above DG, fixed
 // order), the four waves meet once in LDS.
+// The merge of one query head's split records (256 threads): thread (s, dg) owns 8 dims of one split, so all partials arrive with one round
+// of independent 16-byte loads; each wave folds its splits in registers (butterfly over the lane bits above DG, fixed order), the four waves
+// meet once in LDS.  `nsplit` records are read; sm_o is [4][HD + 4] floats of LDS.  Shared by attn_combine_kernel and the in-kernel fold.
 template <int HD>
-__global__ __launch_bounds__(256) void attn_combine_kernel(const AttnArgs a) {
+__device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, float* out_head, float (*sm_o)[HD + 4]) {
   constexpr int DG = HD / 8;            // lanes per split (dim groups of 8)
   constexpr int SPB = 256 / DG;         // splits per pass (32 for hd 64, 16 for hd 128)
   constexpr int NPASS = 32 / SPB;       // 1 or 2 passes cover the 32 possible splits
-  __shared__ __attribute__((aligned(16))) float sm_o[4][HD + 4];   // per wave: o[HD], M, L
-  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const float* p = a.part + blockIdx.y * a.part_stride + (size_t)h * a.nsplit * (HD + 4);
-  float* out_row = a.out + blockIdx.y * a.q_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int dg = tid % DG, sl = tid / DG;
   f32x4 d0[NPASS], d1[NPASS];
   float pm[NPASS], pl[NPASS];
 #pragma unroll
-  for (int ps = 0; ps < NPASS; ps++) {   // every load of the kernel is issued here
+  for (int ps = 0; ps < NPASS; ps++) {   // every load of the merge is issued here
     const int s = ps * SPB + sl;
     d0[ps] = f32x4{0.f, 0.f, 0.f, 0.f}; d1[ps] = d0[ps]; pm[ps] = -INFINITY; pl[ps] = 0.f;
-    if (s < a.nsplit) {
+    if (s < nsplit) {
       const float* rec = p + (size_t)s * (HD + 4);
       const f32x4* src = reinterpret_cast<const f32x4*>(rec + dg * 8);
       d0[ps] = src[0]; d1[ps] = src[1];
@@ -341,8 +382,16 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnArgs a) {
     acc = fmaf(sm_o[1][tid], s1, acc); acc = fmaf(sm_o[2][tid], s2, acc); acc = fmaf(sm_o[3][tid], s3, acc);
     float LL = sm_o[0][HD + 1] * s0;
     LL = fmaf(sm_o[1][HD + 1], s1, LL); LL = fmaf(sm_o[2][HD + 1], s2, LL); LL = fmaf(sm_o[3][HD + 1], s3, LL);
-    out_row[h * HD + tid] = acc / LL;
+    out_head[tid] = acc / LL;
   }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sm_o[4][HD + 4];   // per wave: o[HD], M, L
+  const int h = blockIdx.x;
+  const float* p = a.part + blockIdx.y * a.part_stride + (size_t)h * a.nsplit * (HD + 4);
+  attn_combine_head<HD>(p, a.nsplit, a.out + blockIdx.y * a.q_stride + (size_t)h * HD, sm_o);
 }
 
 }  // namespace tgx

@@ -157,6 +157,10 @@ struct tgx_ctx {
   // all ~1000 workgroups costs what the 1-workgroup finalize launch cost (0.7109 -> 0.7123 ms/token).
   int attn_fold = 0;
   int lm_fuse = 0;
+  // attn.fold_ticket = 1 (round 3): the last-arriving split workgroup of each (row, kv head, head group) merges the group's records inside the
+  // attention launch (per-group arrival ticket) — no attn_combine launch.  Off by default: measured in profiles/r03_attn_fold.txt
+  int attn_ticket = 0;
+  unsigned* attn_tickets = nullptr;   // [max_batch][kv_heads][8] counters resting at 0
   int prefill_skinny = 1;    // option prefill.skinny: 0 sends prompts of <= 32 rows through the tiled GEMMs as well
   int skinny_wgs = 256;      // option skinny.wgs: workgroups a skinny product aims for by splitting K
   int skinny_gu_split = 0;   // option skinny.gu_split: 0 keeps the gate_up product unsplit (siluMul in its epilogue, one launch less)
@@ -538,6 +542,19 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
     return;
   }
   a.pf.n_compute = 0;
+  if (c->attn_ticket && c->attn_tickets && !QKN && DT != tgx::DT_F32 && ngroups <= 8 && !attn_fold_ok(c, R)) {   // in-kernel combine: no second launch
+    if constexpr (!QKN && DT != tgx::DT_F32) {
+      a.fold_ticket = c->attn_tickets;
+      const dim3 gridf(gx, R, ngroups), blkf(256);
+      switch (G) {
+        case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, false, false, true>), gridf, blkf, 0, c->stream, a); break;
+        case 2: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 4, false, false, true>), gridf, blkf, 0, c->stream, a); break;
+        case 3: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 3, 4, false, false, true>), gridf, blkf, 0, c->stream, a); break;
+        default: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 4, false, false, true>), gridf, blkf, 0, c->stream, a); break;
+      }
+    }
+    return;
+  }
   const dim3 grid(gx, R, ngroups), blk(256);
   if (!(c->debug_skip & 1)) switch (G) {
     case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, QKN>), grid, blk, 0, c->stream, a); break;
@@ -1939,6 +1956,8 @@ int tgx_finalize(tgx_ctx* c) {
 #undef TGX_DMA_ATTR_D
 #undef TGX_DMA_ATTR
 #undef TGX_DMA_ATTR1
+  if ((rc = dev_alloc(c, &c->attn_tickets, (size_t)d.max_batch * d.kv_heads * 8))) return rc;
+  HIP_OK(c, hipMemset(c->attn_tickets, 0, (size_t)d.max_batch * d.kv_heads * 8 * 4));
   // persistent engine (option engine.mode): granule buffers of its in-launch edges, the tag epoch, the give-up word
   if (!c->gpt2 && c->dt != tgx::DT_F32) {
     if ((rc = dev_alloc(c, &c->eng_gx1, (size_t)H))) return rc;
@@ -1966,7 +1985,7 @@ void tgx_destroy(tgx_ctx* c) {
   drop_step_graphs(c);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->wpe); fr(c->final_norm_b); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->lm_ticket); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
-  fr(c->eng_gx1); fr(c->eng_gh); fr(c->eng_gx2); fr(c->eng_epoch); fr(c->eng_err); fr(c->eng_stats);
+  fr(c->attn_tickets); fr(c->eng_gx1); fr(c->eng_gh); fr(c->eng_gx2); fr(c->eng_epoch); fr(c->eng_err); fr(c->eng_stats);
   fr(c->ch_x); fr(c->ch_q); fr(c->ch_kraw); fr(c->ch_attn); fr(c->ch_h); fr(c->ch_part); fr(c->ch_pos);
   fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl); fr(c->ws_part); fr(c->ws_ssq); fr(c->ws_pos); fr(c->ws_attn_part);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); fr(w.in_norm_b); fr(w.post_norm_b); fr(w.bo); fr(w.bfc); fr(w.bdown); }
@@ -2311,6 +2330,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.attn_mirror")) { c->attn_mirror = value; return TGX_OK; }
   if (!strcmp(key, "attn.qk_fuse")) { c->qk_fuse = value; return TGX_OK; }
   if (!strcmp(key, "attn.fold_combine")) { c->attn_fold = value != 0; return TGX_OK; }
+  if (!strcmp(key, "attn.fold_ticket")) { drop_step_graphs(c); c->attn_ticket = value != 0; return TGX_OK; }
   if (!strcmp(key, "lmhead.fuse_finalize")) { c->lm_fuse = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.wgs")) { if (value < 1) return set_err(c, TGX_ERR_INVALID, "skinny.wgs must be >= 1"); c->skinny_wgs = value; return TGX_OK; }
   if (!strcmp(key, "prefill.skinny")) { c->prefill_skinny = value; return TGX_OK; }
