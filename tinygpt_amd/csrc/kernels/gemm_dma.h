@@ -48,19 +48,17 @@ __device__ __forceinline__ void dma_1k(const void* gsrc, unsigned lds_dst) {
 // DBK = k per stage: 64 (128-byte rows, 8 chunk slots, swizzle by (row >> 1) & 7) or 32 (64-byte rows, 4 slots, (row >> 2) & 3: half the LDS per
 // stage, so that the 128-row tile keeps three workgroups per CU)
 // NS = ring stages: NS - 1 stages are in flight while one is consumed; the waits are counted (this wave's pieces of the later stages may still fly)
+// The tile body: rows [m0, m0 + 64 MI) x columns [n0, n0 + 128) of C; `three` = the third split term of A is multiplied in as well.
 template <int DT, int EPI, int MI, int DBK, int NS>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs a) {
+__device__ __forceinline__ void gemm_dma_tile(const GemmArgs& a, const int m0, const int n0, const bool three, bf16_t* dma_lds) {
   constexpr int TM = 64 * MI;
   constexpr int CPR = DBK / 8;                 // 16-byte chunks per tile row
   constexpr int RPP = 64 / CPR;                // tile rows per 1-KiB piece
   constexpr int SW_SH = DBK == 64 ? 1 : 2, SW_MASK = CPR - 1;
-  extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
-  const bool three = a.A_lo2 != nullptr && (int)(blockIdx.x + 1) * GBN > a.three_from;      // workgroup-uniform
   const int NA = three ? 3 : 2;
   const int stage_elems = (NA * TM + GBN) * DBK;                      // A_hi | A_lo | [A_lo2] | B
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 1, wn = wv & 1;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * GBN;
   const unsigned lds_base = (unsigned)(size_t)dma_lds;                // LDS byte offset of the ring (low 32 bits of the generic address)
 
   f32x16 acc[MI][2];
@@ -164,6 +162,33 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs a) {
     }
 }
 
+
+template <int DT, int EPI, int MI, int DBK, int NS>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
+  const bool three = a.A_lo2 != nullptr && (int)(blockIdx.x + 1) * GBN > a.three_from;      // workgroup-uniform
+  gemm_dma_tile<DT, EPI, MI, DBK, NS>(a, (int)blockIdx.y * 64 * MI, (int)blockIdx.x * GBN, three, dma_lds);
+}
+
+// The QKV product of a bf16 prompt as ONE balanced launch (round 3).  Its Q columns take two split terms, its K / V columns three (their results are
+// rounded into the cache): as one grid of 128 x 128 tiles that is 256 two-term + 128 three-term workgroups on 256 CUs — 1.5 per CU, and a CU that
+// draws two three-term tiles carries 6 units of work against an average of 3.5.  Here the first `nq` workgroups take the Q columns in 128-row tiles
+// (2 units each), the rest take the K / V columns in 64-ROW tiles with three terms (1.5 units each): 256 + 256 workgroups on Llama-3.2-1B at 2048
+// tokens, one of each kind co-resident per CU (49 + 41 KB of LDS) — 3.5 units everywhere.
+template <int DT, int DBK, int NS>
+__global__ __launch_bounds__(256) void gemm_dma_qkv_kernel(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
+  const int qcols = a.three_from / GBN, nq = qcols * ((a.M + 127) / 128);
+  const int b = (int)blockIdx.x;
+  if (b < nq) {
+    const int ry = b / qcols, cx = b - ry * qcols;
+    gemm_dma_tile<DT, GEMM_STORE, 2, DBK, NS>(a, ry * 128, cx * GBN, false, dma_lds);
+  } else {
+    const int kcols = (a.N - a.three_from + GBN - 1) / GBN, k = b - nq;
+    const int ry = k / kcols, cx = k - ry * kcols;
+    gemm_dma_tile<DT, GEMM_STORE, 1, DBK, NS>(a, ry * 64, a.three_from + cx * GBN, true, dma_lds);
+  }
+}
 
 // ---- 256 x 256 tile, 8 waves, three-stage LDS-DMA ring (the wide products: gate_up / c_fc) -------------------------------------------
 // Why a bigger tile and a deeper ring: one stage of the 128² kernel holds 0.2-0.4 µs of MFMA work per wave, an LDS-DMA piece takes 1-2 µs

@@ -147,6 +147,7 @@ struct tgx_ctx {
   float* ws_attn_part = nullptr;                        // fp32 prefill: split-attention partials of one block of rows
   float* ws_ssq = nullptr;                              // [32][SK_NCB] partial sums of squares of the batched step's rows
   int gemm_splitk = 1;       // experiment: 0 disables split-K
+  int qkv_balanced = 1;      // option prefill.qkv_balanced: the bf16 QKV product as one launch of equal-work tiles (round 3)
   int attn_mirror = 1;       // experiment: prefill attention block order
   int qk_fuse = 1;           // experiment: 0 keeps Qwen3's separate q/k norm launch
   // Two launch folds that are built, parity-tested and OFF by default because they measured slower on MI355X (profiles/r02_launch_folds.txt):
@@ -911,6 +912,14 @@ void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float
         else hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_STORE>), g8, b8, lds8, c->stream, g);)
       return;
     }
+  }
+  if ((c->gemm_dma & 3) && c->qkv_balanced && three_terms && epi == tgx::GEMM_STORE && three_from > 0 && three_from % tgx::GBN == 0 && N > three_from && K % 64 == 0 && M >= 128) {
+    // the QKV product of a bf16 prompt: Q columns as two-term 128-row tiles, K / V columns as three-term 64-row tiles, ONE launch with
+    // equal work per workgroup pair (kernels/gemm_dma.h gemm_dma_qkv_kernel)
+    const int nq = (three_from / tgx::GBN) * ((M + 127) / 128), nkv = ((N - three_from + tgx::GBN - 1) / tgx::GBN) * ((M + 63) / 64);
+    const size_t ldsq = std::max(tgx::gemm_dma_lds_bytes(2, false, 32, 2), tgx::gemm_dma_lds_bytes(1, true, 32, 2));
+    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma_qkv_kernel<DT, 32, 2>), dim3(nq + nkv), blk, ldsq, c->stream, g))
+    return;
   }
   if ((c->gemm_dma & 3) && K % 64 == 0) {     // operand tiles by LDS-DMA into a ring of stages (kernels/gemm_dma.h): one barrier per K step
     // geometry per tile height (option prefill.gemm_dma bits 4-7 / 8-11 override: value = BK/32 + 4*(stages-2)): 128-row tiles k = 32 x 3 stages,
@@ -2327,6 +2336,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.f32_flash")) { c->f32_flash = value; return TGX_OK; }
   if (!strcmp(key, "prefill.f32_min_rows")) { c->prefill_f32_min_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk")) { c->gemm_splitk = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.qkv_balanced")) { c->qkv_balanced = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_mirror")) { c->attn_mirror = value; return TGX_OK; }
   if (!strcmp(key, "attn.qk_fuse")) { c->qk_fuse = value; return TGX_OK; }
   if (!strcmp(key, "attn.fold_combine")) { c->attn_fold = value != 0; return TGX_OK; }
