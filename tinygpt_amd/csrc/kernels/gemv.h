@@ -165,7 +165,7 @@ struct GemvArgs {
   // per-workgroup partials and does what finalize_greedy_kernel does for each of the R rows — one launch per token less.  nullptr: off
   // (sampled steps, tgx_forward: the sampler / tgx_sample finish the step).
   unsigned int* ticket;
-  FinalizeArgs fin[4];
+  const FinalizeArgs* fin;   // [R] in device memory (written by write_finalize_args_kernel ahead of the launch): 0.5 KB less kernarg on every GEMV launch
   // L2 prefetch chaining (l2_prefetch.h): workgroups with blockIdx.x >= pf.n_compute touch the next launches' weights and exit
   PfArgs pf;
 };
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       __syncthreads();
       if (s_last) {
 #pragma unroll 1
-        for (int r = 0; r < R; r++) finalize_row<DT>(a.fin[r]);
+        for (int r = 0; r < R; r++) { const FinalizeArgs f = a.fin[r]; finalize_row<DT>(f); }
       }
     }
   }
@@ -629,6 +629,8 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(QkNormArgs a) {
 
 template <int DT>
 __global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs a) { finalize_row<DT>(a); }
+// stores one row's finalize arguments where the lm_head launch's last-arriving workgroup reads them (option lmhead.fuse_finalize)
+__global__ void write_finalize_args_kernel(const FinalizeArgs a, FinalizeArgs* dst) { if (threadIdx.x == 0) *dst = a; }
 
 // The greedy finalize of every row of a decode batch in ONE launch (blockIdx.x = row; the batched-MFMA decode step): the step counter is
 // advanced by bump_step_kernel afterwards, because rows running concurrently must all read the same step value.

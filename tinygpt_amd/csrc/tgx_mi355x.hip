@@ -171,6 +171,7 @@ struct tgx_ctx {
   // GEMV row groups vs matrix cores: Llama-3.2-1B B = 2 0.794 / 0.991, B = 3 ~1.45 / 1.003, B = 4 1.042 / 1.007; Mistral-7B B = 4 5.04 / 4.01
   int decode_mfma_min = 3;
   unsigned int* lm_ticket = nullptr;   // arrival counter of the lm_head launch (rests at 0)
+  tgx::FinalizeArgs* fin_dev = nullptr;   // [4] finalize arguments of the fused lm_head launch (option lmhead.fuse_finalize)
   bool prefill_mfma = true;
   int prefill_min_rows = 4;  // prompts shorter than this go through the decode kernels, 4 positions per pass (set in tgx_create)
   int f32_flash = 1;               // option prefill.f32_flash: 0 = attention of the fp32 prefill through the decode attention kernel
@@ -437,7 +438,7 @@ tgx::GemvArgs gemv_row(const tgx_ctx* c, tgx::GemvArgs a, int r) {
   if (a.part_val) a.part_val += (size_t)r * a.part_stride;
   if (a.part_idx) a.part_idx += (size_t)r * a.part_stride;
   if (a.attn_part) a.attn_part += (size_t)r * a.part_in_stride;
-  if (a.ticket && r) a.fin[0] = a.fin[r];
+  if (a.ticket && r) a.fin += r;
   return a;
 }
 
@@ -1045,7 +1046,9 @@ void launch_lm_head(tgx_ctx* c, int row0, int R, bool fuse_greedy = false) {
   a.logits = r.logits; a.part_val = r.part_val; a.part_idx = r.part_idx;
   if (fuse_greedy) {
     a.ticket = c->lm_ticket;
-    for (int k = 0; k < R; k++) a.fin[k] = make_finalize_args(c, row0 + k, /*advance_pos=*/true, /*log_step=*/true);
+    for (int k = 0; k < R; k++)      // the rows' finalize arguments go to device memory ahead of the launch (a captured node like any other)
+      hipLaunchKernelGGL(tgx::write_finalize_args_kernel, dim3(1), dim3(64), 0, c->stream, make_finalize_args(c, row0 + k, /*advance_pos=*/true, /*log_step=*/true), c->fin_dev + k);
+    a.fin = c->fin_dev;
   }
   if (c->gpt2) {   // ln_f -> wte^T (tied head, ModelGPT2.h:170-176)
     a.norm_b = c->final_norm_b;
@@ -1932,6 +1935,7 @@ int tgx_finalize(tgx_ctx* c) {
   if ((V + tgx::SAMP_TILE - 1) / tgx::SAMP_TILE > tgx::SAMP_MAX_WG) return set_err(c, TGX_ERR_UNSUPPORTED, "vocabulary %d exceeds the sampler's %d entries", V, tgx::SAMP_MAX_WG * tgx::SAMP_TILE);
   if ((rc = dev_alloc(c, &c->nop_word, 1))) return rc;
   if ((rc = dev_alloc(c, &c->lm_ticket, 1))) return rc;
+  if ((rc = dev_alloc(c, &c->fin_dev, 4))) return rc;
   HIP_OK(c, hipMemset(c->lm_ticket, 0, 4));
   if ((rc = dev_alloc(c, &c->scratch_x, (size_t)H))) return rc;
   HIP_OK(c, hipMemset(c->scratch_x, 0, (size_t)H * 4));
@@ -1993,7 +1997,7 @@ void tgx_destroy(tgx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   drop_step_graphs(c);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->wpe); fr(c->final_norm_b); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->lm_ticket); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
+  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->wpe); fr(c->final_norm_b); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->nop_word); fr(c->lm_ticket); fr(c->fin_dev); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch);
   fr(c->attn_tickets); fr(c->eng_gx1); fr(c->eng_gh); fr(c->eng_gx2); fr(c->eng_epoch); fr(c->eng_err); fr(c->eng_stats);
   fr(c->ch_x); fr(c->ch_q); fr(c->ch_kraw); fr(c->ch_attn); fr(c->ch_h); fr(c->ch_part); fr(c->ch_pos);
   fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl); fr(c->ws_part); fr(c->ws_ssq); fr(c->ws_pos); fr(c->ws_attn_part);
