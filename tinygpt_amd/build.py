@@ -32,15 +32,20 @@ def sources():
 
 def build_lib(force: bool = False, verbose: bool = False, extra_flags=()):
     srcs, deps = sources()
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
-        return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
     if os.environ.get("TGX_DISSECT") == "1":      # experiment build: the debug.gemv / debug.attn switches become live
         extra_flags = list(extra_flags) + ["-DTGX_DISSECT=1"]
     cmd = [HIPCC] + FLAGS + list(extra_flags) + srcs + ["-o", LIB]
+    # the flag set is part of the staleness test (a stamp next to the library): toggling TGX_VGPR_FORM / TGX_DISSECT / extra_flags rebuilds
+    stamp, want = LIB + ".flags", " ".join(cmd)
+    same_flags = os.path.exists(stamp) and open(stamp).read() == want
+    if not force and same_flags and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(want)
     return LIB
 
 

@@ -34,14 +34,14 @@ struct GPTConfig {       // src/engine/GPTEngine.h:25-32 (+ where to find the de
   int deviceOrdinal = 0;
   int maxBatch = 4;
   uint64_t seed = 0;
+  std::string tokenizerDir;          // tokenizer.json + tokenizer_config.json; default: modelDir (lets --synthetic runs take text)
 #ifdef TGXH_TEST_HOOKS
   // Only in the test build (tests/_build/libtgx_host_test.so, tgx_cli_test: -DTGXH_TEST_HOOKS): bind another library that exports the tgx ABI
   // (the CPU oracle) to check host logic without a GPU.  The shipped library and CLI do not contain these fields or the code that reads them:
-  // they can only dlopen libtgx_mi355x.so from their own directory.
+  // they can only dlopen libtgx_mi355x.so from their own directory.  LAST in the struct: every field above keeps its offset in both builds.
   std::string backendLib;
   std::string backendPrefix = "tgx_";
 #endif
-  std::string tokenizerDir;          // tokenizer.json + tokenizer_config.json; default: modelDir (lets --synthetic runs take text)
 };
 
 struct GPTOutput {       // src/engine/GPTEngine.h:34-40
