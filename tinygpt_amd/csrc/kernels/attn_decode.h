@@ -49,6 +49,7 @@ struct AttnArgs {
   unsigned* fold_ticket;
   // L2 prefetch chaining (l2_prefetch.h; split form only): workgroups with blockIdx.x >= pf.n_compute touch the next launches' weights
   PfArgs pf;
+  PfArgs pf_comb;   // the same for the attn_combine launch that follows (host side: copied into `pf` of the combine's argument block)
 };
 
 template <int HD>
@@ -386,9 +387,14 @@ __device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, fl
   }
 }
 
-template <int HD>
+template <int HD, bool PF = false>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sm_o[4][HD + 4];   // per wave: o[HD], M, L
+  if (PF && (int)blockIdx.x >= a.pf.n_compute) {      // prefetch workgroup (l2_prefetch.h): the combine moves a few KB, the fabric is idle
+    const unsigned v = pf_run(a.pf);
+    if (v == 0x9e3779b9u && threadIdx.x == 1023) *a.pf.sink = v;
+    return;
+  }
   const int h = blockIdx.x;
   const float* p = a.part + blockIdx.y * a.part_stride + (size_t)h * a.nsplit * (HD + 4);
   attn_combine_head<HD>(p, a.nsplit, a.out + blockIdx.y * a.q_stride + (size_t)h * HD, sm_o);

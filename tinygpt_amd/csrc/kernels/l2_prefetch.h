@@ -26,6 +26,7 @@ struct PfTarget {
   int N, hd;                // rows of W;  PF_ROWS_ROPE: head_dim
   int units, grid, upb;     // consumer launch geometry
   int budget_wp;            // workgroup passes per XCD to prefetch (consumer order)
+  int wp_start;             // first workgroup pass of the list to touch (an earlier launch covered [0, wp_start))
 };
 
 struct PfArgs {
@@ -65,7 +66,7 @@ __device__ __forceinline__ unsigned pf_run(const PfArgs& a) {
     const int lpr = (p.row_bytes + a.stride - 1) / a.stride;   // touches per row
     const int lrun = p.upb * lpr;                              // touches per run of upb rows
     const int ipw = (2 * lrun + 63) >> 6;                      // touch instructions per workgroup pass
-    const int total = p.budget_wp * ipw;
+    const int total = p.budget_wp * ipw, first_i = p.wp_start * ipw;
     const int half = p.hd >> 1;
     const unsigned char* Wb = static_cast<const unsigned char*>(p.W);
     const size_t last_byte = (size_t)p.N * p.row_bytes - 4;
@@ -83,7 +84,7 @@ __device__ __forceinline__ unsigned pf_run(const PfArgs& a) {
       return *reinterpret_cast<const unsigned*>(Wb + min(off, last_byte));
     };
 #pragma unroll 1
-    for (int i0 = W; i0 < total; i0 += 8 * Wtot) {             // eight touch instructions in flight per wave
+    for (int i0 = first_i + W; i0 < total; i0 += 8 * Wtot) {   // eight touch instructions in flight per wave
       unsigned v[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) v[j] = touch(min(i0 + j * Wtot, total - 1));

@@ -206,6 +206,8 @@ struct tgx_ctx {
   int pf_gu_kb = 2048;        // attn(l)    -> gate_up(l) head
   int pf_dn_kb = 0;           // gate_up(l) -> down(l) head
   int pf_qkv_kb = 4096;       // down(l)    -> qkv(l + 1)     (whole matrix: 1.6 MB per XCD)
+  int pf_comb_kb = 0;         // combine(l) -> gate_up(l) head (the combine launch carries the prefetch workgroups)
+  int pf_oproj_gu_kb = 0;     // o_proj(l)  -> gate_up(l), behind what attention / combine covered
   // The persistent weight-streaming engine (kernels/engine.h), batch-1 decode steps of the RMSNorm families in 16-bit storage.  Option
   // engine.mode: 0 = off (default: the GEMV launches measured faster on MI355X, profiles/r03_engine.txt), 1 = gate_up + down in one launch,
   // 2 = o_proj + gate_up + down + the next layer's qkv in one launch (3 launches per layer instead of 6).
@@ -513,6 +515,17 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
   a.direct = c->attn_direct ? 1 : 0;
   if (a.direct || (c->attn_mfma && !QKN && DT != tgx::DT_F32)) a.pf.t[0].W = nullptr;   // prefetch workgroups ride in the VALU split form only
   a.pf.n_compute = 0;
+  auto launch_combine = [&]() {      // the merge of the split records; with option pf.comb_kb it carries prefetch workgroups (its own traffic is a few KB)
+    if ((c->debug_skip & 2) || attn_fold_ok(c, R)) return;
+    if (a.pf_comb.t[0].W && R == 1) {
+      tgx::AttnArgs b = a;
+      b.pf = a.pf_comb; b.pf.n_compute = a.heads; b.pf.stride = c->pf_stride; b.pf.sink = reinterpret_cast<unsigned*>(c->nop_word);
+      const int gx = (a.heads + c->pf_wgs + 7) / 8 * 8;
+      hipLaunchKernelGGL((tgx::attn_combine_kernel<HD, true>), dim3(gx, R), dim3(256), 0, c->stream, b);
+      return;
+    }
+    hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
+  };
   if (a.direct) {   // short context: one 16-wave workgroup per query head, no combine launch.  Measured (tok/s, direct vs split at context
     // ~120 / ~300 / ~430): see DESIGN.md §5; 1 head per workgroup beats 2 and 4 here (the K/V block is L2-resident, the softmax chain is not)
     const dim3 grid(a.kv_heads, R, gfull), blk(1024);
@@ -524,7 +537,7 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
       const dim3 gm(a.kv_heads * a.nsplit, R), bm(256);
       hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD>), gm, bm, tgx::attn_mfma_lds_bytes<HD>(), c->stream, a);
     }
-    if (!(c->debug_skip & 2) && !attn_fold_ok(c, R)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
+    launch_combine();
     return;
   }
   int gx = a.kv_heads * a.nsplit;
@@ -540,7 +553,7 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
         default: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 4, false, true>), gridp, blkp, 0, c->stream, a); break;
       }
     }
-    if (!(c->debug_skip & 2) && !attn_fold_ok(c, R)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
+    launch_combine();
     return;
   }
   a.pf.n_compute = 0;
@@ -565,7 +578,7 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
     default: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 4, QKN>), grid, blk, 0, c->stream, a); break;
   }
   // the split partials are merged by the o_proj launch's prologue (PRO_ATTNCOMB) unless that fold is off or its LDS stage would not fit
-  if (!(c->debug_skip & 2) && !attn_fold_ok(c, R)) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
+  launch_combine();
 }
 
 void launch_attn(tgx_ctx* c, const tgx::AttnArgs& a, int R) {
@@ -588,7 +601,7 @@ bool qk_fused(const tgx_ctx* c, long long kv_stride) { return c->d.qk_norm && c-
 // ---- L2 prefetch chaining (kernels/l2_prefetch.h) ---------------------------------------------------------------------------------
 // The consumer launch of class `cls` at layer `l` (batch 1) as a prefetch target: its weight matrix, unit -> rows map and workgroup -> units
 // map exactly as launch_gemv will set them, cut at `kb` KB per XCD.
-tgx::PfTarget pf_target(const tgx_ctx* c, int l, int cls, int kb) {
+tgx::PfTarget pf_target(const tgx_ctx* c, int l, int cls, int kb, int skip_kb = 0) {
   tgx::PfTarget t{};
   const tgx_model_desc& d = c->d;
   if (!c->pf_mode || kb <= 0 || l < 0 || l >= d.layers) return t;
@@ -607,7 +620,8 @@ tgx::PfTarget pf_target(const tgx_ctx* c, int l, int cls, int kb) {
   t.row_bytes = (int)(K * c->esz);
   const long long wp_bytes = 2LL * t.upb * t.row_bytes;                                     // one consumer workgroup, one pass
   const long long all = ((long long)units + 8LL * t.upb - 1) / (8LL * t.upb);              // passes x workgroups of one XCD
-  t.budget_wp = (int)std::max<long long>(1, std::min(all, (long long)kb * 1024 / wp_bytes));
+  t.wp_start = (int)std::min(all, (long long)skip_kb * 1024 / wp_bytes);
+  t.budget_wp = (int)std::max<long long>(1, std::min(all, t.wp_start + (long long)kb * 1024 / wp_bytes));
   return t;
 }
 bool pf_active(const tgx_ctx* c, int R, const float* resid, const RowState* rv) { return c->pf_mode && R == 1 && resid == rv[0].x && !c->gpt2 && c->dt != tgx::DT_F32; }
@@ -654,7 +668,7 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
       a.scale = 1.0f / sqrtf((float)hd);
       a.q_stride = qd; a.kv_stride = kv_stride; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
-      if (pf_active(c, R, resid, rv)) a.pf.t[0] = pf_target(c, l, TGX_KERNEL_GATEUP, c->pf_gu_kb);
+      if (pf_active(c, R, resid, rv)) { a.pf.t[0] = pf_target(c, l, TGX_KERNEL_GATEUP, c->pf_gu_kb); a.pf_comb.t[0] = pf_target(c, l, TGX_KERNEL_GATEUP, c->pf_comb_kb, c->pf_gu_kb); }
       if (qk_fused(c, kv_stride)) {
         a.k_raw = r.k_raw; a.kraw_stride = kvd; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm;
         a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.eps = d.norm_eps;
@@ -672,6 +686,7 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
         launch_gemv<tgx::PRO_ATTNCOMB, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_OPROJ, R);
         break;
       }
+      if (pf_active(c, R, resid, rv)) a.pf.t[0] = pf_target(c, l, TGX_KERNEL_GATEUP, c->pf_oproj_gu_kb, c->pf_gu_kb + c->pf_comb_kb);
       launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_OPROJ, R);
       break;
     }
@@ -2355,7 +2370,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
   if (!strncmp(key, "pf.", 3)) {   // L2 prefetch chaining (kernels/l2_prefetch.h); the captured step graphs hold the old launch geometry
     int* dst = !strcmp(key, "pf.mode") ? &c->pf_mode : !strcmp(key, "pf.wgs") ? &c->pf_wgs : !strcmp(key, "pf.stride") ? &c->pf_stride : !strcmp(key, "pf.oproj_kb") ? &c->pf_oproj_kb
-             : !strcmp(key, "pf.gu_kb") ? &c->pf_gu_kb : !strcmp(key, "pf.dn_kb") ? &c->pf_dn_kb : !strcmp(key, "pf.qkv_kb") ? &c->pf_qkv_kb : nullptr;
+             : !strcmp(key, "pf.gu_kb") ? &c->pf_gu_kb : !strcmp(key, "pf.dn_kb") ? &c->pf_dn_kb : !strcmp(key, "pf.qkv_kb") ? &c->pf_qkv_kb : !strcmp(key, "pf.comb_kb") ? &c->pf_comb_kb : !strcmp(key, "pf.oproj_gu_kb") ? &c->pf_oproj_gu_kb : nullptr;
     if (!dst) return set_err(c, TGX_ERR_INVALID, "unknown option %s", key);
     if (value < 0 || (dst == &c->pf_wgs && (value < 8 || value > 1024)) || (dst == &c->pf_stride && value != 64 && value != 128 && value != 256)) return set_err(c, TGX_ERR_INVALID, "%s out of range", key);
     drop_step_graphs(c);
