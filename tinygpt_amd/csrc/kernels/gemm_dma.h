@@ -49,8 +49,9 @@ __device__ __forceinline__ void dma_1k(const void* gsrc, unsigned lds_dst) {
 // stage, so that the 128-row tile keeps three workgroups per CU)
 // NS = ring stages: NS - 1 stages are in flight while one is consumed; the waits are counted (this wave's pieces of the later stages may still fly)
 // The tile body: rows [m0, m0 + 64 MI) x columns [n0, n0 + 128) of C; `three` = the third split term of A is multiplied in as well.
+// [k_begin, k_begin + k_len) = this workgroup's share of K (the whole of it unless EPI == GEMM_PARTIAL: split-K slab `zslab` of a short prompt).
 template <int DT, int EPI, int MI, int DBK, int NS>
-__device__ __forceinline__ void gemm_dma_tile(const GemmArgs& a, const int m0, const int n0, const bool three, bf16_t* dma_lds) {
+__device__ __forceinline__ void gemm_dma_tile(const GemmArgs& a, const int m0, const int n0, const bool three, bf16_t* dma_lds, const int k_begin, const int k_len, const int zslab) {
   constexpr int TM = 64 * MI;
   constexpr int CPR = DBK / 8;                 // 16-byte chunks per tile row
   constexpr int RPP = 64 / CPR;                // tile rows per 1-KiB piece
@@ -71,7 +72,7 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmArgs& a, const int m0, c
 
   // DMA map: a piece = 8 tile rows; lane l -> row (l >> 3) of the piece, LDS slot (l & 7) -> global chunk slot ^ ((row >> 1) & 7)
   const int prow = lane / CPR, pslot = lane % CPR;
-  const bool inter = EPI == GEMM_SILU;
+  const bool inter = EPI == GEMM_SILU || (EPI == GEMM_PARTIAL && a.interleave);
   auto issue_stage = [&](int k0, int stage) {
     const unsigned sbase = lds_base + (unsigned)(stage * stage_elems * 2);
     // A tiles: TM / 8 pieces each, dealt to the 4 waves
@@ -98,16 +99,16 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmArgs& a, const int m0, c
     return *reinterpret_cast<const bf16x8*>(tile + row * DBK + ((kchunk ^ ((row >> SW_SH) & SW_MASK)) << 3));
   };
 
-  const int nk = a.K / DBK;
+  const int nk = k_len / DBK;
   const int ppw = (NA * TM + GBN) / RPP / 4;                         // pieces per wave and stage
 #pragma unroll
   for (int sg = 0; sg < NS - 1; sg++)
-    if (sg < nk) issue_stage(sg * DBK, sg);
+    if (sg < nk) issue_stage(k_begin + sg * DBK, sg);
   for (int k = 0; k < nk; k++) {
     // stage k has landed for this wave once only the pieces of the stages issued after it are outstanding (LDS-DMA completes in order)
     wait_vmcnt(min(NS - 2, nk - 1 - k) * ppw);
     __builtin_amdgcn_s_barrier();                                    // ... for every wave; and every wave is done reading stage k-1
-    if (k + NS - 1 < nk) issue_stage((k + NS - 1) * DBK, (k + NS - 1) % NS);    // into the buffer stage k-1 occupied
+    if (k + NS - 1 < nk) issue_stage(k_begin + (k + NS - 1) * DBK, (k + NS - 1) % NS);    // into the buffer stage k-1 occupied
     const bf16_t* st = dma_lds + (size_t)(k % NS) * stage_elems;
     const bf16_t *tAh = st, *tAl = st + TM * DBK, *tAl2 = st + 2 * TM * DBK, *tB = st + NA * TM * DBK;
 #pragma unroll
@@ -145,6 +146,14 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmArgs& a, const int m0, c
         continue;
       }
       if (col >= a.N) continue;
+      if (EPI == GEMM_PARTIAL) {          // split-K slab: summed in z order by gemm_splitk_reduce_kernel or the next row-wise kernel
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < a.M) a.part[((size_t)zslab * a.M + row) * a.N + col] = acc[i][j][r];
+        }
+        continue;
+      }
       const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
@@ -167,7 +176,12 @@ template <int DT, int EPI, int MI, int DBK, int NS>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
   const bool three = a.A_lo2 != nullptr && (int)(blockIdx.x + 1) * GBN > a.three_from;      // workgroup-uniform
-  gemm_dma_tile<DT, EPI, MI, DBK, NS>(a, (int)blockIdx.y * 64 * MI, (int)blockIdx.x * GBN, three, dma_lds);
+  if constexpr (EPI == GEMM_PARTIAL) {
+    const int k_begin = (int)blockIdx.z * a.k_per, k_len = min(a.K, k_begin + a.k_per) - k_begin;
+    gemm_dma_tile<DT, EPI, MI, DBK, NS>(a, (int)blockIdx.y * 64 * MI, (int)blockIdx.x * GBN, three, dma_lds, k_begin, k_len, (int)blockIdx.z);
+  } else {
+    gemm_dma_tile<DT, EPI, MI, DBK, NS>(a, (int)blockIdx.y * 64 * MI, (int)blockIdx.x * GBN, three, dma_lds, 0, a.K, 0);
+  }
 }
 
 // The QKV product of a bf16 prompt as ONE balanced launch (round 3).  Its Q columns take two split terms, its K / V columns three (their results are
@@ -182,11 +196,11 @@ __global__ __launch_bounds__(256) void gemm_dma_qkv_kernel(const GemmArgs a) {
   const int b = (int)blockIdx.x;
   if (b < nq) {
     const int ry = b / qcols, cx = b - ry * qcols;
-    gemm_dma_tile<DT, GEMM_STORE, 2, DBK, NS>(a, ry * 128, cx * GBN, false, dma_lds);
+    gemm_dma_tile<DT, GEMM_STORE, 2, DBK, NS>(a, ry * 128, cx * GBN, false, dma_lds, 0, a.K, 0);
   } else {
     const int kcols = (a.N - a.three_from + GBN - 1) / GBN, k = b - nq;
     const int ry = k / kcols, cx = k - ry * kcols;
-    gemm_dma_tile<DT, GEMM_STORE, 1, DBK, NS>(a, ry * 64, a.three_from + cx * GBN, true, dma_lds);
+    gemm_dma_tile<DT, GEMM_STORE, 1, DBK, NS>(a, ry * 64, a.three_from + cx * GBN, true, dma_lds, 0, a.K, 0);
   }
 }
 

@@ -147,6 +147,7 @@ struct tgx_ctx {
   float* ws_attn_part = nullptr;                        // fp32 prefill: split-attention partials of one block of rows
   float* ws_ssq = nullptr;                              // [32][SK_NCB] partial sums of squares of the batched step's rows
   int gemm_splitk = 1;       // experiment: 0 disables split-K
+  int splitk_dma = 1;        // option prefill.splitk_dma: the split-K slabs of a short prompt through the LDS-DMA GEMM (round 3)
   int qkv_balanced = 1;      // option prefill.qkv_balanced: the bf16 QKV product as one launch of equal-work tiles (round 3)
   int attn_mirror = 1;       // experiment: prefill attention block order
   int qk_fuse = 1;           // experiment: 0 keeps Qwen3's separate q/k norm launch
@@ -898,8 +899,24 @@ void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float
     const dim3 gz(grid.x, grid.y, nsplit);
     const size_t nout = (size_t)M * (epi == tgx::GEMM_SILU ? N / 2 : N);
     const dim3 rg((unsigned)((nout + 255) / 256));
+    // the slabs' GEMM: operand tiles by LDS-DMA (round 3; option prefill.splitk_dma) — the register-staged kernel streamed a short prompt's weights at
+    // 1-2 TB/s (S = 48: gate_up 32 us for 67 MB); 64-row tiles whenever the prompt fits them, k = 64 per stage (32 for the 128-row three-term tile)
+    // measured (Llama-3.2-1B, ms per prompt, DMA vs register-staged slabs): S = 40 1.61 / 1.79, 48 1.65 / 1.76, 64 1.71 / 1.87; 96 2.08 / 1.99, 128 2.12 / 2.09,
+    // 256 2.65 / 2.68; Mistral-7B S = 48 5.40 / 6.23 — the 64-row tile wins, the 128-row one does not: prompts of <= 64 rows only (value 2 = always)
+    const bool dma_part = c->splitk_dma && (M <= 64 || c->splitk_dma == 2) && (c->gemm_dma & 3) && g.k_per % 64 == 0 && K % 64 == 0;
+    if (dma_part) {
+      const int mi = (small || M <= 64) ? 1 : 2;
+      const int dbk = (mi == 2 && three_terms) ? 32 : 64;
+      const dim3 gd((N + tgx::GBN - 1) / tgx::GBN, (M + 64 * mi - 1) / (64 * mi), nsplit);
+      const size_t lds = tgx::gemm_dma_lds_bytes(mi, three_terms, dbk, 2);
+      TGX_DT16_SWITCH(c->dt,
+        if (mi == 1) hipLaunchKernelGGL((tgx::gemm_dma_kernel<DT, tgx::GEMM_PARTIAL, 1, 64, 2>), gd, blk, lds, c->stream, g);
+        else if (dbk == 64) hipLaunchKernelGGL((tgx::gemm_dma_kernel<DT, tgx::GEMM_PARTIAL, 2, 64, 2>), gd, blk, lds, c->stream, g);
+        else hipLaunchKernelGGL((tgx::gemm_dma_kernel<DT, tgx::GEMM_PARTIAL, 2, 32, 2>), gd, blk, lds, c->stream, g);)
+    }
     TGX_DT16_SWITCH(c->dt,
-      if (small) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_PARTIAL, 1>), gz, blk, dyn, c->stream, g);
+      if (dma_part) {}
+      else if (small) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_PARTIAL, 1>), gz, blk, dyn, c->stream, g);
       else hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_PARTIAL, 2>), gz, blk, dyn, c->stream, g);
       if (defer && c->defer_reduce && M >= 192 && (epi == tgx::GEMM_RESIDUAL || epi == tgx::GEMM_STORE)) { *defer = nsplit; }   // below ~192 rows the row-wise consumers are too few workgroups to sum 16 slabs quickly (S = 64: 1.82 -> 1.87 ms; S = 256: 2.80 -> 2.70)
       else if (epi == tgx::GEMM_SILU) hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_SILU>), rg, blk, 0, c->stream, g);
@@ -1981,6 +1998,9 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_BF16, tgx::GEMM_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_F16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_F16, tgx::GEMM_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
+#define TGX_DMA_ATTR_P(DT_) TGX_DMA_ATTR1(DT_, tgx::GEMM_PARTIAL, 1, 64, 2) TGX_DMA_ATTR1(DT_, tgx::GEMM_PARTIAL, 2, 64, 2) TGX_DMA_ATTR1(DT_, tgx::GEMM_PARTIAL, 2, 32, 2)
+  TGX_DMA_ATTR_P(tgx::DT_BF16) TGX_DMA_ATTR_P(tgx::DT_F16)
+#undef TGX_DMA_ATTR_P
 #undef TGX_DMA_ATTR_D
 #undef TGX_DMA_ATTR
 #undef TGX_DMA_ATTR1
@@ -2356,6 +2376,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.f32_min_rows")) { c->prefill_f32_min_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk")) { c->gemm_splitk = value; return TGX_OK; }
   if (!strcmp(key, "prefill.qkv_balanced")) { c->qkv_balanced = value != 0; return TGX_OK; }
+  if (!strcmp(key, "prefill.splitk_dma")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "prefill.splitk_dma is 0, 1 (<= 64 rows) or 2 (always)"); c->splitk_dma = value; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_mirror")) { c->attn_mirror = value; return TGX_OK; }
   if (!strcmp(key, "attn.qk_fuse")) { c->qk_fuse = value; return TGX_OK; }
   if (!strcmp(key, "attn.fold_combine")) { c->attn_fold = value != 0; return TGX_OK; }
