@@ -7,6 +7,10 @@
 // WEIGHT STREAM NEVER STOPS: a loader wave per CU walks the static tile schedule of all ops and lands the next op's weights in LDS
 // (global_load_lds, nt) while the current op's output vector is still being exchanged.
 //
+// MEASURED (profiles/r03_engine.txt): parity-green and deterministic, and SLOWER than the launches — 33.6 vs 29.8 us per layer for the four ops, 22.3 vs
+// 21.3 for the MLP pair; the stream runs at 6.1 TB/s, but every all-to-all edge costs 3.4-4.5 us against ~2.65 us for a launch boundary plus the
+// dependent fetch, and the ring (4.8 us of stream) cannot hide the chain start -> o_proj -> x' edge.  Hence option engine.mode, default 0.
+//
 // Roles of the 5 waves of a workgroup (MI355X_MICROARCH.md "ldsdma-fill", "prefetch-credit", "gather-pass"):
 //   wave 0    loader     16 x 1-KiB global_load_lds_dwordx4 per 16-KiB tile into a ring of NS slots; counted vmcnt -> `landed`
 //   wave 1-3  consumers  tile t goes to consumer t mod 3: 8 weight rows x 1024 k from LDS (ds_read_b128), fp32 FMA against the activation
