@@ -185,6 +185,7 @@ struct tgx_ctx {
   int gemm_dma = 15 | (1 << 4) | (2 << 8);
   int debug_attn = 0;        // experiment: AttnArgs.dbg
   int attn_gmax = 0;         // experiment: query heads per attention workgroup (default 2)
+  int attn_direct_g = 1;     // option attn.direct_g: 1 = heads per workgroup of the direct attention form by batch rows (2 from 12 rows, 4 from 24 at head_dim 64), 0 = always one, -g = force g
   int attn_direct_max = 384; // contexts up to this many keys take the one-workgroup-per-head attention (no split, no combine launch); set in tgx_create
   bool attn_direct = false;  // mode of the launches being issued / captured
   bool step_graph_direct = false;
@@ -529,6 +530,25 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
   };
   if (a.direct) {   // short context: one 16-wave workgroup per query head, no combine launch.  Measured (tok/s, direct vs split at context
     // ~120 / ~300 / ~430): see DESIGN.md §5; 1 head per workgroup beats 2 and 4 here (the K/V block is L2-resident, the softmax chain is not)
+    // Batches (round 3): with R rows the K/V working set (R x kv_heads x T rows) no longer fits the L2s, and one workgroup per QUERY head reads each kv
+    // head gfull times — Llama-3.2-1B B = 32 at context ~600: 24 us per layer, a quarter of the step.  From `attn.direct_rows` rows on, a workgroup takes
+    // two query heads of a kv head (option attn.direct_g: 1, 2 or 4 heads).
+    // measured ms/step by heads per workgroup (1 / 2 / 4): Llama-3.2-1B context 600 B = 16 1.105 / 1.058 / 1.132, B = 32 1.551 / 1.421 / 1.382; context 2k
+    // B = 16 1.354 / 1.208 / 1.384, B = 32 2.458 / 1.906 / 1.680; Mistral-7B context 600 B = 16 4.11 / 3.94 / 4.35, B = 32 6.08 / 5.47 / 5.53
+    int dg = 1;
+    if (!QKN && c->attn_direct_g > 0) dg = R >= 24 ? (HD == 64 ? 4 : 2) : (R >= 12 ? 2 : 1);
+    if (!QKN && c->attn_direct_g < 0) dg = -c->attn_direct_g;          // experiments: force
+    dg = std::min(dg, gfull);
+    if (dg >= 2 && gfull % dg == 0) {
+      const dim3 gridg(a.kv_heads, R, gfull / dg), blkg(1024);
+      if constexpr (!QKN) {
+        if (!(c->debug_skip & 1)) {
+          if (dg == 2) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 16, false>), gridg, blkg, 0, c->stream, a);
+          else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 16, false>), gridg, blkg, 0, c->stream, a);
+        }
+      }
+      return;
+    }
     const dim3 grid(a.kv_heads, R, gfull), blk(1024);
     if (!(c->debug_skip & 1)) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 16, QKN>), grid, blk, 0, c->stream, a);
     return;
@@ -1165,8 +1185,12 @@ bool decode_mfma_ok(const tgx_ctx* c);
 // The attention form of the launches about to be issued / captured, from the context the call ends at: direct (one workgroup per head, no
 // combine) for short contexts, the MFMA decode attention for long ones, the VALU split form in between.  One place for all callers
 // (the prefill-by-steps branch used to leave attn_mfma at whatever the previous decode call had chosen).
-void update_attn_modes(tgx_ctx* c, int n_positions) {
-  c->attn_direct = c->past + n_positions <= c->attn_direct_max;
+void update_attn_modes(tgx_ctx* c, int n_positions, int rows_per_launch = -1) {   // rows_per_launch: batch rows that share an attention launch (-1: the batch)
+  // batches (round 3): the rows themselves fill the chip, so the one-workgroup-per-(kv head, row) form stays ahead of the split form far beyond the
+  // batch-1 crossover — Llama-3.2-1B at context 2k: B = 8 1.250 -> 1.105 ms/step, B = 32 2.360 -> 1.680; Mistral-7B at 600: B = 32 6.91 -> 5.47
+  const int rpl = rows_per_launch < 0 ? c->batch : rows_per_launch;
+  const long long direct_lim = (long long)c->attn_direct_max * (rpl >= 4 ? rpl : 1);
+  c->attn_direct = c->past + n_positions <= direct_lim;
   c->attn_mfma = !c->attn_direct && c->past >= attn_mfma_threshold(c) && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
 }
 
@@ -2085,7 +2109,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     // prefill by steps (fp32 storage, GPT-2, prompts shorter than 4 tokens, shapes the GEMM tile does not cover): up to 4 consecutive
     // positions per pass through the decode kernels — the chunk rows share this row's cache (kv_stride 0), each attends the
     // keys up to its own position, so the result equals position-by-position passes at a quarter of the weight traffic
-    update_attn_modes(c, seq);
+    update_attn_modes(c, seq, 1);      // the chunk rows of a pass are positions of ONE sequence
     for (int s0 = 0; s0 < seq;) {
       const int rem = seq - s0, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
       tgx::EmbedChunkArgs e{};
@@ -2364,6 +2388,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
     c->attn_gmax = value; return TGX_OK;
   }
   if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
+  if (!strcmp(key, "attn.direct_g")) { if (value != 0 && value != 1 && value != -1 && value != -2 && value != -4) return set_err(c, TGX_ERR_INVALID, "attn.direct_g is 0, 1 or -1 / -2 / -4"); drop_step_graphs(c); c->attn_direct_g = value; return TGX_OK; }
   if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "prefill.defer_reduce")) { c->defer_reduce = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.ksplit")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.ksplit must be 0, 1 (<= 16 rows) or 2 (<= 32 rows)"); c->skinny_ksplit = value; return TGX_OK; }
