@@ -191,6 +191,7 @@ struct tgx_ctx {
   bool step_graph_direct = false;
   // contexts from attn_mfma_min keys on take the MFMA decode attention (kernels/attn_decode_mfma.h); like the direct form it is a mode of the
   // captured step: the graphs are re-captured when a decode call crosses the limit.  Not for Qwen3's fused q/k norm, not for fp32 storage.
+  int skinny_terms = 1;            // option skinny.terms: batches of 17-32 rows take gate_up's activations as terms prepared once per layer (round 3)
   int skinny_ksplit = 1;           // wide products (gate_up, lm_head) of the batched step on the barrier-free K-split kernel (option skinny.ksplit)
   int defer_reduce = 1;            // split-K slabs of the prefill's N = hidden / QKV products are summed by the next row-wise kernel (option prefill.defer_reduce)
   int attn_mfma_min = -1;          // -1: the measured crossover of the geometry (attn_mfma_threshold); option attn.mfma_min overrides
@@ -1215,7 +1216,7 @@ void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
 // the (epilogue, terms, activation source) combinations the batched step uses; every one exists for 2 dtypes x MB 1,2 x NBW 1,2
 #define TGX_SKINNY_COMBOS(X)                                                                                                   \
   X(tgx::GEMM_PARTIAL, 3, 2) X(tgx::GEMM_STORE, 3, 2) X(tgx::GEMM_PARTIAL, 2, 2) X(tgx::GEMM_STORE, 2, 2) X(tgx::GEMM_SILU, 2, 2) \
-  X(tgx::GEMM_PARTIAL, 2, 1) X(tgx::GEMM_RESIDUAL, 2, 1) X(tgx::GEMM_PARTIAL, 2, 0) X(tgx::GEMM_RESIDUAL, 2, 0)
+  X(tgx::GEMM_PARTIAL, 2, 1) X(tgx::GEMM_RESIDUAL, 2, 1) X(tgx::GEMM_PARTIAL, 2, 0) X(tgx::GEMM_RESIDUAL, 2, 0) X(tgx::GEMM_SILU, 2, 0) X(tgx::GEMM_STORE, 2, 0)
 
 template <int DT, int EPI, int NT, int ASRC>
 int skinny_set_attr_dt(tgx_ctx* c) {
@@ -1401,6 +1402,14 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
     if (gu_ks) {     // {sum slabs, residual, RMSNorm, 16-bit terms} in one row-wise launch, then the barrier-free wide product
       launch_norm_terms(c, r.x, w.post_norm, M, H, os);
       launch_ksplit(c, tgx::GEMM_SILU, w.wgu, nullptr, 2 * I, M, 2 * I, H);
+    } else if (c->skinny_terms) {
+      // 17-32 rows (round 3): {sum slabs, residual, RMSNorm, 16-bit terms} ONCE per layer in the row-wise launch that replaces reduce_rows; the panel
+      // kernel then stages stored terms instead of normalising and splitting every 256-k panel in each of its 256 workgroups
+      launch_norm_terms(c, r.x, w.post_norm, M, H, os);
+      SkinnyCall gu;
+      gu.epi = tgx::GEMM_SILU; gu.W = w.wgu; gu.M = M; gu.N = 2 * I; gu.K = H; gu.ldc = 2 * I; gu.nt = 2; gu.asrc = 0; gu.a_hi = c->ws_ah; gu.a_lo = c->ws_al;
+      gu.allow_split = c->skinny_gu_split != 0;
+      gs = launch_skinny(c, gu);
     } else {
     if (os > 1) launch_reduce_rows(c, tgx::GEMM_RESIDUAL, os, nullptr, r.x, H, M, H, ssq);
     else hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
@@ -2391,6 +2400,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.direct_g")) { if (value != 0 && value != 1 && value != -1 && value != -2 && value != -4) return set_err(c, TGX_ERR_INVALID, "attn.direct_g is 0, 1 or -1 / -2 / -4"); drop_step_graphs(c); c->attn_direct_g = value; return TGX_OK; }
   if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "prefill.defer_reduce")) { c->defer_reduce = value != 0; return TGX_OK; }
+  if (!strcmp(key, "skinny.terms")) { drop_step_graphs(c); c->skinny_terms = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.ksplit")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.ksplit must be 0, 1 (<= 16 rows) or 2 (<= 32 rows)"); c->skinny_ksplit = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_tm")) { c->gemm_tm = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_dma")) { c->gemm_dma = value; return TGX_OK; }
