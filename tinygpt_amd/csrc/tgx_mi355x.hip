@@ -185,6 +185,7 @@ struct tgx_ctx {
   int gemm_dma = 15 | (1 << 4) | (2 << 8);
   int debug_attn = 0;        // experiment: AttnArgs.dbg
   int attn_gmax = 0;         // experiment: query heads per attention workgroup (default 2)
+  int attn_direct_nw4 = 0;   // option attn.direct_nw4 (experiment)
   int attn_direct_g = 1;     // option attn.direct_g: 1 = heads per workgroup of the direct attention form by batch rows (2 from 12 rows, 4 from 24 at head_dim 64), 0 = always one, -g = force g
   int attn_direct_max = 384; // contexts up to this many keys take the one-workgroup-per-head attention (no split, no combine launch); set in tgx_create
   bool attn_direct = false;  // mode of the launches being issued / captured
@@ -548,6 +549,13 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
           else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 16, false>), gridg, blkg, 0, c->stream, a);
         }
       }
+      return;
+    }
+    // very short contexts (option attn.direct_nw4: keys up to which the direct form runs FOUR waves per head instead of sixteen): one pass of a 4-wave
+    // workgroup covers 128 keys at head_dim 64 (64 at 128), and four records merge faster than sixteen
+    if (c->attn_direct_nw4 > 0 && c->past + 1 <= c->attn_direct_nw4) {
+      const dim3 grid4(a.kv_heads, R, gfull), blk4(256);
+      if (!(c->debug_skip & 1)) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, QKN>), grid4, blk4, 0, c->stream, a);
       return;
     }
     const dim3 grid(a.kv_heads, R, gfull), blk(1024);
@@ -2397,6 +2405,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
     c->attn_gmax = value; return TGX_OK;
   }
   if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
+  if (!strcmp(key, "attn.direct_nw4")) { drop_step_graphs(c); c->attn_direct_nw4 = value; return TGX_OK; }
   if (!strcmp(key, "attn.direct_g")) { if (value != 0 && value != 1 && value != -1 && value != -2 && value != -4) return set_err(c, TGX_ERR_INVALID, "attn.direct_g is 0, 1 or -1 / -2 / -4"); drop_step_graphs(c); c->attn_direct_g = value; return TGX_OK; }
   if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "prefill.defer_reduce")) { c->defer_reduce = value != 0; return TGX_OK; }
