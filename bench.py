@@ -200,6 +200,9 @@ def main():
     limit = 768 if desc.head_dim == 64 else 384
     if args.prompt + 1 + args.warmup <= limit < args.prompt + 1 + args.warmup + args.steps:
         model.set_option("attn.direct_max", 0)
+    nw4 = 256 if desc.head_dim == 64 else 0           # the four-wave form of very short contexts: same rule (a crossing would capture a graph inside the timed region)
+    if nw4 and args.prompt + 1 + args.warmup <= nw4 < args.prompt + 1 + args.warmup + args.steps:
+        model.set_option("attn.direct_nw4", 0)
     prompt = synth.synth_prompt(desc.vocab, args.prompt, 1234 + rank)[None, :]
     model.forward(prompt)                                           # untimed: allocates the prefill workspace, warms the code objects
     model.synchronize()

@@ -120,12 +120,16 @@ struct tgx_ctx {
   hipEvent_t ticket_ev[MAX_TICKET_EVENTS] = {};
   int32_t last_sampled0 = -1;
 
-  hipGraphExec_t step_graph = nullptr;
+  hipGraphExec_t step_graph = nullptr;      // the current entry of the cache below
   hipGraphExec_t multi_graph = nullptr;   // graph_steps consecutive decode steps (tgx_decode with many steps)
+  // captured step graphs by (batch, sampler config, attention form): a generation that crosses an attention-form limit, or an engine that alternates between
+  // sampler configurations / batch sizes, re-uses what it captured before instead of re-capturing (round 3; round 2 dropped the graphs at every change)
+  struct GraphSet { hipGraphExec_t step = nullptr, multi = nullptr; int batch = 0; tgx_sampler_cfg cfg{}; bool direct = false, mfma = false, nw4 = false; unsigned long long used = 0; };
+  GraphSet graph_cache[6];
+  unsigned long long graph_clock = 0;
+  int graph_cur = -1;
   bool mirror_to_host = true;             // finalize / pick kernels also store the token into the pinned host ring (tgx_fetch_token)
   int graph_steps = 8;                    // measured: 1 -> 1389 tok/s, 8 -> 1396, 16 -> 1399 (the gap between two graph launches is ~4 us)
-  int step_graph_batch = 0;
-  tgx_sampler_cfg step_graph_cfg{};
   unsigned long long* seed_dev = nullptr;
   unsigned long long seed_on_dev = 0;         // value last copied to seed_dev: an unchanged seed costs no copy and no stream sync
   bool seed_valid = false;
@@ -185,18 +189,18 @@ struct tgx_ctx {
   int gemm_dma = 15 | (1 << 4) | (2 << 8);
   int debug_attn = 0;        // experiment: AttnArgs.dbg
   int attn_gmax = 0;         // experiment: query heads per attention workgroup (default 2)
-  int attn_direct_nw4 = 0;   // option attn.direct_nw4 (experiment)
+  int attn_direct_nw4 = 0;   // option attn.direct_nw4: contexts up to this many keys run the direct attention form with four waves per head (set in tgx_create)
+  bool attn_nw4 = false;     // mode of the launches being issued / captured
   int attn_direct_g = 1;     // option attn.direct_g: 1 = heads per workgroup of the direct attention form by batch rows (2 from 12 rows, 4 from 24 at head_dim 64), 0 = always one, -g = force g
   int attn_direct_max = 384; // contexts up to this many keys take the one-workgroup-per-head attention (no split, no combine launch); set in tgx_create
   bool attn_direct = false;  // mode of the launches being issued / captured
-  bool step_graph_direct = false;
   // contexts from attn_mfma_min keys on take the MFMA decode attention (kernels/attn_decode_mfma.h); like the direct form it is a mode of the
   // captured step: the graphs are re-captured when a decode call crosses the limit.  Not for Qwen3's fused q/k norm, not for fp32 storage.
   int skinny_terms = 1;            // option skinny.terms: batches of 17-32 rows take gate_up's activations as terms prepared once per layer (round 3)
   int skinny_ksplit = 1;           // wide products (gate_up, lm_head) of the batched step on the barrier-free K-split kernel (option skinny.ksplit)
   int defer_reduce = 1;            // split-K slabs of the prefill's N = hidden / QKV products are summed by the next row-wise kernel (option prefill.defer_reduce)
   int attn_mfma_min = -1;          // -1: the measured crossover of the geometry (attn_mfma_threshold); option attn.mfma_min overrides
-  bool attn_mfma = false, step_graph_mfma = false;
+  bool attn_mfma = false;
   int debug_gemv = 0;        // experiment: GemvArgs.dbg = value & 15 for the kernel classes selected by bits 8.. (1 << (8 + class))
   int debug_skip = 0;        // experiment: bit0 skip attn decode kernel, bit1 skip combine (results invalid)
   int prof_same_layer = 0;   // experiment: tgx_profile_decode replays ONE layer's weights (Infinity-Cache resident)
@@ -553,7 +557,7 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
     }
     // very short contexts (option attn.direct_nw4: keys up to which the direct form runs FOUR waves per head instead of sixteen): one pass of a 4-wave
     // workgroup covers 128 keys at head_dim 64 (64 at 128), and four records merge faster than sixteen
-    if (c->attn_direct_nw4 > 0 && c->past + 1 <= c->attn_direct_nw4) {
+    if (c->attn_nw4 && dg == 1) {
       const dim3 grid4(a.kv_heads, R, gfull), blk4(256);
       if (!(c->debug_skip & 1)) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, QKN>), grid4, blk4, 0, c->stream, a);
       return;
@@ -1200,6 +1204,7 @@ void update_attn_modes(tgx_ctx* c, int n_positions, int rows_per_launch = -1) { 
   const int rpl = rows_per_launch < 0 ? c->batch : rows_per_launch;
   const long long direct_lim = (long long)c->attn_direct_max * (rpl >= 4 ? rpl : 1);
   c->attn_direct = c->past + n_positions <= direct_lim;
+  c->attn_nw4 = c->attn_direct && rpl < 4 && c->attn_direct_nw4 > 0 && c->past + n_positions <= c->attn_direct_nw4;
   c->attn_mfma = !c->attn_direct && c->past >= attn_mfma_threshold(c) && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
 }
 
@@ -1681,24 +1686,44 @@ int capture_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, int steps, hipGraphExe
 }
 
 void drop_step_graphs(tgx_ctx* c) {
-  if (!c->step_graph && !c->multi_graph) return;
+  bool any = false;
+  for (auto& g : c->graph_cache) any |= g.step != nullptr || g.multi != nullptr;
+  c->step_graph = nullptr; c->multi_graph = nullptr; c->graph_cur = -1;
+  if (!any) return;
   (void)hipStreamSynchronize(c->stream);
-  if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
-  if (c->multi_graph) { (void)hipGraphExecDestroy(c->multi_graph); c->multi_graph = nullptr; }
+  for (auto& g : c->graph_cache) {
+    if (g.step) (void)hipGraphExecDestroy(g.step);
+    if (g.multi) (void)hipGraphExecDestroy(g.multi);
+    g = tgx_ctx::GraphSet{};
+  }
 }
 
 int ensure_step_graph(tgx_ctx* c, const tgx_sampler_cfg& cfg, bool want_multi) {
   if (!c->use_graph) return TGX_OK;
-  if (!(c->step_graph && c->step_graph_batch == c->batch && same_cfg(c->step_graph_cfg, cfg) && c->step_graph_direct == c->attn_direct && c->step_graph_mfma == c->attn_mfma)) {
-    drop_step_graphs(c);
-    int rc = capture_steps(c, cfg, 1, &c->step_graph);
-    if (rc) return rc;
-    c->step_graph_batch = c->batch;
-    c->step_graph_cfg = cfg;
-    c->step_graph_direct = c->attn_direct;
-    c->step_graph_mfma = c->attn_mfma;
+  int hit = -1, victim = 0;
+  for (int i = 0; i < 6; i++) {
+    const tgx_ctx::GraphSet& g = c->graph_cache[i];
+    if (g.step && g.batch == c->batch && same_cfg(g.cfg, cfg) && g.direct == c->attn_direct && g.mfma == c->attn_mfma && g.nw4 == c->attn_nw4) { hit = i; break; }
+    if (!g.step) victim = i;
+    else if (c->graph_cache[victim].step && g.used < c->graph_cache[victim].used) victim = i;
   }
-  if (want_multi && !c->multi_graph && c->graph_steps > 1) return capture_steps(c, cfg, c->graph_steps, &c->multi_graph);
+  if (hit < 0) {
+    tgx_ctx::GraphSet& g = c->graph_cache[victim];
+    if (g.step || g.multi) {      // evict the least recently used set (its replays may still be in flight)
+      HIP_OK(c, hipStreamSynchronize(c->stream));
+      if (g.step) (void)hipGraphExecDestroy(g.step);
+      if (g.multi) (void)hipGraphExecDestroy(g.multi);
+      g = tgx_ctx::GraphSet{};
+    }
+    int rc = capture_steps(c, cfg, 1, &g.step);
+    if (rc) return rc;
+    g.batch = c->batch; g.cfg = cfg; g.direct = c->attn_direct; g.mfma = c->attn_mfma; g.nw4 = c->attn_nw4;
+    hit = victim;
+  }
+  tgx_ctx::GraphSet& g = c->graph_cache[hit];
+  if (want_multi && !g.multi && c->graph_steps > 1) { int rc = capture_steps(c, cfg, c->graph_steps, &g.multi); if (rc) return rc; }
+  g.used = ++c->graph_clock;
+  c->graph_cur = hit; c->step_graph = g.step; c->multi_graph = g.multi;
   return TGX_OK;
 }
 
@@ -1715,28 +1740,36 @@ int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int 
     }
     c->have_probs = true;
   }
-  // short contexts: attention without the split / combine pair (one launch less per layer); the graphs are re-captured when a
-  // call crosses the limit
-  update_attn_modes(c, n);
   if (decode_mfma_ok(c)) {   // the batched step's workspace must exist before the step is captured
     int rc = ensure_skinny_ws(c, std::min(32, c->batch));
     if (rc) return rc;
   }
-  if (c->use_graph) {
-    const int K = c->graph_steps;
-    // any multi-step call captures the K-step graph as well (a short warm-up call then leaves nothing to capture inside a later, longer
-    // call); one-step streaming calls never pay for it
-    int rc = ensure_step_graph(c, cfg, /*want_multi=*/n >= 2);
-    if (rc) return rc;
-    int i = 0;
-    if (c->multi_graph) for (; i + K <= n; i += K) HIP_OK(c, hipGraphLaunch(c->multi_graph, c->stream));
-    for (; i < n; i++) HIP_OK(c, hipGraphLaunch(c->step_graph, c->stream));
-  } else {
-    for (int i = 0; i < n; i++) launch_decode_step(c, cfg);
-    HIP_OK(c, hipGetLastError());
+  // The attention form depends on the context (four-wave direct / sixteen-wave direct / split + combine / matrix cores): a call that crosses a limit is
+  // issued in chunks, each on the form of its own contexts, from the cache of captured graphs
+  int remaining = n;
+  while (remaining > 0) {
+    int m = remaining;
+    const long long lims[2] = {c->batch < 4 ? (long long)c->attn_direct_nw4 : 0LL, (long long)c->attn_direct_max * (c->batch >= 4 ? c->batch : 1)};
+    for (long long lim : lims)
+      if (lim > 0 && c->past + 1 <= lim && c->past + m > lim) m = (int)(lim - c->past);
+    update_attn_modes(c, m);
+    if (c->use_graph) {
+      const int K = c->graph_steps;
+      // any multi-step call captures the K-step graph as well (a short warm-up call then leaves nothing to capture inside a later, longer
+      // call); one-step streaming calls never pay for it
+      int rc = ensure_step_graph(c, cfg, /*want_multi=*/m >= 2);
+      if (rc) return rc;
+      int i = 0;
+      if (c->multi_graph) for (; i + K <= m; i += K) HIP_OK(c, hipGraphLaunch(c->multi_graph, c->stream));
+      for (; i < m; i++) HIP_OK(c, hipGraphLaunch(c->step_graph, c->stream));
+    } else {
+      for (int i = 0; i < m; i++) launch_decode_step(c, cfg);
+      HIP_OK(c, hipGetLastError());
+    }
+    c->past += m;
+    c->steps_issued += m;
+    remaining -= m;
   }
-  c->past += n;
-  c->steps_issued += n;
   return TGX_OK;
 }
 
@@ -1809,6 +1842,8 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   // measured crossover of the direct and the split attention (tools/sweep.py --grid attn.direct_max=0,100000): context ~850-1100 at
   // head_dim 64 (Qwen2.5-0.5B, Llama-3.2-1B), ~500 at 128 (Mistral-7B: half the tokens per wave-load)
   c->attn_direct_max = d.head_dim == 64 ? 768 : 384;
+  // four waves per head up to 256 keys at head_dim 64 (Qwen2.5-0.5B 16-token prompt 0.579 -> 0.565 ms/token, Llama-3.2-1B 0.648 -> 0.634; from ~256 keys and at head_dim 128 the sixteen-wave form is ahead)
+  c->attn_direct_nw4 = d.head_dim == 64 ? 256 : 0;
   // very short prompts: ONE pass through the batched decode kernels (4 positions) still beats the skinny MFMA prefill on small models
   // (Llama-3.2-1B: S = 4 1.00 vs 1.07 ms, S = 5 1.55 vs 1.07; Mistral-7B S = 4 4.65 vs 4.09) — tools/prefill_crossover.py, profiles/r02_prefill_short.txt
   c->prefill_min_rows = d.hidden > 2048 ? 4 : 5;
