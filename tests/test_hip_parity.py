@@ -496,6 +496,32 @@ def test_attention_combine_by_the_last_arriving_split_equals_separate_launch(nam
     m.set_option("attn.fold_ticket", 0)
 
 
+def test_one_long_decode_call_equals_single_steps_across_the_attention_form_limits(hip):
+    """A decode call that crosses the limits of the attention forms (four-wave direct <= 256 keys, sixteen-wave direct <= 768, split + combine beyond)
+    is issued in chunks, each on the form of its own contexts, from the cache of captured graphs (round 3): its ids and final logits must be
+    bit-identical to the same generation issued one step at a time, and a second generation (graphs re-used) must repeat them."""
+    import copy
+    from tinygpt_amd import known_desc, synth
+    from tinygpt_amd.ffi import Model
+    d = copy.deepcopy(known_desc("llama-3.2-1b"))
+    d.layers, d.vocab, d.max_ctx = 2, 4096, 1024
+    m = Model(d, hip).load_synthetic(1234, 0.02).finalize()
+    prompt = synth.synth_prompt(d.vocab, 200, 9)[None, :]
+    runs = []
+    for mode in ("one call", "single steps", "one call again"):
+        m.reset_cache(); m.forward(prompt)
+        first = m.sample(GREEDY).copy()
+        if mode == "single steps":
+            ids = np.concatenate([m.decode(1, GREEDY) for _ in range(620)])
+        else:
+            ids = m.decode(620, GREEDY).copy()               # contexts 201 .. 820: crosses 256 and 768
+        runs.append((first, ids, m.logits(rounded=False).copy()))
+    for k in (1, 2):
+        np.testing.assert_array_equal(runs[0][0], runs[k][0])
+        np.testing.assert_array_equal(runs[0][1], runs[k][1])
+        np.testing.assert_array_equal(runs[0][2], runs[k][2])
+
+
 @pytest.mark.parametrize("fam,batch", [("llama_tiny", 1), ("qwen2_tiny", 3), ("gpt2_hd64", 4)])
 def test_greedy_finalize_fused_into_lm_head_equals_separate_launch(fam, batch, hip, oracle_lib):
     """Option lmhead.fuse_finalize (off by default: measured no faster): the lm_head launch's last-arriving workgroup reduces the argmax
