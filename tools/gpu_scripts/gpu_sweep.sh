@@ -1,4 +1,7 @@
-cd /root/repo
-python tools/sweep.py --model gpt2 --prompt 64 --steps 128 --grid "qkv.ks=1,2,4;oproj.ks=1,2,4" 2>&1 | tail -9
-python tools/sweep.py --model gpt2 --prompt 64 --steps 128 --grid "gateup.ks=1,2,4;down.ks=1,2,4" 2>&1 | tail -9
-python tools/sweep.py --model gpt2 --prompt 64 --steps 128 --grid "qkv.bpc=1,2,4;gateup.bpc=1,2,4;down.bpc=1,2,4" 2>&1 | sort -t'>' -k2 -n | head -5
+#!/bin/bash
+# launch-geometry sweep at the bench's operating point
+mkdir -p gpurun_out/sweep
+R=$GRAFT_REPO_ROOT
+for g in "qkv.bpc=4,6,8" "qkv.ks=1,2,4" "oproj.ks=1,2,4" "oproj.bpc=2,4,8" "gateup.bpc=2,4,6,8" "gateup.ks=1,2" "down.bpc=2,4,8" "down.ks=2,4" "attn.gmax=1,2,4"; do
+  echo "== $g"; python $R/tools/sweep.py --prompt 2048 --steps 128 --grid "$g" 2>&1 | tail -5
+done | tee gpurun_out/sweep/r03.txt
