@@ -24,11 +24,13 @@ def hip():
     return product_backend()   # raises if the .so is missing: no fallback
 
 
-def make_pair(fam, hip, oracle_lib, max_batch=1, dtype="bf16"):
+def make_pair(fam, hip, oracle_lib, max_batch=1, dtype="bf16", max_ctx=None):
     from oracle.oracle_ffi import OracleModel
     from tinygpt_amd.ffi import Model
     cfg, g = load_golden(fam)
     d = desc_from_hf_config(cfg, dtype, max_batch=max(max_batch, g["prompt"].shape[0]))    # the GPT-2 fixture is the CLI's batch of 4
+    if max_ctx:
+        d.max_ctx = max_ctx
     seed, std = int(g["seed"]), float(g["std"])
     gpu = Model(d, hip).load_synthetic(seed, std).finalize()
     ref = OracleModel(d).load_synthetic(seed, std).finalize()
@@ -233,6 +235,46 @@ def test_batches_beyond_four_rows_run_on_the_matrix_cores(family, dtype, rows, h
     gpu.reset_cache(); gpu.forward(ids); t0 = gpu.sample(GREEDY).copy(); a = gpu.decode(11, GREEDY).copy()
     gpu.reset_cache(); gpu.forward(ids); gpu.sample(GREEDY); b = np.concatenate([gpu.decode(1, GREEDY) for _ in range(11)])
     np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("family,dtype,rows,plen,force", [("llama_tiny", "bf16", 8, 200, 1), ("llama_tiny", "bf16", 26, 70, 0), ("qwen2_tiny", "bf16", 9, 100, 1),
+                                                            ("mistral_tiny", "fp16", 8, 100, 1), ("mistral_tiny", "fp16", 24, 61, 0)])
+def test_batch_attention_on_the_matrix_cores_equals_the_oracle(family, dtype, rows, plen, force, hip, oracle_lib):
+    """Batches of 24+ rows run the direct-form attention of a step on the matrix cores (attn_decode_mfma_kernel with a.direct: one workgroup per
+    (row, kv head), the group's 2 / 3 query heads as the narrow MFMA operand, four waves walking blocks of 64 keys — here 1-4 blocks, so some waves hold
+    no key at all —, no split records and no combine launch; option attn.batch_mfma forces it for the smaller batches).  Each row has its own prompt;
+    6 teacher-forced steps against the oracle (<= 1e-3, ids where the gap is clear) and against the VALU form of the same step (<= 2e-4).
+    mistral_tiny runs in fp16 as in the other batch tests: in bf16 its end-to-end distance over 24 rows is the K / V rounding-flip floor, 0.5-1.6e-3 on BOTH
+    forms (tools/dbg_batch_attn.py prints them side by side; the forms agree to 1e-5 there).  Attention.h:71-112."""
+    gpu, ref, g = make_pair(family, hip, oracle_lib, max_batch=rows, dtype=dtype, max_ctx=plen + 8)
+    V = gpu.desc.vocab
+    ids = np.stack([synth.synth_prompt(V, plen, 40 + b) for b in range(rows)])
+    if force:
+        gpu.set_option("attn.batch_mfma", 1)
+    gpu.forward(ids); ref.forward(ids)
+    tok = ref.sample(GREEDY)
+    np.testing.assert_array_equal(gpu.sample(GREEDY), tok)
+    seen = []
+    for step in range(6):
+        onehot = np.full((rows, V), -1.0, np.float32); onehot[np.arange(rows), tok] = 1.0
+        gpu.set_logits(onehot); np.testing.assert_array_equal(gpu.sample(GREEDY), tok)
+        tg = gpu.decode(1, GREEDY)[0]
+        tr = ref.decode(1, GREEDY)[0]
+        lg, lr = gpu.logits(rounded=False), ref.logits(rounded=False)
+        assert rel_err(lg, lr) < TOL_ORACLE, (step, rel_err(lg, lr))
+        top2 = np.sort(lr, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 2e-3 * np.abs(lr).max()
+        np.testing.assert_array_equal(tg[clear], tr[clear])
+        seen.append((tok.copy(), lg.copy()))
+        tok = tr
+    # the same steps on the VALU form
+    gpu.set_option("attn.batch_mfma", 0)
+    gpu.reset_cache(); gpu.forward(ids); gpu.sample(GREEDY)
+    for step in range(6):
+        t, lm = seen[step]
+        onehot = np.full((rows, V), -1.0, np.float32); onehot[np.arange(rows), t] = 1.0
+        gpu.set_logits(onehot); gpu.sample(GREEDY); gpu.decode(1, GREEDY)
+        assert rel_err(gpu.logits(rounded=False), lm) < 2e-4, (step, rel_err(gpu.logits(rounded=False), lm))
 
 
 def test_sampled_decode_of_eight_rows_equals_the_oracle(hip, oracle_lib):

@@ -23,11 +23,13 @@
 
 namespace tgx {
 
-template <int HD>
-__host__ __device__ constexpr size_t attn_mfma_lds_bytes() { return (size_t)4 * 64 * (HD + 32) * 2; }
+template <int HD, int NW = 4>
+__host__ __device__ constexpr size_t attn_mfma_lds_bytes() { return (size_t)NW * 64 * (HD + 32) * 2; }
 
-template <int DT, int HD>
-__global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnArgs a) {
+// NW = waves per workgroup (4; 8 for the batched direct form at head_dim 64).  a.direct (round 3, batches): ONE workgroup holds all the keys of its
+// (row, kv head) — no split records, no combine launch: the merged rows are normalised and written straight into the o_proj input.
+template <int DT, int HD, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void attn_decode_mfma_kernel(const AttnArgs a) {
   typedef elem_t<DT> E;
   constexpr int LV = HD + 32;                 // 16-bit row stride of the wave's V tile ([key][d]; read with the transposing LDS read, as attn_prefill_kernel)
   constexpr int KS = HD / 16;                 // MFMA k-steps over the head dimension
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnArgs a)
   extern __shared__ __attribute__((aligned(16))) bf16_t amf_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5, ql = lane & 31;
   bf16_t* sV = amf_lds + (size_t)wv * 64 * LV;         // this wave's V tile [64 keys][LV]
-  const int nsp = a.nsplit;
+  const int nsp = a.direct ? 1 : a.nsplit;
   const int kvh = blockIdx.x / nsp, sp = blockIdx.x - kvh * nsp;
   const int G = a.gfull;
   const float* q_row = a.q + blockIdx.y * a.q_stride;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnArgs a)
       for (int kk = 0; kk < KS; kk++) kdst[sub][kk] = *reinterpret_cast<const u32x4*>(krow + kk * 16);
     }
   };
-  const int blk0 = sp * 4 + wv, bstep = nsp * 4;
+  const int blk0 = sp * NW + wv, bstep = nsp * NW;
   if (PREF && blk0 < nblk) load_block(blk0, vvr, kfr);
   for (int blk = blk0; blk < nblk; blk += bstep) {     // wave-uniform trip count
     const int key0 = blk * 64;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnArgs a)
 
   // the four waves meet in LDS (one (o[HD], m, l) record per wave and query head), merged in wave order — the VALU kernel's step 2
   __syncthreads();                                       // every wave is done with its V tile: the space is reused
-  float* red = reinterpret_cast<float*>(amf_lds);        // [4][G][HD + 4]
+  float* red = reinterpret_cast<float*>(amf_lds);        // [NW][G][HD + 4]
   if (qvalid) {
     float* dst = red + ((size_t)wv * G + ql) * (HD + 4);
 #pragma unroll
@@ -210,18 +212,22 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnArgs a)
     if (hh == 0) { dst[HD] = m_run; dst[HD + 1] = l_run; }
   }
   __syncthreads();
-  for (int idx = tid; idx < G * HD; idx += 256) {
+  for (int idx = tid; idx < G * HD; idx += 64 * NW) {
     const int g = idx / HD, d = idx - g * HD;
     float M = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < 4; w++) M = fmaxf(M, red[((size_t)w * G + g) * (HD + 4) + HD]);
+    for (int w = 0; w < NW; w++) M = fmaxf(M, red[((size_t)w * G + g) * (HD + 4) + HD]);
     float acc = 0.f, L = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
+    for (int w = 0; w < NW; w++) {
       const float* rec = red + ((size_t)w * G + g) * (HD + 4);
       const float sw = (rec[HD] == -INFINITY) ? 0.f : exp2f(rec[HD] - M);
       acc = fmaf(rec[d], sw, acc);
       L = fmaf(rec[HD + 1], sw, L);
+    }
+    if (a.direct) {      // the only "split": softmax normalisation here (a row always holds its own key: L > 0)
+      a.out[blockIdx.y * a.q_stride + (size_t)(kvh * G + g) * HD + d] = acc / L;
+      continue;
     }
     float* out = part_row + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);
     out[d] = acc;
