@@ -237,10 +237,12 @@ def test_batches_beyond_four_rows_run_on_the_matrix_cores(family, dtype, rows, h
     np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("family,dtype,rows,plen,force", [("llama_tiny", "bf16", 8, 200, 1), ("llama_tiny", "bf16", 26, 70, 0), ("qwen2_tiny", "bf16", 9, 100, 1),
-                                                            ("mistral_tiny", "fp16", 8, 100, 1), ("mistral_tiny", "fp16", 24, 61, 0)])
+@pytest.mark.parametrize("family,dtype,rows,plen,force", [("llama_tiny", "bf16", 8, 200, 1), ("llama_tiny", "bf16", 26, 70, 1), ("qwen2_tiny", "bf16", 9, 100, 1),
+                                                            ("qwen2_tiny", "bf16", 25, 60, 0), ("mistral_tiny", "fp16", 8, 100, 1), ("mistral_tiny", "fp16", 24, 61, 1),
+                                                            ("qwen3_tiny", "bf16", 8, 100, 1)])
 def test_batch_attention_on_the_matrix_cores_equals_the_oracle(family, dtype, rows, plen, force, hip, oracle_lib):
-    """Batches of 24+ rows run the direct-form attention of a step on the matrix cores (attn_decode_mfma_kernel with a.direct: one workgroup per
+    """Batches of 24+ rows of a model with 3+ query heads per kv head (force = 0: qwen2_tiny; the option forces the others) run the direct-form
+    attention of a step on the matrix cores (attn_decode_mfma_kernel with a.direct: one workgroup per
     (row, kv head), the group's 2 / 3 query heads as the narrow MFMA operand, four waves walking blocks of 64 keys — here 1-4 blocks, so some waves hold
     no key at all —, no split records and no combine launch; option attn.batch_mfma forces it for the smaller batches).  Each row has its own prompt;
     6 teacher-forced steps against the oracle (<= 1e-3, ids where the gap is clear) and against the VALU form of the same step (<= 2e-4).
@@ -267,14 +269,23 @@ def test_batch_attention_on_the_matrix_cores_equals_the_oracle(family, dtype, ro
         np.testing.assert_array_equal(tg[clear], tr[clear])
         seen.append((tok.copy(), lg.copy()))
         tok = tr
-    # the same steps on the VALU form
-    gpu.set_option("attn.batch_mfma", 0)
-    gpu.reset_cache(); gpu.forward(ids); gpu.sample(GREEDY)
-    for step in range(6):
-        t, lm = seen[step]
-        onehot = np.full((rows, V), -1.0, np.float32); onehot[np.arange(rows), t] = 1.0
-        gpu.set_logits(onehot); gpu.sample(GREEDY); gpu.decode(1, GREEDY)
-        assert rel_err(gpu.logits(rounded=False), lm) < 2e-4, (step, rel_err(gpu.logits(rounded=False), lm))
+    # the same steps (a) with the QKV product's finish (slab sums, bias, q / k norm, RoPE, cache append) as its own launch instead of the attention
+    # launch's prologue: the same arithmetic in the same order -> bit-identical; (b) on the VALU form
+    for opt, exact in ((("attn.raw_fuse", 0), True), (("attn.batch_mfma", 0), False)):
+        gpu.set_option(*opt)
+        gpu.reset_cache(); gpu.forward(ids); gpu.sample(GREEDY)
+        for step in range(6):
+            t, lm = seen[step]
+            onehot = np.full((rows, V), -1.0, np.float32); onehot[np.arange(rows), t] = 1.0
+            gpu.set_logits(onehot); gpu.sample(GREEDY); gpu.decode(1, GREEDY)
+            if exact:
+                np.testing.assert_array_equal(gpu.logits(rounded=False), lm)
+            else:
+                assert rel_err(gpu.logits(rounded=False), lm) < 2e-4, (step, rel_err(gpu.logits(rounded=False), lm))
+    for row in (0, rows - 1):                   # the rows the fused prologue appended, against the oracle's cache
+        for layer in (0, 1):
+            for g_, r_ in zip(gpu.read_kv(row, layer), ref.read_kv(row, layer)):
+                assert g_.shape == r_.shape and np.abs(g_ - r_).max() <= 2.0 ** -6 * np.abs(r_).max()
 
 
 def test_sampled_decode_of_eight_rows_equals_the_oracle(hip, oracle_lib):

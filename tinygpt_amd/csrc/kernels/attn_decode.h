@@ -50,6 +50,13 @@ struct AttnArgs {
   // L2 prefetch chaining (l2_prefetch.h; split form only): workgroups with blockIdx.x >= pf.n_compute touch the next launches' weights
   PfArgs pf;
   PfArgs pf_comb;   // the same for the attn_combine launch that follows (host side: copied into `pf` of the combine's argument block)
+  // batched step (attn_decode_mfma_kernel template RAW): the finish of the QKV product — sum of its split-K slabs + bias, [Qwen3 q / k RMSNorm,] RoPE at
+  // pos[row], KVCacheManager::append — runs in the attention launch's prologue for the workgroup's own (row, kv head): q never touches memory and
+  // the row-wise rope_kv_rows launch disappears.  Columns of a QKV row: [q: heads x hd | k: kv_heads x hd | v: kv_heads x hd]
+  const float* raw_qkv;   // [raw_rows][qd + 2 kvd] fp32 with the bias added, or nullptr: the sums of raw_part
+  const float* raw_part;  // [raw_nsplit][raw_rows][qd + 2 kvd]
+  const void* raw_bias;   // [qd + 2 kvd] storage dtype or nullptr (with raw_part only)
+  int raw_nsplit, raw_rows;
 };
 
 template <int HD>

@@ -26,9 +26,18 @@ namespace tgx {
 template <int HD, int NW = 4>
 __host__ __device__ constexpr size_t attn_mfma_lds_bytes() { return (size_t)NW * 64 * (HD + 32) * 2; }
 
-// NW = waves per workgroup (4; 8 for the batched direct form at head_dim 64).  a.direct (round 3, batches): ONE workgroup holds all the keys of its
-// (row, kv head) — no split records, no combine launch: the merged rows are normalised and written straight into the o_proj input.
-template <int DT, int HD, int NW = 4>
+// RAW form: room for the finished q heads (fp32, at most 8 per kv head) and this step's k / v rows (storage dtype) behind the waves' V tiles
+constexpr int ATTN_RAW_GMAX = 8;
+template <int HD, int NW = 4>
+__host__ __device__ constexpr size_t attn_mfma_raw_lds_bytes() { return attn_mfma_lds_bytes<HD, NW>() + (size_t)ATTN_RAW_GMAX * HD * 4 + (size_t)2 * HD * 2; }
+
+// NW = waves per workgroup.  a.direct (round 3, batches): ONE workgroup holds all the keys of its (row, kv head) — no split records, no combine
+// launch: the merged rows are normalised and written straight into the o_proj input.
+// RAW (with a.direct): the workgroup first finishes its own slice of the QKV product (AttnArgs.raw_*: slab sums + bias, q / k norm at head_dim 128, RoPE,
+// cache append) — the G q heads go to LDS as fp32 and feed the Q^T fragments, the new k / v rows go to the cache AND to LDS, from where the lanes that
+// hold key `pos` take them (the global copy was stored by this same workgroup a moment ago: never read back in this launch).  Same arithmetic, in the
+// same order, as rope_kv_rows_kernel (skinny.h): the two forms are bit-identical.
+template <int DT, int HD, int NW = 4, bool RAW = false>
 __global__ __launch_bounds__(64 * NW) void attn_decode_mfma_kernel(const AttnArgs a) {
   typedef elem_t<DT> E;
   constexpr int LV = HD + 32;                 // 16-bit row stride of the wave's V tile ([key][d]; read with the transposing LDS read, as attn_prefill_kernel)
@@ -48,6 +57,77 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_mfma_kernel(const AttnArg
   float* part_row = a.part + blockIdx.y * a.part_stride;
   const int n_keys = a.pos[blockIdx.y] + 1;
   const bool qvalid = ql < G;
+  const int nblk = (n_keys + 63) >> 6;
+  // register sets of one block's loads: V rows (chunk c = lane + 64 i -> key row c / CH, 16-byte column c % CH) and the K fragments
+  // (row = key 32 sub + ql, 8 d at 16 kk + 8 hh); the NEXT block's loads are issued before the current block's arithmetic
+  constexpr bool PREF = HD == 64;            // head_dim 128: a second register set spills (measured 40 -> 68 us per layer at 24k keys)
+  u32x4 vvr[CH], kfr[2][KS], vnx[PREF ? CH : 1], knx[2][PREF ? KS : 1];
+  auto load_block = [&](int blk, u32x4* vdst, u32x4 (*kdst)[KS]) {
+    const int key0 = blk * 64;
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+      const int c = lane + 64 * i, row = c / CH, kc = c - row * CH;
+      vdst[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)min(key0 + row, n_keys - 1) * HD + kc * 8);     // clamped inside the context; masked by P = 0
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      const E* krow = kbase + (size_t)min(key0 + 32 * sub + ql, n_keys - 1) * HD + 8 * hh;
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++) kdst[sub][kk] = *reinterpret_cast<const u32x4*>(krow + kk * 16);
+    }
+  };
+  const int blk0 = sp * NW + wv, bstep = nsp * NW;
+  if (PREF && blk0 < nblk) load_block(blk0, vvr, kfr);     // in flight during the Q fragments' (RAW: the QKV finish's) loads
+  float* sQ = reinterpret_cast<float*>(amf_lds + (size_t)NW * 64 * LV);      // RAW: [G][HD] fp32
+  bf16_t* sKn = reinterpret_cast<bf16_t*>(sQ + ATTN_RAW_GMAX * HD);           // RAW: this step's key row [HD], storage dtype
+  bf16_t* sVn = sKn + HD;                                                     //      and value row
+  if constexpr (RAW) {
+    constexpr int half = HD / 2;
+    const int pos = n_keys - 1, row = blockIdx.y;
+    const int qd = a.heads * HD, kvd = a.kv_heads * HD, N = qd + 2 * kvd;
+    const size_t slab = (size_t)a.raw_rows * N;
+    auto value = [&](int idx) -> float {
+      if (a.raw_qkv) return a.raw_qkv[(size_t)row * N + idx];
+      const float* src = a.raw_part + (size_t)row * N + idx;
+      float t[16];
+#pragma unroll
+      for (int z = 0; z < 16; z++) t[z] = z < a.raw_nsplit ? src[z * slab] : 0.f;    // all slabs in flight together; summed in z order
+      float v = t[0];
+#pragma unroll
+      for (int z = 1; z < 16; z++) v += t[z];
+      for (int z = 16; z < a.raw_nsplit; z++) v += src[z * slab];
+      if (a.raw_bias) v += elem_to_f32<DT>(static_cast<const E*>(a.raw_bias)[idx]);
+      return v;
+    };
+    // G + 2 head vectors (the group's q heads, k, v) x HD / 2 rotation pairs; a vector's pairs are consecutive threads (half a wave at head_dim 64, a wave at 128)
+    for (int it = tid; it < (G + 2) * half; it += 64 * NW) {
+      const int vec = it / half, p = it - vec * half;
+      const int col = vec < G ? (kvh * G + vec) * HD : (vec == G ? qd + kvh * HD : qd + kvd + kvh * HD);
+      float x0 = value(col + p), x1 = value(col + p + half);
+      if constexpr (HD == 128) {       // Qwen3: per-head RMSNorm of q and k over head_dim (one wave = one vector here)
+        if (a.q_norm_w != nullptr && vec <= G) {
+          const float ss = wave_sum(head_sq_pair(x0, x1));
+          const float inv = head_rms_inv(ss, HD, a.eps);
+          const E* w = static_cast<const E*>(vec < G ? a.q_norm_w : a.k_norm_w);
+          x0 = elem_to_f32<DT>(w[p]) * (x0 * inv);
+          x1 = elem_to_f32<DT>(w[p + half]) * (x1 * inv);
+        }
+      }
+      if (vec <= G) {
+        const float cs = a.rope_cos[(size_t)pos * half + p], sn = a.rope_sin[(size_t)pos * half + p];
+        rope_rotate_pair(x0, x1, cs, sn);
+      }
+      if (vec < G) { sQ[vec * HD + p] = x0; sQ[vec * HD + p + half] = x1; }
+      else {
+        E* cache = const_cast<E*>(vec == G ? kbase : vbase) + (size_t)pos * HD;     // KVCacheManager::append
+        E* stage = reinterpret_cast<E*>(vec == G ? sKn : sVn);
+        const E e0 = f32_to_elem<DT>(x0), e1 = f32_to_elem<DT>(x1);
+        cache[p] = e0; cache[p + half] = e1;
+        stage[p] = e0; stage[p + half] = e1;
+      }
+    }
+    __syncthreads();
+  }
 
   // Q^T fragments (B operand: column = query head ql, 8 consecutive d at 16 kk + 8 hh), fp32 -> hi / lo terms
   bf16x8 qh[KS], qlo[KS];
@@ -55,7 +135,8 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_mfma_kernel(const AttnArg
   for (int kk = 0; kk < KS; kk++) {
     unsigned int wh[4] = {0u, 0u, 0u, 0u}, wl[4] = {0u, 0u, 0u, 0u};
     if (qvalid) {
-      const f32x4* qp = reinterpret_cast<const f32x4*>(q_row + (size_t)(kvh * G + ql) * HD + kk * 16 + 8 * hh);
+      const f32x4* qp = RAW ? reinterpret_cast<const f32x4*>(sQ + ql * HD + kk * 16 + 8 * hh)
+                            : reinterpret_cast<const f32x4*>(q_row + (size_t)(kvh * G + ql) * HD + kk * 16 + 8 * hh);
       const f32x4 q0 = qp[0], q1 = qp[1];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
@@ -79,32 +160,26 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_mfma_kernel(const AttnArg
   f32x16 zero16;
 #pragma unroll
   for (int r = 0; r < 16; r++) zero16[r] = 0.f;
-  const int nblk = (n_keys + 63) >> 6;
-  // register sets of one block's loads: V rows (chunk c = lane + 64 i -> key row c / CH, 16-byte column c % CH) and the K fragments
-  // (row = key 32 sub + ql, 8 d at 16 kk + 8 hh); the NEXT block's loads are issued before the current block's arithmetic
-  constexpr bool PREF = HD == 64;            // head_dim 128: a second register set spills (measured 40 -> 68 us per layer at 24k keys)
-  u32x4 vvr[CH], kfr[2][KS], vnx[PREF ? CH : 1], knx[2][PREF ? KS : 1];
-  auto load_block = [&](int blk, u32x4* vdst, u32x4 (*kdst)[KS]) {
-    const int key0 = blk * 64;
-#pragma unroll
-    for (int i = 0; i < CH; i++) {
-      const int c = lane + 64 * i, row = c / CH, kc = c - row * CH;
-      vdst[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)min(key0 + row, n_keys - 1) * HD + kc * 8);     // clamped inside the context; masked by P = 0
-    }
-#pragma unroll
-    for (int sub = 0; sub < 2; sub++) {
-      const E* krow = kbase + (size_t)min(key0 + 32 * sub + ql, n_keys - 1) * HD + 8 * hh;
-#pragma unroll
-      for (int kk = 0; kk < KS; kk++) kdst[sub][kk] = *reinterpret_cast<const u32x4*>(krow + kk * 16);
-    }
-  };
-  const int blk0 = sp * NW + wv, bstep = nsp * NW;
-  if (PREF && blk0 < nblk) load_block(blk0, vvr, kfr);
   for (int blk = blk0; blk < nblk; blk += bstep) {     // wave-uniform trip count
     const int key0 = blk * 64;
     const bool has_next = PREF && blk + bstep < nblk;
     if constexpr (PREF) { if (has_next) load_block(blk + bstep, vnx, knx); }
     else load_block(blk, vvr, kfr);
+    if constexpr (RAW) {
+      if (key0 + 64 >= n_keys) {      // the block that holds this step's own key: rows from it on (clamped copies, masked below) come from LDS
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++)
+          if (key0 + 32 * sub + ql >= n_keys - 1) {
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) kfr[sub][kk] = *reinterpret_cast<const u32x4*>(sKn + kk * 16 + 8 * hh);
+          }
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+          const int c = lane + 64 * i, row = c / CH, kc = c - row * CH;
+          if (key0 + row >= n_keys - 1) vvr[i] = *reinterpret_cast<const u32x4*>(sVn + kc * 8);
+        }
+      }
+    }
     f32x16 sacc[2];
     float mx = -INFINITY;
 #pragma unroll

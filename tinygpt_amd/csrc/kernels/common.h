@@ -129,6 +129,15 @@ __device__ __forceinline__ float dot8(float acc, const Slice8<DT>& w, const f32x
   return acc;
 }
 
+// RoPE rotation of one (p, p + hd/2) pair and the per-head RMSNorm factor with the contractions written out: the batched step computes them either in
+// rope_kv_rows_kernel (skinny.h) or in the attention launch's prologue (attn_decode_mfma.h RAW) and the two must agree bit for bit
+__device__ __forceinline__ void rope_rotate_pair(float& x0, float& x1, float cs, float sn) {
+  const float r0 = fmaf(x0, cs, -__fmul_rn(x1, sn)), r1 = fmaf(x1, cs, __fmul_rn(x0, sn));
+  x0 = r0; x1 = r1;
+}
+__device__ __forceinline__ float head_sq_pair(float x0, float x1) { return fmaf(x0, x0, __fmul_rn(x1, x1)); }
+__device__ __forceinline__ float head_rms_inv(float ss, int hd, float eps) { return 1.0f / sqrtf(__fadd_rn(__fdiv_rn(ss, (float)hd), eps)); }
+
 // ---- cross-lane reductions ----------------------------------------------------------------------
 // 64-lane sum on the DPP crossbar (no LDS traffic): quad butterflies, half-row / row mirrors, then the two
 // row broadcasts of the GFX9 wave64 reduction; the total lands in lane 63 and is returned wave-uniform.

@@ -335,8 +335,8 @@ __global__ __launch_bounds__(64) void rope_kv_rows_kernel(const RopeRowsArgs a) 
   float x0 = value(hh * a.hd + pc), x1 = value(hh * a.hd + pc + half);
   if (!act) { x0 = 0.f; x1 = 0.f; }
   if (a.q_norm_w != nullptr && hh < a.heads + a.kv_heads) {     // per-head RMSNorm over head_dim (lanes beyond hd/2 hold zeros)
-    const float ss = wave_sum(x0 * x0 + x1 * x1);
-    const float inv = 1.0f / sqrtf(ss / (float)a.hd + a.eps);
+    const float ss = wave_sum(head_sq_pair(x0, x1));
+    const float inv = head_rms_inv(ss, a.hd, a.eps);
     const E* w = static_cast<const E*>(hh < a.heads ? a.q_norm_w : a.k_norm_w);
     x0 = elem_to_f32<DT>(w[pc]) * (x0 * inv);
     x1 = elem_to_f32<DT>(w[pc + half]) * (x1 * inv);
@@ -344,8 +344,7 @@ __global__ __launch_bounds__(64) void rope_kv_rows_kernel(const RopeRowsArgs a) 
   if (!act) return;
   if (hh < a.heads + a.kv_heads) {
     const float cs = a.rope_cos[(size_t)pos * half + p], sn = a.rope_sin[(size_t)pos * half + p];
-    const float r0 = x0 * cs - x1 * sn, r1 = x1 * cs + x0 * sn;
-    x0 = r0; x1 = r1;
+    rope_rotate_pair(x0, x1, cs, sn);
   }
   if (hh < a.heads) {
     float* q = a.q_out + (size_t)r * a.q_stride + hh * a.hd;

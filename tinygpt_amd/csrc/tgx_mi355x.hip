@@ -192,6 +192,7 @@ struct tgx_ctx {
   int attn_gmax = 0;         // experiment: query heads per attention workgroup (default 2)
   int attn_direct_nw4 = 0;   // option attn.direct_nw4: contexts up to this many keys run the direct attention form with four waves per head (set in tgx_create)
   bool attn_nw4 = false;     // mode of the launches being issued / captured
+  int attn_raw_fuse = 1;     // option attn.raw_fuse: that form also finishes the QKV product (slab sums, bias, q / k norm, RoPE, cache append) in its prologue
   int attn_batch_mfma = 24;  // option attn.batch_mfma: batches of this many rows and more run their direct-form attention on the matrix cores (0 = never)
   int attn_direct_g = 1;     // option attn.direct_g: 1 = heads per workgroup of the direct attention form by batch rows (2 from 12 rows, 4 from 24 at head_dim 64), 0 = always one, -g = force g
   int attn_direct_max = 384; // contexts up to this many keys take the one-workgroup-per-head attention (no split, no combine launch); set in tgx_create
@@ -513,6 +514,12 @@ bool attn_fold_ok(const tgx_ctx* c, int R) {
   return c->attn_fold && c->engine_mode < 2 && !c->attn_direct && (size_t)R * c->d.heads * c->d.head_dim * 4 <= 65536;
 }
 
+// the direct-form attention of a batched step runs on the matrix cores from attn.batch_mfma rows when a kv head serves 3+ query heads (the VALU form's
+// cost grows with the heads per workgroup, the MFMA form's does not: Qwen3-1.7B, 2 heads per kv head, B = 32 2.29 (VALU) vs 2.39 ms/step)
+bool attn_batch_on_mfma(const tgx_ctx* c, int R) {
+  return c->attn_batch_mfma > 0 && R >= c->attn_batch_mfma && (c->d.heads / c->d.kv_heads >= 3 || c->attn_batch_mfma == 1);
+}
+
 template <int DT, int HD, bool QKN = false>
 void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
   // the query heads of a kv group go to workgroups two at a time (blockIdx.z): the per-head state (8 output registers, the
@@ -548,13 +555,14 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
     // not — one workgroup per (row, kv head), all the group's query heads as the narrow operand, no split, no combine launch.  Measured ms/step (VALU /
     // MFMA, 4 waves; 8 waves the same within 0.5 %): Llama-3.2-1B context 600 B = 16 1.047 / 1.068, B = 24 1.308 / 1.259, B = 32 1.356 / 1.307; context 2k
     // B = 16 1.210 / 1.224, B = 24 1.608 / 1.453, B = 32 1.708 / 1.562; Mistral-7B B = 16 3.92 / 4.10, B = 32 5.38 / 5.12: from 24 rows (below, rows x kv heads
-    // workgroups leave CUs empty)
+    // workgroups leave CUs empty).  With AttnArgs.raw_* set the launch also finishes the QKV product (attn.raw_fuse: B = 32 1.335 -> 1.326, B = 8 1.000 -> 0.978)
     if constexpr (!QKN && DT != tgx::DT_F32) {
-      if (c->attn_batch_mfma > 0 && R >= c->attn_batch_mfma) {
+      if (attn_batch_on_mfma(c, R)) {
         const dim3 gm(a.kv_heads, R);
         if (!(c->debug_skip & 1)) {
-          constexpr size_t lds4 = tgx::attn_mfma_lds_bytes<HD, 4>();
-          hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4>), gm, dim3(256), lds4, c->stream, a);
+          constexpr size_t lds4 = tgx::attn_mfma_lds_bytes<HD, 4>(), ldsr = tgx::attn_mfma_raw_lds_bytes<HD, 4>();
+          if (a.raw_part || a.raw_qkv) hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, true>), gm, dim3(256), ldsr, c->stream, a);   // + the QKV product's finish
+          else hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4>), gm, dim3(256), lds4, c->stream, a);
         }
         return;
       }
@@ -1416,7 +1424,11 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
     q.epi = tgx::GEMM_STORE; q.W = w.wqkv; q.bias = w.bqkv; q.C = c->ws_out; q.ldc = qd + 2 * kvd; q.M = M; q.N = qd + 2 * kvd; q.K = H;
     q.nt = nt_qkv; q.asrc = 2; q.a_f32 = r.x; q.lda = H; q.norm_w = w.in_norm; q.ssq_in = ssq;
     const int qs = launch_skinny(c, q);
-    {
+    // the QKV product's finish (slab sums + bias, q / k norm, RoPE, cache append) inside the attention launch when that is the batched matrix-core form
+    // (option attn.raw_fuse): one launch per layer less
+    const bool raw_fuse = c->attn_raw_fuse && c->attn_direct && attn_batch_on_mfma(c, M) && !(c->debug_skip & 1) &&
+                          d.heads / d.kv_heads <= tgx::ATTN_RAW_GMAX && !(d.qk_norm && hd != 128);
+    if (!raw_fuse) {
       tgx::RopeRowsArgs a{};
       if (qs > 1) { a.part = c->ws_part; a.nsplit = qs; a.bias = w.bqkv; } else a.QKV = c->ws_out;
       a.rows = M; a.q_out = r.q; a.q_stride = qd; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
@@ -1432,6 +1444,11 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
       a.scale = 1.0f / sqrtf((float)hd);
       a.q_stride = qd; a.kv_stride = (long long)c->kv_row_elems; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
+      if (raw_fuse) {
+        if (qs > 1) { a.raw_part = c->ws_part; a.raw_nsplit = qs; a.raw_bias = w.bqkv; } else a.raw_qkv = c->ws_out;
+        a.raw_rows = M; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.eps = d.norm_eps;
+        a.q_norm_w = d.qk_norm ? w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? w.k_norm : nullptr;
+      }
       const int fold = c->attn_fold; c->attn_fold = 0;          // the o_proj product here reads the merged output
       launch_attn(c, a, M);
       c->attn_fold = fold;
@@ -2089,6 +2106,8 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_PARTIAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_PARTIAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   if ((rc = skinny_set_attrs(c))) return rc;
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 128, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<128>()));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_F16, 128, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<128>()));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_lds_bytes<128>()));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_F16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_lds_bytes<128>()));
 #define TGX_DMA_ATTR1(DT_, EPI_, MI_, BK_, NS_) HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma_kernel<DT_, EPI_, MI_, BK_, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(160 * 1024, tgx::gemm_dma_lds_bytes(MI_, true, BK_, NS_))));
@@ -2474,6 +2493,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   }
   if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
   if (!strcmp(key, "attn.direct_nw4")) { drop_step_graphs(c); c->attn_direct_nw4 = value; return TGX_OK; }
+  if (!strcmp(key, "attn.raw_fuse")) { drop_step_graphs(c); c->attn_raw_fuse = value != 0; return TGX_OK; }
   if (!strcmp(key, "attn.batch_mfma")) { if (value < 0) return set_err(c, TGX_ERR_INVALID, "attn.batch_mfma is a row count (0 = off)"); drop_step_graphs(c); c->attn_batch_mfma = value; return TGX_OK; }
   if (!strcmp(key, "attn.direct_g")) { if (value != 0 && value != 1 && value != -1 && value != -2 && value != -4) return set_err(c, TGX_ERR_INVALID, "attn.direct_g is 0, 1 or -1 / -2 / -4"); drop_step_graphs(c); c->attn_direct_g = value; return TGX_OK; }
   if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
