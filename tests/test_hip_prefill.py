@@ -77,3 +77,55 @@ def test_real_layer_shapes_prefill_equals_steps(name, S, dtype):
         assert rel_err(k1, k0) < ulp and rel_err(v1, v0) < ulp
     if dtype == "fp32":
         assert rel_err(l1, l0) < 1e-4
+
+
+@pytest.mark.parametrize("fam,dtype", [("llama_tiny", "bf16"), ("qwen2_tiny", "bf16"), ("qwen3_tiny", "bf16"), ("mistral_tiny", "fp16")])
+@pytest.mark.parametrize("nb,S", [(1, 33), (1, 48), (1, 64), (2, 29), (3, 21)])
+def test_prompts_of_33_to_64_rows_on_the_skinny_kernels(fam, dtype, nb, S, oracle_lib):
+    """Prompts whose rows (batch x length) number 33..64 run every product as a skinny MFMA GEMM with FOUR 16-row activation blocks (round 3,
+    kernels/skinny.h MB = 4; option prefill.skinny_rows = 32 sends them back to the tiled split-K GEMMs): against the oracle (<= 1e-3, first id where
+    the gap is clear) and against the tiled path (<= 1e-3; K tails at hidden 192, QKV bias, q / k norm, head_dim 128, three-term QKV product in bf16)."""
+    from oracle.oracle_ffi import OracleModel
+    cfg, g = load_golden(fam)
+    d = desc_from_hf_config(cfg, dtype, max_batch=nb)
+    d.max_ctx = 80
+    gpu = Model(d, product_backend()).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
+    ref = OracleModel(d).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
+    ids = np.stack([synth.synth_prompt(d.vocab, S, 9 + b) for b in range(nb)])
+    ref.forward(ids)
+    lr = ref.logits(rounded=False)
+    out = {}
+    for rows in (64, 32):
+        gpu.set_option("prefill.skinny_rows", rows)
+        gpu.reset_cache(); gpu.forward(ids)
+        lg = gpu.logits(rounded=False).copy()
+        assert rel_err(lg, lr) < 1e-3, (rows, rel_err(lg, lr))
+        first = gpu.sample(GREEDY).copy()
+        out[rows] = (lg, first, gpu.decode(4, GREEDY).copy(), [gpu.read_kv(nb - 1, l) for l in range(d.layers)])
+    top2 = np.sort(lr, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 2e-3 * np.abs(lr).max()
+    np.testing.assert_array_equal(out[64][1][clear], ref.sample(GREEDY)[clear])
+    assert rel_err(out[64][0], out[32][0]) < 1e-3
+    ulp = {"bf16": 8e-3, "fp16": 1e-3}[dtype]
+    for (k1, v1), (k0, v0) in zip(out[64][3], out[32][3]):
+        assert rel_err(k1, k0) < ulp and rel_err(v1, v0) < ulp
+
+
+@pytest.mark.parametrize("name,S,dtype", [("llama-3.2-1b", 48, "bf16"), ("mistral-7b-v0.3", 40, "bf16"), ("qwen2.5-0.5b", 64, "bf16"), ("qwen3-1.7b", 57, "fp16")])
+def test_real_layer_shapes_33_to_64_row_prompts_skinny_equals_tiled(name, S, dtype):
+    """the same at real hidden / intermediate / head geometry (2 layers, 4096-entry vocabulary): the four-block skinny path against the tiled split-K path"""
+    d = copy.deepcopy(known_desc(name, dtype))
+    d.layers, d.vocab, d.max_ctx = 2, 4096, 128
+    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    prompt = synth.synth_prompt(d.vocab, S, 77)[None, :]
+    res = {}
+    m.set_option("prefill.skinny_hidden_max", 1 << 20)       # by default hidden > 2048 keeps 33-64-row prompts on the tiled path (faster there)
+    for rows in (64, 32):
+        m.set_option("prefill.skinny_rows", rows)
+        res[rows] = run(m, prompt, mfma=True, n_decode=3)
+    assert rel_err(res[64][0], res[32][0]) < 1e-3, rel_err(res[64][0], res[32][0])
+    np.testing.assert_array_equal(res[64][1], res[32][1])
+    np.testing.assert_array_equal(res[64][2], res[32][2])
+    ulp = {"bf16": 8e-3, "fp16": 1e-3}[dtype]
+    for (k1, v1), (k0, v0) in zip(res[64][3], res[32][3]):
+        assert rel_err(k1, k0) < ulp and rel_err(v1, v0) < ulp

@@ -167,6 +167,12 @@ struct tgx_ctx {
   // attention launch (per-group arrival ticket) — no attn_combine launch.  Off by default: measured in profiles/r03_attn_fold.txt
   int attn_ticket = 0;
   unsigned* attn_tickets = nullptr;   // [max_batch][kv_heads][8] counters resting at 0
+  // option prefill.skinny_rows: prompts of up to this many workspace rows take the skinny GEMMs (32: round 2; 33-64: four activation blocks, round 3).
+  // Measured ms per prompt, four-block skinny / tiled split-K: Llama-3.2-1B S = 33 1.48 / 1.51, 48 1.51 / 1.58, 64 1.57 / 1.70; Qwen2.5-0.5B S = 48 1.46 / 1.81;
+  // Llama-3.2-3B S = 48 3.54 / 3.33, Mistral-7B 6.76 / 5.52 — four blocks put 8 MFMAs + 9 LDS fragment reads behind every 32 k of a weight row: at
+  // hidden > 2048 the tiled path's weight stream is faster (option prefill.skinny_hidden_max)
+  int prefill_skinny_rows = 64;
+  int prefill_skinny_hidden_max = 2048;
   int prefill_skinny = 1;    // option prefill.skinny: 0 sends prompts of <= 32 rows through the tiled GEMMs as well
   int skinny_wgs = 256;      // option skinny.wgs: workgroups a skinny product aims for by splitting K
   int skinny_gu_split = 0;   // option skinny.gu_split: 0 keeps the gate_up product unsplit (siluMul in its epilogue, one launch less)
@@ -1266,12 +1272,14 @@ void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
 // the (epilogue, terms, activation source) combinations the batched step uses; every one exists for 2 dtypes x MB 1,2 x NBW 1,2
 #define TGX_SKINNY_COMBOS(X)                                                                                                   \
   X(tgx::GEMM_PARTIAL, 3, 2) X(tgx::GEMM_STORE, 3, 2) X(tgx::GEMM_PARTIAL, 2, 2) X(tgx::GEMM_STORE, 2, 2) X(tgx::GEMM_SILU, 2, 2) \
-  X(tgx::GEMM_PARTIAL, 2, 1) X(tgx::GEMM_RESIDUAL, 2, 1) X(tgx::GEMM_PARTIAL, 2, 0) X(tgx::GEMM_RESIDUAL, 2, 0) X(tgx::GEMM_SILU, 2, 0) X(tgx::GEMM_STORE, 2, 0)
+  X(tgx::GEMM_PARTIAL, 2, 1) X(tgx::GEMM_RESIDUAL, 2, 1) X(tgx::GEMM_PARTIAL, 2, 0) X(tgx::GEMM_RESIDUAL, 2, 0) X(tgx::GEMM_SILU, 2, 0) X(tgx::GEMM_STORE, 2, 0) \
+  X(tgx::GEMM_PARTIAL, 3, 0) X(tgx::GEMM_STORE, 3, 0)
 
 template <int DT, int EPI, int NT, int ASRC>
 int skinny_set_attr_dt(tgx_ctx* c) {
 #define TGX_SK_A(MB_, CFG_) HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::skinny_gemm_kernel<DT, EPI, MB_, NT, CFG_, ASRC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::skinny_lds_bytes(MB_, NT, CFG_)));
   TGX_SK_A(1, 0) TGX_SK_A(1, 1) TGX_SK_A(1, 2) TGX_SK_A(2, 0) TGX_SK_A(2, 1) TGX_SK_A(2, 2)
+  if constexpr (ASRC == 0) { TGX_SK_A(4, 0) TGX_SK_A(4, 1) TGX_SK_A(4, 2) }
 #undef TGX_SK_A
   return TGX_OK;
 }
@@ -1290,7 +1298,11 @@ void skinny_dispatch(tgx_ctx* c, dim3 grid, int mb, int cfg, const tgx::GemmArgs
   const size_t lds = tgx::skinny_lds_bytes(mb, NT, cfg);
 #define TGX_SK_L(MB_, CFG_) hipLaunchKernelGGL((tgx::skinny_gemm_kernel<DT, EPI, MB_, NT, CFG_, ASRC>), grid, blk, lds, c->stream, g)
   TGX_DT16_SWITCH(c->dt,
-    if (mb == 2) { if (cfg == 2) TGX_SK_L(2, 2); else if (cfg == 1) TGX_SK_L(2, 1); else TGX_SK_L(2, 0); }
+    if (mb == 4) {     // 33-64 rows (round 3): four activation blocks, geometries 0 and 2, stored terms only (staging with RMSNorm spills: 262 us for gate_up)
+      if constexpr (ASRC == 0) { if (cfg == 2) TGX_SK_L(4, 2); else if (cfg == 1) TGX_SK_L(4, 1); else TGX_SK_L(4, 0); }
+      else c->err = "internal: 33-64-row skinny GEMM takes stored 16-bit terms";
+    }
+    else if (mb == 2) { if (cfg == 2) TGX_SK_L(2, 2); else if (cfg == 1) TGX_SK_L(2, 1); else TGX_SK_L(2, 0); }
     else { if (cfg == 2) TGX_SK_L(1, 2); else if (cfg == 1) TGX_SK_L(1, 1); else TGX_SK_L(1, 0); })
 #undef TGX_SK_L
 }
@@ -1305,21 +1317,22 @@ struct SkinnyCall {
   float* C = nullptr; int ldc = 0;
   int M = 0, N = 0, K = 0;
   int nt = 2, asrc = 0;
-  const bf16_t *a_hi = nullptr, *a_lo = nullptr;
+  const bf16_t *a_hi = nullptr, *a_lo = nullptr, *a_lo2 = nullptr;
   const float* a_f32 = nullptr; int lda = 0;
   const ebyte* norm_w = nullptr; const float* ssq_in = nullptr;
   bool allow_split = true;
 };
 int launch_skinny(tgx_ctx* c, const SkinnyCall& k) {
   tgx::GemmArgs g{};
-  g.A_hi = k.a_hi; g.A_lo = k.a_lo; g.A_f32 = k.a_f32; g.lda = k.lda;
+  g.A_hi = k.a_hi; g.A_lo = k.a_lo; g.A_lo2 = k.a_lo2; g.A_f32 = k.a_f32; g.lda = k.lda;
   g.norm_w = reinterpret_cast<const bf16_t*>(k.norm_w); g.ssq_part = k.ssq_in; g.ssq_ncb = tgx::SK_NCB; g.eps = c->d.norm_eps;
   g.inter = k.N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
   g.B = reinterpret_cast<const bf16_t*>(k.W); g.bias = reinterpret_cast<const bf16_t*>(k.bias); g.C = k.C; g.M = k.M; g.N = k.N; g.K = k.K; g.ldc = k.ldc;
-  const int mb = k.M > 16 ? 2 : 1;
+  const int mb = k.M > 32 ? 4 : (k.M > 16 ? 2 : 1);
   // 128-row groups when they alone oversubscribe the chip (the lm_head), else 64-row groups: twice the workgroups for the same bytes
   int cfg = (k.N + 127) / 128 >= 2 * c->num_cus ? 2 : c->skinny_cfg_mid;
   if (c->skinny_cfg_force >= 0) cfg = c->skinny_cfg_force;
+  if (mb == 4 && k.nt == 3 && cfg == 0) cfg = 1;     // three terms x four blocks: the 256-k panel's register image spills (80 us for the QKV product); 128-k panels
   const int kp = tgx::skinny_kp(cfg);
   const int panels = (k.K + kp - 1) / kp;
   const int gx = (k.N + tgx::skinny_rows(cfg) - 1) / tgx::skinny_rows(cfg);
@@ -1374,7 +1387,7 @@ int ensure_skinny_ws(tgx_ctx* c, int rows) {
     HIP_OK(c, hipMalloc((void**)&c->ws_part, need));
     c->ws_part_bytes = need;
   }
-  if (!c->ws_ssq) HIP_OK(c, hipMalloc((void**)&c->ws_ssq, (size_t)32 * tgx::SK_NCB * 4));
+  if (!c->ws_ssq) HIP_OK(c, hipMalloc((void**)&c->ws_ssq, (size_t)64 * tgx::SK_NCB * 4));
   return TGX_OK;
 }
 
@@ -1397,9 +1410,9 @@ void launch_ksplit(tgx_ctx* c, int epi, const ebyte* W, float* C, int ldc, int M
 #undef TGX_KS
 }
 // RMSNorm of the rows of x into 16-bit terms (ws_ah / ws_al), first adding a pending split-K residual (nsplit > 1: the slabs in ws_part)
-void launch_norm_terms(tgx_ctx* c, float* x, const ebyte* norm_w, int M, int H, int nsplit) {
+void launch_norm_terms(tgx_ctx* c, float* x, const ebyte* norm_w, int M, int H, int nsplit, bool third = false) {
   TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, x, reinterpret_cast<const bf16_t*>(norm_w), c->d.norm_eps, H,
-                                          c->ws_ah, c->ws_al, (bf16_t*)nullptr, (const float*)(nsplit > 1 ? c->ws_part : nullptr), nsplit, (long long)M * H, (const bf16_t*)nullptr))
+                                          c->ws_ah, c->ws_al, third ? c->ws_al2 : (bf16_t*)nullptr, (const float*)(nsplit > 1 ? c->ws_part : nullptr), nsplit, (long long)M * H, (const bf16_t*)nullptr))
 }
 
 // One decode step for rows [row0, row0 + M), M <= 32, with every nn::Linear as ONE pass over its weights (GPTEngine.cpp:154-168: the
@@ -1523,12 +1536,20 @@ void launch_prefill_skinny(tgx_ctx* c, int row0, int NB, int S) {
   const int nt_qkv = c->dt == tgx::DT_BF16 ? 3 : 2;
   float* ssq = c->ws_ssq;
   TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_rows_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const long long*)c->rows[(size_t)row0].prompt, (const bf16_t*)c->embed, c->ws_x, H, S, (long long)d.max_ctx))
-  hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)c->ws_x, (long long)H, H, ssq);
+  // 33-64 rows (four activation blocks): RMSNorm + the 16-bit terms once per product in a row-wise launch (which also takes the pending split-K
+  // residual), the panel kernel stages stored terms — its RMSNorm-on-the-way form runs out of registers at four blocks
+  const bool terms = M > 32;
+  int pend = 0;             // slabs of the previous layer's down product not yet added to ws_x (terms form)
+  if (!terms) hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)c->ws_x, (long long)H, H, ssq);
   for (int l = 0; l < d.layers; l++) {
     const LayerW& w = c->L[(size_t)l];
     SkinnyCall q;
     q.epi = tgx::GEMM_STORE; q.W = w.wqkv; q.bias = w.bqkv; q.C = c->ws_out; q.ldc = nq; q.M = M; q.N = nq; q.K = H;
     q.nt = nt_qkv; q.asrc = 2; q.a_f32 = c->ws_x; q.lda = H; q.norm_w = w.in_norm; q.ssq_in = ssq;
+    if (terms) {
+      launch_norm_terms(c, c->ws_x, w.in_norm, M, H, pend, nt_qkv == 3); pend = 0;
+      q.asrc = 0; q.a_hi = c->ws_ah; q.a_lo = c->ws_al; q.a_lo2 = c->ws_al2; q.a_f32 = nullptr; q.norm_w = nullptr; q.ssq_in = nullptr;
+    }
     const int qs = launch_skinny(c, q);
     if (qs > 1) launch_reduce_rows(c, tgx::GEMM_STORE, qs, w.bqkv, c->ws_out, nq, M, nq, nullptr);
     for (int b = 0; b < NB; b++) {
@@ -1561,6 +1582,12 @@ void launch_prefill_skinny(tgx_ctx* c, int row0, int NB, int S) {
     if (ksplit_ok(c, M, 2 * I, H)) {       // prompts of <= 16 rows: as the batched decode step (the o_proj product has consumed ws_ah / ws_al by now)
       launch_norm_terms(c, c->ws_x, w.post_norm, M, H, os);
       launch_ksplit(c, tgx::GEMM_SILU, w.wgu, nullptr, 2 * I, M, 2 * I, H);
+    } else if (terms) {
+      launch_norm_terms(c, c->ws_x, w.post_norm, M, H, os);
+      SkinnyCall gu;
+      gu.epi = tgx::GEMM_SILU; gu.W = w.wgu; gu.M = M; gu.N = 2 * I; gu.K = H; gu.ldc = 2 * I; gu.nt = 2; gu.asrc = 0; gu.a_hi = c->ws_ah; gu.a_lo = c->ws_al;
+      gu.allow_split = c->skinny_gu_split != 0;
+      gs = launch_skinny(c, gu);
     } else {
     if (os > 1) launch_reduce_rows(c, tgx::GEMM_RESIDUAL, os, nullptr, c->ws_x, H, M, H, ssq);
     else hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)c->ws_x, (long long)H, H, ssq);
@@ -1578,8 +1605,9 @@ void launch_prefill_skinny(tgx_ctx* c, int row0, int NB, int S) {
     SkinnyCall dn;
     dn.epi = tgx::GEMM_RESIDUAL; dn.W = w.wdown; dn.C = c->ws_x; dn.ldc = H; dn.M = M; dn.N = H; dn.K = I; dn.nt = 2; dn.asrc = 0; dn.a_hi = c->ws_hh; dn.a_lo = c->ws_hl;
     const int ds = launch_skinny(c, dn);
-    if (ds > 1) launch_reduce_rows(c, tgx::GEMM_RESIDUAL, ds, nullptr, c->ws_x, H, M, H, ssq);
-    else hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)c->ws_x, (long long)H, H, ssq);
+    if (terms && l + 1 < d.layers) pend = ds;        // the next layer's norm launch adds the slabs
+    else if (ds > 1) launch_reduce_rows(c, tgx::GEMM_RESIDUAL, ds, nullptr, c->ws_x, H, M, H, ssq);
+    else if (!terms) hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)c->ws_x, (long long)H, H, ssq);
   }
   for (int b = 0; b < NB; b++)     // the last position of every batch row feeds lm_head
     (void)hipMemcpyAsync(c->rows[(size_t)(row0 + b)].x, c->ws_x + ((size_t)(b + 1) * S - 1) * H, (size_t)H * 4, hipMemcpyDeviceToDevice, c->stream);
@@ -2194,7 +2222,8 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     const int per = std::max(1, std::min(batch, 8192 / seq));
     for (int row0 = 0; row0 < batch; row0 += per) {
       const int nb = std::min(per, batch - row0);
-      const bool skinny = !f32_path && !c->gpt2 && c->prefill_skinny && nb * seq <= 32 && c->d.vocab >= 128;     // a few rows: the weight stream of a decode step
+      const bool skinny = !f32_path && !c->gpt2 && c->prefill_skinny && c->d.vocab >= 128 &&     // a few rows: the weight stream of a decode step
+                          (nb * seq <= 32 ? c->prefill_skinny_rows >= nb * seq : (nb * seq <= c->prefill_skinny_rows && c->d.hidden <= c->prefill_skinny_hidden_max));
       int rc = skinny ? ensure_skinny_ws(c, nb * seq) : ensure_prefill_ws(c, nb * seq);
       if (rc) return rc;
       if (f32_path && (rc = ensure_f32_part(c, nb * seq))) return rc;
@@ -2509,6 +2538,8 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.f32_min_rows")) { c->prefill_f32_min_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk")) { c->gemm_splitk = value; return TGX_OK; }
   if (!strcmp(key, "prefill.qkv_balanced")) { c->qkv_balanced = value != 0; return TGX_OK; }
+  if (!strcmp(key, "prefill.skinny_hidden_max")) { c->prefill_skinny_hidden_max = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.skinny_rows")) { if (value < 0 || value > 64) return set_err(c, TGX_ERR_INVALID, "prefill.skinny_rows is 0..64"); c->prefill_skinny_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.hidden_256")) { c->hidden_256 = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk_dma")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "prefill.splitk_dma is 0, 1 (<= 64 rows) or 2 (always)"); c->splitk_dma = value; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_mirror")) { c->attn_mirror = value; return TGX_OK; }
