@@ -173,6 +173,7 @@ struct tgx_ctx {
   // hidden > 2048 the tiled path's weight stream is faster (option prefill.skinny_hidden_max)
   int prefill_skinny_rows = 64;
   int prefill_skinny_hidden_max = 2048;
+  int decode_step_rows = 64;   // option decode.step_rows: rows of a batch that share one pass over the weights in the matrix-core step (32: round 2)
   int prefill_skinny = 1;    // option prefill.skinny: 0 sends prompts of <= 32 rows through the tiled GEMMs as well
   int skinny_wgs = 256;      // option skinny.wgs: workgroups a skinny product aims for by splitting K
   int skinny_gu_split = 0;   // option skinny.gu_split: 0 keeps the gate_up product unsplit (siluMul in its epilogue, one launch less)
@@ -1253,7 +1254,10 @@ void update_attn_modes(tgx_ctx* c, int n_positions, int rows_per_launch = -1) { 
 
 void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
   if (decode_mfma_ok(c)) {   // more than 4 rows: every Linear is one pass over its weights for up to 32 rows (kernels/skinny.h)
-    for (int row0 = 0; row0 < c->batch; row0 += 32) launch_decode_step_mfma(c, row0, std::min(32, c->batch - row0), cfg);
+    // rows per weight pass (option decode.step_rows: 32 or 64): batches beyond 32 rows take four activation blocks per skinny product (one pass over
+    // the weights for up to 64 rows) instead of two passes of two blocks
+    const int per = c->decode_step_rows;
+    for (int row0 = 0; row0 < c->batch; row0 += per) launch_decode_step_mfma(c, row0, std::min(per, c->batch - row0), cfg);
     return;
   }
   // batch rows share each pass over the weights in groups of 4 / 2 / 1 (the batched GEMV's R template)
@@ -1280,6 +1284,7 @@ int skinny_set_attr_dt(tgx_ctx* c) {
 #define TGX_SK_A(MB_, CFG_) HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::skinny_gemm_kernel<DT, EPI, MB_, NT, CFG_, ASRC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::skinny_lds_bytes(MB_, NT, CFG_)));
   TGX_SK_A(1, 0) TGX_SK_A(1, 1) TGX_SK_A(1, 2) TGX_SK_A(2, 0) TGX_SK_A(2, 1) TGX_SK_A(2, 2)
   if constexpr (ASRC == 0) { TGX_SK_A(4, 0) TGX_SK_A(4, 1) TGX_SK_A(4, 2) }
+  if constexpr (ASRC == 1) { TGX_SK_A(4, 1) }
 #undef TGX_SK_A
   return TGX_OK;
 }
@@ -1300,7 +1305,8 @@ void skinny_dispatch(tgx_ctx* c, dim3 grid, int mb, int cfg, const tgx::GemmArgs
   TGX_DT16_SWITCH(c->dt,
     if (mb == 4) {     // 33-64 rows (round 3): four activation blocks, geometries 0 and 2, stored terms only (staging with RMSNorm spills: 262 us for gate_up)
       if constexpr (ASRC == 0) { if (cfg == 2) TGX_SK_L(4, 2); else if (cfg == 1) TGX_SK_L(4, 1); else TGX_SK_L(4, 0); }
-      else c->err = "internal: 33-64-row skinny GEMM takes stored 16-bit terms";
+      else if constexpr (ASRC == 1) TGX_SK_L(4, 1);             // fp32 rows split on the way (the o_proj product of a decode step): 128-k panels only
+      else c->err = "internal: 33-64-row skinny GEMM takes stored 16-bit terms or plain fp32 rows";
     }
     else if (mb == 2) { if (cfg == 2) TGX_SK_L(2, 2); else if (cfg == 1) TGX_SK_L(2, 1); else TGX_SK_L(2, 0); }
     else { if (cfg == 2) TGX_SK_L(1, 2); else if (cfg == 1) TGX_SK_L(1, 1); else TGX_SK_L(1, 0); })
@@ -1332,6 +1338,7 @@ int launch_skinny(tgx_ctx* c, const SkinnyCall& k) {
   // 128-row groups when they alone oversubscribe the chip (the lm_head), else 64-row groups: twice the workgroups for the same bytes
   int cfg = (k.N + 127) / 128 >= 2 * c->num_cus ? 2 : c->skinny_cfg_mid;
   if (c->skinny_cfg_force >= 0) cfg = c->skinny_cfg_force;
+  if (mb == 4 && k.asrc == 1) cfg = 1;
   if (mb == 4 && k.nt == 3 && cfg == 0) cfg = 1;     // three terms x four blocks: the 256-k panel's register image spills (80 us for the QKV product); 128-k panels
   const int kp = tgx::skinny_kp(cfg);
   const int panels = (k.K + kp - 1) / kp;
@@ -1429,13 +1436,21 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
   const int nt_qkv = c->dt == tgx::DT_BF16 ? 3 : 2;
   float* ssq = c->ws_ssq;
   const bool lm_ks = ksplit_ok(c, M, V, H);
+  // 33-64 rows (round 3): four activation blocks; every RMSNorm-fused product takes its activations as 16-bit terms prepared once per product by the
+  // row-wise launch that also adds the pending split-K residual (the RMSNorm-on-the-way staging runs out of registers at four blocks)
+  const bool terms = M > 32;
+  int pend = 0;            // terms form: slabs of the previous layer's down product not yet added to the rows
   // the rows start as embedding rows (the finalize of the previous step gathered them): their sums of squares for the first RMSNorm
-  hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
+  if (!terms) hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
   for (int l = 0; l < d.layers; l++) {
     const LayerW& w = c->L[(size_t)l];
     SkinnyCall q;
     q.epi = tgx::GEMM_STORE; q.W = w.wqkv; q.bias = w.bqkv; q.C = c->ws_out; q.ldc = qd + 2 * kvd; q.M = M; q.N = qd + 2 * kvd; q.K = H;
     q.nt = nt_qkv; q.asrc = 2; q.a_f32 = r.x; q.lda = H; q.norm_w = w.in_norm; q.ssq_in = ssq;
+    if (terms) {
+      launch_norm_terms(c, r.x, w.in_norm, M, H, pend, nt_qkv == 3); pend = 0;
+      q.asrc = 0; q.a_hi = c->ws_ah; q.a_lo = c->ws_al; q.a_lo2 = c->ws_al2; q.a_f32 = nullptr; q.norm_w = nullptr; q.ssq_in = nullptr;
+    }
     const int qs = launch_skinny(c, q);
     // the QKV product's finish (slab sums + bias, q / k norm, RoPE, cache append) inside the attention launch when that is the batched matrix-core form
     // (option attn.raw_fuse): one launch per layer less
@@ -1474,7 +1489,7 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
     if (gu_ks) {     // {sum slabs, residual, RMSNorm, 16-bit terms} in one row-wise launch, then the barrier-free wide product
       launch_norm_terms(c, r.x, w.post_norm, M, H, os);
       launch_ksplit(c, tgx::GEMM_SILU, w.wgu, nullptr, 2 * I, M, 2 * I, H);
-    } else if (c->skinny_terms) {
+    } else if (c->skinny_terms || terms) {
       // 17-32 rows (round 3): {sum slabs, residual, RMSNorm, 16-bit terms} ONCE per layer in the row-wise launch that replaces reduce_rows; the panel
       // kernel then stages stored terms instead of normalising and splitting every 256-k panel in each of its 256 workgroups
       launch_norm_terms(c, r.x, w.post_norm, M, H, os);
@@ -1499,7 +1514,8 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
     SkinnyCall dn;
     dn.epi = tgx::GEMM_RESIDUAL; dn.W = w.wdown; dn.C = r.x; dn.ldc = H; dn.M = M; dn.N = H; dn.K = I; dn.nt = 2; dn.asrc = 0; dn.a_hi = c->ws_hh; dn.a_lo = c->ws_hl;
     const int ds = launch_skinny(c, dn);
-    if (l + 1 == d.layers && lm_ks) launch_norm_terms(c, r.x, c->final_norm, M, H, ds);      // the last residual goes straight into model.norm's terms
+    if (l + 1 == d.layers && (lm_ks || terms)) launch_norm_terms(c, r.x, c->final_norm, M, H, ds);      // the last residual goes straight into model.norm's terms
+    else if (terms) pend = ds;                                                                         // the next layer's norm launch adds the slabs
     else if (ds > 1) launch_reduce_rows(c, tgx::GEMM_RESIDUAL, ds, nullptr, r.x, H, M, H, ssq);
     else hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
   }
@@ -1509,6 +1525,7 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
   SkinnyCall lm;
   lm.epi = tgx::GEMM_STORE; lm.W = d.tied ? c->embed : c->lm_head; lm.C = r.logits; lm.ldc = V; lm.M = M; lm.N = V; lm.K = H; lm.nt = 2; lm.asrc = 2;
   lm.a_f32 = r.x; lm.lda = H; lm.norm_w = c->final_norm; lm.ssq_in = ssq; lm.allow_split = false;
+  if (terms) { lm.asrc = 0; lm.a_hi = c->ws_ah; lm.a_lo = c->ws_al; lm.a_f32 = nullptr; lm.norm_w = nullptr; lm.ssq_in = nullptr; }
   launch_skinny(c, lm);
   }
   hipLaunchKernelGGL(tgx::argmax_partials_rows_kernel, dim3(c->lm_grid, M), dim3(256), 0, c->stream, (const float*)r.logits, (long long)V, V, r.part_val, r.part_idx, (long long)c->lm_grid);
@@ -1815,7 +1832,7 @@ int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int 
     c->have_probs = true;
   }
   if (decode_mfma_ok(c)) {   // the batched step's workspace must exist before the step is captured
-    int rc = ensure_skinny_ws(c, std::min(32, c->batch));
+    int rc = ensure_skinny_ws(c, std::min(c->decode_step_rows, c->batch));
     if (rc) return rc;
   }
   // The attention form depends on the context (four-wave direct / sixteen-wave direct / split + combine / matrix cores): a call that crosses a limit is
@@ -2538,6 +2555,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.f32_min_rows")) { c->prefill_f32_min_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk")) { c->gemm_splitk = value; return TGX_OK; }
   if (!strcmp(key, "prefill.qkv_balanced")) { c->qkv_balanced = value != 0; return TGX_OK; }
+  if (!strcmp(key, "decode.step_rows")) { if (value != 32 && value != 64) return set_err(c, TGX_ERR_INVALID, "decode.step_rows is 32 or 64"); drop_step_graphs(c); c->decode_step_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.skinny_hidden_max")) { c->prefill_skinny_hidden_max = value; return TGX_OK; }
   if (!strcmp(key, "prefill.skinny_rows")) { if (value < 0 || value > 64) return set_err(c, TGX_ERR_INVALID, "prefill.skinny_rows is 0..64"); c->prefill_skinny_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.hidden_256")) { c->hidden_256 = value != 0; return TGX_OK; }
