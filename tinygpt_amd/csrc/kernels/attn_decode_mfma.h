@@ -37,7 +37,9 @@ __host__ __device__ constexpr size_t attn_mfma_raw_lds_bytes() { return attn_mfm
 // cache append) — the G q heads go to LDS as fp32 and feed the Q^T fragments, the new k / v rows go to the cache AND to LDS, from where the lanes that
 // hold key `pos` take them (the global copy was stored by this same workgroup a moment ago: never read back in this launch).  Same arithmetic, in the
 // same order, as rope_kv_rows_kernel (skinny.h): the two forms are bit-identical.
-template <int DT, int HD, int NW = 4, bool RAW = false>
+// LOOKAHEAD: the next block's K / V loads are issued before the current block's arithmetic (a second register set: 309 registers at head_dim 64 = one
+// wave per SIMD).  Without it the RAW form fits 256: two workgroups per CU, for batches with more (row, kv head) workgroups than CUs.
+template <int DT, int HD, int NW = 4, bool RAW = false, bool LOOKAHEAD = true>
 __global__ __launch_bounds__(64 * NW) void attn_decode_mfma_kernel(const AttnArgs a) {
   typedef elem_t<DT> E;
   constexpr int LV = HD + 32;                 // 16-bit row stride of the wave's V tile ([key][d]; read with the transposing LDS read, as attn_prefill_kernel)
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_mfma_kernel(const AttnArg
   const int nblk = (n_keys + 63) >> 6;
   // register sets of one block's loads: V rows (chunk c = lane + 64 i -> key row c / CH, 16-byte column c % CH) and the K fragments
   // (row = key 32 sub + ql, 8 d at 16 kk + 8 hh); the NEXT block's loads are issued before the current block's arithmetic
-  constexpr bool PREF = HD == 64;            // head_dim 128: a second register set spills (measured 40 -> 68 us per layer at 24k keys)
+  constexpr bool PREF = HD == 64 && LOOKAHEAD;   // head_dim 128: a second register set spills (measured 40 -> 68 us per layer at 24k keys)
   u32x4 vvr[CH], kfr[2][KS], vnx[PREF ? CH : 1], knx[2][PREF ? KS : 1];
   auto load_block = [&](int blk, u32x4* vdst, u32x4 (*kdst)[KS]) {
     const int key0 = blk * 64;

@@ -200,6 +200,7 @@ struct tgx_ctx {
   int attn_direct_nw4 = 0;   // option attn.direct_nw4: contexts up to this many keys run the direct attention form with four waves per head (set in tgx_create)
   bool attn_nw4 = false;     // mode of the launches being issued / captured
   int attn_raw_fuse = 1;     // option attn.raw_fuse: that form also finishes the QKV product (slab sums, bias, q / k norm, RoPE, cache append) in its prologue
+  int attn_batch_la = 0;     // option attn.batch_la: K / V look-ahead registers of that form at head_dim 64 (-1: only while its workgroups number at most one per CU)
   int attn_batch_mfma = 24;  // option attn.batch_mfma: batches of this many rows and more run their direct-form attention on the matrix cores (0 = never)
   int attn_direct_g = 1;     // option attn.direct_g: 1 = heads per workgroup of the direct attention form by batch rows (2 from 12 rows, 4 from 24 at head_dim 64), 0 = always one, -g = force g
   int attn_direct_max = 384; // contexts up to this many keys take the one-workgroup-per-head attention (no split, no combine launch); set in tgx_create
@@ -568,8 +569,17 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
         const dim3 gm(a.kv_heads, R);
         if (!(c->debug_skip & 1)) {
           constexpr size_t lds4 = tgx::attn_mfma_lds_bytes<HD, 4>(), ldsr = tgx::attn_mfma_raw_lds_bytes<HD, 4>();
-          if (a.raw_part || a.raw_qkv) hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, true>), gm, dim3(256), ldsr, c->stream, a);   // + the QKV product's finish
-          else hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4>), gm, dim3(256), lds4, c->stream, a);
+          // head_dim 64: the form without the second K / V register set — 208 instead of 309 registers, two workgroups per CU.  Measured ms/step with /
+          // without (Llama-3.2-1B, context 600): B = 32 1.317 / 1.314, B = 48 1.814 / 1.713, B = 64 1.902 / 1.796 — never behind: the default
+          // (option attn.batch_la: 1 = look-ahead, -1 = only while the workgroups number at most one per CU)
+          const bool la = HD != 64 || (c->attn_batch_la >= 0 ? c->attn_batch_la != 0 : (int)(gm.x * gm.y) <= c->num_cus);
+          if (a.raw_part || a.raw_qkv) {     // + the QKV product's finish
+            if (la) hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, true>), gm, dim3(256), ldsr, c->stream, a);
+            else hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, true, false>), gm, dim3(256), ldsr, c->stream, a);
+          } else {
+            if (la) hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4>), gm, dim3(256), lds4, c->stream, a);
+            else hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, false, false>), gm, dim3(256), lds4, c->stream, a);
+          }
         }
         return;
       }
@@ -2540,6 +2550,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
   if (!strcmp(key, "attn.direct_nw4")) { drop_step_graphs(c); c->attn_direct_nw4 = value; return TGX_OK; }
   if (!strcmp(key, "attn.raw_fuse")) { drop_step_graphs(c); c->attn_raw_fuse = value != 0; return TGX_OK; }
+  if (!strcmp(key, "attn.batch_la")) { if (value < -1 || value > 1) return set_err(c, TGX_ERR_INVALID, "attn.batch_la is -1, 0 or 1"); drop_step_graphs(c); c->attn_batch_la = value; return TGX_OK; }
   if (!strcmp(key, "attn.batch_mfma")) { if (value < 0) return set_err(c, TGX_ERR_INVALID, "attn.batch_mfma is a row count (0 = off)"); drop_step_graphs(c); c->attn_batch_mfma = value; return TGX_OK; }
   if (!strcmp(key, "attn.direct_g")) { if (value != 0 && value != 1 && value != -1 && value != -2 && value != -4) return set_err(c, TGX_ERR_INVALID, "attn.direct_g is 0, 1 or -1 / -2 / -4"); drop_step_graphs(c); c->attn_direct_g = value; return TGX_OK; }
   if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
