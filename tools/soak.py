@@ -9,7 +9,7 @@ from tinygpt_amd.ffi import GREEDY, Model
 import copy
 name = sys.argv[1] if len(sys.argv) > 1 else "llama-3.2-1b"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-d = copy.deepcopy(known_desc(name)); d.max_ctx = 4096; d.max_batch = 16
+d = copy.deepcopy(known_desc(name)); d.max_ctx = 4096; d.max_batch = 64
 m = Model(d).load_synthetic(1234, 0.02).finalize()
 bad = 0
 for S in (2048, 3200, 300, 40, 12):
@@ -54,5 +54,26 @@ for B in (12, 16):
     for r in (1, 2):
         if not np.array_equal(outs[0], outs[r]): bad += 1; print(f"MISMATCH long-context decode B={B} run {r}", flush=True)
     print(f"decode B={B} at context 1500+: 3 x 200 steps equal: {all(np.array_equal(outs[0], o) for o in outs)}", flush=True)
+# round 3, later: batches of 24-64 rows — the matrix-core attention with the QKV finish in its prologue (the workgroup's clamped K / V loads race with its own
+# store of the new row and must never be used), four-block skinny products, 64-row passes
+for B, plen in ((24, 600), (32, 600), (48, 300), (64, 600), (64, 70)):
+    ids = np.stack([synth.synth_prompt(d.vocab, plen, 31 + b) for b in range(B)])
+    outs = []
+    t0 = time.time()
+    for r in range(3):
+        m.reset_cache(); m.forward(ids); m.sample(GREEDY)
+        outs.append(m.decode(250, GREEDY).copy())
+    for r in (1, 2):
+        if not np.array_equal(outs[0], outs[r]): bad += 1; print(f"MISMATCH decode B={B} prompt {plen} run {r}", flush=True)
+    print(f"decode B={B} from context {plen}: 3 x 250 steps equal: {all(np.array_equal(outs[0], o) for o in outs)}  ({time.time() - t0:.1f} s)", flush=True)
+for S in (33, 48, 64):
+    ids = synth.synth_prompt(d.vocab, S, 3)[None, :]
+    ref = None
+    for r in range(3 * reps):
+        m.reset_cache(); m.forward(ids)
+        lg = m.logits(False).copy()
+        if ref is None: ref = lg
+        elif not np.array_equal(ref, lg): bad += 1; print(f"MISMATCH prefill S={S} rep {r}", flush=True)
+    print(f"prefill S={S}: {3 * reps} repetitions", flush=True)
 print("SOAK", "FAILED" if bad else "OK", bad)
 sys.exit(1 if bad else 0)
