@@ -1411,8 +1411,11 @@ int ensure_skinny_ws(tgx_ctx* c, int rows) {
 // The wide products of a batch of <= 32 rows on the barrier-free K-split kernel (kernels/skinny_ksplit.h); activations = the 16-bit terms
 // rmsnorm_split_kernel left in ws_ah / ws_al.  false: shape not covered (the caller takes the panel kernel).
 bool ksplit_ok(const tgx_ctx* c, int M, int N, int K) {
-  // 17-32 rows (two activation blocks, two weight slots) measured level with the panel kernel on Llama-3.2-1B and 3 % behind on Mistral-7B: option value 2 only
-  return c->skinny_ksplit && M <= (c->skinny_ksplit >= 2 ? 32 : 16) && K % 256 == 0 && K >= 768 && N >= 64 * c->num_cus;
+  // 17-32 rows (two activation blocks, two weight slots), ms/step panel / K-split kernel (round 3 closing build): Llama-3.2-1B (K = 2048) B = 17 1.314 / 1.253,
+  // 24 1.275 / 1.237, 32 1.316 / 1.312; Llama-3.2-3B (K = 3072) 2.834 / 2.853, 2.891 / 2.984, 3.015 / 3.199; Mistral-7B (K = 4096) B = 32 5.11 / 5.38: at K = 2048
+  // only (option value 2: always)
+  const int max_rows = c->skinny_ksplit >= 2 || K == 2048 ? 32 : 16;
+  return c->skinny_ksplit && M <= max_rows && K % 256 == 0 && K >= 768 && N >= 64 * c->num_cus;
 }
 void launch_ksplit(tgx_ctx* c, int epi, const ebyte* W, float* C, int ldc, int M, int N, int K) {
   tgx::GemmArgs g{};
