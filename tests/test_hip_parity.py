@@ -252,7 +252,7 @@ def test_batches_beyond_four_rows_run_on_the_matrix_cores(family, dtype, rows, h
                                                             ("qwen2_tiny", "bf16", 25, 60, 0), ("mistral_tiny", "fp16", 8, 100, 1), ("mistral_tiny", "fp16", 24, 61, 1),
                                                             ("qwen3_tiny", "bf16", 8, 100, 1)])
 def test_batch_attention_on_the_matrix_cores_equals_the_oracle(family, dtype, rows, plen, force, hip, oracle_lib):
-    """Batches of 24+ rows of a model with 3+ query heads per kv head (force = 0: qwen2_tiny; the option forces the others) run the direct-form
+    """Batches of 17+ rows of a model with 3+ query heads per kv head (force = 0: qwen2_tiny; the option forces the others) run the direct-form
     attention of a step on the matrix cores (attn_decode_mfma_kernel with a.direct: one workgroup per
     (row, kv head), the group's 2 / 3 query heads as the narrow MFMA operand, four waves walking blocks of 64 keys — here 1-4 blocks, so some waves hold
     no key at all —, no split records and no combine launch; option attn.batch_mfma forces it for the smaller batches).  Each row has its own prompt;

@@ -201,7 +201,7 @@ struct tgx_ctx {
   bool attn_nw4 = false;     // mode of the launches being issued / captured
   int attn_raw_fuse = 1;     // option attn.raw_fuse: that form also finishes the QKV product (slab sums, bias, q / k norm, RoPE, cache append) in its prologue
   int attn_batch_la = 0;     // option attn.batch_la: K / V look-ahead registers of that form at head_dim 64 (-1: only while its workgroups number at most one per CU)
-  int attn_batch_mfma = 24;  // option attn.batch_mfma: batches of this many rows and more run their direct-form attention on the matrix cores (0 = never)
+  int attn_batch_mfma = 17;  // option attn.batch_mfma: batches of this many rows and more run their direct-form attention on the matrix cores (0 = never)
   int attn_direct_g = 1;     // option attn.direct_g: 1 = heads per workgroup of the direct attention form by batch rows (2 from 12 rows, 4 from 24 at head_dim 64), 0 = always one, -g = force g
   int attn_direct_max = 384; // contexts up to this many keys take the one-workgroup-per-head attention (no split, no combine launch); set in tgx_create
   bool attn_direct = false;  // mode of the launches being issued / captured
@@ -522,7 +522,7 @@ bool attn_fold_ok(const tgx_ctx* c, int R) {
   return c->attn_fold && c->engine_mode < 2 && !c->attn_direct && (size_t)R * c->d.heads * c->d.head_dim * 4 <= 65536;
 }
 
-// the direct-form attention of a batched step runs on the matrix cores from attn.batch_mfma rows when a kv head serves 3+ query heads (the VALU form's
+// the direct-form attention of a batched step runs on the matrix cores from attn.batch_mfma rows (17) when a kv head serves 3+ query heads (the VALU form's
 // cost grows with the heads per workgroup, the MFMA form's does not: Qwen3-1.7B, 2 heads per kv head, B = 32 2.29 (VALU) vs 2.39 ms/step)
 bool attn_batch_on_mfma(const tgx_ctx* c, int R) {
   return c->attn_batch_mfma > 0 && R >= c->attn_batch_mfma && (c->d.heads / c->d.kv_heads >= 3 || c->attn_batch_mfma == 1);
@@ -563,7 +563,9 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
     // not — one workgroup per (row, kv head), all the group's query heads as the narrow operand, no split, no combine launch.  Measured ms/step (VALU /
     // MFMA, 4 waves; 8 waves the same within 0.5 %): Llama-3.2-1B context 600 B = 16 1.047 / 1.068, B = 24 1.308 / 1.259, B = 32 1.356 / 1.307; context 2k
     // B = 16 1.210 / 1.224, B = 24 1.608 / 1.453, B = 32 1.708 / 1.562; Mistral-7B B = 16 3.92 / 4.10, B = 32 5.38 / 5.12: from 24 rows (below, rows x kv heads
-    // workgroups leave CUs empty).  With AttnArgs.raw_* set the launch also finishes the QKV product (attn.raw_fuse: B = 32 1.335 -> 1.326, B = 8 1.000 -> 0.978)
+    // workgroups leave CUs empty).  Closing build (no look-ahead set, QKV finish in the prologue), VALU / MFMA: B = 12 1.005 / 1.007, B = 16 1.052 / 1.072,
+    // B = 17 1.247 / 1.159, B = 20 1.293 / 1.200, context 2k B = 17 1.553 / 1.340; Mistral-7B B = 16 3.92 / 4.07, B = 17 4.89 / 4.78: from 17 rows.
+    // With AttnArgs.raw_* set the launch also finishes the QKV product (attn.raw_fuse: B = 32 1.335 -> 1.326, B = 8 1.000 -> 0.978)
     if constexpr (!QKN && DT != tgx::DT_F32) {
       if (attn_batch_on_mfma(c, R)) {
         const dim3 gm(a.kv_heads, R);
