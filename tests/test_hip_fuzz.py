@@ -82,3 +82,57 @@ def test_random_geometry_graph_decode_equals_eager_passes(seed):
         tok = ids[step]
     assert rel_err(l, l_graph) < 1e-4, (seed, d, rel_err(l, l_graph))
     m.close()
+
+
+def random_mfma_desc(rng):
+    """geometries the matrix-core step covers (hidden, q width and intermediate size multiples of 64; 16-bit storage; no GPT-2), small enough for the oracle"""
+    fam = rng.choice(["llama", "qwen2", "qwen3", "mistral"])
+    hd = int(rng.choice([64, 128]))
+    kv = int(rng.choice([1, 2, 4]))
+    group = int(rng.choice([1, 2, 3, 4, 7, 8]))
+    heads = kv * group
+    while heads * hd > 1024:
+        heads -= kv
+    hidden = heads * hd if fam != "qwen3" else int(rng.choice([192, 320, 512]))
+    inter = int(rng.choice([192, 320, 1024, 1344]))
+    vocab = int(rng.choice([257, 1001, 2048]))
+    return ModelDesc(family=fam, hidden=hidden, layers=int(rng.integers(1, 3)), heads=heads, kv_heads=kv, head_dim=hd, inter=inter, vocab=vocab, max_ctx=112,
+                     qkv_bias=fam == "qwen2", tied=bool(rng.integers(0, 2)), compute_dtype=str(rng.choice(["bf16", "fp16"])), norm_eps=1e-5,
+                     rope_theta=float(rng.choice([10000.0, 1000000.0])), n_positions=0, max_batch=int(rng.choice([6, 12, 17, 24, 33, 48, 64, 70])), qk_norm=fam == "qwen3")
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("TGX_FUZZ_SEEDS_BATCH", "40")))))
+def test_random_batched_steps_match_oracle(seed, oracle_lib):
+    """Round 3's batched step over random geometries and batch sizes (6 .. 70 rows: one / two / four activation blocks, K-split wide products, the
+    matrix-core attention with the QKV finish in its prologue or the VALU forms by heads per kv head, 64-row + remainder passes) and prompts whose
+    rows number 6 .. 100+ (skinny prompts up to 64 rows, tiled beyond): prompt logits and 4 teacher-forced graph steps against the oracle.  16-bit
+    storage with std-0.05 weights: the K / V rounding-flip floor of these small models bounds the comparison at 6e-3 (see the module docstring); ids
+    are compared where the oracle's top-2 gap exceeds it."""
+    from oracle.oracle_ffi import OracleModel
+    rng = np.random.default_rng(9000 + seed)
+    d = random_mfma_desc(rng)
+    B = d.max_batch
+    S = int(rng.choice([1, 2, 5, 9, 20, 40])) if B > 16 else int(rng.choice([3, 7, 10]))
+    prompt = np.stack([synth.synth_prompt(d.vocab, S, seed * 13 + b) for b in range(B)])
+    gpu, ref = Model(d, product_backend()), OracleModel(d)
+    for name, bits in synth.synth_checkpoint(d, 177 + seed, 0.05):
+        gpu.upload(name, bits); ref.upload(name, bits)
+    gpu.finalize(); ref.finalize()
+    gpu.forward(prompt); ref.forward(prompt)
+    tol = 6e-3
+    lg, lr = gpu.logits(rounded=False), ref.logits(rounded=False)
+    assert rel_err(lg, lr) < tol, (seed, "prompt", d, S, rel_err(lg, lr))
+    tok = ref.sample(GREEDY); gpu.sample(GREEDY)
+    for step in range(4):
+        onehot = np.full((B, d.vocab), -1.0, np.float32); onehot[np.arange(B), tok] = 1.0
+        gpu.set_logits(onehot); np.testing.assert_array_equal(gpu.sample(GREEDY), tok)
+        tg = gpu.decode(1, GREEDY)[0]
+        tr = ref.decode(1, GREEDY)[0]
+        lg, lr = gpu.logits(rounded=False), ref.logits(rounded=False)
+        assert rel_err(lg, lr) < tol, (seed, step, d, S, rel_err(lg, lr))
+        top2 = np.sort(lr, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 2 * tol * np.abs(lr).max()
+        np.testing.assert_array_equal(tg[clear], tr[clear])
+        tok = tr
+    assert gpu.past_length == ref.past_length
+    gpu.close(); ref.close()

@@ -147,6 +147,7 @@ struct tgx_ctx {
   bf16_t *ws_qh = nullptr, *ws_ql = nullptr;          // [S][qd] rotated queries (hi, lo)
   bf16_t *ws_hh = nullptr, *ws_hl = nullptr;          // [S][I] siluMul output (hi, lo): the down product's A operand
   float* ws_part = nullptr; size_t ws_part_bytes = 0;   // split-K slabs of the short-prompt GEMMs
+  const char* launch_fault = nullptr;                   // a launcher could not issue a kernel (a combination that is not instantiated): the issuing entry point fails with it
   int* ws_pos = nullptr;                                // fp32 prefill: [rows] positions of the prompt rows
   float* ws_attn_part = nullptr;                        // fp32 prefill: split-attention partials of one block of rows
   float* ws_ssq = nullptr;                              // [32][SK_NCB] partial sums of squares of the batched step's rows
@@ -262,6 +263,12 @@ int set_err(tgx_ctx* c, int code, const char* fmt, ...) {
     hipError_t e_ = (call);                                                                      \
     if (e_ != hipSuccess)                                                                        \
       return set_err((c), TGX_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// launchers return void / slab counts: a kernel they could not issue is recorded in launch_fault and turned into a status by the entry point
+#define LAUNCH_OK(c)                                                                             \
+  do {                                                                                           \
+    if ((c)->launch_fault) { const char* f_ = (c)->launch_fault; (c)->launch_fault = nullptr; return set_err((c), TGX_ERR_UNSUPPORTED, "%s", f_); } \
   } while (0)
 
 inline uint16_t host_f32_to_bf16(float f) {
@@ -1318,7 +1325,7 @@ void skinny_dispatch(tgx_ctx* c, dim3 grid, int mb, int cfg, const tgx::GemmArgs
     if (mb == 4) {     // 33-64 rows (round 3): four activation blocks, geometries 0 and 2, stored terms only (staging with RMSNorm spills: 262 us for gate_up)
       if constexpr (ASRC == 0) { if (cfg == 2) TGX_SK_L(4, 2); else if (cfg == 1) TGX_SK_L(4, 1); else TGX_SK_L(4, 0); }
       else if constexpr (ASRC == 1) TGX_SK_L(4, 1);             // fp32 rows split on the way (the o_proj product of a decode step): 128-k panels only
-      else c->err = "internal: 33-64-row skinny GEMM takes stored 16-bit terms or plain fp32 rows";
+      else c->launch_fault = "internal: 33-64-row skinny GEMM takes stored 16-bit terms or plain fp32 rows";
     }
     else if (mb == 2) { if (cfg == 2) TGX_SK_L(2, 2); else if (cfg == 1) TGX_SK_L(2, 1); else TGX_SK_L(2, 0); }
     else { if (cfg == 2) TGX_SK_L(1, 2); else if (cfg == 1) TGX_SK_L(1, 1); else TGX_SK_L(1, 0); })
@@ -1372,7 +1379,7 @@ int launch_skinny(tgx_ctx* c, const SkinnyCall& k) {
 #define X(E, N, A) if (!launched && epi == E && k.nt == N && k.asrc == A) { skinny_dispatch<E, N, A>(c, grid, mb, cfg, g); launched = true; }
   TGX_SKINNY_COMBOS(X)
 #undef X
-  if (!launched) { c->err = "internal: skinny GEMM combination not instantiated"; return -1; }
+  if (!launched) { c->launch_fault = "internal: skinny GEMM combination not instantiated"; return 1; }
   return nsplit;
 }
 
@@ -1786,6 +1793,8 @@ int capture_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, int steps, hipGraphExe
   const hipError_t cap = hipStreamEndCapture(c->stream, &g);
   c->mirror_to_host = true;
   HIP_OK(c, cap);
+  if (c->launch_fault) (void)hipGraphDestroy(g);
+  LAUNCH_OK(c);
   HIP_OK(c, hipGraphInstantiate(out, g, nullptr, nullptr, 0));
   (void)hipGraphDestroy(g);
   return TGX_OK;
@@ -1871,6 +1880,7 @@ int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int 
     } else {
       for (int i = 0; i < m; i++) launch_decode_step(c, cfg);
       HIP_OK(c, hipGetLastError());
+      LAUNCH_OK(c);
     }
     c->past += m;
     c->steps_issued += m;
@@ -2291,6 +2301,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     }
   }
   HIP_OK(c, hipGetLastError());
+  LAUNCH_OK(c);
   HIP_OK(c, hipStreamSynchronize(c->stream));   // host `ids` may be pageable and reused by the caller
   c->past += seq;
   c->have_logits = true;
