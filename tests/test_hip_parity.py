@@ -727,3 +727,33 @@ def test_qwen3_qk_norm_fused_into_attention(dtype, hip, oracle_lib):
         for kk in (k1, k0):
             assert np.all(np.abs(kk - kr) <= ulp * (np.abs(kr) + 0.1 * np.abs(kr).max()))
         assert np.all(np.abs(v1 - v0) <= ulp * (np.abs(v0) + 0.1 * np.abs(v0).max()))      # layer 1: downstream of layer 0's (one-ulp) key differences
+
+
+@pytest.mark.parametrize("family,dtype,rows", [("llama_tiny", "bf16", 24), ("qwen2_tiny", "bf16", 40), ("mistral_tiny", "fp16", 64), ("qwen3_tiny", "bf16", 33)])
+def test_lds_dma_ring_skinny_kernel_is_bit_identical_to_the_panel_kernel(family, dtype, rows, hip, oracle_lib):
+    """Products on stored 16-bit terms run on the LDS-DMA ring kernel from 17 rows (kernels/skinny_dma.h: activation terms and weight rows straight into a
+    ring of LDS stages, XOR-swizzled on the source side, counted waits) — the same MFMAs in the same order as the panel kernel of kernels/skinny.h, so a
+    batched decode (gate_up, down, o_proj of the prompt, the 33-64-row lm_head) and a 40-row prompt must give bit-identical logits with option skinny.dma
+    on and off; and the oracle's within 1e-3."""
+    gpu, ref, g = make_pair(family, hip, oracle_lib, max_batch=rows, dtype=dtype, max_ctx=64)
+    V = gpu.desc.vocab
+    ids = np.stack([synth.synth_prompt(V, 11, 70 + b) for b in range(rows)])
+    outs = {}
+    for dma in (1, 0):
+        gpu.set_option("skinny.dma", dma)
+        gpu.reset_cache(); gpu.forward(ids); first = gpu.sample(GREEDY).copy()
+        toks = gpu.decode(6, GREEDY).copy()
+        outs[dma] = (first, toks, gpu.logits(rounded=False).copy())
+    np.testing.assert_array_equal(outs[1][0], outs[0][0])
+    np.testing.assert_array_equal(outs[1][1], outs[0][1])
+    np.testing.assert_array_equal(outs[1][2], outs[0][2])
+    ref.forward(ids); ref.sample(GREEDY)
+    for step in range(6):                       # teacher-forced by the GPU's ids: the oracle's logits at the same state
+        ref.forward(outs[1][1][step - 1][:, None] if step else outs[1][0][:, None]); ref.sample(GREEDY)
+    assert rel_err(outs[1][2], ref.logits(rounded=False)) < TOL_ORACLE
+    one = synth.synth_prompt(V, 40, 5)[None, :]  # a 40-row prompt (four activation blocks on hidden <= 2048)
+    lg = {}
+    for dma in (1, 0):
+        gpu.set_option("skinny.dma", dma)
+        gpu.reset_cache(); gpu.forward(one); lg[dma] = gpu.logits(rounded=False)[:1].copy()
+    np.testing.assert_array_equal(lg[1], lg[0])

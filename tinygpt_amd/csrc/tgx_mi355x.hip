@@ -26,6 +26,7 @@
 #include "kernels/skinny_ksplit.h"
 #include "kernels/gemm_f32.h"
 #include "kernels/gemm_dma.h"
+#include "kernels/skinny_dma.h"
 #include "kernels/engine.h"
 
 using tgx::bf16_t;
@@ -174,6 +175,9 @@ struct tgx_ctx {
   // hidden > 2048 the tiled path's weight stream is faster (option prefill.skinny_hidden_max)
   int prefill_skinny_rows = 64;
   int prefill_skinny_hidden_max = 2048;
+  int skinny_dma = 1;          // option skinny.dma: products on stored 16-bit terms (two terms) run on the LDS-DMA ring kernel (kernels/skinny_dma.h) from skinny.dma_rows rows
+  int skinny_dma_rows = 17;
+  int skinny_dma_nbw = 0;      // option skinny.dma_nbw: weight blocks per wave of that kernel (0: as the panel kernel's geometry, 1 = 64-row, 2 = 128-row workgroups)
   int decode_step_rows = 64;   // option decode.step_rows: rows of a batch that share one pass over the weights in the matrix-core step (32: round 2)
   int prefill_skinny = 1;    // option prefill.skinny: 0 sends prompts of <= 32 rows through the tiled GEMMs as well
   int skinny_wgs = 256;      // option skinny.wgs: workgroups a skinny product aims for by splitting K
@@ -1332,6 +1336,32 @@ void skinny_dispatch(tgx_ctx* c, dim3 grid, int mb, int cfg, const tgx::GemmArgs
 #undef TGX_SK_L
 }
 
+// the LDS-DMA ring form of the products on stored terms (kernels/skinny_dma.h): same grid, same results
+template <int EPI>
+void skinny_dma_dispatch(tgx_ctx* c, dim3 grid, int mb, int nbw, const tgx::GemmArgs& g) {
+  const dim3 blk(256);
+  const size_t lds = tgx::skd_lds_bytes(mb, nbw);
+#define TGX_SKD_L(MB_, NBW_) hipLaunchKernelGGL((tgx::skinny_dma_kernel<DT, EPI, MB_, NBW_>), grid, blk, lds, c->stream, g)
+  TGX_DT16_SWITCH(c->dt,
+    if (nbw == 2) { if (mb == 4) TGX_SKD_L(4, 2); else if (mb == 2) TGX_SKD_L(2, 2); else TGX_SKD_L(1, 2); }
+    else { if (mb == 4) TGX_SKD_L(4, 1); else if (mb == 2) TGX_SKD_L(2, 1); else TGX_SKD_L(1, 1); })
+#undef TGX_SKD_L
+}
+template <int DT, int EPI>
+int skinny_dma_set_attr_dt(tgx_ctx* c) {
+#define TGX_SKD_A(MB_, NBW_) HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::skinny_dma_kernel<DT, EPI, MB_, NBW_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::skd_lds_bytes(MB_, NBW_)));
+  TGX_SKD_A(1, 1) TGX_SKD_A(2, 1) TGX_SKD_A(4, 1) TGX_SKD_A(1, 2) TGX_SKD_A(2, 2) TGX_SKD_A(4, 2)
+#undef TGX_SKD_A
+  return TGX_OK;
+}
+int skinny_dma_set_attrs(tgx_ctx* c) {
+  int rc;
+#define X(E) if ((rc = skinny_dma_set_attr_dt<tgx::DT_BF16, E>(c)) || (rc = skinny_dma_set_attr_dt<tgx::DT_F16, E>(c))) return rc;
+  X(tgx::GEMM_PARTIAL) X(tgx::GEMM_RESIDUAL) X(tgx::GEMM_SILU) X(tgx::GEMM_STORE)
+#undef X
+  return TGX_OK;
+}
+
 // One nn::Linear of a batched step: Y[M][N] = X[M][K] . W^T for M <= 32 activation rows, X given as 16-bit terms (asrc 0), fp32 rows
 // (1) or fp32 rows to be RMS-normalised on the way (2).  Wide products (>= ~one 64-row group per CU) run unsplit with their epilogue;
 // narrow ones (N = hidden, the QKV rows) split K over blockIdx.y into fp32 slabs — the return value is the number of slabs the caller's
@@ -1375,6 +1405,17 @@ int launch_skinny(tgx_ctx* c, const SkinnyCall& k) {
     epi = tgx::GEMM_PARTIAL;
   }
   const dim3 grid(gx, nsplit);
+  if (c->skinny_dma && k.asrc == 0 && k.nt == 2 && k.M >= c->skinny_dma_rows && k.K % 64 == 0 && (nsplit == 1 || g.k_per % 64 == 0)) {
+    const int nbw = c->skinny_dma_nbw ? c->skinny_dma_nbw : tgx::skinny_nbw(cfg);
+    const dim3 grid((k.N + 64 * nbw - 1) / (64 * nbw), nsplit);
+    switch (epi) {
+      case tgx::GEMM_PARTIAL: skinny_dma_dispatch<tgx::GEMM_PARTIAL>(c, grid, mb, nbw, g); return nsplit;
+      case tgx::GEMM_RESIDUAL: skinny_dma_dispatch<tgx::GEMM_RESIDUAL>(c, grid, mb, nbw, g); return nsplit;
+      case tgx::GEMM_SILU: skinny_dma_dispatch<tgx::GEMM_SILU>(c, grid, mb, nbw, g); return nsplit;
+      case tgx::GEMM_STORE: skinny_dma_dispatch<tgx::GEMM_STORE>(c, grid, mb, nbw, g); return nsplit;
+      default: break;
+    }
+  }
   bool launched = false;
 #define X(E, N, A) if (!launched && epi == E && k.nt == N && k.asrc == A) { skinny_dispatch<E, N, A>(c, grid, mb, cfg, g); launched = true; }
   TGX_SKINNY_COMBOS(X)
@@ -1506,12 +1547,13 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
     SkinnyCall o;
     o.epi = tgx::GEMM_RESIDUAL; o.W = w.wo; o.C = r.x; o.ldc = H; o.M = M; o.N = H; o.K = qd; o.nt = 2; o.asrc = 1; o.a_f32 = r.attn; o.lda = qd;
     const int os = launch_skinny(c, o);
-    const bool gu_ks = ksplit_ok(c, M, 2 * I, H);
+    const bool gu_dma = c->skinny_dma && M >= c->skinny_dma_rows && M > 16 && H % 64 == 0;     // 17+ rows: the LDS-DMA ring kernel on stored terms (16.8 vs 19.5 us at 32 rows)
+    const bool gu_ks = !gu_dma && ksplit_ok(c, M, 2 * I, H);
     int gs = 1;
     if (gu_ks) {     // {sum slabs, residual, RMSNorm, 16-bit terms} in one row-wise launch, then the barrier-free wide product
       launch_norm_terms(c, r.x, w.post_norm, M, H, os);
       launch_ksplit(c, tgx::GEMM_SILU, w.wgu, nullptr, 2 * I, M, 2 * I, H);
-    } else if (c->skinny_terms || terms) {
+    } else if (c->skinny_terms || terms || gu_dma) {
       // 17-32 rows (round 3): {sum slabs, residual, RMSNorm, 16-bit terms} ONCE per layer in the row-wise launch that replaces reduce_rows; the panel
       // kernel then stages stored terms instead of normalising and splitting every 256-k panel in each of its 256 workgroups
       launch_norm_terms(c, r.x, w.post_norm, M, H, os);
@@ -2176,6 +2218,7 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_PARTIAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_PARTIAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   if ((rc = skinny_set_attrs(c))) return rc;
+  if ((rc = skinny_dma_set_attrs(c))) return rc;
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 128, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<128>()));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_F16, 128, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<128>()));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_lds_bytes<128>()));
@@ -2571,6 +2614,9 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.direct_g")) { if (value != 0 && value != 1 && value != -1 && value != -2 && value != -4) return set_err(c, TGX_ERR_INVALID, "attn.direct_g is 0, 1 or -1 / -2 / -4"); drop_step_graphs(c); c->attn_direct_g = value; return TGX_OK; }
   if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "prefill.defer_reduce")) { c->defer_reduce = value != 0; return TGX_OK; }
+  if (!strcmp(key, "skinny.dma")) { drop_step_graphs(c); c->skinny_dma = value != 0; return TGX_OK; }
+  if (!strcmp(key, "skinny.dma_nbw")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.dma_nbw is 0, 1 or 2"); drop_step_graphs(c); c->skinny_dma_nbw = value; return TGX_OK; }
+  if (!strcmp(key, "skinny.dma_rows")) { if (value < 1) return set_err(c, TGX_ERR_INVALID, "skinny.dma_rows is a row count"); drop_step_graphs(c); c->skinny_dma_rows = value; return TGX_OK; }
   if (!strcmp(key, "skinny.terms")) { drop_step_graphs(c); c->skinny_terms = value; return TGX_OK; }     // 2: the QKV and lm_head products of 17-32-row batches as well (experiment)
   if (!strcmp(key, "skinny.ksplit")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.ksplit must be 0, 1 (<= 16 rows) or 2 (<= 32 rows)"); c->skinny_ksplit = value; return TGX_OK; }
   if (!strcmp(key, "prefill.gemm_tm")) { c->gemm_tm = value; return TGX_OK; }

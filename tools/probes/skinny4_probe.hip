@@ -8,6 +8,7 @@
 #include <vector>
 #include "kernels/common.h"
 #include "kernels/skinny.h"
+#include "kernels/skinny_dma.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 template <int MB, int CFG, int EPI>
 static void run(const char* what, int M, int N, int K, int nsplit, const tgx::bf16_t* W, const tgx::bf16_t* ah, const tgx::bf16_t* al, tgx::bf16_t* oh, tgx::bf16_t* ol, float* part) {
@@ -27,6 +28,24 @@ static void run(const char* what, int M, int N, int K, int nsplit, const tgx::bf
   }
   printf("DIS=%2d %-8s MB %d cfg %d M %2d N %5d K %4d x%2d: %6.1f us  (%.2f TB/s of weights)\n", TGX_SKINNY_DIS, what, MB, CFG, M, N, K, nsplit, best * 1e3, (double)N * K * 2 / (best * 1e-3) / 1e12);
 }
+template <int MB, int NBW, int EPI>
+static void run_dma(const char* what, int M, int N, int K, int nsplit, const tgx::bf16_t* W, const tgx::bf16_t* ah, const tgx::bf16_t* al, tgx::bf16_t* oh, tgx::bf16_t* ol, float* part) {
+  tgx::GemmArgs g{};
+  g.A_hi = ah; g.A_lo = al; g.inter = N / 2; g.out_hi = oh; g.out_lo = ol; g.B = W; g.M = M; g.N = N; g.K = K; g.ldc = N;
+  if (EPI == tgx::GEMM_PARTIAL) { g.part = part; g.nsplit = nsplit; g.k_per = K / nsplit; }
+  auto kern = tgx::skinny_dma_kernel<tgx::DT_BF16, EPI, MB, NBW>;
+  const size_t lds = tgx::skd_lds_bytes(MB, NBW);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int r = 0; r < 20; r++) {
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(kern, dim3((N + 64 * NBW - 1) / (64 * NBW), nsplit), dim3(256), lds, 0, g);
+    CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r >= 3 && ms < best) best = ms;
+  }
+  printf("DMA ring %-8s MB %d nbw %d M %2d N %5d K %4d x%2d: %6.1f us  (%.2f TB/s of weights)  depth %d, %zu KB of LDS\n", what, MB, NBW, M, N, K, nsplit, best * 1e3, (double)N * K * 2 / (best * 1e-3) / 1e12, tgx::skd_depth(MB, NBW), lds / 1024);
+}
 int main() {
   const size_t NK = (size_t)16384 * 2048;
   std::vector<unsigned short> hw(NK);
@@ -45,6 +64,15 @@ int main() {
     run<4, 2, tgx::GEMM_SILU>("gate_up", 64, 16384, 2048, 1, W[(rot++) % NC], ah, al, oh, ol, part);
     run<2, 0, tgx::GEMM_PARTIAL>("down", 32, 2048, 8192, 16, W[(rot++) % NC], ah, al, oh, ol, part);
     run<4, 0, tgx::GEMM_PARTIAL>("down", 64, 2048, 8192, 16, W[(rot++) % NC], ah, al, oh, ol, part);
+#if TGX_SKINNY_DIS == 0
+    run_dma<1, 1, tgx::GEMM_SILU>("gate_up", 16, 16384, 2048, 1, W[(rot++) % NC], ah, al, oh, ol, part);
+    run_dma<2, 1, tgx::GEMM_SILU>("gate_up", 32, 16384, 2048, 1, W[(rot++) % NC], ah, al, oh, ol, part);
+    run_dma<4, 1, tgx::GEMM_SILU>("gate_up", 64, 16384, 2048, 1, W[(rot++) % NC], ah, al, oh, ol, part);
+    run_dma<4, 2, tgx::GEMM_SILU>("gate_up", 64, 16384, 2048, 1, W[(rot++) % NC], ah, al, oh, ol, part);
+    run_dma<2, 1, tgx::GEMM_PARTIAL>("down", 32, 2048, 8192, 16, W[(rot++) % NC], ah, al, oh, ol, part);
+    run_dma<4, 1, tgx::GEMM_PARTIAL>("down", 64, 2048, 8192, 16, W[(rot++) % NC], ah, al, oh, ol, part);
+    run_dma<4, 1, tgx::GEMM_PARTIAL>("down", 64, 2048, 8192, 8, W[(rot++) % NC], ah, al, oh, ol, part);
+#endif
   }
   return 0;
 }
