@@ -738,6 +738,8 @@ def test_lds_dma_ring_skinny_kernel_is_bit_identical_to_the_panel_kernel(family,
     gpu, ref, g = make_pair(family, hip, oracle_lib, max_batch=rows, dtype=dtype, max_ctx=64)
     V = gpu.desc.vocab
     ids = np.stack([synth.synth_prompt(V, 11, 70 + b) for b in range(rows)])
+    gpu.set_option("skinny.terms", 2)           # both runs prepare the QKV / lm_head activations of 17-32-row steps as stored terms (with skinny.dma on that is the default)
+    gpu.set_option("skinny.dma_oproj", 0)       # and both take the attention rows as fp32 (the terms-out form of the attention exists for the DMA kernel only)
     outs = {}
     for dma in (1, 0):
         gpu.set_option("skinny.dma", dma)

@@ -57,6 +57,9 @@ struct AttnArgs {
   const float* raw_part;  // [raw_nsplit][raw_rows][qd + 2 kvd]
   const void* raw_bias;   // [qd + 2 kvd] storage dtype or nullptr (with raw_part only)
   int raw_nsplit, raw_rows;
+  // direct MFMA form: when set, the normalised rows leave as exact 16-bit split terms (row stride q_stride) — the o_proj product of a batched step then takes
+  // stored terms (kernels/skinny_dma.h) instead of splitting fp32 rows while staging
+  unsigned short *out_hi, *out_lo;
 };
 
 template <int HD>

@@ -39,26 +39,28 @@ __device__ __forceinline__ void dma_1k_nt(const void* gsrc, unsigned lds_dst) { 
 }
 
 constexpr int SKD_KS = 64;                               // k per stage: 128-byte rows
-__host__ __device__ constexpr int skd_stage_bytes(int mb, int nbw) { return (2 * mb * 16 + 4 * 16 * nbw) * SKD_KS * 2; }
+__host__ __device__ constexpr int skd_xrows(int mb, int nt) { return (nt * mb * 16 + 31) / 32 * 32; }      // rows of a stage's activation image: whole 1-KiB pieces per wave
+__host__ __device__ constexpr int skd_stage_bytes(int mb, int nbw, int nt = 2) { return (skd_xrows(mb, nt) + 4 * 16 * nbw) * SKD_KS * 2; }
 // ring depth, measured (tools/probes/skinny4_probe.hip, -DTGX_SKD_DEPTH_MAX=n; us at depth 3 / 4 / 5 / 6): gate_up 16 rows 17.8 / 15.6 / 15.4 / 15.4, 32 rows
 // 18.5 / 16.8 / 17.0 / 17.3, 64 rows 22.1 / 22.1 / 22.3 / 22.7; down (16 K splits of 512 k) 32 rows 11.0 / 11.5 / 12.2 / 13.4, 64 rows 14.6 / 16.5 / 17.7 / 18.3 —
 // short K ranges pay the ring's fill, and a shallow ring leaves room for a second workgroup per CU: 4 stages, 3 at four activation blocks
 #ifndef TGX_SKD_DEPTH_MAX
 #define TGX_SKD_DEPTH_MAX 0
 #endif
-__host__ __device__ constexpr int skd_depth(int mb, int nbw) { return TGX_SKD_DEPTH_MAX ? ((144 * 1024) / skd_stage_bytes(mb, nbw) > TGX_SKD_DEPTH_MAX ? TGX_SKD_DEPTH_MAX : (144 * 1024) / skd_stage_bytes(mb, nbw)) : (mb >= 4 ? 3 : 4); }
-__host__ __device__ constexpr size_t skd_lds_bytes(int mb, int nbw) { return (size_t)skd_depth(mb, nbw) * skd_stage_bytes(mb, nbw); }
+__host__ __device__ constexpr int skd_depth(int mb, int nbw, int nt = 2) { return TGX_SKD_DEPTH_MAX ? ((144 * 1024) / skd_stage_bytes(mb, nbw, nt) > TGX_SKD_DEPTH_MAX ? TGX_SKD_DEPTH_MAX : (144 * 1024) / skd_stage_bytes(mb, nbw, nt)) : (mb >= 4 ? 3 : 4); }
+__host__ __device__ constexpr size_t skd_lds_bytes(int mb, int nbw, int nt = 2) { return (size_t)skd_depth(mb, nbw, nt) * skd_stage_bytes(mb, nbw, nt); }
 
-// MB = 16-row activation blocks (1, 2, 4), NBW = 16-row weight blocks per wave (1: 64-row workgroups, 2: 128-row workgroups); two terms (hi, lo).
+// MB = 16-row activation blocks (1, 2, 4), NBW = 16-row weight blocks per wave (1: 64-row workgroups, 2: 128-row workgroups); NT = terms per activation
+// (2: hi, lo; 3: + A_lo2, the QKV product whose K / V results are rounded to 16 bits again).
 // Needs K % 64 == 0 and, for split products, k_per % 64 == 0 (the launcher falls back to skinny.h otherwise).  grid = (N / (64 NBW), K splits).
-template <int DT, int EPI, int MB, int NBW>
+template <int DT, int EPI, int MB, int NBW, int NT = 2>
 __global__ __launch_bounds__(256) void skinny_dma_kernel(const GemmArgs a) {
-  constexpr int KS = SKD_KS, NT = 2, WR = 16 * NBW, XROWS = NT * MB * 16;
+  constexpr int KS = SKD_KS, WR = 16 * NBW, XROWS = skd_xrows(MB, NT);
   constexpr int XPW = XROWS / 8 / 4;                   // activation pieces per wave and stage (a 1-KiB piece = 8 rows of 128 bytes)
   constexpr int WPW = WR / 8;                          // weight pieces per wave and stage
   constexpr int PPW = XPW + WPW;
-  constexpr int D = skd_depth(MB, NBW);
-  constexpr int STAGE = skd_stage_bytes(MB, NBW);
+  constexpr int D = skd_depth(MB, NBW, NT);
+  constexpr int STAGE = skd_stage_bytes(MB, NBW, NT);
   static_assert(XROWS % 32 == 0 && D >= 3, "stage geometry");
   extern __shared__ __attribute__((aligned(1024))) unsigned char skd_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,9 +78,9 @@ __global__ __launch_bounds__(256) void skinny_dma_kernel(const GemmArgs a) {
 #pragma unroll
   for (int j = 0; j < XPW; j++) {
     const int piece = wv + 4 * j, row = piece * 8 + prow;             // row of the stage's activation image: term t, activation row m
-    const int t = row / (MB * 16), m = row - t * (MB * 16);
+    const int t = min(row / (MB * 16), NT - 1), m = row - t * (MB * 16);                  // (rows of the padding beyond NT x MB x 16: copies, never read)
     const int chunk = pchunk ^ ((row >> 1) & 7);
-    src[j] = (t == 0 ? a.A_hi : a.A_lo) + (size_t)min(m, a.M - 1) * a.K + chunk * 8;      // rows past M: clamped copies, masked at the store
+    src[j] = (t == 0 ? a.A_hi : (t == 1 ? a.A_lo : a.A_lo2)) + (size_t)min(m, a.M - 1) * a.K + chunk * 8;      // rows past M: clamped copies, masked at the store
     dst[j] = (unsigned)(piece * 1024);
   }
 #pragma unroll

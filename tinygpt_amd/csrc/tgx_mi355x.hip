@@ -174,9 +174,11 @@ struct tgx_ctx {
   // Llama-3.2-3B S = 48 3.54 / 3.33, Mistral-7B 6.76 / 5.52 — four blocks put 8 MFMAs + 9 LDS fragment reads behind every 32 k of a weight row: at
   // hidden > 2048 the tiled path's weight stream is faster (option prefill.skinny_hidden_max)
   int prefill_skinny_rows = 64;
-  int prefill_skinny_hidden_max = 2048;
+  int prefill_skinny_hidden_max = 8192;   // (the 2048 limit of the panel-kernel form is gone with the LDS-DMA ring kernel: Llama-3.2-3B S = 48 3.12 -> 2.98 ms, Mistral-7B 5.36 / 5.38)
   int skinny_dma = 1;          // option skinny.dma: products on stored 16-bit terms (two terms) run on the LDS-DMA ring kernel (kernels/skinny_dma.h) from skinny.dma_rows rows
-  int skinny_dma_rows = 17;
+  int skinny_dma_rows = 1;
+  int skinny_dma_oproj = 1;    // option skinny.dma_oproj: the matrix-core attention of a batched step writes 16-bit terms, the o_proj product takes that kernel
+  int skinny_dma_qkv = 1;      // option skinny.dma_qkv: batches of 17-32 rows prepare the QKV / lm_head activations as stored terms as well, so that those products take that kernel
   int skinny_dma_nbw = 0;      // option skinny.dma_nbw: weight blocks per wave of that kernel (0: as the panel kernel's geometry, 1 = 64-row, 2 = 128-row workgroups)
   int decode_step_rows = 64;   // option decode.step_rows: rows of a batch that share one pass over the weights in the matrix-core step (32: round 2)
   int prefill_skinny = 1;    // option prefill.skinny: 0 sends prompts of <= 32 rows through the tiled GEMMs as well
@@ -1337,19 +1339,19 @@ void skinny_dispatch(tgx_ctx* c, dim3 grid, int mb, int cfg, const tgx::GemmArgs
 }
 
 // the LDS-DMA ring form of the products on stored terms (kernels/skinny_dma.h): same grid, same results
-template <int EPI>
+template <int EPI, int NT = 2>
 void skinny_dma_dispatch(tgx_ctx* c, dim3 grid, int mb, int nbw, const tgx::GemmArgs& g) {
   const dim3 blk(256);
-  const size_t lds = tgx::skd_lds_bytes(mb, nbw);
-#define TGX_SKD_L(MB_, NBW_) hipLaunchKernelGGL((tgx::skinny_dma_kernel<DT, EPI, MB_, NBW_>), grid, blk, lds, c->stream, g)
+  const size_t lds = tgx::skd_lds_bytes(mb, nbw, NT);
+#define TGX_SKD_L(MB_, NBW_) hipLaunchKernelGGL((tgx::skinny_dma_kernel<DT, EPI, MB_, NBW_, NT>), grid, blk, lds, c->stream, g)
   TGX_DT16_SWITCH(c->dt,
     if (nbw == 2) { if (mb == 4) TGX_SKD_L(4, 2); else if (mb == 2) TGX_SKD_L(2, 2); else TGX_SKD_L(1, 2); }
     else { if (mb == 4) TGX_SKD_L(4, 1); else if (mb == 2) TGX_SKD_L(2, 1); else TGX_SKD_L(1, 1); })
 #undef TGX_SKD_L
 }
-template <int DT, int EPI>
+template <int DT, int EPI, int NT = 2>
 int skinny_dma_set_attr_dt(tgx_ctx* c) {
-#define TGX_SKD_A(MB_, NBW_) HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::skinny_dma_kernel<DT, EPI, MB_, NBW_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::skd_lds_bytes(MB_, NBW_)));
+#define TGX_SKD_A(MB_, NBW_) HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::skinny_dma_kernel<DT, EPI, MB_, NBW_, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::skd_lds_bytes(MB_, NBW_, NT)));
   TGX_SKD_A(1, 1) TGX_SKD_A(2, 1) TGX_SKD_A(4, 1) TGX_SKD_A(1, 2) TGX_SKD_A(2, 2) TGX_SKD_A(4, 2)
 #undef TGX_SKD_A
   return TGX_OK;
@@ -1359,6 +1361,7 @@ int skinny_dma_set_attrs(tgx_ctx* c) {
 #define X(E) if ((rc = skinny_dma_set_attr_dt<tgx::DT_BF16, E>(c)) || (rc = skinny_dma_set_attr_dt<tgx::DT_F16, E>(c))) return rc;
   X(tgx::GEMM_PARTIAL) X(tgx::GEMM_RESIDUAL) X(tgx::GEMM_SILU) X(tgx::GEMM_STORE)
 #undef X
+  if ((rc = skinny_dma_set_attr_dt<tgx::DT_BF16, tgx::GEMM_PARTIAL, 3>(c)) || (rc = skinny_dma_set_attr_dt<tgx::DT_BF16, tgx::GEMM_STORE, 3>(c))) return rc;   // three terms: the bf16 QKV product
   return TGX_OK;
 }
 
@@ -1405,6 +1408,22 @@ int launch_skinny(tgx_ctx* c, const SkinnyCall& k) {
     epi = tgx::GEMM_PARTIAL;
   }
   const dim3 grid(gx, nsplit);
+  if (c->skinny_dma && k.asrc == 0 && k.nt == 3 && k.a_lo2 && c->dt == tgx::DT_BF16 && k.M >= c->skinny_dma_rows && k.K % 64 == 0 && (nsplit == 1 || g.k_per % 64 == 0) &&
+      (epi == tgx::GEMM_PARTIAL || epi == tgx::GEMM_STORE)) {
+    const int nbw = c->skinny_dma_nbw ? c->skinny_dma_nbw : tgx::skinny_nbw(cfg);
+    const dim3 grid((k.N + 64 * nbw - 1) / (64 * nbw), nsplit);
+    const dim3 blk(256);
+    const size_t lds = tgx::skd_lds_bytes(mb, nbw, 3);
+#define TGX_SKD3(E_) do { if (nbw == 2) { if (mb == 4) hipLaunchKernelGGL((tgx::skinny_dma_kernel<tgx::DT_BF16, E_, 4, 2, 3>), grid, blk, lds, c->stream, g); \
+                                          else if (mb == 2) hipLaunchKernelGGL((tgx::skinny_dma_kernel<tgx::DT_BF16, E_, 2, 2, 3>), grid, blk, lds, c->stream, g); \
+                                          else hipLaunchKernelGGL((tgx::skinny_dma_kernel<tgx::DT_BF16, E_, 1, 2, 3>), grid, blk, lds, c->stream, g); } \
+                          else { if (mb == 4) hipLaunchKernelGGL((tgx::skinny_dma_kernel<tgx::DT_BF16, E_, 4, 1, 3>), grid, blk, lds, c->stream, g); \
+                                 else if (mb == 2) hipLaunchKernelGGL((tgx::skinny_dma_kernel<tgx::DT_BF16, E_, 2, 1, 3>), grid, blk, lds, c->stream, g); \
+                                 else hipLaunchKernelGGL((tgx::skinny_dma_kernel<tgx::DT_BF16, E_, 1, 1, 3>), grid, blk, lds, c->stream, g); } } while (0)
+    if (epi == tgx::GEMM_PARTIAL) TGX_SKD3(tgx::GEMM_PARTIAL); else TGX_SKD3(tgx::GEMM_STORE);
+#undef TGX_SKD3
+    return nsplit;
+  }
   if (c->skinny_dma && k.asrc == 0 && k.nt == 2 && k.M >= c->skinny_dma_rows && k.K % 64 == 0 && (nsplit == 1 || g.k_per % 64 == 0)) {
     const int nbw = c->skinny_dma_nbw ? c->skinny_dma_nbw : tgx::skinny_nbw(cfg);
     const dim3 grid((k.N + 64 * nbw - 1) / (64 * nbw), nsplit);
@@ -1501,7 +1520,7 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
   const bool lm_ks = ksplit_ok(c, M, V, H);
   // 33-64 rows (round 3): four activation blocks; every RMSNorm-fused product takes its activations as 16-bit terms prepared once per product by the
   // row-wise launch that also adds the pending split-K residual (the RMSNorm-on-the-way staging runs out of registers at four blocks)
-  const bool terms = M > 32 || (c->skinny_terms >= 2 && M > 16);
+  const bool terms = M > 32 || ((c->skinny_terms >= 2 || (c->skinny_dma && c->skinny_dma_qkv && M >= c->skinny_dma_rows && H % 64 == 0)) && M > 16);
   int pend = 0;            // terms form: slabs of the previous layer's down product not yet added to the rows
   // the rows start as embedding rows (the finalize of the previous step gathered them): their sums of squares for the first RMSNorm
   if (!terms) hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
@@ -1519,6 +1538,8 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
     // (option attn.raw_fuse): one launch per layer less
     const bool raw_fuse = c->attn_raw_fuse && c->attn_direct && attn_batch_on_mfma(c, M) && !(c->debug_skip & 1) &&
                           d.heads / d.kv_heads <= tgx::ATTN_RAW_GMAX && !(d.qk_norm && hd != 128);
+    // the matrix-core attention of the step leaves its rows as 16-bit terms for the o_proj product (option skinny.dma_oproj)
+    const bool attn_terms = c->skinny_dma && c->skinny_dma_oproj && c->attn_direct && attn_batch_on_mfma(c, M) && !(c->debug_skip & 1) && M >= c->skinny_dma_rows && qd % 64 == 0;
     if (!raw_fuse) {
       tgx::RopeRowsArgs a{};
       if (qs > 1) { a.part = c->ws_part; a.nsplit = qs; a.bias = w.bqkv; } else a.QKV = c->ws_out;
@@ -1540,12 +1561,14 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
         a.raw_rows = M; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.eps = d.norm_eps;
         a.q_norm_w = d.qk_norm ? w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? w.k_norm : nullptr;
       }
+      if (attn_terms) { a.out_hi = c->ws_ah; a.out_lo = c->ws_al; }
       const int fold = c->attn_fold; c->attn_fold = 0;          // the o_proj product here reads the merged output
       launch_attn(c, a, M);
       c->attn_fold = fold;
     }
     SkinnyCall o;
     o.epi = tgx::GEMM_RESIDUAL; o.W = w.wo; o.C = r.x; o.ldc = H; o.M = M; o.N = H; o.K = qd; o.nt = 2; o.asrc = 1; o.a_f32 = r.attn; o.lda = qd;
+    if (attn_terms) { o.asrc = 0; o.a_hi = c->ws_ah; o.a_lo = c->ws_al; o.a_f32 = nullptr; }
     const int os = launch_skinny(c, o);
     const bool gu_dma = c->skinny_dma && M >= c->skinny_dma_rows && M > 16 && H % 64 == 0;     // 17+ rows: the LDS-DMA ring kernel on stored terms (16.8 vs 19.5 us at 32 rows)
     const bool gu_ks = !gu_dma && ksplit_ok(c, M, 2 * I, H);
@@ -2615,6 +2638,8 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "prefill.defer_reduce")) { c->defer_reduce = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.dma")) { drop_step_graphs(c); c->skinny_dma = value != 0; return TGX_OK; }
+  if (!strcmp(key, "skinny.dma_oproj")) { drop_step_graphs(c); c->skinny_dma_oproj = value != 0; return TGX_OK; }
+  if (!strcmp(key, "skinny.dma_qkv")) { drop_step_graphs(c); c->skinny_dma_qkv = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.dma_nbw")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.dma_nbw is 0, 1 or 2"); drop_step_graphs(c); c->skinny_dma_nbw = value; return TGX_OK; }
   if (!strcmp(key, "skinny.dma_rows")) { if (value < 1) return set_err(c, TGX_ERR_INVALID, "skinny.dma_rows is a row count"); drop_step_graphs(c); c->skinny_dma_rows = value; return TGX_OK; }
   if (!strcmp(key, "skinny.terms")) { drop_step_graphs(c); c->skinny_terms = value; return TGX_OK; }     // 2: the QKV and lm_head products of 17-32-row batches as well (experiment)
