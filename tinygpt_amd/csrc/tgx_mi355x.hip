@@ -1520,7 +1520,7 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
   const bool lm_ks = ksplit_ok(c, M, V, H);
   // 33-64 rows (round 3): four activation blocks; every RMSNorm-fused product takes its activations as 16-bit terms prepared once per product by the
   // row-wise launch that also adds the pending split-K residual (the RMSNorm-on-the-way staging runs out of registers at four blocks)
-  const bool terms = M > 32 || ((c->skinny_terms >= 2 || (c->skinny_dma && c->skinny_dma_qkv && M >= c->skinny_dma_rows && H % 64 == 0)) && M > 16);
+  const bool terms = M > 32 || ((c->skinny_terms >= 2 || (c->skinny_dma && c->skinny_dma_qkv && M >= c->skinny_dma_rows && H % 64 == 0)) && M > (c->skinny_dma_qkv >= 2 ? 4 : 16));
   int pend = 0;            // terms form: slabs of the previous layer's down product not yet added to the rows
   // the rows start as embedding rows (the finalize of the previous step gathered them): their sums of squares for the first RMSNorm
   if (!terms) hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
@@ -2639,7 +2639,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.defer_reduce")) { c->defer_reduce = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.dma")) { drop_step_graphs(c); c->skinny_dma = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.dma_oproj")) { drop_step_graphs(c); c->skinny_dma_oproj = value != 0; return TGX_OK; }
-  if (!strcmp(key, "skinny.dma_qkv")) { drop_step_graphs(c); c->skinny_dma_qkv = value != 0; return TGX_OK; }
+  if (!strcmp(key, "skinny.dma_qkv")) { drop_step_graphs(c); c->skinny_dma_qkv = value; return TGX_OK; }     // 2: batches of 5-16 rows as well (experiment)
   if (!strcmp(key, "skinny.dma_nbw")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.dma_nbw is 0, 1 or 2"); drop_step_graphs(c); c->skinny_dma_nbw = value; return TGX_OK; }
   if (!strcmp(key, "skinny.dma_rows")) { if (value < 1) return set_err(c, TGX_ERR_INVALID, "skinny.dma_rows is a row count"); drop_step_graphs(c); c->skinny_dma_rows = value; return TGX_OK; }
   if (!strcmp(key, "skinny.terms")) { drop_step_graphs(c); c->skinny_terms = value; return TGX_OK; }     // 2: the QKV and lm_head products of 17-32-row batches as well (experiment)
