@@ -85,7 +85,17 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(float* X, const bf16
     if (part) {
       const float* p = part + (size_t)blockIdx.x * H + 8 * c;
       f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
-      for (int z = 0; z < nsplit; z++) {
+      int z = 0;
+      for (; z + 8 <= nsplit; z += 8) {          // eight slabs in flight together (a batched step has one workgroup per row: the loop was a chain of L2 round trips); summed in z order
+        f32x4 a0[8], a1[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a0[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(z + u) * slab); a1[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(z + u) * slab + 4); }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+          for (int t = 0; t < 4; t++) { s0[t] += a0[u][t]; s1[t] += a1[u][t]; }
+      }
+      for (; z < nsplit; z++) {
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (size_t)z * slab), a1 = *reinterpret_cast<const f32x4*>(p + (size_t)z * slab + 4);
 #pragma unroll
         for (int t = 0; t < 4; t++) { s0[t] += a0[t]; s1[t] += a1[t]; }
