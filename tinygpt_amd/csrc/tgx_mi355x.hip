@@ -178,7 +178,10 @@ struct tgx_ctx {
   int skinny_dma = 1;          // option skinny.dma: products on stored 16-bit terms (two terms) run on the LDS-DMA ring kernel (kernels/skinny_dma.h) from skinny.dma_rows rows
   int skinny_dma_rows = 1;
   int skinny_dma_oproj = 1;    // option skinny.dma_oproj: the matrix-core attention of a batched step writes 16-bit terms, the o_proj product takes that kernel
-  int skinny_dma_qkv = 1;      // option skinny.dma_qkv: batches of 17-32 rows prepare the QKV / lm_head activations as stored terms as well, so that those products take that kernel
+  // option skinny.dma_qkv: batches of up to 32 rows prepare the QKV / lm_head activations as stored terms as well (the 33-64-row form), so that the QKV product takes
+  // that kernel: 1 = from 17 rows, 2 = from 5.  Llama-3.2-1B ms/step 1 / 2: B = 5 0.898 / 0.867, 8 0.905 / 0.880, 12 0.962 / 0.939, 16 1.022 / 1.001; context 2k B = 8
+  // 1.071 / 1.050; Mistral-7B B = 8 3.587 / 3.556, B = 16 3.876 / 3.909
+  int skinny_dma_qkv = 2;
   int skinny_dma_nbw = 0;      // option skinny.dma_nbw: weight blocks per wave of that kernel (0: as the panel kernel's geometry, 1 = 64-row, 2 = 128-row workgroups)
   int decode_step_rows = 64;   // option decode.step_rows: rows of a batch that share one pass over the weights in the matrix-core step (32: round 2)
   int prefill_skinny = 1;    // option prefill.skinny: 0 sends prompts of <= 32 rows through the tiled GEMMs as well
@@ -2639,7 +2642,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.defer_reduce")) { c->defer_reduce = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.dma")) { drop_step_graphs(c); c->skinny_dma = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.dma_oproj")) { drop_step_graphs(c); c->skinny_dma_oproj = value != 0; return TGX_OK; }
-  if (!strcmp(key, "skinny.dma_qkv")) { drop_step_graphs(c); c->skinny_dma_qkv = value; return TGX_OK; }     // 2: batches of 5-16 rows as well (experiment)
+  if (!strcmp(key, "skinny.dma_qkv")) { drop_step_graphs(c); c->skinny_dma_qkv = value; return TGX_OK; }
   if (!strcmp(key, "skinny.dma_nbw")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.dma_nbw is 0, 1 or 2"); drop_step_graphs(c); c->skinny_dma_nbw = value; return TGX_OK; }
   if (!strcmp(key, "skinny.dma_rows")) { if (value < 1) return set_err(c, TGX_ERR_INVALID, "skinny.dma_rows is a row count"); drop_step_graphs(c); c->skinny_dma_rows = value; return TGX_OK; }
   if (!strcmp(key, "skinny.terms")) { drop_step_graphs(c); c->skinny_terms = value; return TGX_OK; }     // 2: the QKV and lm_head products of 17-32-row batches as well (experiment)
