@@ -57,7 +57,7 @@ struct AttnArgs {
   const float* raw_part;  // [raw_nsplit][raw_rows][qd + 2 kvd]
   const void* raw_bias;   // [qd + 2 kvd] storage dtype or nullptr (with raw_part only)
   int raw_nsplit, raw_rows;
-  // direct MFMA form: when set, the normalised rows leave as exact 16-bit split terms (row stride q_stride) — the o_proj product of a batched step then takes
+  // direct forms: when set, the normalised rows leave as exact 16-bit split terms (row stride q_stride) — the o_proj product of a batched step then takes
   // stored terms (kernels/skinny_dma.h) instead of splitting fp32 rows while staging
   unsigned short *out_hi, *out_lo;
 };
@@ -283,8 +283,17 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
       L = w == 0 ? red[0][g][HD + 1] * sw : fmaf(red[w][g][HD + 1], sw, L);
     }
     if (!head_live(g)) continue;
-    if (a.direct) {   // the only split: softmax normalisation here, straight into the o_proj input
-      a.out[blockIdx.y * a.q_stride + (size_t)head_of(g) * HD + d] = acc / L;
+    if (a.direct) {   // the only split: softmax normalisation here, straight into the o_proj input (fp32 rows, or 16-bit split terms for a batched step)
+      const size_t o = blockIdx.y * a.q_stride + (size_t)head_of(g) * HD + d;
+      if constexpr (DT != DT_F32) {
+        if (a.out_hi) {          // x = hi + lo, hi = round16(x), lo = round16(x - hi)  (prefill.h split16)
+          const float v = acc / L;
+          const E h = f32_to_elem<DT>(v);
+          a.out_hi[o] = h; a.out_lo[o] = f32_to_elem<DT>(v - elem_to_f32<DT>(h));
+          continue;
+        }
+      }
+      a.out[o] = acc / L;
       continue;
     }
     float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);

@@ -177,7 +177,7 @@ struct tgx_ctx {
   int prefill_skinny_hidden_max = 8192;   // (the 2048 limit of the panel-kernel form is gone with the LDS-DMA ring kernel: Llama-3.2-3B S = 48 3.12 -> 2.98 ms, Mistral-7B 5.36 / 5.38)
   int skinny_dma = 1;          // option skinny.dma: products on stored 16-bit terms (two terms) run on the LDS-DMA ring kernel (kernels/skinny_dma.h) from skinny.dma_rows rows
   int skinny_dma_rows = 1;
-  int skinny_dma_oproj = 1;    // option skinny.dma_oproj: the matrix-core attention of a batched step writes 16-bit terms, the o_proj product takes that kernel
+  int skinny_dma_oproj = 2;    // option skinny.dma_oproj: the matrix-core attention of a batched step writes 16-bit terms, the o_proj product takes that kernel
   // option skinny.dma_qkv: batches of up to 32 rows prepare the QKV / lm_head activations as stored terms as well (the 33-64-row form), so that the QKV product takes
   // that kernel: 1 = from 17 rows, 2 = from 5.  Llama-3.2-1B ms/step 1 / 2: B = 5 0.898 / 0.867, 8 0.905 / 0.880, 12 0.962 / 0.939, 16 1.022 / 1.001; context 2k B = 8
   // 1.071 / 1.050; Mistral-7B B = 8 3.587 / 3.556, B = 16 3.876 / 3.909
@@ -1541,8 +1541,9 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
     // (option attn.raw_fuse): one launch per layer less
     const bool raw_fuse = c->attn_raw_fuse && c->attn_direct && attn_batch_on_mfma(c, M) && !(c->debug_skip & 1) &&
                           d.heads / d.kv_heads <= tgx::ATTN_RAW_GMAX && !(d.qk_norm && hd != 128);
-    // the matrix-core attention of the step leaves its rows as 16-bit terms for the o_proj product (option skinny.dma_oproj)
-    const bool attn_terms = c->skinny_dma && c->skinny_dma_oproj && c->attn_direct && attn_batch_on_mfma(c, M) && !(c->debug_skip & 1) && M >= c->skinny_dma_rows && qd % 64 == 0;
+    // the direct-form attention of the step leaves its rows as 16-bit terms for the o_proj product (option skinny.dma_oproj: 1 = the matrix-core form only, 2 = every direct form)
+    const bool attn_terms = c->skinny_dma && c->skinny_dma_oproj && c->attn_direct && (c->skinny_dma_oproj >= 2 || attn_batch_on_mfma(c, M)) && !(c->debug_skip & 1) &&
+                            M >= c->skinny_dma_rows && qd % 64 == 0;
     if (!raw_fuse) {
       tgx::RopeRowsArgs a{};
       if (qs > 1) { a.part = c->ws_part; a.nsplit = qs; a.bias = w.bqkv; } else a.QKV = c->ws_out;
@@ -2641,7 +2642,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "prefill.defer_reduce")) { c->defer_reduce = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.dma")) { drop_step_graphs(c); c->skinny_dma = value != 0; return TGX_OK; }
-  if (!strcmp(key, "skinny.dma_oproj")) { drop_step_graphs(c); c->skinny_dma_oproj = value != 0; return TGX_OK; }
+  if (!strcmp(key, "skinny.dma_oproj")) { drop_step_graphs(c); c->skinny_dma_oproj = value; return TGX_OK; }
   if (!strcmp(key, "skinny.dma_qkv")) { drop_step_graphs(c); c->skinny_dma_qkv = value; return TGX_OK; }
   if (!strcmp(key, "skinny.dma_nbw")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "skinny.dma_nbw is 0, 1 or 2"); drop_step_graphs(c); c->skinny_dma_nbw = value; return TGX_OK; }
   if (!strcmp(key, "skinny.dma_rows")) { if (value < 1) return set_err(c, TGX_ERR_INVALID, "skinny.dma_rows is a row count"); drop_step_graphs(c); c->skinny_dma_rows = value; return TGX_OK; }
