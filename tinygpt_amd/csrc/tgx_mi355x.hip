@@ -603,7 +603,9 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
       }
     }
     int dg = 1;
-    if (!QKN && c->attn_direct_g > 0) dg = R >= 24 ? (HD == 64 ? 4 : 2) : (R >= 12 ? 2 : 1);
+    // (two heads per workgroup as soon as one workgroup per query head would exceed one round of CUs: Llama-3.2-1B B = 9 0.937 -> 0.905 ms/step, B = 10 at context 2k
+    //  1.194 -> 1.100; at 8 rows and fewer one head per workgroup stays ahead: B = 8 0.870 vs 0.895)
+    if (!QKN && c->attn_direct_g > 0) dg = R >= 24 ? (HD == 64 ? 4 : 2) : ((R >= 12 || R * a.heads > c->num_cus) ? 2 : 1);
     if (!QKN && c->attn_direct_g < 0) dg = -c->attn_direct_g;          // experiments: force
     dg = std::min(dg, gfull);
     if (dg >= 2 && gfull % dg == 0) {
