@@ -98,12 +98,12 @@ def random_mfma_desc(rng):
     vocab = int(rng.choice([257, 1001, 2048]))
     return ModelDesc(family=fam, hidden=hidden, layers=int(rng.integers(1, 3)), heads=heads, kv_heads=kv, head_dim=hd, inter=inter, vocab=vocab, max_ctx=112,
                      qkv_bias=fam == "qwen2", tied=bool(rng.integers(0, 2)), compute_dtype=str(rng.choice(["bf16", "fp16"])), norm_eps=1e-5,
-                     rope_theta=float(rng.choice([10000.0, 1000000.0])), n_positions=0, max_batch=int(rng.choice([6, 12, 17, 24, 33, 48, 64, 70])), qk_norm=fam == "qwen3")
+                     rope_theta=float(rng.choice([10000.0, 1000000.0])), n_positions=0, max_batch=int(rng.choice([6, 12, 17, 24, 33, 48, 64, 70, 100, 128])), qk_norm=fam == "qwen3")
 
 
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("TGX_FUZZ_SEEDS_BATCH", "40")))))
 def test_random_batched_steps_match_oracle(seed, oracle_lib):
-    """Round 3's batched step over random geometries and batch sizes (6 .. 70 rows: one / two / four activation blocks, K-split wide products, the
+    """Round 3's batched step over random geometries and batch sizes (6 .. 128 rows: one / two / four / eight activation blocks, K-split wide products, the
     matrix-core attention with the QKV finish in its prologue or the VALU forms by heads per kv head, 64-row + remainder passes) and prompts whose
     rows number 6 .. 100+ (skinny prompts up to 64 rows, tiled beyond): prompt logits and 4 teacher-forced graph steps against the oracle.  16-bit
     storage with std-0.05 weights: the K / V rounding-flip floor of these small models bounds the comparison at 6e-3 (see the module docstring); ids

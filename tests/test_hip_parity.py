@@ -188,13 +188,13 @@ def test_a_sequence_decodes_the_same_alone_and_inside_a_batch(family, hip, oracl
                 assert int(cur[at]) == int(toks[step + 1][0])
 
 
-@pytest.mark.parametrize("rows", [5, 8, 16, 23, 32, 37, 40, 64, 70])
+@pytest.mark.parametrize("rows", [5, 8, 16, 23, 32, 37, 40, 64, 70, 100, 128, 135])
 @pytest.mark.parametrize("family,dtype", [("llama_tiny", "bf16"), ("qwen2_tiny", "bf16"), ("qwen3_tiny", "bf16"), ("mistral_tiny", "fp16")])
 def test_batches_beyond_four_rows_run_on_the_matrix_cores(family, dtype, rows, hip, oracle_lib):
     """SURVEY.md §8(f).4's kernel half (GPTEngine.cpp:154-168 pushes any [B,1] batch through each nn::Linear): decode batches of 5+ rows
     run every Linear as ONE skinny MFMA GEMM over up to 64 rows (kernels/skinny.h: 16 / 32-row activation blocks, from 33 rows four blocks on
     stored 16-bit terms — round 3 —, K tails at hidden 192 / 320, split-K slabs for the narrow products, QKV bias, Qwen3 q/k norm, head_dim 128,
-    fp16) — 37 / 40 / 64 rows = one four-block pass, 70 rows = a 64-row pass + a 6-row pass.
+    fp16) — 37 / 40 / 64 rows = one four-block pass, 70 / 100 / 128 rows = one eight-block pass (kernels/skinny_dma.h), 135 rows = a 128-row pass + a 7-row pass.
     Every row must equal the oracle's row: greedy ids exactly over 6 steps, logits within 1e-3, cache rows within one ulp of the storage dtype."""
     gpu, ref, g = make_pair(family, hip, oracle_lib, max_batch=rows, dtype=dtype)
     p = g["prompt"]

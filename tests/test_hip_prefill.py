@@ -80,22 +80,23 @@ def test_real_layer_shapes_prefill_equals_steps(name, S, dtype):
 
 
 @pytest.mark.parametrize("fam,dtype", [("llama_tiny", "bf16"), ("qwen2_tiny", "bf16"), ("qwen3_tiny", "bf16"), ("mistral_tiny", "fp16")])
-@pytest.mark.parametrize("nb,S", [(1, 33), (1, 48), (1, 64), (2, 29), (3, 21)])
+@pytest.mark.parametrize("nb,S", [(1, 33), (1, 48), (1, 64), (2, 29), (3, 21), (1, 65), (1, 100), (1, 128), (3, 40)])
 def test_prompts_of_33_to_64_rows_on_the_skinny_kernels(fam, dtype, nb, S, oracle_lib):
-    """Prompts whose rows (batch x length) number 33..64 run every product as a skinny MFMA GEMM with FOUR 16-row activation blocks (round 3,
-    kernels/skinny.h MB = 4; option prefill.skinny_rows = 32 sends them back to the tiled split-K GEMMs): against the oracle (<= 1e-3, first id where
+    """Prompts whose rows (batch x length) number 33..64 run every product as a skinny MFMA GEMM with FOUR 16-row activation blocks, 65..128 rows with
+    EIGHT (round 3, kernels/skinny.h MB = 4, kernels/skinny_dma.h MB = 4 / 8; option prefill.skinny_rows = 32 sends them back to the tiled split-K GEMMs;
+    the fixtures' hidden sizes are below the 2048 limit of the eight-block form): against the oracle (<= 1e-3, first id where
     the gap is clear) and against the tiled path (<= 1e-3; K tails at hidden 192, QKV bias, q / k norm, head_dim 128, three-term QKV product in bf16)."""
     from oracle.oracle_ffi import OracleModel
     cfg, g = load_golden(fam)
     d = desc_from_hf_config(cfg, dtype, max_batch=nb)
-    d.max_ctx = 80
+    d.max_ctx = 136
     gpu = Model(d, product_backend()).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
     ref = OracleModel(d).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
     ids = np.stack([synth.synth_prompt(d.vocab, S, 9 + b) for b in range(nb)])
     ref.forward(ids)
     lr = ref.logits(rounded=False)
     out = {}
-    for rows in (64, 32):
+    for rows in (128, 32):
         gpu.set_option("prefill.skinny_rows", rows)
         gpu.reset_cache(); gpu.forward(ids)
         lg = gpu.logits(rounded=False).copy()
@@ -104,10 +105,10 @@ def test_prompts_of_33_to_64_rows_on_the_skinny_kernels(fam, dtype, nb, S, oracl
         out[rows] = (lg, first, gpu.decode(4, GREEDY).copy(), [gpu.read_kv(nb - 1, l) for l in range(d.layers)])
     top2 = np.sort(lr, axis=1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 2e-3 * np.abs(lr).max()
-    np.testing.assert_array_equal(out[64][1][clear], ref.sample(GREEDY)[clear])
-    assert rel_err(out[64][0], out[32][0]) < 1e-3
+    np.testing.assert_array_equal(out[128][1][clear], ref.sample(GREEDY)[clear])
+    assert rel_err(out[128][0], out[32][0]) < 1e-3
     ulp = {"bf16": 8e-3, "fp16": 1e-3}[dtype]
-    for (k1, v1), (k0, v0) in zip(out[64][3], out[32][3]):
+    for (k1, v1), (k0, v0) in zip(out[128][3], out[32][3]):
         assert rel_err(k1, k0) < ulp and rel_err(v1, v0) < ulp
 
 

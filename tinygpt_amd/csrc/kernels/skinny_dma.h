@@ -47,10 +47,13 @@ __host__ __device__ constexpr int skd_stage_bytes(int mb, int nbw, int nt = 2) {
 #ifndef TGX_SKD_DEPTH_MAX
 #define TGX_SKD_DEPTH_MAX 0
 #endif
-__host__ __device__ constexpr int skd_depth(int mb, int nbw, int nt = 2) { return TGX_SKD_DEPTH_MAX ? ((144 * 1024) / skd_stage_bytes(mb, nbw, nt) > TGX_SKD_DEPTH_MAX ? TGX_SKD_DEPTH_MAX : (144 * 1024) / skd_stage_bytes(mb, nbw, nt)) : (mb >= 4 ? 3 : 4); }
+__host__ __device__ constexpr int skd_depth(int mb, int nbw, int nt = 2) {
+  return TGX_SKD_DEPTH_MAX ? ((144 * 1024) / skd_stage_bytes(mb, nbw, nt) > TGX_SKD_DEPTH_MAX ? TGX_SKD_DEPTH_MAX : (144 * 1024) / skd_stage_bytes(mb, nbw, nt))
+                           : (3 * skd_stage_bytes(mb, nbw, nt) > 160 * 1024 ? 2 : (mb >= 4 ? 3 : 4));      // (eight blocks x three terms: a double buffer is what fits)
+}
 __host__ __device__ constexpr size_t skd_lds_bytes(int mb, int nbw, int nt = 2) { return (size_t)skd_depth(mb, nbw, nt) * skd_stage_bytes(mb, nbw, nt); }
 
-// MB = 16-row activation blocks (1, 2, 4), NBW = 16-row weight blocks per wave (1: 64-row workgroups, 2: 128-row workgroups); NT = terms per activation
+// MB = 16-row activation blocks (1, 2, 4; 8 = 128 rows, 64-row workgroups only), NBW = 16-row weight blocks per wave (1: 64-row workgroups, 2: 128-row workgroups); NT = terms per activation
 // (2: hi, lo; 3: + A_lo2, the QKV product whose K / V results are rounded to 16 bits again).
 // Needs K % 64 == 0 and, for split products, k_per % 64 == 0 (the launcher falls back to skinny.h otherwise).  grid = (N / (64 NBW), K splits).
 template <int DT, int EPI, int MB, int NBW, int NT = 2>
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void skinny_dma_kernel(const GemmArgs a) {
   constexpr int PPW = XPW + WPW;
   constexpr int D = skd_depth(MB, NBW, NT);
   constexpr int STAGE = skd_stage_bytes(MB, NBW, NT);
-  static_assert(XROWS % 32 == 0 && D >= 3, "stage geometry");
+  static_assert(XROWS % 32 == 0 && D >= 2, "stage geometry");
   extern __shared__ __attribute__((aligned(1024))) unsigned char skd_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds_base = (unsigned)(size_t)skd_lds;

@@ -173,7 +173,10 @@ struct tgx_ctx {
   // Measured ms per prompt, four-block skinny / tiled split-K: Llama-3.2-1B S = 33 1.48 / 1.51, 48 1.51 / 1.58, 64 1.57 / 1.70; Qwen2.5-0.5B S = 48 1.46 / 1.81;
   // Llama-3.2-3B S = 48 3.54 / 3.33, Mistral-7B 6.76 / 5.52 — four blocks put 8 MFMAs + 9 LDS fragment reads behind every 32 k of a weight row: at
   // hidden > 2048 the tiled path's weight stream is faster (option prefill.skinny_hidden_max)
-  int prefill_skinny_rows = 64;
+  // 65-128 rows (eight blocks, LDS-DMA ring kernel only), skinny / tiled: Llama-3.2-1B S = 65 1.65 / 1.89, 96 1.71 / 1.96, 128 1.82 / 2.05; Mistral-7B S = 96 8.01 / 7.56 -> hidden <= 2048
+  // (option prefill.skinny_hidden_max_wide)
+  int prefill_skinny_hidden_max_wide = 2048;
+  int prefill_skinny_rows = 128;
   int prefill_skinny_hidden_max = 8192;   // (the 2048 limit of the panel-kernel form is gone with the LDS-DMA ring kernel: Llama-3.2-3B S = 48 3.12 -> 2.98 ms, Mistral-7B 5.36 / 5.38)
   int skinny_dma = 1;          // option skinny.dma: products on stored 16-bit terms (two terms) run on the LDS-DMA ring kernel (kernels/skinny_dma.h) from skinny.dma_rows rows
   int skinny_dma_rows = 1;
@@ -183,7 +186,7 @@ struct tgx_ctx {
   // 1.071 / 1.050; Mistral-7B B = 8 3.587 / 3.556, B = 16 3.876 / 3.909
   int skinny_dma_qkv = 2;
   int skinny_dma_nbw = 0;      // option skinny.dma_nbw: weight blocks per wave of that kernel (0: as the panel kernel's geometry, 1 = 64-row, 2 = 128-row workgroups)
-  int decode_step_rows = 64;   // option decode.step_rows: rows of a batch that share one pass over the weights in the matrix-core step (32: round 2)
+  int decode_step_rows = 128;   // option decode.step_rows: rows of a batch that share one pass over the weights in the matrix-core step (32: round 2; 128: eight blocks on the LDS-DMA ring kernel — Llama-3.2-1B B = 128 2.99 -> 2.32 ms/step, Mistral-7B 13.25 -> 10.47)
   int prefill_skinny = 1;    // option prefill.skinny: 0 sends prompts of <= 32 rows through the tiled GEMMs as well
   int skinny_wgs = 256;      // option skinny.wgs: workgroups a skinny product aims for by splitting K
   int skinny_gu_split = 0;   // option skinny.gu_split: 0 keeps the gate_up product unsplit (siluMul in its epilogue, one launch less)
@@ -1286,7 +1289,9 @@ void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
   if (decode_mfma_ok(c)) {   // more than 4 rows: every Linear is one pass over its weights for up to 32 rows (kernels/skinny.h)
     // rows per weight pass (option decode.step_rows: 32 or 64): batches beyond 32 rows take four activation blocks per skinny product (one pass over
     // the weights for up to 64 rows) instead of two passes of two blocks
-    const int per = c->decode_step_rows;
+    // (128 rows = eight blocks exist on the LDS-DMA ring kernel only: every product must then take stored terms, i.e. the attention a direct form that writes them)
+    const bool wide_ok = c->skinny_dma && c->skinny_dma_oproj >= 2 && c->attn_direct && c->dt != tgx::DT_F32;
+    const int per = c->decode_step_rows > 64 && !wide_ok ? 64 : c->decode_step_rows;
     for (int row0 = 0; row0 < c->batch; row0 += per) launch_decode_step_mfma(c, row0, std::min(per, c->batch - row0), cfg);
     return;
   }
@@ -1350,14 +1355,15 @@ void skinny_dma_dispatch(tgx_ctx* c, dim3 grid, int mb, int nbw, const tgx::Gemm
   const size_t lds = tgx::skd_lds_bytes(mb, nbw, NT);
 #define TGX_SKD_L(MB_, NBW_) hipLaunchKernelGGL((tgx::skinny_dma_kernel<DT, EPI, MB_, NBW_, NT>), grid, blk, lds, c->stream, g)
   TGX_DT16_SWITCH(c->dt,
-    if (nbw == 2) { if (mb == 4) TGX_SKD_L(4, 2); else if (mb == 2) TGX_SKD_L(2, 2); else TGX_SKD_L(1, 2); }
+    if (mb == 8) TGX_SKD_L(8, 1);
+    else if (nbw == 2) { if (mb == 4) TGX_SKD_L(4, 2); else if (mb == 2) TGX_SKD_L(2, 2); else TGX_SKD_L(1, 2); }
     else { if (mb == 4) TGX_SKD_L(4, 1); else if (mb == 2) TGX_SKD_L(2, 1); else TGX_SKD_L(1, 1); })
 #undef TGX_SKD_L
 }
 template <int DT, int EPI, int NT = 2>
 int skinny_dma_set_attr_dt(tgx_ctx* c) {
 #define TGX_SKD_A(MB_, NBW_) HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::skinny_dma_kernel<DT, EPI, MB_, NBW_, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::skd_lds_bytes(MB_, NBW_, NT)));
-  TGX_SKD_A(1, 1) TGX_SKD_A(2, 1) TGX_SKD_A(4, 1) TGX_SKD_A(1, 2) TGX_SKD_A(2, 2) TGX_SKD_A(4, 2)
+  TGX_SKD_A(1, 1) TGX_SKD_A(2, 1) TGX_SKD_A(4, 1) TGX_SKD_A(1, 2) TGX_SKD_A(2, 2) TGX_SKD_A(4, 2) TGX_SKD_A(8, 1)
 #undef TGX_SKD_A
   return TGX_OK;
 }
@@ -1391,7 +1397,7 @@ int launch_skinny(tgx_ctx* c, const SkinnyCall& k) {
   g.norm_w = reinterpret_cast<const bf16_t*>(k.norm_w); g.ssq_part = k.ssq_in; g.ssq_ncb = tgx::SK_NCB; g.eps = c->d.norm_eps;
   g.inter = k.N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
   g.B = reinterpret_cast<const bf16_t*>(k.W); g.bias = reinterpret_cast<const bf16_t*>(k.bias); g.C = k.C; g.M = k.M; g.N = k.N; g.K = k.K; g.ldc = k.ldc;
-  const int mb = k.M > 32 ? 4 : (k.M > 16 ? 2 : 1);
+  const int mb = k.M > 64 ? 8 : (k.M > 32 ? 4 : (k.M > 16 ? 2 : 1));       // eight blocks (65-128 rows): the LDS-DMA ring kernel only
   // 128-row groups when they alone oversubscribe the chip (the lm_head), else 64-row groups: twice the workgroups for the same bytes
   int cfg = (k.N + 127) / 128 >= 2 * c->num_cus ? 2 : c->skinny_cfg_mid;
   if (c->skinny_cfg_force >= 0) cfg = c->skinny_cfg_force;
@@ -1415,10 +1421,15 @@ int launch_skinny(tgx_ctx* c, const SkinnyCall& k) {
   const dim3 grid(gx, nsplit);
   if (c->skinny_dma && k.asrc == 0 && k.nt == 3 && k.a_lo2 && c->dt == tgx::DT_BF16 && k.M >= c->skinny_dma_rows && k.K % 64 == 0 && (nsplit == 1 || g.k_per % 64 == 0) &&
       (epi == tgx::GEMM_PARTIAL || epi == tgx::GEMM_STORE)) {
-    const int nbw = c->skinny_dma_nbw ? c->skinny_dma_nbw : tgx::skinny_nbw(cfg);
+    const int nbw = mb == 8 ? 1 : (c->skinny_dma_nbw ? c->skinny_dma_nbw : tgx::skinny_nbw(cfg));
     const dim3 grid((k.N + 64 * nbw - 1) / (64 * nbw), nsplit);
     const dim3 blk(256);
     const size_t lds = tgx::skd_lds_bytes(mb, nbw, 3);
+    if (mb == 8) {
+      if (epi == tgx::GEMM_PARTIAL) hipLaunchKernelGGL((tgx::skinny_dma_kernel<tgx::DT_BF16, tgx::GEMM_PARTIAL, 8, 1, 3>), grid, blk, lds, c->stream, g);
+      else hipLaunchKernelGGL((tgx::skinny_dma_kernel<tgx::DT_BF16, tgx::GEMM_STORE, 8, 1, 3>), grid, blk, lds, c->stream, g);
+      return nsplit;
+    }
 #define TGX_SKD3(E_) do { if (nbw == 2) { if (mb == 4) hipLaunchKernelGGL((tgx::skinny_dma_kernel<tgx::DT_BF16, E_, 4, 2, 3>), grid, blk, lds, c->stream, g); \
                                           else if (mb == 2) hipLaunchKernelGGL((tgx::skinny_dma_kernel<tgx::DT_BF16, E_, 2, 2, 3>), grid, blk, lds, c->stream, g); \
                                           else hipLaunchKernelGGL((tgx::skinny_dma_kernel<tgx::DT_BF16, E_, 1, 2, 3>), grid, blk, lds, c->stream, g); } \
@@ -1430,7 +1441,7 @@ int launch_skinny(tgx_ctx* c, const SkinnyCall& k) {
     return nsplit;
   }
   if (c->skinny_dma && k.asrc == 0 && k.nt == 2 && k.M >= c->skinny_dma_rows && k.K % 64 == 0 && (nsplit == 1 || g.k_per % 64 == 0)) {
-    const int nbw = c->skinny_dma_nbw ? c->skinny_dma_nbw : tgx::skinny_nbw(cfg);
+    const int nbw = mb == 8 ? 1 : (c->skinny_dma_nbw ? c->skinny_dma_nbw : tgx::skinny_nbw(cfg));
     const dim3 grid((k.N + 64 * nbw - 1) / (64 * nbw), nsplit);
     switch (epi) {
       case tgx::GEMM_PARTIAL: skinny_dma_dispatch<tgx::GEMM_PARTIAL>(c, grid, mb, nbw, g); return nsplit;
@@ -1440,6 +1451,7 @@ int launch_skinny(tgx_ctx* c, const SkinnyCall& k) {
       default: break;
     }
   }
+  if (mb == 8) { c->launch_fault = "internal: 65-128 activation rows need the LDS-DMA ring kernel (stored terms, K a multiple of 64)"; return 1; }
   bool launched = false;
 #define X(E, N, A) if (!launched && epi == E && k.nt == N && k.asrc == A) { skinny_dispatch<E, N, A>(c, grid, mb, cfg, g); launched = true; }
   TGX_SKINNY_COMBOS(X)
@@ -1478,7 +1490,7 @@ int ensure_skinny_ws(tgx_ctx* c, int rows) {
     HIP_OK(c, hipMalloc((void**)&c->ws_part, need));
     c->ws_part_bytes = need;
   }
-  if (!c->ws_ssq) HIP_OK(c, hipMalloc((void**)&c->ws_ssq, (size_t)64 * tgx::SK_NCB * 4));
+  if (!c->ws_ssq) HIP_OK(c, hipMalloc((void**)&c->ws_ssq, (size_t)128 * tgx::SK_NCB * 4));
   return TGX_OK;
 }
 
@@ -2337,7 +2349,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     for (int row0 = 0; row0 < batch; row0 += per) {
       const int nb = std::min(per, batch - row0);
       const bool skinny = !f32_path && !c->gpt2 && c->prefill_skinny && c->d.vocab >= 128 &&     // a few rows: the weight stream of a decode step
-                          (nb * seq <= 32 ? c->prefill_skinny_rows >= nb * seq : (nb * seq <= c->prefill_skinny_rows && c->d.hidden <= c->prefill_skinny_hidden_max));
+                          (nb * seq <= 32 ? c->prefill_skinny_rows >= nb * seq : (nb * seq <= c->prefill_skinny_rows && c->d.hidden <= c->prefill_skinny_hidden_max && (nb * seq <= 64 || (c->skinny_dma && c->d.hidden <= c->prefill_skinny_hidden_max_wide))));
       int rc = skinny ? ensure_skinny_ws(c, nb * seq) : ensure_prefill_ws(c, nb * seq);
       if (rc) return rc;
       if (f32_path && (rc = ensure_f32_part(c, nb * seq))) return rc;
@@ -2659,9 +2671,10 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.f32_min_rows")) { c->prefill_f32_min_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk")) { c->gemm_splitk = value; return TGX_OK; }
   if (!strcmp(key, "prefill.qkv_balanced")) { c->qkv_balanced = value != 0; return TGX_OK; }
-  if (!strcmp(key, "decode.step_rows")) { if (value != 32 && value != 64) return set_err(c, TGX_ERR_INVALID, "decode.step_rows is 32 or 64"); drop_step_graphs(c); c->decode_step_rows = value; return TGX_OK; }
+  if (!strcmp(key, "decode.step_rows")) { if (value != 32 && value != 64 && value != 128) return set_err(c, TGX_ERR_INVALID, "decode.step_rows is 32, 64 or 128"); drop_step_graphs(c); c->decode_step_rows = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.skinny_hidden_max_wide")) { c->prefill_skinny_hidden_max_wide = value; return TGX_OK; }
   if (!strcmp(key, "prefill.skinny_hidden_max")) { c->prefill_skinny_hidden_max = value; return TGX_OK; }
-  if (!strcmp(key, "prefill.skinny_rows")) { if (value < 0 || value > 64) return set_err(c, TGX_ERR_INVALID, "prefill.skinny_rows is 0..64"); c->prefill_skinny_rows = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.skinny_rows")) { if (value < 0 || value > 128) return set_err(c, TGX_ERR_INVALID, "prefill.skinny_rows is 0..128"); c->prefill_skinny_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.hidden_256")) { c->hidden_256 = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk_dma")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "prefill.splitk_dma is 0, 1 (<= 64 rows) or 2 (always)"); c->splitk_dma = value; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_mirror")) { c->attn_mirror = value; return TGX_OK; }

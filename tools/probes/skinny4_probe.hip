@@ -54,9 +54,9 @@ int main() {
   constexpr int NC = 12;      // rotating weight copies: nothing repeats out of the Infinity Cache
   tgx::bf16_t* W[NC]; tgx::bf16_t *ah, *al, *oh, *ol; float* part;
   for (int i = 0; i < NC; i++) { CK(hipMalloc(&W[i], NK * 2)); CK(hipMemcpy(W[i], hw.data(), NK * 2, hipMemcpyHostToDevice)); }
-  CK(hipMalloc(&ah, (size_t)64 * 8192 * 2)); CK(hipMalloc(&al, (size_t)64 * 8192 * 2));
+  CK(hipMalloc(&ah, (size_t)128 * 8192 * 2)); CK(hipMalloc(&al, (size_t)128 * 8192 * 2));
   CK(hipMemcpy(ah, hw.data(), (size_t)64 * 8192 * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(al, hw.data() + 64 * 8192, (size_t)64 * 8192 * 2, hipMemcpyHostToDevice));
-  CK(hipMalloc(&oh, (size_t)64 * 8192 * 2)); CK(hipMalloc(&ol, (size_t)64 * 8192 * 2)); CK(hipMalloc(&part, (size_t)16 * 64 * 2048 * 4));
+  CK(hipMalloc(&oh, (size_t)128 * 8192 * 2)); CK(hipMalloc(&ol, (size_t)128 * 8192 * 2)); CK(hipMalloc(&part, (size_t)16 * 128 * 2048 * 4));
   int rot = 0;
   for (int rep = 0; rep < 2; rep++) {
     run<2, 0, tgx::GEMM_SILU>("gate_up", 32, 16384, 2048, 1, W[(rot++) % NC], ah, al, oh, ol, part);
@@ -72,6 +72,10 @@ int main() {
     run_dma<2, 1, tgx::GEMM_PARTIAL>("down", 32, 2048, 8192, 16, W[(rot++) % NC], ah, al, oh, ol, part);
     run_dma<4, 1, tgx::GEMM_PARTIAL>("down", 64, 2048, 8192, 16, W[(rot++) % NC], ah, al, oh, ol, part);
     run_dma<4, 1, tgx::GEMM_PARTIAL>("down", 64, 2048, 8192, 8, W[(rot++) % NC], ah, al, oh, ol, part);
+    run_dma<8, 1, tgx::GEMM_SILU>("gate_up", 128, 16384, 2048, 1, W[(rot++) % NC], ah, al, oh, ol, part);      // eight blocks (128 rows): experiment
+    run_dma<8, 2, tgx::GEMM_SILU>("gate_up", 128, 16384, 2048, 1, W[(rot++) % NC], ah, al, oh, ol, part);
+    run_dma<8, 1, tgx::GEMM_PARTIAL>("down", 128, 2048, 8192, 8, W[(rot++) % NC], ah, al, oh, ol, part);
+    run_dma<8, 1, tgx::GEMM_PARTIAL>("down", 128, 2048, 8192, 16, W[(rot++) % NC], ah, al, oh, ol, part);
 #endif
   }
   return 0;
