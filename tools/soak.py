@@ -9,7 +9,7 @@ from tinygpt_amd.ffi import GREEDY, Model
 import copy
 name = sys.argv[1] if len(sys.argv) > 1 else "llama-3.2-1b"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-d = copy.deepcopy(known_desc(name)); d.max_ctx = 4096; d.max_batch = 64
+d = copy.deepcopy(known_desc(name)); d.max_ctx = 4096; d.max_batch = 128
 m = Model(d).load_synthetic(1234, 0.02).finalize()
 bad = 0
 for S in (2048, 3200, 300, 40, 12):
@@ -56,7 +56,7 @@ for B in (12, 16):
     print(f"decode B={B} at context 1500+: 3 x 200 steps equal: {all(np.array_equal(outs[0], o) for o in outs)}", flush=True)
 # round 3, later: batches of 24-64 rows — the matrix-core attention with the QKV finish in its prologue (the workgroup's clamped K / V loads race with its own
 # store of the new row and must never be used), four-block skinny products, 64-row passes
-for B, plen in ((24, 600), (32, 600), (48, 300), (64, 600), (64, 70)):
+for B, plen in ((24, 600), (32, 600), (48, 300), (64, 600), (64, 70), (100, 200), (128, 500)):
     ids = np.stack([synth.synth_prompt(d.vocab, plen, 31 + b) for b in range(B)])
     outs = []
     t0 = time.time()
@@ -66,7 +66,7 @@ for B, plen in ((24, 600), (32, 600), (48, 300), (64, 600), (64, 70)):
     for r in (1, 2):
         if not np.array_equal(outs[0], outs[r]): bad += 1; print(f"MISMATCH decode B={B} prompt {plen} run {r}", flush=True)
     print(f"decode B={B} from context {plen}: 3 x 250 steps equal: {all(np.array_equal(outs[0], o) for o in outs)}  ({time.time() - t0:.1f} s)", flush=True)
-for S in (33, 48, 64):
+for S in (33, 48, 64, 100, 128):
     ids = synth.synth_prompt(d.vocab, S, 3)[None, :]
     ref = None
     for r in range(3 * reps):
