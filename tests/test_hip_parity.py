@@ -759,3 +759,31 @@ def test_lds_dma_ring_skinny_kernel_is_bit_identical_to_the_panel_kernel(family,
         gpu.set_option("skinny.dma", dma)
         gpu.reset_cache(); gpu.forward(one); lg[dma] = gpu.logits(rounded=False)[:1].copy()
     np.testing.assert_array_equal(lg[1], lg[0])
+
+
+@pytest.mark.parametrize("family,dtype,rows,plen", [("llama_tiny", "bf16", 6, 30), ("llama_tiny", "bf16", 12, 100), ("llama_tiny", "bf16", 26, 40), ("qwen2_tiny", "bf16", 8, 50),
+                                                     ("qwen2_tiny", "bf16", 13, 50), ("mistral_tiny", "fp16", 10, 60), ("mistral_tiny", "bf16", 30, 20)])
+def test_qkv_finish_inside_the_valu_attention_launch_is_bit_identical(family, dtype, rows, plen, hip, oracle_lib):
+    """The VALU direct attention forms of a batched step (one / two / four query heads per workgroup) finish the QKV product in their prologue as the
+    matrix-core form does (attn_decode_kernel template RAW: slab sums + bias, RoPE, cache append by the kv head's first head group, this position's k / v
+    through LDS): against the separate rope_kv_rows launch (option attn.raw_fuse = 0) the logits of 5 free-running steps and the appended cache rows
+    must be bit-identical; and the oracle's ids where its gap is clear."""
+    gpu, ref, g = make_pair(family, hip, oracle_lib, max_batch=rows, dtype=dtype, max_ctx=plen + 8)
+    V = gpu.desc.vocab
+    ids = np.stack([synth.synth_prompt(V, plen, 90 + b) for b in range(rows)])
+    gpu.set_option("attn.batch_mfma", 0)          # the VALU forms at every batch size
+    res = {}
+    for fuse in (2, 0):
+        gpu.set_option("attn.raw_fuse", fuse)
+        gpu.reset_cache(); gpu.forward(ids); first = gpu.sample(GREEDY).copy()
+        toks = gpu.decode(5, GREEDY).copy()
+        res[fuse] = (first, toks, gpu.logits(rounded=False).copy(), [gpu.read_kv(r, gpu.desc.layers - 1) for r in (0, rows - 1)])
+    np.testing.assert_array_equal(res[2][1], res[0][1])
+    np.testing.assert_array_equal(res[2][2], res[0][2])
+    for (k2, v2), (k0, v0) in zip(res[2][3], res[0][3]):
+        np.testing.assert_array_equal(k2, k0); np.testing.assert_array_equal(v2, v0)
+    ref.forward(ids); tok = ref.sample(GREEDY)
+    np.testing.assert_array_equal(res[2][0], tok)
+    for step in range(5):
+        ref.forward(res[2][1][step - 1][:, None] if step else res[2][0][:, None]); ref.sample(GREEDY)
+    assert rel_err(res[2][2], ref.logits(rounded=False)) < (TOL_ORACLE if dtype == "fp16" or family != "mistral_tiny" else 3e-3)

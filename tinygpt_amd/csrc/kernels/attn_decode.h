@@ -67,7 +67,10 @@ __device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, fl
 
 // NW = waves per workgroup: 4 for the split form; 16 for the direct form (short contexts), where ONE workgroup covers a block of
 // NW * TPW * UNR tokens (512 at head_dim 64, 256 at 128) per pass over the load -> softmax chain.
-template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool PF = false, bool FOLD = false>
+// RAW (direct forms of a batched step): the workgroup first finishes its own slice of the QKV product (AttnArgs.raw_*: slab sums + bias, q / k norm at
+// head_dim 128, RoPE, cache append by the kv head's first head group) — q, k and v of this position go through LDS, the row-wise rope_kv_rows launch
+// disappears; the same arithmetic in the same order (common.h rope_rotate_pair / head_rms_inv): bit-identical to it.  See attn_decode_mfma.h for the MFMA twin.
+template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool PF = false, bool FOLD = false, bool RAW = false>
 __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) {
   typedef elem_t<DT> E;
   constexpr int LPT = HD / 8;         // lanes per token row
@@ -76,6 +79,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
   constexpr float LOG2E = 1.4426950408889634f;
   // per wave and query head: o[HD], m, l  (m in the exp2 domain)
   __shared__ __attribute__((aligned(16))) float red[NW][G][HD + 4];
+  __shared__ __attribute__((aligned(16))) float raw_q[RAW ? G : 1][RAW ? HD : 4], raw_kv[2][RAW ? HD : 4];      // RAW: this position's q heads (fp32) and k / v rows (as the cache holds them)
 
   if (TGX_DBG(a, 4)) return;
   if (PF && (int)blockIdx.x >= a.pf.n_compute) {      // prefetch workgroup: the attention pair leaves the fabric idle
@@ -108,17 +112,72 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
     kv[r] = load_slice<DT>(kbase + (size_t)tc * HD, 0);
     vv[r] = load_slice<DT>(vbase + (size_t)tc * HD, 0);
   }
+  const int n_keys = a.pos[blockIdx.y] + 1;
+  if constexpr (RAW) {
+    constexpr int half = HD / 2;
+    const int pos = n_keys - 1, row = blockIdx.y;
+    const int qd = a.heads * HD, kvd = a.kv_heads * HD, N = qd + 2 * kvd;
+    const size_t slab = (size_t)a.raw_rows * N;
+    auto value = [&](int idx) -> float {
+      if (a.raw_qkv) return a.raw_qkv[(size_t)row * N + idx];
+      const float* src = a.raw_part + (size_t)row * N + idx;
+      float t[16];
+#pragma unroll
+      for (int z = 0; z < 16; z++) t[z] = z < a.raw_nsplit ? src[z * slab] : 0.f;    // all slabs in flight together; summed in z order
+      float v = t[0];
+#pragma unroll
+      for (int z = 1; z < 16; z++) v += t[z];
+      for (int z = 16; z < a.raw_nsplit; z++) v += src[z * slab];
+      if (a.raw_bias) v += elem_to_f32<DT>(static_cast<const E*>(a.raw_bias)[idx]);
+      return v;
+    };
+    // G + 2 head vectors (this workgroup's q heads, k, v) x HD / 2 rotation pairs; a vector's pairs are consecutive threads (half a wave at head_dim 64, a wave at 128)
+    for (int it = threadIdx.x; it < (G + 2) * half; it += 64 * NW) {
+      const int vec = it / half, p = it - vec * half;
+      const int col = vec < G ? head_of(vec) * HD : (vec == G ? qd + kvh * HD : qd + kvd + kvh * HD);
+      float x0 = value(col + p), x1 = value(col + p + half);
+      if constexpr (HD == 128) {       // Qwen3: per-head RMSNorm of q and k over head_dim (one wave = one vector here)
+        if (a.q_norm_w != nullptr && vec <= G) {
+          const float ss = wave_sum(head_sq_pair(x0, x1));
+          const float inv = head_rms_inv(ss, HD, a.eps);
+          const E* w = static_cast<const E*>(vec < G ? a.q_norm_w : a.k_norm_w);
+          x0 = elem_to_f32<DT>(w[p]) * (x0 * inv);
+          x1 = elem_to_f32<DT>(w[p + half]) * (x1 * inv);
+        }
+      }
+      if (vec <= G) {
+        const float cs = a.rope_cos[(size_t)pos * half + p], sn = a.rope_sin[(size_t)pos * half + p];
+        rope_rotate_pair(x0, x1, cs, sn);
+      }
+      if (vec < G) { raw_q[vec][p] = x0; raw_q[vec][p + half] = x1; }
+      else {
+        const E e0 = f32_to_elem<DT>(x0), e1 = f32_to_elem<DT>(x1);
+        if (g_base == 0) {                                                                // KVCacheManager::append, once per kv head
+          E* cache = const_cast<E*>(vec == G ? kbase : vbase) - part_i * 8 + (size_t)pos * HD;
+          cache[p] = e0; cache[p + half] = e1;
+        }
+        raw_kv[vec - G][p] = elem_to_f32<DT>(e0); raw_kv[vec - G][p + half] = elem_to_f32<DT>(e1);
+      }
+    }
+    __syncthreads();
+  }
   float qf[G][8];
 #pragma unroll
   for (int g = 0; g < G; g++) {
-    const f32x4* qp = reinterpret_cast<const f32x4*>(q_row + (size_t)head_of(g) * HD + part_i * 8);
+    const f32x4* qp;
+    if constexpr (RAW) qp = reinterpret_cast<const f32x4*>(&raw_q[g][part_i * 8]);
+    else qp = reinterpret_cast<const f32x4*>(q_row + (size_t)head_of(g) * HD + part_i * 8);
     const f32x4 q0 = qp[0], q1 = qp[1];
 #pragma unroll
     for (int j = 0; j < 4; j++) { qf[g][j] = q0[j]; qf[g][4 + j] = q1[j]; }
   }
-  const int n_keys = a.pos[blockIdx.y] + 1;
   const float qscale = a.scale * LOG2E;     // softmax in base 2: exp(x) = exp2(x * log2 e)
-  float knew[8];                            // QKN: this lane group's slice of the current position's key, as the cache will hold it
+  float knew[8];                            // QKN / RAW: this lane group's slice of the current position's key, as the cache will hold it
+  float vnew[8];                            // RAW: and of its value row
+  if constexpr (RAW) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) { knew[j] = raw_kv[0][part_i * 8 + j]; vnew[j] = raw_kv[1][part_i * 8 + j]; }
+  }
   if constexpr (QKN) {
     // a head row is spread over LPT lanes (8 dims each): lanes 0..LPT/2-1 hold the first half, their partners (lane ^ LPT/2) the second;
     // RoPE pairs (p, p + hd/2) therefore meet over one lane exchange
@@ -194,6 +253,12 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
       float kf[8], vf[8];
       slice_unpack<DT>(kv[r], kf);
       slice_unpack<DT>(vv[r], vf);
+      if constexpr (RAW) {
+        if (t0 + r * TPW + slot == n_keys - 1) {      // this step's own key / value: from the prologue (the cache row was stored a moment ago, possibly by another workgroup)
+#pragma unroll
+          for (int j = 0; j < 8; j++) { kf[j] = knew[j]; vf[j] = vnew[j]; }
+        }
+      }
       if constexpr (QKN) {
         const int tok = t0 + r * TPW + slot;
         if (tok == n_keys - 1) {            // the key of this step: computed above, not yet in the cache

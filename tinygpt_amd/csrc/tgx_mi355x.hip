@@ -212,7 +212,7 @@ struct tgx_ctx {
   int attn_gmax = 0;         // experiment: query heads per attention workgroup (default 2)
   int attn_direct_nw4 = 0;   // option attn.direct_nw4: contexts up to this many keys run the direct attention form with four waves per head (set in tgx_create)
   bool attn_nw4 = false;     // mode of the launches being issued / captured
-  int attn_raw_fuse = 1;     // option attn.raw_fuse: that form also finishes the QKV product (slab sums, bias, q / k norm, RoPE, cache append) in its prologue
+  int attn_raw_fuse = 2;     // option attn.raw_fuse: that form also finishes the QKV product (slab sums, bias, q / k norm, RoPE, cache append) in its prologue
   int attn_batch_la = 0;     // option attn.batch_la: K / V look-ahead registers of that form at head_dim 64 (-1: only while its workgroups number at most one per CU)
   int attn_batch_mfma = 17;  // option attn.batch_mfma: batches of this many rows and more run their direct-form attention on the matrix cores (0 = never)
   int attn_direct_g = 1;     // option attn.direct_g: 1 = heads per workgroup of the direct attention form by batch rows (2 from 12 rows, 4 from 24 at head_dim 64), 0 = always one, -g = force g
@@ -611,8 +611,16 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
     if (!QKN && c->attn_direct_g > 0) dg = R >= 24 ? (HD == 64 ? 4 : 2) : ((R >= 12 || R * a.heads > c->num_cus) ? 2 : 1);
     if (!QKN && c->attn_direct_g < 0) dg = -c->attn_direct_g;          // experiments: force
     dg = std::min(dg, gfull);
+    const bool raw = a.raw_part || a.raw_qkv;       // + the QKV product's finish in the prologue (batched step)
     if (dg >= 2 && gfull % dg == 0) {
       const dim3 gridg(a.kv_heads, R, gfull / dg), blkg(1024);
+      if constexpr (!QKN && DT != tgx::DT_F32) {
+        if (raw && !(c->debug_skip & 1)) {
+          if (dg == 2) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 16, false, false, false, true>), gridg, blkg, 0, c->stream, a);
+          else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 16, false, false, false, true>), gridg, blkg, 0, c->stream, a);
+          return;
+        }
+      }
       if constexpr (!QKN) {
         if (!(c->debug_skip & 1)) {
           if (dg == 2) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 16, false>), gridg, blkg, 0, c->stream, a);
@@ -620,6 +628,12 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
         }
       }
       return;
+    }
+    if constexpr (!QKN && DT != tgx::DT_F32) {
+      if (raw && !(c->debug_skip & 1)) {          // (every remaining direct form of a batched step is one head per workgroup: also a group size dg does not divide)
+        hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 16, false, false, false, true>), dim3(a.kv_heads, R, gfull), dim3(1024), 0, c->stream, a);
+        return;
+      }
     }
     // very short contexts (option attn.direct_nw4: keys up to which the direct form runs FOUR waves per head instead of sixteen): one pass of a 4-wave
     // workgroup covers 128 keys at head_dim 64 (64 at 128), and four records merge faster than sixteen
@@ -1553,8 +1567,8 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
     const int qs = launch_skinny(c, q);
     // the QKV product's finish (slab sums + bias, q / k norm, RoPE, cache append) inside the attention launch when that is the batched matrix-core form
     // (option attn.raw_fuse): one launch per layer less
-    const bool raw_fuse = c->attn_raw_fuse && c->attn_direct && attn_batch_on_mfma(c, M) && !(c->debug_skip & 1) &&
-                          d.heads / d.kv_heads <= tgx::ATTN_RAW_GMAX && !(d.qk_norm && hd != 128);
+    const bool raw_fuse = c->attn_raw_fuse && c->attn_direct && !(c->debug_skip & 1) && !(d.qk_norm && hd != 128) &&
+                          (attn_batch_on_mfma(c, M) ? d.heads / d.kv_heads <= tgx::ATTN_RAW_GMAX : c->attn_raw_fuse >= 2);      // 2: the VALU direct forms as well
     // the direct-form attention of the step leaves its rows as 16-bit terms for the o_proj product (option skinny.dma_oproj: 1 = the matrix-core form only, 2 = every direct form)
     const bool attn_terms = c->skinny_dma && c->skinny_dma_oproj && c->attn_direct && (c->skinny_dma_oproj >= 2 || attn_batch_on_mfma(c, M)) && !(c->debug_skip & 1) &&
                             M >= c->skinny_dma_rows && qd % 64 == 0;
@@ -2649,7 +2663,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   }
   if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
   if (!strcmp(key, "attn.direct_nw4")) { drop_step_graphs(c); c->attn_direct_nw4 = value; return TGX_OK; }
-  if (!strcmp(key, "attn.raw_fuse")) { drop_step_graphs(c); c->attn_raw_fuse = value != 0; return TGX_OK; }
+  if (!strcmp(key, "attn.raw_fuse")) { drop_step_graphs(c); c->attn_raw_fuse = value; return TGX_OK; }
   if (!strcmp(key, "attn.batch_la")) { if (value < -1 || value > 1) return set_err(c, TGX_ERR_INVALID, "attn.batch_la is -1, 0 or 1"); drop_step_graphs(c); c->attn_batch_la = value; return TGX_OK; }
   if (!strcmp(key, "attn.batch_mfma")) { if (value < 0) return set_err(c, TGX_ERR_INVALID, "attn.batch_mfma is a row count (0 = off)"); drop_step_graphs(c); c->attn_batch_mfma = value; return TGX_OK; }
   if (!strcmp(key, "attn.direct_g")) { if (value != 0 && value != 1 && value != -1 && value != -2 && value != -4) return set_err(c, TGX_ERR_INVALID, "attn.direct_g is 0, 1 or -1 / -2 / -4"); drop_step_graphs(c); c->attn_direct_g = value; return TGX_OK; }
