@@ -222,6 +222,7 @@ struct tgx_ctx {
   // captured step: the graphs are re-captured when a decode call crosses the limit.  Not for Qwen3's fused q/k norm, not for fp32 storage.
   int skinny_terms = 1;            // option skinny.terms: batches of 17-32 rows take gate_up's activations as terms prepared once per layer (round 3)
   int skinny_ksplit = 1;           // wide products (gate_up, lm_head) of the batched step on the barrier-free K-split kernel (option skinny.ksplit)
+  int defer_min_rows = 129;        // option prefill.defer_min_rows (192 until the row-wise norm launch loaded its slabs eight at a time: Llama-3.2-1B S = 160 2.51 -> 2.41 ms, 191 2.54 -> 2.46; Mistral-7B S = 160 9.90 -> 9.65)
   int defer_reduce = 1;            // split-K slabs of the prefill's N = hidden / QKV products are summed by the next row-wise kernel (option prefill.defer_reduce)
   int attn_mfma_min = -1;          // -1: the measured crossover of the geometry (attn_mfma_threshold); option attn.mfma_min overrides
   bool attn_mfma = false;
@@ -1031,7 +1032,7 @@ void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float
       if (dma_part) {}
       else if (small) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_PARTIAL, 1>), gz, blk, dyn, c->stream, g);
       else hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_PARTIAL, 2>), gz, blk, dyn, c->stream, g);
-      if (defer && c->defer_reduce && M >= 192 && (epi == tgx::GEMM_RESIDUAL || epi == tgx::GEMM_STORE)) { *defer = nsplit; }   // below ~192 rows the row-wise consumers are too few workgroups to sum 16 slabs quickly (S = 64: 1.82 -> 1.87 ms; S = 256: 2.80 -> 2.70)
+      if (defer && c->defer_reduce && M >= c->defer_min_rows && (epi == tgx::GEMM_RESIDUAL || epi == tgx::GEMM_STORE)) { *defer = nsplit; }   // with few rows the row-wise consumers are too few workgroups to sum 16 slabs quickly (round 2, S = 64: 1.82 -> 1.87 ms; S = 256: 2.80 -> 2.70)
       else if (epi == tgx::GEMM_SILU) hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_SILU>), rg, blk, 0, c->stream, g);
       else if (epi == tgx::GEMM_GELU) hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_GELU>), rg, blk, 0, c->stream, g);
       else if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_RESIDUAL>), rg, blk, 0, c->stream, g);
@@ -2668,6 +2669,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.batch_mfma")) { if (value < 0) return set_err(c, TGX_ERR_INVALID, "attn.batch_mfma is a row count (0 = off)"); drop_step_graphs(c); c->attn_batch_mfma = value; return TGX_OK; }
   if (!strcmp(key, "attn.direct_g")) { if (value != 0 && value != 1 && value != -1 && value != -2 && value != -4) return set_err(c, TGX_ERR_INVALID, "attn.direct_g is 0, 1 or -1 / -2 / -4"); drop_step_graphs(c); c->attn_direct_g = value; return TGX_OK; }
   if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.defer_min_rows")) { c->defer_min_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.defer_reduce")) { c->defer_reduce = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.dma")) { drop_step_graphs(c); c->skinny_dma = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.dma_oproj")) { drop_step_graphs(c); c->skinny_dma_oproj = value; return TGX_OK; }
