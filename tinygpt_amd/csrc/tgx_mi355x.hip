@@ -213,6 +213,7 @@ struct tgx_ctx {
   int attn_direct_nw4 = 0;   // option attn.direct_nw4: contexts up to this many keys run the direct attention form with four waves per head (set in tgx_create)
   bool attn_nw4 = false;     // mode of the launches being issued / captured
   int attn_raw_fuse = 2;     // option attn.raw_fuse: that form also finishes the QKV product (slab sums, bias, q / k norm, RoPE, cache append) in its prologue
+  int attn_batch_nw8 = 1;    // option attn.batch_nw8: eight waves per workgroup of that form while its workgroups number at most one per CU (Llama-3.2-1B B = 17 1.052 -> 1.030 ms/step, 32 1.189 -> 1.171; context 2k B = 17 1.239 -> 1.183; 2 = always: B = 64 1.518 -> 1.582)
   int attn_batch_la = 0;     // option attn.batch_la: K / V look-ahead registers of that form at head_dim 64 (-1: only while its workgroups number at most one per CU)
   int attn_batch_mfma = 17;  // option attn.batch_mfma: batches of this many rows and more run their direct-form attention on the matrix cores (0 = never)
   int attn_direct_g = 1;     // option attn.direct_g: 1 = heads per workgroup of the direct attention form by batch rows (2 from 12 rows, 4 from 24 at head_dim 64), 0 = always one, -g = force g
@@ -595,6 +596,15 @@ void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R) {
           // without (Llama-3.2-1B, context 600): B = 32 1.317 / 1.314, B = 48 1.814 / 1.713, B = 64 1.902 / 1.796 — never behind: the default
           // (option attn.batch_la: 1 = look-ahead, -1 = only while the workgroups number at most one per CU)
           const bool la = HD != 64 || (c->attn_batch_la >= 0 ? c->attn_batch_la != 0 : (int)(gm.x * gm.y) <= c->num_cus);
+          // eight waves per workgroup (head_dim 64, option attn.batch_nw8: 1 = while the workgroups number at most one per CU, 2 = always): the blocks of 64 keys and the
+          // QKV finish's slab sums spread over twice the waves
+          if constexpr (HD == 64) {
+            if ((a.raw_part || a.raw_qkv) && (c->attn_batch_nw8 >= 2 || (c->attn_batch_nw8 == 1 && (int)(gm.x * gm.y) <= c->num_cus))) {
+              constexpr size_t lds8 = tgx::attn_mfma_raw_lds_bytes<HD, 8>();
+              hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 8, true, false>), gm, dim3(512), lds8, c->stream, a);
+              return;
+            }
+          }
           if (a.raw_part || a.raw_qkv) {     // + the QKV product's finish
             if (la) hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, true>), gm, dim3(256), ldsr, c->stream, a);
             else hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, true, false>), gm, dim3(256), ldsr, c->stream, a);
@@ -2275,6 +2285,8 @@ int tgx_finalize(tgx_ctx* c) {
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_PARTIAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   if ((rc = skinny_set_attrs(c))) return rc;
   if ((rc = skinny_dma_set_attrs(c))) return rc;
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 64, 8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<64, 8>()));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_F16, 64, 8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<64, 8>()));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 128, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<128>()));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_F16, 128, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<128>()));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_lds_bytes<128>()));
@@ -2665,6 +2677,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
   if (!strcmp(key, "attn.direct_nw4")) { drop_step_graphs(c); c->attn_direct_nw4 = value; return TGX_OK; }
   if (!strcmp(key, "attn.raw_fuse")) { drop_step_graphs(c); c->attn_raw_fuse = value; return TGX_OK; }
+  if (!strcmp(key, "attn.batch_nw8")) { drop_step_graphs(c); c->attn_batch_nw8 = value; return TGX_OK; }
   if (!strcmp(key, "attn.batch_la")) { if (value < -1 || value > 1) return set_err(c, TGX_ERR_INVALID, "attn.batch_la is -1, 0 or 1"); drop_step_graphs(c); c->attn_batch_la = value; return TGX_OK; }
   if (!strcmp(key, "attn.batch_mfma")) { if (value < 0) return set_err(c, TGX_ERR_INVALID, "attn.batch_mfma is a row count (0 = off)"); drop_step_graphs(c); c->attn_batch_mfma = value; return TGX_OK; }
   if (!strcmp(key, "attn.direct_g")) { if (value != 0 && value != 1 && value != -1 && value != -2 && value != -4) return set_err(c, TGX_ERR_INVALID, "attn.direct_g is 0, 1 or -1 / -2 / -4"); drop_step_graphs(c); c->attn_direct_g = value; return TGX_OK; }
