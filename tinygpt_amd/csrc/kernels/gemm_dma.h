@@ -373,7 +373,8 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
     const int piece = wv + 8 * p, row = piece * RPP + prow;
     const int chunk = pslot ^ ((row >> 1) & 7);
     const size_t g = (size_t)min(m0 + row, a.M - 1) * a.K + chunk * 8;
-    const size_t brow = (size_t)min(n0 + row, a.N - 1);
+    const int nb = min(n0 + row, a.N - 1);
+    const size_t brow = EPI == GEMM_SILU ? (size_t)((nb & 1) ? a.inter : 0) + (size_t)(nb >> 1) : (size_t)nb;     // gate / up rows interleaved as tile columns
     gsrc[3 * p] = a.A_hi + g; gsrc[3 * p + 1] = a.A_lo + g; gsrc[3 * p + 2] = a.B + brow * a.K + chunk * 8;
     ldst[3 * p] = (unsigned)(piece * 1024); ldst[3 * p + 1] = ldst[3 * p] + (unsigned)(TMN * DBK * 2); ldst[3 * p + 2] = ldst[3 * p] + (unsigned)(2 * TMN * DBK * 2);
   }
@@ -444,6 +445,10 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (EPI == GEMM_SILU) {          // the gate_up product of a 129-384-row prompt (round 3): siluMul + 16-bit split as in the 256 x 256 kernel
+        silu_block_store<DT>(acc[i][j], lane, col, m0 + wm * 64 + i * 32, a);
+        continue;
+      }
       if (col >= a.N) continue;
       const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
 #pragma unroll

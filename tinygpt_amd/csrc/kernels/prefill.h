@@ -181,7 +181,27 @@ __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) 
   auto fetch4 = [&](int col) {
     if (a.QKV) return *reinterpret_cast<const f32x4*>(row + col);
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < a.nsplit; z++) {
+    int z = 0;
+    for (; z + 8 <= a.nsplit; z += 8) {        // eight slabs in flight together, summed in z order (as rmsnorm_split_kernel)
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = *reinterpret_cast<const f32x4*>(row + (size_t)(z + u) * a.slab + col);
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] += t[u][e];
+    }
+    if (z + 4 <= a.nsplit) {
+      f32x4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) t[u] = *reinterpret_cast<const f32x4*>(row + (size_t)(z + u) * a.slab + col);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] += t[u][e];
+      z += 4;
+    }
+    for (; z < a.nsplit; z++) {
       const f32x4 t = *reinterpret_cast<const f32x4*>(row + (size_t)z * a.slab + col);
 #pragma unroll
       for (int e = 0; e < 4; e++) v[e] += t[e];

@@ -207,6 +207,7 @@ struct tgx_ctx {
   // gemm_x2_kernel everywhere (round 1).  Default 7 | k32x2 << 4 | k64x2 << 8: Llama-3.2-1B 2048 tokens 11.4-11.7 -> 10.0-10.3 ms (tools/dma_sweep.py)
   // bit 3 = the N = hidden products (o_proj, down) on the 8-wave 128 x 128 kernel with the K step split between wave pairs when their tiles number ~one per CU
   int gemm_dma = 15 | (1 << 4) | (2 << 8);
+  int wide_8k = 1;           // option prefill.wide_8k: gate_up of 129-384-row prompts on the eight-wave 128 x 128 kernel
   int hidden_256 = 1;        // option prefill.hidden_256: o_proj / down on the 256 x 256 eight-wave kernel when their tiles fill the chip
   int debug_attn = 0;        // experiment: AttnArgs.dbg
   int attn_gmax = 0;         // experiment: query heads per attention workgroup (default 2)
@@ -1068,6 +1069,17 @@ void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float
       if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_RESIDUAL>), g8, b8, lds8, c->stream, g);
       else hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_STORE>), g8, b8, lds8, c->stream, g);)
     return;
+  }
+  if ((c->gemm_dma & 8) && c->wide_8k && K % 64 == 0 && !three_terms && epi == tgx::GEMM_SILU) {
+    // the wide product of a prompt too short for 256 x 256 tiles (129-384 rows: 128-384 tiles of 128 x 128): the eight-wave kernel with the K step split between
+    // wave pairs instead of the four-wave one (option prefill.wide_8k: Llama-3.2-1B S = 256 gate_up 61 us per layer)
+    const int t128 = ((N + 127) / 128) * ((M + 127) / 128);
+    if (2 * t128 >= c->num_cus && 2 * t128 <= 3 * c->num_cus) {
+      const dim3 g8((N + 127) / 128, (M + 127) / 128), b8(512);
+      const size_t lds8 = (size_t)3 * 3 * 128 * 64 * 2;
+      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_SILU>), g8, b8, lds8, c->stream, g))
+      return;
+    }
   }
   if ((c->gemm_dma & 8) && K % 64 == 0 && !three_terms && (epi == tgx::GEMM_RESIDUAL || epi == tgx::GEMM_STORE)) {
     // N = hidden products whose 128 x 128 tiles number between half a chip and a chip and a half: eight waves per tile, K step split between wave pairs
@@ -2295,6 +2307,8 @@ int tgx_finalize(tgx_ctx* c) {
 #define TGX_DMA_ATTR(DT_, EPI_, MI_) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 4) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 4)
 #define TGX_DMA_ATTR_D(DT_) TGX_DMA_ATTR(DT_, tgx::GEMM_SILU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_GELU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 2)
   TGX_DMA_ATTR_D(tgx::DT_BF16) TGX_DMA_ATTR_D(tgx::DT_F16)
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_F16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_F16, tgx::GEMM_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
@@ -2704,6 +2718,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.skinny_hidden_max_wide")) { c->prefill_skinny_hidden_max_wide = value; return TGX_OK; }
   if (!strcmp(key, "prefill.skinny_hidden_max")) { c->prefill_skinny_hidden_max = value; return TGX_OK; }
   if (!strcmp(key, "prefill.skinny_rows")) { if (value < 0 || value > 128) return set_err(c, TGX_ERR_INVALID, "prefill.skinny_rows is 0..128"); c->prefill_skinny_rows = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.wide_8k")) { c->wide_8k = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.hidden_256")) { c->hidden_256 = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk_dma")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "prefill.splitk_dma is 0, 1 (<= 64 rows) or 2 (always)"); c->splitk_dma = value; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_mirror")) { c->attn_mirror = value; return TGX_OK; }
