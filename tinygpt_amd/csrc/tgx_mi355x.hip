@@ -207,6 +207,8 @@ struct tgx_ctx {
   // gemm_x2_kernel everywhere (round 1).  Default 7 | k32x2 << 4 | k64x2 << 8: Llama-3.2-1B 2048 tokens 11.4-11.7 -> 10.0-10.3 ms (tools/dma_sweep.py)
   // bit 3 = the N = hidden products (o_proj, down) on the 8-wave 128 x 128 kernel with the K step split between wave pairs when their tiles number ~one per CU
   int gemm_dma = 15 | (1 << 4) | (2 << 8);
+  int wide_8k_max = 8;       // option prefill.wide_8k_max: ... while its tiles number at most this many half-chips (8 = 4 tiles per CU: everything below the 256 x 256 kernel's range;
+                             // 3 / 8: Llama-3.2-1B S = 512 3.62 / 3.44 ms, 768 5.06 / 4.94; Mistral-7B S = 256 11.16 / 10.81, 512 22.5 / 21.4)
   int wide_8k = 1;           // option prefill.wide_8k: gate_up of 129-384-row prompts on the eight-wave 128 x 128 kernel
   int hidden_256 = 1;        // option prefill.hidden_256: o_proj / down on the 256 x 256 eight-wave kernel when their tiles fill the chip
   int debug_attn = 0;        // experiment: AttnArgs.dbg
@@ -1074,7 +1076,7 @@ void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float
     // the wide product of a prompt too short for 256 x 256 tiles (129-384 rows: 128-384 tiles of 128 x 128): the eight-wave kernel with the K step split between
     // wave pairs instead of the four-wave one (option prefill.wide_8k: Llama-3.2-1B S = 256 gate_up 61 us per layer)
     const int t128 = ((N + 127) / 128) * ((M + 127) / 128);
-    if (2 * t128 >= c->num_cus && 2 * t128 <= 3 * c->num_cus) {
+    if (2 * t128 >= c->num_cus && 2 * t128 <= c->wide_8k_max * c->num_cus) {
       const dim3 g8((N + 127) / 128, (M + 127) / 128), b8(512);
       const size_t lds8 = (size_t)3 * 3 * 128 * 64 * 2;
       TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_SILU>), g8, b8, lds8, c->stream, g))
@@ -2718,6 +2720,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.skinny_hidden_max_wide")) { c->prefill_skinny_hidden_max_wide = value; return TGX_OK; }
   if (!strcmp(key, "prefill.skinny_hidden_max")) { c->prefill_skinny_hidden_max = value; return TGX_OK; }
   if (!strcmp(key, "prefill.skinny_rows")) { if (value < 0 || value > 128) return set_err(c, TGX_ERR_INVALID, "prefill.skinny_rows is 0..128"); c->prefill_skinny_rows = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.wide_8k_max")) { c->wide_8k_max = value; return TGX_OK; }
   if (!strcmp(key, "prefill.wide_8k")) { c->wide_8k = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.hidden_256")) { c->hidden_256 = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk_dma")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "prefill.splitk_dma is 0, 1 (<= 64 rows) or 2 (always)"); c->splitk_dma = value; return TGX_OK; }
