@@ -111,11 +111,14 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(float* X, const bf16
     }
   };
   f32x4 xr[NV][2];
+  u32x4 wr[NV];                       // the norm weights of the thread's chunks: loaded with the row, not after the workgroup's sum (one L2 round trip off the chain)
   float ss = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; j++) {
     const int c = threadIdx.x + 256 * j;
     xr[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; xr[j][1] = xr[j][0];
+    wr[j] = u32x4{0u, 0u, 0u, 0u};
+    if (c < nch) wr[j] = *reinterpret_cast<const u32x4*>(w + 8 * c);
     if (c < nch) fetch(c, xr[j][0], xr[j][1]);
 #pragma unroll
     for (int t = 0; t < 4; t++) { ss = fmaf(xr[j][0][t], xr[j][0][t], ss); ss = fmaf(xr[j][1][t], xr[j][1][t], ss); }
@@ -128,8 +131,7 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(float* X, const bf16
   }
   ss = block_sum_256(ss, sc);
   const float inv = 1.0f / sqrtf(ss / (float)H + eps);
-  auto emit = [&](int c, const f32x4& v0, const f32x4& v1) {
-    const u32x4 wv = *reinterpret_cast<const u32x4*>(w + 8 * c);
+  auto emit = [&](int c, const f32x4& v0, const f32x4& v1, const u32x4 wv) {
     unsigned int h[4], l[4], l2[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -153,10 +155,10 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(float* X, const bf16
 #pragma unroll
   for (int j = 0; j < NV; j++) {
     const int c = threadIdx.x + 256 * j;
-    if (c < nch) emit(c, xr[j][0], xr[j][1]);
+    if (c < nch) emit(c, xr[j][0], xr[j][1], wr[j]);
   }
   for (int c = threadIdx.x + 256 * NV; c < nch; c += 256)
-    emit(c, *reinterpret_cast<const f32x4*>(x + 8 * c), *reinterpret_cast<const f32x4*>(x + 8 * c + 4));
+    emit(c, *reinterpret_cast<const f32x4*>(x + 8 * c), *reinterpret_cast<const f32x4*>(x + 8 * c + 4), *reinterpret_cast<const u32x4*>(w + 8 * c));
 }
 
 // ---- split -> RoPE(q), RoPE(k) at pastLength+s -> cache append; q as bf16 hi/lo ------------------------------------
