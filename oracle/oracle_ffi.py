@@ -22,6 +22,7 @@ ORACLE_EXTRA = {
     "read_rope": (c_int, [c_void_p, c_int, POINTER(c_float)]),
     "set_logits": (c_int, [c_void_p, POINTER(c_float), c_int]),
     "set_threads": (c_int, [c_int]),
+    "set_reorder": (c_int, [c_void_p, c_int]),
 }
 
 
@@ -52,6 +53,11 @@ class OracleModel(Model):
         ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64).reshape(-1))
         self._check(self.be.set_next_token(self._ctx, ids.ctypes.data_as(POINTER(c_int64)), len(ids)))
         self.batch = len(ids)
+
+    def set_reorder(self, on: bool = True):
+        """every reduction from the last element to the first: a second fp32 schedule of the same arithmetic (test hook)"""
+        self._check(self.be.set_reorder(self._ctx, 1 if on else 0))
+        return self
 
     def rope_tables(self, n_pos: int):
         half = self.desc.head_dim // 2

@@ -84,6 +84,7 @@ typedef struct tgxo_ctx {
   int bf16;
   int f16;                       /* compute_dtype fp16: parameters and KV cache hold half-rounded values */
   int round_act;
+  int reorder;                   /* tgxo_set_reorder: every reduction runs in the REVERSE element order (a second, equally valid fp32 schedule) */
   mat_t embed, wpe, lm_head;
   vec_t final_norm;
   layer_t* L;
@@ -394,6 +395,21 @@ TGXO_EXPORT int tgxo_finalize(tgxo_ctx* c) {
 static inline float dot_row(const tgxo_ctx* c, const mat_t* m, int64_t row, const float* x) {
   int64_t K = m->cols;
   float acc = 0.f;
+  if (c->reorder) {               /* the same products summed from the last element to the first (tgxo_set_reorder) */
+    if (c->bf16) {
+      const uint16_t* w = m->wb + row * K;
+#pragma omp simd reduction(+ : acc)
+      for (int64_t k = K - 1; k >= 0; k--) {
+        uint32_t u = (uint32_t)w[k] << 16; float f; memcpy(&f, &u, 4);
+        acc += f * x[k];
+      }
+    } else {
+      const float* w = m->wf + row * K;
+#pragma omp simd reduction(+ : acc)
+      for (int64_t k = K - 1; k >= 0; k--) acc += w[k] * x[k];
+    }
+    return acc;
+  }
   if (c->bf16) {
     const uint16_t* w = m->wb + row * K;
 #pragma omp simd reduction(+ : acc)
@@ -428,17 +444,20 @@ static void linear(const tgxo_ctx* c, const mat_t* m, const float* x, int S, flo
 
 static void rmsnorm(const tgxo_ctx* c, const float* x, const float* w, int n, float* y) {
   float ss = 0.f;
-  for (int i = 0; i < n; i++) ss += x[i] * x[i];
+  if (c->reorder) for (int i = n - 1; i >= 0; i--) ss += x[i] * x[i];
+  else for (int i = 0; i < n; i++) ss += x[i] * x[i];
   float inv = 1.0f / sqrtf(ss / (float)n + c->d.norm_eps);
   for (int i = 0; i < n; i++) y[i] = R(c, w[i] * R(c, x[i] * inv));
 }
 
 static void layernorm(const tgxo_ctx* c, const float* x, const float* w, const float* b, int n, float* y) {
   float mean = 0.f;
-  for (int i = 0; i < n; i++) mean += x[i];
+  if (c->reorder) for (int i = n - 1; i >= 0; i--) mean += x[i];
+  else for (int i = 0; i < n; i++) mean += x[i];
   mean /= (float)n;
   float var = 0.f;
-  for (int i = 0; i < n; i++) { float t = x[i] - mean; var += t * t; }
+  if (c->reorder) for (int i = n - 1; i >= 0; i--) { float t = x[i] - mean; var += t * t; }
+  else for (int i = 0; i < n; i++) { float t = x[i] - mean; var += t * t; }
   var /= (float)n;
   float inv = 1.0f / sqrtf(var + c->d.norm_eps);
   for (int i = 0; i < n; i++) y[i] = R(c, (x[i] - mean) * inv * w[i] + b[i]);
@@ -463,20 +482,24 @@ static void rope_head(const tgxo_ctx* c, float* v, int pos) {
 
 /* softmax(q.K^T * scale) . V for one query head over keys [0, nkeys) */
 static void attend(const tgxo_ctx* c, const float* q, const float* K, const float* V, int nkeys, int kvd, float* out, float* sc) {
-  int hd = c->d.head_dim;
+  int hd = c->d.head_dim, ro = c->reorder;
   float scale = 1.0f / sqrtf((float)hd), mx = -INFINITY;
   for (int j = 0; j < nkeys; j++) {
     const float* k = K + (size_t)j * kvd;
     float a = 0.f;
-    for (int t = 0; t < hd; t++) a += q[t] * k[t];
+    if (ro) for (int t = hd - 1; t >= 0; t--) a += q[t] * k[t];
+    else for (int t = 0; t < hd; t++) a += q[t] * k[t];
     sc[j] = a * scale;
     if (sc[j] > mx) mx = sc[j];
   }
   float sum = 0.f;
-  for (int j = 0; j < nkeys; j++) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+  for (int j = 0; j < nkeys; j++) sc[j] = expf(sc[j] - mx);
+  if (ro) for (int j = nkeys - 1; j >= 0; j--) sum += sc[j];
+  else for (int j = 0; j < nkeys; j++) sum += sc[j];
   float inv = 1.0f / sum;
   for (int t = 0; t < hd; t++) out[t] = 0.f;
-  for (int j = 0; j < nkeys; j++) {
+  for (int jj = 0; jj < nkeys; jj++) {
+    int j = ro ? nkeys - 1 - jj : jj;
     const float* v = V + (size_t)j * kvd;
     float p = sc[j] * inv;
     for (int t = 0; t < hd; t++) out[t] += p * v[t];
@@ -723,6 +746,11 @@ TGXO_EXPORT int tgxo_set_logits(tgxo_ctx* c, const float* logits, int batch) {
   c->last_batch = batch;
   return 0;
 }
+
+/* Test hook (tests/test_oracle_reorder.py): 1 = every reduction of this context (Linear dot products, RMSNorm / LayerNorm sums, q.k, softmax sum, P.V) runs from the
+ * last element to the first.  Same products, another fp32 summation order: the distance between the two schedules is the floor any OTHER correct
+ * implementation (the HIP kernels) can be held to. */
+TGXO_EXPORT int tgxo_set_reorder(tgxo_ctx* c, int on) { if (!c) return 1; c->reorder = on != 0; return 0; }
 
 TGXO_EXPORT int tgxo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
 

@@ -1,0 +1,32 @@
+#!/bin/bash
+# One parametrised job script for the GPU box (replaces round 1-3's tools/gpu_scripts/gpu_r0*.sh one-offs):
+#   gpurun --timeout 900 -- 'bash tools/gpu_job.sh <out-tag> <job> [<job> ...]'
+# Every job writes under gpurun_out/<out-tag>/ (merged back by gpurun); summaries worth keeping are copied into profiles/ by hand.
+set -u
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/$TAG; mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+
+job_suite()   { (time timeout 2700 python -m pytest tests -m gpu -x -q) > $O/pytest.log 2>&1; tail -5 $O/pytest.log; }
+job_smoke()   { python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log; }
+job_bench()   { python bench.py > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench_line.json; cut -c1-600 $O/bench_line.json; }
+job_quick()   { python tools/quick_bench.py --prompt 2048 --steps 256 ${QB_ARGS:-} > $O/quick.log 2>&1; cat $O/quick.log; }
+# the attention pair at the bench's operating point: splits per kv head x merge placement
+job_attn_pair() {
+  for ns in 4 6 8 12 17 32; do
+    python tools/sweep.py --prompt 2048 --steps 256 --pre "attn.nsplit=$ns" --grid "attn.fold_combine=0,1" 2>&1 | sed "s/^/nsplit=$ns /"
+  done > $O/attn_pair.log 2>&1; cat $O/attn_pair.log
+}
+job_kernarg_probe() { for b in kernarg_probe kernarg_probe_pre; do echo "== $b"; timeout 120 tools/probes/build/$b; done > $O/kernarg_probe.log 2>&1; cat $O/kernarg_probe.log; }
+# rocprofv3 kernel trace of the bench command (eager launches: rocprofv3 cannot trace hipGraphLaunch) + the per-class sequence table
+job_trace() {
+  cd /tmp; rm -rf /tmp/tr
+  rocprofv3 --kernel-trace --stats -d /tmp/tr -o tr -- python $R/bench.py --no-graph --no-cpu-baseline > $O/trace_bench.log 2>&1
+  db=$(find /tmp/tr -name "*.db" | head -1)
+  python $R/tools/rocpd_stats.py $db > $O/kernel_stats.txt 2>&1; python $R/tools/rocpd_seq.py $db >> $O/kernel_stats.txt 2>&1
+  tail -1 $O/trace_bench.log >> $O/kernel_stats.txt; head -24 $O/kernel_stats.txt | cut -c1-200; cd $R
+}
+
+for j in "$@"; do echo "=== job $j"; job_$j; done
