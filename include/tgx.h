@@ -202,13 +202,6 @@ TGX_API int tgx_write_kv(tgx_ctx* ctx, int row, int layer, const float* k_in, co
 TGX_API int tgx_profile_decode(tgx_ctx* ctx, int n_reps, int64_t* launches /*[TGX_KERNEL_COUNT]*/,
                        double* total_ms /*[TGX_KERNEL_COUNT]*/);
 
-/* Timeline of the persistent decode engine (option "engine.mode" > 0 with "engine.stats" = 1; kernels/engine.h): the last decode
- * step's per-layer, per-CU stamps in 100 MHz ticks since each launch's first instruction — loader (last tile of op k issued, all landed,
- * ticks blocked on a full ring), gatherer (op k's input staged, ticks inside granule sweeps), consumers (op k finished, ticks waiting for
- * input / for tiles).  out = [layers][cus][fields] or nullptr to query the three sizes only.  Diagnostic use (profiles/r03_engine.txt);
- * the reference has no counterpart (its layers are separate op dispatches, DecoderLayer.h:38-43). */
-TGX_API int tgx_engine_read_stats(tgx_ctx* ctx, uint64_t* out, int64_t capacity, int32_t* out_layers, int32_t* out_cus, int32_t* out_fields);
-
 /* Final probability vector(s) [batch*vocab] of the last non-greedy tgx_sample / decode step: what the
  * reference passes to multinomial (Sampler.cpp:77) — zero where top-k/top-p/min-p removed a token. */
 TGX_API int tgx_read_probs(tgx_ctx* ctx, float* out);

@@ -501,25 +501,28 @@ def test_direct_attention_equals_split(name, lens, hip):
         assert rel_err(outs[1][2], outs[0][2]) < 1e-5, (n, rel_err(outs[1][2], outs[0][2]))
 
 
-@pytest.mark.parametrize("name,lens,batch", [("llama-3.2-1b", (1, 127, 128, 129, 1500, 1536, 2047, 3100), 1), ("llama-3.2-1b", (130, 900), 4),
-                                             ("mistral-7b-v0.3", (63, 64, 65, 700, 2100), 1), ("qwen2.5-0.5b", (300, 1100), 2), ("llama-3.2-3b", (200,), 3)])
-def test_attention_combine_folded_into_o_proj_equals_separate_launch(name, lens, batch, hip):
-    """Split-form attention: the merge of the per-split partials can run in the o_proj launch's prologue (PRO_ATTNCOMB, through LDS) instead
-    of a launch of its own (option attn.fold_combine; off by default: measured slower).  Same records, same fp32 merge in another association order: logits equal to fp32
-    rounding and greedy ids equal, at contexts around the split block size (128 tokens at head_dim 64, 64 at 128), with 1..18+ active
-    splits, more than one round of 12 splits, beyond 32 blocks (round-robin), and for batch rows 2 / 3 (2+1) / 4 that share the launch."""
+@pytest.mark.parametrize("name,lens,batch,dtype", [("llama-3.2-1b", (1, 127, 128, 129, 1500, 1536, 2047, 3100), 1, "bf16"), ("llama-3.2-1b", (130, 900), 2, "bf16"),
+                                                   ("qwen2.5-0.5b", (63, 300, 1100, 2500), 1, "bf16"), ("qwen2.5-0.5b", (700,), 1, "fp16"), ("llama-3.2-1b", (900,), 3, "bf16")])
+def test_k_sliced_o_proj_with_the_attention_merge_equals_combine_plus_o_proj(name, lens, batch, dtype, hip):
+    """Batch-1 steps on the split attention form (round 4, kernels/oproj_sliced.h; option oproj.sliced, on by default): o_proj is sliced over K, each workgroup
+    merges the split records of ITS 2-4 heads in its prologue (no attn_combine launch) and adds its partial dot products into fixed-point accumulators that
+    carry the residual stream to gate_up and down (Attention.h:108-112 + :90, DecoderLayer.h:40-41).  Against the separate combine + row-sliced o_proj:
+    same records, same merge arithmetic, another summation order of the o_proj dot products (+ 2^-32 fixed-point rounding): logits within 1e-5, greedy ids
+    equal, at contexts around the split block size (128 tokens at head_dim 64), with 1..25 active splits and beyond 32 blocks (round-robin).  The sliced
+    form runs twice: the second run must be bit-identical (integer atomics commute; the accumulators were left at zero).  Batches of 2 / 3 rows never take
+    the sliced form (the rows share the weight pass): the option must not change them at all."""
     import copy
     from tinygpt_amd import known_desc, synth
     from tinygpt_amd.ffi import Model
-    d = copy.deepcopy(known_desc(name))
+    d = copy.deepcopy(known_desc(name, dtype))
     d.layers, d.vocab, d.max_ctx, d.max_batch = 2, 4096, 4224, batch
     m = Model(d, hip).load_synthetic(1234, 0.02).finalize()
     m.set_option("attn.direct_max", 0)                  # the split form at every context
     for n in lens:
         prompt = np.stack([synth.synth_prompt(d.vocab, n, 100 + n + 7 * b) for b in range(batch)])
         outs = []
-        for fold in (0, 1):
-            m.set_option("attn.fold_combine", fold)
+        for sliced in (0, 1, 1):
+            m.set_option("oproj.sliced", sliced)
             m.reset_cache(); m.forward(prompt)
             first = m.sample(GREEDY).copy()
             rest = m.decode(5, GREEDY).copy()
@@ -527,37 +530,10 @@ def test_attention_combine_folded_into_o_proj_equals_separate_launch(name, lens,
         np.testing.assert_array_equal(outs[0][0], outs[1][0])
         np.testing.assert_array_equal(outs[0][1], outs[1][1])
         assert rel_err(outs[1][2], outs[0][2]) < 1e-5, (n, rel_err(outs[1][2], outs[0][2]))
-
-
-@pytest.mark.parametrize("name,lens,batch", [("llama-3.2-1b", (1, 127, 128, 129, 1500, 2047, 3100), 1), ("llama-3.2-1b", (130, 900), 2),
-                                             ("mistral-7b-v0.3", (63, 65, 700, 2100), 1), ("qwen2.5-0.5b", (300, 1100), 2)])
-def test_attention_combine_by_the_last_arriving_split_equals_separate_launch(name, lens, batch, hip):
-    """Option attn.fold_ticket (round 3; off by default, numbers in profiles/r03_attn_fold.txt): the last split workgroup of each (row, kv
-    head, head group) to arrive at the group's ticket merges the group's records inside the attention launch — the SAME merge code as
-    attn_combine_kernel over the same records (only the active splits are read), so logits and ids must be bit-identical to the two-launch
-    form, at contexts around the block size, with 1..25 active splits, beyond 32 blocks (round-robin) and for batch rows sharing the launch;
-    run twice so that a ticket left non-zero would show."""
-    import copy
-    from tinygpt_amd import known_desc, synth
-    from tinygpt_amd.ffi import Model
-    d = copy.deepcopy(known_desc(name))
-    d.layers, d.vocab, d.max_ctx, d.max_batch = 2, 4096, 4224, batch
-    m = Model(d, hip).load_synthetic(1234, 0.02).finalize()
-    m.set_option("attn.direct_max", 0)                  # the split form at every context
-    for n in lens:
-        prompt = np.stack([synth.synth_prompt(d.vocab, n, 100 + n + 7 * b) for b in range(batch)])
-        outs = []
-        for fold in (0, 1, 1):
-            m.set_option("attn.fold_ticket", fold)
-            m.reset_cache(); m.forward(prompt)
-            first = m.sample(GREEDY).copy()
-            rest = m.decode(5, GREEDY).copy()
-            outs.append((first, rest, m.logits(rounded=False).copy()))
-        for k in (1, 2):
-            np.testing.assert_array_equal(outs[0][0], outs[k][0])
-            np.testing.assert_array_equal(outs[0][1], outs[k][1])
-            np.testing.assert_array_equal(outs[0][2], outs[k][2])
-    m.set_option("attn.fold_ticket", 0)
+        np.testing.assert_array_equal(outs[1][1], outs[2][1])
+        np.testing.assert_array_equal(outs[1][2], outs[2][2])
+        if batch > 1:
+            np.testing.assert_array_equal(outs[0][2], outs[1][2])
 
 
 def test_one_long_decode_call_equals_single_steps_across_the_attention_form_limits(hip):
@@ -584,31 +560,6 @@ def test_one_long_decode_call_equals_single_steps_across_the_attention_form_limi
         np.testing.assert_array_equal(runs[0][0], runs[k][0])
         np.testing.assert_array_equal(runs[0][1], runs[k][1])
         np.testing.assert_array_equal(runs[0][2], runs[k][2])
-
-
-@pytest.mark.parametrize("fam,batch", [("llama_tiny", 1), ("qwen2_tiny", 3), ("gpt2_hd64", 4)])
-def test_greedy_finalize_fused_into_lm_head_equals_separate_launch(fam, batch, hip, oracle_lib):
-    """Option lmhead.fuse_finalize (off by default: measured no faster): the lm_head launch's last-arriving workgroup reduces the argmax
-    partials and publishes token / position / next embedding row (arrival ticket, agent-scope stores + one acquire).  Ids over a long
-    free-running decode and the final logits must be bit-identical to the separate finalize launch, and equal to the oracle's."""
-    from oracle.oracle_ffi import OracleModel
-    from tinygpt_amd.ffi import Model
-    cfg, g = load_golden(fam)
-    d = desc_from_hf_config(cfg, "bf16", max_batch=batch)
-    m = Model(d, hip).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
-    prompt = np.stack([synth.synth_prompt(d.vocab, 9, 50 + b) for b in range(batch)])
-    outs = []
-    for fuse in (0, 1, 1):
-        m.set_option("lmhead.fuse_finalize", fuse)
-        m.reset_cache(); m.forward(prompt)
-        first = m.sample(GREEDY).copy()
-        rest = m.decode(min(96, d.max_ctx - 9 - 1), GREEDY).copy()
-        outs.append((first, rest, m.logits(rounded=False).copy()))
-    for o in outs[1:]:
-        np.testing.assert_array_equal(o[0], outs[0][0]); np.testing.assert_array_equal(o[1], outs[0][1]); np.testing.assert_array_equal(o[2], outs[0][2])
-    ref = OracleModel(d).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
-    ref.forward(prompt); ref.sample(GREEDY)
-    np.testing.assert_array_equal(ref.decode(24, GREEDY), outs[1][1][:24])
 
 
 @pytest.mark.parametrize("name,ctx,dtype", [("llama-3.2-1b", 3000, "bf16"), ("mistral-7b-v0.3", 2100, "bf16"), ("qwen2.5-0.5b", 2500, "fp16")])

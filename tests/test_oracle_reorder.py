@@ -97,7 +97,7 @@ def flip_floor(name, tol_granted, oracle_lib, prompt_len, steps):
         print(f"  layer {layer}: K entries differing {fk:.3%} (max |dK| / max |K| = {sk:.2e}), V {fv:.3%} ({sv:.2e}); one bf16 ulp = {2.0 ** -8:.2e}")
         if layer == 0:
             assert fk > 0 or fv > 0                        # flips exist already in the first layer, whose inputs are identical on both sides
-            assert sk <= 2.0 ** -8 and sv <= 2.0 ** -8     # ... and there each is ONE rounding step
+            assert sk <= 2.0 ** -7 and sv <= 2.0 ** -7     # ... and there each is ONE rounding step (a bf16 ulp is 2^-8 .. 2^-7 of the value)
     floor = max(errs)
     assert floor > 5e-4, errs                    # the floor is real: 1e-3 end to end is not a testable bar at this depth
     assert floor < tol_granted, errs             # and the tolerance the GPU test grants sits above it

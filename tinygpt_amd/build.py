@@ -22,28 +22,44 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvi
          ] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("TGX_VGPR_FORM", "1") == "1" else [])
 
 
-def sources():
-    out = [os.path.join(CSRC, "tgx_mi355x.hip")]
-    deps = list(out) + [os.path.join(HERE, "..", "include", "tgx.h")]
+TUS = ["abi", "decode", "attn", "sampler", "prefill", "prefill_f32", "skinny"]     # csrc/<name>.hip, compiled in parallel (csrc/ctx.h lists what each holds)
+OBJDIR = os.path.join(LIBDIR, "obj")
+
+
+def _deps():
+    deps = [os.path.join(HERE, "..", "include", "tgx.h"), os.path.join(CSRC, "ctx.h")]
     kd = os.path.join(CSRC, "kernels")
-    deps += [os.path.join(kd, f) for f in sorted(os.listdir(kd))]
-    return out, deps
+    return deps + [os.path.join(kd, f) for f in sorted(os.listdir(kd))]
 
 
 def build_lib(force: bool = False, verbose: bool = False, extra_flags=()):
-    srcs, deps = sources()
+    """hipcc -c every translation unit (one process each, all at once: the longest is the GEMV instantiations of decode.hip, ~80 s), then link."""
     if os.environ.get("TGX_DISSECT") == "1":      # experiment build: the debug.gemv / debug.attn switches become live
         extra_flags = list(extra_flags) + ["-DTGX_DISSECT=1"]
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + srcs + ["-o", LIB]
+    cflags = [f for f in FLAGS if f != "-shared"] + list(extra_flags)
     # the flag set is part of the staleness test (a stamp next to the library): toggling TGX_VGPR_FORM / TGX_DISSECT / extra_flags rebuilds
-    stamp, want = LIB + ".flags", " ".join(cmd)
+    stamp, want = LIB + ".flags", " ".join([HIPCC] + cflags)
     same_flags = os.path.exists(stamp) and open(stamp).read() == want
-    if not force and same_flags and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
-        return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJDIR, exist_ok=True)
+    deps = _deps()
+    jobs = []
+    for tu in TUS:
+        src, obj = os.path.join(CSRC, tu + ".hip"), os.path.join(OBJDIR, tu + ".o")
+        fresh = same_flags and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps + [src])
+        if force or not fresh:
+            cmd = [HIPCC] + cflags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((tu, subprocess.Popen(cmd)))
+    failed = [tu for tu, p in jobs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc -c " + ", ".join(failed))
+    objs = [os.path.join(OBJDIR, tu + ".o") for tu in TUS]
+    if jobs or not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(o) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
     with open(stamp, "w") as f:
         f.write(want)
     return LIB

@@ -17,7 +17,6 @@
 // one (m, l, o[HD]) partial per query head per split).  attn_combine_kernel merges the splits.
 #pragma once
 #include "common.h"
-#include "l2_prefetch.h"
 
 namespace tgx {
 
@@ -44,12 +43,6 @@ struct AttnArgs {
   float eps;
   long long kraw_stride;
   int dbg;   // experiments only (tgx_set_option "debug.attn"): 1 skip K/V work, 2 skip the LDS merge, 4 exit at once — results invalid
-  // in-kernel combine (template FOLD, split form): the LAST split workgroup of a (row, kv head, head group) to arrive at this counter merges
-  // the group's records itself and writes a.out — no attn_combine launch.  [rows][kv_heads][groups] counters that rest at 0.
-  unsigned* fold_ticket;
-  // L2 prefetch chaining (l2_prefetch.h; split form only): workgroups with blockIdx.x >= pf.n_compute touch the next launches' weights
-  PfArgs pf;
-  PfArgs pf_comb;   // the same for the attn_combine launch that follows (host side: copied into `pf` of the combine's argument block)
   // batched step (attn_decode_mfma_kernel template RAW): the finish of the QKV product — sum of its split-K slabs + bias, [Qwen3 q / k RMSNorm,] RoPE at
   // pos[row], KVCacheManager::append — runs in the attention launch's prologue for the workgroup's own (row, kv head): q never touches memory and
   // the row-wise rope_kv_rows launch disappears.  Columns of a QKV row: [q: heads x hd | k: kv_heads x hd | v: kv_heads x hd]
@@ -70,7 +63,7 @@ __device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, fl
 // RAW (direct forms of a batched step): the workgroup first finishes its own slice of the QKV product (AttnArgs.raw_*: slab sums + bias, q / k norm at
 // head_dim 128, RoPE, cache append by the kv head's first head group) — q, k and v of this position go through LDS, the row-wise rope_kv_rows launch
 // disappears; the same arithmetic in the same order (common.h rope_rotate_pair / head_rms_inv): bit-identical to it.  See attn_decode_mfma.h for the MFMA twin.
-template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool PF = false, bool FOLD = false, bool RAW = false>
+template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool RAW = false>
 __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) {
   typedef elem_t<DT> E;
   constexpr int LPT = HD / 8;         // lanes per token row
@@ -82,11 +75,6 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
   __shared__ __attribute__((aligned(16))) float raw_q[RAW ? G : 1][RAW ? HD : 4], raw_kv[2][RAW ? HD : 4];      // RAW: this position's q heads (fp32) and k / v rows (as the cache holds them)
 
   if (TGX_DBG(a, 4)) return;
-  if (PF && (int)blockIdx.x >= a.pf.n_compute) {      // prefetch workgroup: the attention pair leaves the fabric idle
-    const unsigned v = pf_run(a.pf);
-    if (v == 0x9e3779b9u && threadIdx.x == 1023) *a.pf.sink = v;
-    return;
-  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* q_row = a.q + blockIdx.y * a.q_stride;
   const E* k_row = static_cast<const E*>(a.k_cache) + blockIdx.y * a.kv_stride;
@@ -224,7 +212,6 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
   if (sp * STEP >= n_keys) {   // this split has no keys at the current context length (workgroup-uniform): publish "empty"
     // (the compiler sinks the loads above below this branch; running empty splits through the masked path instead keeps
     //  them ahead of the position load but measured 1262 vs 1260 tok/s at context 2.3k and 1267 vs 1289 at 300 — rejected)
-    if (FOLD) return;            // the in-kernel merge reads the active splits only: nothing to publish, no ticket to take
     for (int g = threadIdx.x; g < G; g += 64 * NW) {
       if (!head_live(g)) continue;
       float* dst = part_row + ((size_t)head_of(g) * nsp + sp) * (HD + 4);
@@ -362,42 +349,8 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
       continue;
     }
     float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);
-    if (FOLD) {   // read by another workgroup of THIS launch: agent-scope write-through stores (cdna_hip_programming.md Guideline 16, R1)
-      __hip_atomic_store(dst + d, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (d == 0) { __hip_atomic_store(dst + HD, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(dst + HD + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-      continue;
-    }
     dst[d] = acc;
     if (d == 0) { dst[HD] = M; dst[HD + 1] = L; }
-  }
-  if constexpr (FOLD && NW == 4) {
-    // arrival ticket of this (row, kv head, head group): records drained by every storing wave, one relaxed agent-scope increment; the workgroup
-    // that draws the last ticket of the ACTIVE splits resets the counter, takes one agent-scope acquire and merges the group's heads
-    __shared__ int s_last;
-    const int n_act = min(nsp, (n_keys + STEP - 1) / STEP);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned* tk = a.fold_ticket + ((size_t)blockIdx.y * a.kv_heads + kvh) * gridDim.z + blockIdx.z;
-      const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = old == (unsigned)(n_act - 1);
-      if (last) {
-        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      s_last = last;
-    }
-    __syncthreads();
-    if (s_last) {
-#pragma unroll 1
-      for (int g = 0; g < G; g++) {
-        if (!head_live(g)) continue;
-        const int h = head_of(g);
-        __syncthreads();                     // red (the LDS scratch) is reused per head
-        attn_combine_head<HD>(part_row + (size_t)h * a.nsplit * (HD + 4), n_act, a.out + blockIdx.y * a.q_stride + (size_t)h * HD,
-                              reinterpret_cast<float (*)[HD + 4]>(&red[0][0][0]));
-      }
-    }
   }
 }
 
@@ -471,14 +424,9 @@ __device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, fl
   }
 }
 
-template <int HD, bool PF = false>
+template <int HD>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sm_o[4][HD + 4];   // per wave: o[HD], M, L
-  if (PF && (int)blockIdx.x >= a.pf.n_compute) {      // prefetch workgroup (l2_prefetch.h): the combine moves a few KB, the fabric is idle
-    const unsigned v = pf_run(a.pf);
-    if (v == 0x9e3779b9u && threadIdx.x == 1023) *a.pf.sink = v;
-    return;
-  }
   const int h = blockIdx.x;
   const float* p = a.part + blockIdx.y * a.part_stride + (size_t)h * a.nsplit * (HD + 4);
   attn_combine_head<HD>(p, a.nsplit, a.out + blockIdx.y * a.q_stride + (size_t)h * HD, sm_o);

@@ -138,6 +138,17 @@ __device__ __forceinline__ void rope_rotate_pair(float& x0, float& x1, float cs,
 __device__ __forceinline__ float head_sq_pair(float x0, float x1) { return fmaf(x0, x0, __fmul_rn(x1, x1)); }
 __device__ __forceinline__ float head_rms_inv(float ss, int hd, float eps) { return 1.0f / sqrtf(__fadd_rn(__fdiv_rn(ss, (float)hd), eps)); }
 
+// ---- the residual stream in fixed point (kernels/oproj_sliced.h): 2^-32 units in a 64-bit integer — range +-2^31, resolution 2.3e-10 (below the
+// fp32 ulp of any |x| > 4e-3).  Integer adds commute, so a sum of contributions from many workgroups does not depend on their arrival order.
+// f32 -> fixed: v * 2^32 is exact in fp32 (a power-of-two scale), the conversion rounds to nearest.  fixed -> f32: integer part and fraction converted
+// separately and joined by one FMA (three VALU instructions; within ~1 ulp of the correctly rounded value, and a pure function of the accumulator).
+__device__ __forceinline__ long long f32_to_fix(float v) { return __float2ll_rn(v * 4294967296.0f); }
+__device__ __forceinline__ float fix_to_f32(long long a) {
+  const int hi = (int)(a >> 32);
+  const unsigned lo = (unsigned)a;
+  return fmaf((float)lo, 1.0f / 4294967296.0f, (float)hi);
+}
+
 // ---- cross-lane reductions ----------------------------------------------------------------------
 // 64-lane sum on the DPP crossbar (no LDS traffic): quad butterflies, half-row / row mirrors, then the two
 // row broadcasts of the GFX9 wave64 reduction; the total lands in lane 63 and is returned wave-uniform.

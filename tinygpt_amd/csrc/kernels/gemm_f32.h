@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* X, const vo
   }
 }
 
-__global__ void iota_pos_kernel(int* pos, int first, int n) {
+static __global__ void iota_pos_kernel(int* pos, int first, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) pos[i] = first + i;
 }

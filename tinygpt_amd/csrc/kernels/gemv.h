@@ -5,8 +5,7 @@
 //   RMSNorm -> MergedLinear qkv -> split -> RoPE(q),RoPE(k)          PRO_RMSNORM + EPI_QKV_ROPE
 //     -> KVCacheManager::append (Attention.h:94-106)                   (K/V land directly in the cache slot)
 //   Linear o_proj -> x + .  (Attention.h:90, DecoderLayer.h:40)      PRO_PLAIN   + EPI_RESIDUAL
-//     ... after split-form attention (long contexts)                 PRO_ATTNCOMB + EPI_RESIDUAL: the merge of the attention
-//                                                                      splits (flash-decode combine) happens in THIS launch's prologue
+//     ... behind split-form attention at batch 1                     kernels/oproj_sliced.h (K-sliced, merges the attention splits itself)
 //   RMSNorm -> MergedLinear gate_up -> siluMul (GatedMLP.h:37-39)    PRO_RMSNORM + EPI_SILU_MUL
 //   Linear down_proj -> x + .  (GatedMLP.h:40, DecoderLayer.h:41)    PRO_PLAIN   + EPI_RESIDUAL
 //   RMSNorm -> Linear lm_head -> argmax (GPTModel.h:56-57,            PRO_RMSNORM + EPI_LOGITS
@@ -26,15 +25,10 @@
 // hidden sizes whose R x NX slices would not fit one wave) exchange their partial sums of squares through LDS once.
 #pragma once
 #include "common.h"
-#include "l2_prefetch.h"
 
 namespace tgx {
 
-enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_LAYERNORM = 2, PRO_ATTNCOMB = 3 };   // LAYERNORM: GPT-2's nn::LayerNorm with bias (ModelGPT2.h:120-135)
-// PRO_ATTNCOMB (the o_proj launch behind split-form attention): the input vector does not exist in memory yet — the workgroup builds it
-// from the attention kernel's per-split partial records (o[hd], m, l per query head and split; attn_decode.h) while its first weight
-// slices are in flight, leaves it in LDS, and every wave takes its slices from there.  One launch (the former attn_combine_kernel: a
-// 1.5 us boundary plus a load -> merge -> store chain that moved a few KB) less per layer.
+enum { PRO_PLAIN = 0, PRO_RMSNORM = 1, PRO_LAYERNORM = 2 };   // LAYERNORM: GPT-2's nn::LayerNorm with bias (ModelGPT2.h:120-135)
 enum { EPI_QKV_ROPE = 0, EPI_RESIDUAL = 1, EPI_SILU_MUL = 2, EPI_LOGITS = 3, EPI_GELU = 4 };   // GELU: GPT-2's c_fc -> gelu (ModelGPT2.h:96-107)
 
 // ---- greedy finalize: reduce the lm_head partial argmaxes, publish the token, advance the row ---------
@@ -152,22 +146,14 @@ struct GemvArgs {
   float* k_raw;           // [R][kv_heads*hd] fp32 staging for k when raw_qk
   // EPI_RESIDUAL: out[n] += acc;  EPI_SILU_MUL: out[i] = silu(g) * u;  EPI_GELU: out[n] = gelu_new(acc)      (fp32)
   float* out;
-  // PRO_ATTNCOMB: part = [R][heads][attn_nsplit][attn_hd + 4] records (o[hd], m in the exp2 domain, l, pad), rows part_in_stride apart;
-  // the active splits are the first ceil((pos[r] + 1) / attn_step) (token blocks are dealt round-robin, attn_decode.h); uses `pos`
-  const float* attn_part;
-  long long part_in_stride;
-  int attn_nsplit, attn_step, attn_hd;
+  // XACC (batch 1 behind kernels/oproj_sliced.h): the residual stream between o_proj and down lives in fixed-point accumulators —
+  // PRO_RMSNORM reads its input from x_acc (x = fp32(acc)); EPI_RESIDUAL adds its product to fp32(res_acc), stores out and zeroes res_acc
+  const long long* x_acc;   // [K]
+  long long* res_acc;       // [N]
   // EPI_LOGITS
   float* logits;          // [R][N] fp32
   float* part_val;        // [R][gridDim.x] best logit of this workgroup
   int* part_idx;
-  // greedy decode steps: the LAST workgroup of the lm_head launch to arrive at `ticket` (a device counter that rests at 0) reduces the
-  // per-workgroup partials and does what finalize_greedy_kernel does for each of the R rows — one launch per token less.  nullptr: off
-  // (sampled steps, tgx_forward: the sampler / tgx_sample finish the step).
-  unsigned int* ticket;
-  const FinalizeArgs* fin;   // [R] in device memory (written by write_finalize_args_kernel ahead of the launch): 0.5 KB less kernarg on every GEMV launch
-  // L2 prefetch chaining (l2_prefetch.h): workgroups with blockIdx.x >= pf.n_compute touch the next launches' weights and exit
-  PfArgs pf;
 };
 
 // HF "gelu_new" (GPT-2's activation_function): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
@@ -193,18 +179,13 @@ __device__ __forceinline__ void unit_rows(const GemvArgs& a, int u, int& ra, int
   }
 }
 
-// PF: the launch carries prefetch workgroups behind its a.pf.n_compute compute workgroups (a separate instantiation: the plain one keeps
-// its first weight load free of any test on a kernel argument)
-template <int DT, int PRO, int EPI, int NX, int R, bool PF = false>
+// XACC: see GemvArgs.x_acc / res_acc (R == 1 only)
+template <int DT, int PRO, int EPI, int NX, int R, bool XACC = false>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
   typedef elem_t<DT> E;
+  static_assert(!XACC || R == 1, "fixed-point residual: batch 1");
   if (TGX_DBG(a, 4)) return;
-  if (PF && (int)blockIdx.x >= a.pf.n_compute) {      // prefetch workgroup: hints only, no result
-    const unsigned v = pf_run(a.pf);
-    if (v == 0x9e3779b9u && threadIdx.x == 1023) *a.pf.sink = v;    // never true: keeps the touches alive
-    return;
-  }
-  const int n_wg = PF ? a.pf.n_compute : (int)gridDim.x;         // compute workgroups of this launch
+  const int n_wg = (int)gridDim.x;
   // double-buffer the weight registers when the activations leave room; with 4 rows also at up to 4 slices per lane (~250 VGPRs, two
   // waves per SIMD): B = 4 Llama-3.2-3B 1577 -> 1621 tok/s, Mistral-7B 821 -> 845, 1B unchanged; two rows at 3 slices lose 5 % with it
   constexpr bool PIPE = NX * R <= 4 || (R == 4 && NX <= 4);
@@ -247,77 +228,29 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
 
   // 2. this wave's slice of every row's activation vector -> registers (zero outside the range)
   float xr[R][NX][8];
-  if constexpr (PRO == PRO_ATTNCOMB) {
-    // Attention's split partials -> the attention output (== attn_combine: out = sum_s o_s 2^(m_s - M) / sum_s l_s 2^(m_s - M)), built by the
-    // whole workgroup: thread = (query head, 8 output dims); the splits of a head arrive as independent 16-byte loads, CH at a time, and
-    // fold into a running (M, L, o[8]) in split order (fixed order: deterministic).  Result -> LDS xs[R][K].
+  if constexpr (XACC && PRO == PRO_RMSNORM) {
+    // x = fp32(acc), converted ONCE per workgroup and handed to the waves through LDS (dynamic, K floats): every wave converting its own copy cost
+    // 16 KB of accumulator reads and 32 conversions per lane ahead of the first FMA (+2.2 us on the gate_up launch, tools/probes/layer_lab.hip)
     extern __shared__ __attribute__((aligned(16))) float xs[];
-    constexpr int CH = 18;                                  // splits per round of loads: one round up to 2304 keys at head_dim 64 (18 blocks of 128)
-    const int dgn = a.attn_hd >> 3, rec = a.attn_hd + 4;
-#pragma unroll 1
-    for (int r = 0; r < R; r++) {
-      const int* posp = a.pos + r;
-      const float* prow = a.attn_part + (size_t)r * a.part_in_stride;
-#pragma unroll 1
-      for (int item = threadIdx.x; item < (a.K >> 3); item += 256) {
-        const int h = item / dgn, dg = item - h * dgn;
-        const float* p = prow + (size_t)h * a.attn_nsplit * rec;
-        float M = -INFINITY, L = 0.f, o[8];
+    for (int cs = threadIdx.x; cs < nchunk; cs += 256) {
+      const ulonglong2* ag = reinterpret_cast<const ulonglong2*>(a.x_acc + (size_t)cs * 8);
+      ulonglong2 t[4];
 #pragma unroll
-        for (int t = 0; t < 8; t++) o[t] = 0.f;
-        // every split slot holds a valid record (a split without keys publishes m = -inf), so the first round needs no position: its loads
-        // leave together with the launch's first weight loads; only contexts beyond CH blocks wait for the position
-        int n_act = min(a.attn_nsplit, CH);
-#pragma unroll 1
-        for (int s0 = 0; s0 < n_act; s0 += CH) {
-          f32x4 d0[CH], d1[CH];
-          float pm[CH], pl[CH];
+      for (int q = 0; q < 4; q++) t[q] = ag[q];
+      float f[8];
 #pragma unroll
-          for (int i = 0; i < CH; i++) {                    // every load of the round is issued before the first use
-            const int sidx = min(s0 + i, a.attn_nsplit - 1);   // clamped: a legal record; masked below
-            const float* rp = p + (size_t)sidx * rec;
-            const f32x4* src = reinterpret_cast<const f32x4*>(rp + dg * 8);
-            d0[i] = src[0]; d1[i] = src[1];
-            const float2 ml = *reinterpret_cast<const float2*>(rp + a.attn_hd);
-            pm[i] = (s0 + i < a.attn_nsplit) ? ml.x : -INFINITY; pl[i] = ml.y;
-          }
-          if (s0 == 0 && a.attn_nsplit > CH) n_act = min(a.attn_nsplit, (*posp + a.attn_step) / a.attn_step);   // ceil((pos + 1) / step)
-          float mc = pm[0];
-#pragma unroll
-          for (int i = 1; i < CH; i++) mc = fmaxf(mc, pm[i]);
-          const float Mn = fmaxf(M, mc);
-          if (Mn == -INFINITY) continue;                     // only empty splits so far (m = -inf records hold stale data: select, never multiply)
-          const float sc = (M == -INFINITY) ? 0.f : exp2f(M - Mn);
-          L *= sc;
-#pragma unroll
-          for (int t = 0; t < 8; t++) o[t] *= sc;
-#pragma unroll
-          for (int i = 0; i < CH; i++) {
-            if (pm[i] != -INFINITY) {
-              const float e = exp2f(pm[i] - Mn);
-              L = fmaf(pl[i], e, L);
-#pragma unroll
-              for (int t = 0; t < 4; t++) { o[t] = fmaf(d0[i][t], e, o[t]); o[4 + t] = fmaf(d1[i][t], e, o[4 + t]); }
-            }
-          }
-          M = Mn;
-        }
-        f32x4* dst = reinterpret_cast<f32x4*>(xs + (size_t)r * a.K + (size_t)item * 8);
-        dst[0] = f32x4{o[0] / L, o[1] / L, o[2] / L, o[3] / L};
-        dst[1] = f32x4{o[4] / L, o[5] / L, o[6] / L, o[7] / L};
-      }
+      for (int q = 0; q < 4; q++) { f[2 * q] = fix_to_f32((long long)t[q].x); f[2 * q + 1] = fix_to_f32((long long)t[q].y); }
+      f32x4* dst = reinterpret_cast<f32x4*>(xs + (size_t)cs * 8);
+      dst[0] = f32x4{f[0], f[1], f[2], f[3]}; dst[1] = f32x4{f[4], f[5], f[6], f[7]};
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      const f32x4* xl = reinterpret_cast<const f32x4*>(xs + (size_t)r * a.K);
+    for (int j = 0; j < NX; j++) {
+      const f32x4* xl = reinterpret_cast<const f32x4*>(xs + (size_t)cidx[j] * 8);
+      f32x4 v0 = xl[0], v1 = xl[1];
+      if (!cok[j]) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
 #pragma unroll
-      for (int j = 0; j < NX; j++) {
-        f32x4 v0 = xl[2 * cidx[j]], v1 = xl[2 * cidx[j] + 1];
-        if (!cok[j]) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
-#pragma unroll
-        for (int t = 0; t < 4; t++) { xr[r][j][t] = v0[t]; xr[r][j][4 + t] = v1[t]; }
-      }
+      for (int t = 0; t < 4; t++) { xr[0][j][t] = v0[t]; xr[0][j][4 + t] = v1[t]; }
     }
   } else {
 #pragma unroll
@@ -442,7 +375,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       unit_rows<EPI>(a, u, ra, rb, rb_valid);
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        if (EPI == EPI_RESIDUAL) { const float* o = a.out + (size_t)r * a.out_stride; e0[r] = o[ra]; e1[r] = o[rb]; }
+        if (EPI == EPI_RESIDUAL) {
+          if constexpr (XACC) { e0[r] = fix_to_f32(a.res_acc[ra]); e1[r] = fix_to_f32(a.res_acc[rb]); }
+          else { const float* o = a.out + (size_t)r * a.out_stride; e0[r] = o[ra]; e1[r] = o[rb]; }
+        }
         if (EPI == EPI_QKV_ROPE) {
           const int half = a.hd >> 1;
           const int p = u % half;
@@ -525,6 +461,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
           float* o = a.out + (size_t)r * a.out_stride;
           o[ra] = e0[r] + va;
           if (rb_valid) o[rb] = e1[r] + vb;
+          if constexpr (XACC) { a.res_acc[ra] = 0; if (rb_valid) a.res_acc[rb] = 0; }     // this lane is the only reader / writer of its rows' accumulators
         } else if (EPI == EPI_SILU_MUL) {
           a.out[(size_t)r * a.out_stride + u] = (va / (1.0f + expf(-va))) * vb;
         } else if (EPI == EPI_GELU) {
@@ -555,35 +492,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
       float bv = sv[r][0]; int bi = si[r][0];
       for (int w = 1; w < 4; w++)
         if (sv[r][w] > bv || (sv[r][w] == bv && si[r][w] < bi)) { bv = sv[r][w]; bi = si[r][w]; }
-      if (a.ticket) {    // read by another workgroup of THIS launch: agent-scope write-through stores (cdna_hip_programming.md Guideline 16, R1)
-        __hip_atomic_store(reinterpret_cast<int*>(a.part_val) + (size_t)r * a.part_stride + blockIdx.x, __builtin_bit_cast(int, bv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.part_idx + (size_t)r * a.part_stride + blockIdx.x, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        a.part_val[(size_t)r * a.part_stride + blockIdx.x] = bv;
-        a.part_idx[(size_t)r * a.part_stride + blockIdx.x] = bi;
-      }
-    }
-    if (a.ticket) {
-      // arrival ticket: partial stores drained (every storing wave), then one relaxed agent-scope increment; the workgroup that draws the last
-      // ticket is ordered after every other workgroup's partials.  It resets the counter (the next lm_head launch is stream-ordered behind
-      // this one), takes ONE agent-scope acquire (drops its CU's stale lines) and finishes the step for every row.
-      __shared__ int s_last;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const unsigned int old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = old == gridDim.x - 1;
-        if (last) {
-          __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        s_last = last;
-      }
-      __syncthreads();
-      if (s_last) {
-#pragma unroll 1
-        for (int r = 0; r < R; r++) { const FinalizeArgs f = a.fin[r]; finalize_row<DT>(f); }
-      }
+      a.part_val[(size_t)r * a.part_stride + blockIdx.x] = bv;
+      a.part_idx[(size_t)r * a.part_stride + blockIdx.x] = bi;
     }
   }
 }
@@ -629,8 +539,6 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(QkNormArgs a) {
 
 template <int DT>
 __global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs a) { finalize_row<DT>(a); }
-// stores one row's finalize arguments where the lm_head launch's last-arriving workgroup reads them (option lmhead.fuse_finalize)
-__global__ void write_finalize_args_kernel(const FinalizeArgs a, FinalizeArgs* dst) { if (threadIdx.x == 0) *dst = a; }
 
 // The greedy finalize of every row of a decode batch in ONE launch (blockIdx.x = row; the batched-MFMA decode step): the step counter is
 // advanced by bump_step_kernel afterwards, because rows running concurrently must all read the same step value.
@@ -646,7 +554,7 @@ __global__ __launch_bounds__(256) void finalize_rows_kernel(const FinalizeRowsAr
   f.tok += r; f.pos += r; f.x += (size_t)r * a.x_stride; f.row = a.f.row + r; f.bump_step = 0;
   finalize_row<DT>(f);
 }
-__global__ void bump_step_kernel(int* step) { if (threadIdx.x == 0) *step = *step + 1; }
+static __global__ void bump_step_kernel(int* step) { if (threadIdx.x == 0) *step = *step + 1; }
 
 // Prefill-by-steps: chunk row r <- embedding of prompt token r, position pos0 + r (one workgroup per chunk row).
 struct EmbedChunkArgs {
@@ -664,10 +572,10 @@ __global__ __launch_bounds__(256) void embed_chunk_kernel(const EmbedChunkArgs a
   gather_embedding<DT>(a.embed, a.ids[r], a.x + (size_t)r * a.H, a.H, a.wpe, a.pos0 + r);
 }
 
-__global__ void advance_pos_kernel(int* pos) { if (threadIdx.x == 0) *pos = *pos + 1; }
-__global__ void add_pos_kernel(int* pos, int n) { if (threadIdx.x == 0) *pos = *pos + n; }
+static __global__ void advance_pos_kernel(int* pos) { if (threadIdx.x == 0) *pos = *pos + 1; }
+static __global__ void add_pos_kernel(int* pos, int n) { if (threadIdx.x == 0) *pos = *pos + n; }
 // Rebuilds the lm_head epilogue's per-workgroup argmax partials from a logits vector (tgx_set_logits: sampler tests).
-__global__ __launch_bounds__(256) void argmax_partials_kernel(const float* logits, int V, float* part_val, int* part_idx) {
+static __global__ __launch_bounds__(256) void argmax_partials_kernel(const float* logits, int V, float* part_val, int* part_idx) {
   __shared__ float sv[256];
   __shared__ int si[256];
   float bv = -INFINITY; int bi = 0x7fffffff;
@@ -687,6 +595,6 @@ __global__ __launch_bounds__(256) void argmax_partials_kernel(const float* logit
   if (threadIdx.x == 0) { part_val[blockIdx.x] = sv[0]; part_idx[blockIdx.x] = si[0]; }
 }
 
-__global__ void nop_kernel(int* w) { if (threadIdx.x == 999) *w = 0; }
+static __global__ void nop_kernel(int* w) { if (threadIdx.x == 999) *w = 0; }
 
 }  // namespace tgx

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const GemmArgs a) {
 }
 
 // partial sums of squares of fp32 rows (the embedding rows a decode step starts from): same (M, SK_NCB) layout
-__global__ __launch_bounds__(256) void row_ssq_kernel(const float* X, long long ldx, int n, float* ssq_out) {
+static __global__ __launch_bounds__(256) void row_ssq_kernel(const float* X, long long ldx, int n, float* ssq_out) {
   __shared__ float sc[4];
   const int m = blockIdx.x, per = ((n + (int)gridDim.y * 4 - 1) / ((int)gridDim.y * 4)) * 4;
   const int c0 = blockIdx.y * per, c1 = min(n, c0 + per);
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64) void rope_kv_rows_kernel(const RopeRowsArgs a) 
 }
 
 // per-workgroup argmax partials of every row's logits (what the GEMV lm_head's epilogue leaves for the greedy finalize / the sampler)
-__global__ __launch_bounds__(256) void argmax_partials_rows_kernel(const float* logits, long long logits_stride, int V, float* part_val, int* part_idx, long long part_stride) {
+static __global__ __launch_bounds__(256) void argmax_partials_rows_kernel(const float* logits, long long logits_stride, int V, float* part_val, int* part_idx, long long part_stride) {
   __shared__ float sv[256];
   __shared__ int si[256];
   const float* lg = logits + (size_t)blockIdx.y * logits_stride;

@@ -77,7 +77,6 @@ ABI = {
     "set_logits": (c_int, [c_void_p, POINTER(c_float), c_int]),
     "bytes_per_token": (c_int64, [c_void_p, c_int64]),
     "abi_version": (c_int, []),
-    "engine_read_stats": (c_int, [c_void_p, POINTER(c_uint64), c_int64, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
 }
 
 
@@ -271,11 +270,3 @@ class Model:
 
     def bytes_per_token(self, T: int) -> int:
         return self.be.bytes_per_token(self._ctx, T)
-
-    def engine_stats(self) -> np.ndarray:
-        """[layers][cus][fields] timeline stamps of the last decode step's engine launches (options engine.mode > 0, engine.stats = 1)."""
-        nl, nc, nf = c_int32(0), c_int32(0), c_int32(0)
-        self._check(self.be.engine_read_stats(self._ctx, None, 0, ctypes.byref(nl), ctypes.byref(nc), ctypes.byref(nf)))
-        out = np.zeros((nl.value, nc.value, nf.value), dtype=np.uint64)
-        self._check(self.be.engine_read_stats(self._ctx, out.ctypes.data_as(POINTER(c_uint64)), out.size, None, None, None))
-        return out

@@ -29,4 +29,7 @@ job_trace() {
   tail -1 $O/trace_bench.log >> $O/kernel_stats.txt; head -24 $O/kernel_stats.txt | cut -c1-200; cd $R
 }
 
+job_atomic_probe() { timeout 120 tools/probes/build/atomic_probe > $O/atomic_probe.log 2>&1; cat $O/atomic_probe.log; }
+job_lab() { for g in ${LAB_GEOMS:-1b}; do timeout 300 tools/probes/build/layer_lab $g ${LAB_POS:-2064}; done > $O/lab.log 2>&1; cat $O/lab.log; }
+
 for j in "$@"; do echo "=== job $j"; job_$j; done

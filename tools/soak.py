@@ -31,20 +31,17 @@ for B in (3, 8, 16):
     for r in (1, 2):
         if not np.array_equal(outs[0], outs[r]): bad += 1; print(f"MISMATCH decode B={B} run {r}", flush=True)
     print(f"decode B={B}: 3 x 300 steps equal: {all(np.array_equal(outs[0], o) for o in outs)}", flush=True)
-# round 3: the persistent decode engine (bounded spins, tagged granules, LDS-DMA ring) and the batch attention forms under repetition
-for mode in (1, 2):
-    m.set_option("engine.mode", mode)
-    ids = synth.synth_prompt(d.vocab, 700, 5)[None, :]
-    outs = []
-    t0 = time.time()
-    for r in range(3):
-        m.reset_cache(); m.forward(ids); m.sample(GREEDY)
-        outs.append(m.decode(1500, GREEDY).copy())       # 1500 steps x 16 layers of engine launches; tgx_synchronize raises on a give-up
-        m.synchronize()
-    for r in (1, 2):
-        if not np.array_equal(outs[0], outs[r]): bad += 1; print(f"MISMATCH engine.mode={mode} run {r}", flush=True)
-    print(f"engine.mode={mode}: 3 x 1500 steps equal: {all(np.array_equal(outs[0], o) for o in outs)}  ({time.time() - t0:.1f} s)", flush=True)
-m.set_option("engine.mode", 0)
+# round 4: the K-sliced o_proj (fixed-point atomics into accumulators that must return to zero every layer) under repetition, across the attention forms
+ids = synth.synth_prompt(d.vocab, 700, 5)[None, :]
+outs = []
+t0 = time.time()
+for r in range(3):
+    m.reset_cache(); m.forward(ids); m.sample(GREEDY)
+    outs.append(m.decode(1500, GREEDY).copy())       # contexts 701 .. 2200: direct form, then split form with the sliced o_proj
+    m.synchronize()
+for r in (1, 2):
+    if not np.array_equal(outs[0], outs[r]): bad += 1; print(f"MISMATCH sliced o_proj run {r}", flush=True)
+print(f"batch 1, 3 x 1500 steps equal: {all(np.array_equal(outs[0], o) for o in outs)}  ({time.time() - t0:.1f} s)", flush=True)
 for B in (12, 16):
     ids = np.stack([synth.synth_prompt(d.vocab, 1500, 21 + b) for b in range(B)])     # beyond the batch-1 direct limit: the batch form with 2 heads per workgroup
     outs = []
