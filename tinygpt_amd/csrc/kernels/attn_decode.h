@@ -63,12 +63,12 @@ __device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, fl
 // RAW (direct forms of a batched step): the workgroup first finishes its own slice of the QKV product (AttnArgs.raw_*: slab sums + bias, q / k norm at
 // head_dim 128, RoPE, cache append by the kv head's first head group) — q, k and v of this position go through LDS, the row-wise rope_kv_rows launch
 // disappears; the same arithmetic in the same order (common.h rope_rotate_pair / head_rms_inv): bit-identical to it.  See attn_decode_mfma.h for the MFMA twin.
-template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool RAW = false>
+template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool RAW = false, int UNR_ = 4>
 __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) {
   typedef elem_t<DT> E;
   constexpr int LPT = HD / 8;         // lanes per token row
   constexpr int TPW = 64 / LPT;       // tokens per wave-load
-  constexpr int UNR = 4;              // wave-loads of K and of V in flight per iteration
+  constexpr int UNR = UNR_;           // wave-loads of K and of V in flight per iteration (4; experiments: tools/probes/layer_lab.hip)
   constexpr float LOG2E = 1.4426950408889634f;
   // per wave and query head: o[HD], m, l  (m in the exp2 domain)
   __shared__ __attribute__((aligned(16))) float red[NW][G][HD + 4];
@@ -234,41 +234,58 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
 
   while (!(TGX_DBG(a, 1))) {
     if (t0 < n_keys) {          // wave-uniform: a wave whose whole range lies beyond the context skips the arithmetic
+    // the block's UNR scores first (independent dot products), then ONE softmax update per block and head: a maximum over the block, UNR + 1
+    // exponentials and one rescale of the running output instead of 2 UNR exponentials and UNR rescales in a serial chain (round 4)
+    float kf[UNR][8], vf[UNR][8];
+    bool valid[UNR];
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
-      const bool valid = t0 + r * TPW + slot < n_keys;
-      float kf[8], vf[8];
-      slice_unpack<DT>(kv[r], kf);
-      slice_unpack<DT>(vv[r], vf);
+      valid[r] = t0 + r * TPW + slot < n_keys;
+      slice_unpack<DT>(kv[r], kf[r]);
+      slice_unpack<DT>(vv[r], vf[r]);
       if constexpr (RAW) {
         if (t0 + r * TPW + slot == n_keys - 1) {      // this step's own key / value: from the prologue (the cache row was stored a moment ago, possibly by another workgroup)
 #pragma unroll
-          for (int j = 0; j < 8; j++) { kf[j] = knew[j]; vf[j] = vnew[j]; }
+          for (int j = 0; j < 8; j++) { kf[r][j] = knew[j]; vf[r][j] = vnew[j]; }
         }
       }
       if constexpr (QKN) {
         const int tok = t0 + r * TPW + slot;
         if (tok == n_keys - 1) {            // the key of this step: computed above, not yet in the cache
 #pragma unroll
-          for (int j = 0; j < 8; j++) kf[j] = knew[j];
+          for (int j = 0; j < 8; j++) kf[r][j] = knew[j];
           if (g_base == 0) store_slice<DT>(const_cast<E*>(kbase + (size_t)tok * HD), 0, knew);   // KVCacheManager::append, once per kv head
         }
       }
+    }
 #pragma unroll
-      for (int g = 0; g < G; g++) {
-        float s = 0.f;
+    for (int g = 0; g < G; g++) {
+      float sc[UNR];
+      float mb = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < 8; j++) s = fmaf(qf[g][j], kf[j], s);
-        s = row_group_sum<LPT>(s);
-        if (valid) {
-          const float mn = fmaxf(m[g], s);
-          const float alpha = exp2f(m[g] - mn);     // exp2(-inf) = 0 on the first key
-          const float p = exp2f(s - mn);
-          l[g] = l[g] * alpha + p;
+      for (int r = 0; r < UNR; r++) {
+        float t = 0.f;
 #pragma unroll
-          for (int j = 0; j < 8; j++) o[g][j] = o[g][j] * alpha + p * vf[j];
-          m[g] = mn;
+        for (int j = 0; j < 8; j++) t = fmaf(qf[g][j], kf[r][j], t);
+        t = row_group_sum<LPT>(t);
+        sc[r] = valid[r] ? t : -INFINITY;
+        mb = fmaxf(mb, sc[r]);
+      }
+      if (mb != -INFINITY) {                        // (lane-group uniform) some key of this block is valid
+        const float mn = fmaxf(m[g], mb);
+        const float alpha = exp2f(m[g] - mn);       // exp2(-inf) = 0 on the first block
+        float lb = 0.f, ob[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < UNR; r++) {
+          const float p = exp2f(sc[r] - mn);        // 0 for a masked key
+          lb += p;
+#pragma unroll
+          for (int j = 0; j < 8; j++) ob[j] = fmaf(p, vf[r][j], ob[j]);
         }
+        l[g] = fmaf(l[g], alpha, lb);
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[g][j] = fmaf(o[g][j], alpha, ob[j]);
+        m[g] = mn;
       }
     }
     }
@@ -291,6 +308,63 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
         for (int j = 0; j < 8; j++) dst[part_i * 8 + j] = o[g][j];
         if (part_i == 0) { dst[HD] = m[g]; dst[HD + 1] = l[g]; }
       }
+    return;
+  }
+  if constexpr (NW == 4) {
+    // Split form and four-wave direct form (round 4): the NW x TPW token-slot streams of the workgroup meet ONCE in LDS.  Every lane group writes its
+    // (m, l, o[HD]) stream; G x S threads derive each stream's weight 2^(m_i - M) and the sums M, L (one DPP row reduction + one cross-row exchange);
+    // G x HD threads then take their output dim over the S weighted streams.  Replaces a 3-step register butterfly per wave (~30 ds_bpermute per
+    // head) plus a 4-record LDS merge: attention 6.0 -> see profiles/r04_attn_pair.txt.
+    constexpr int S = NW * TPW;                           // streams per head: 32 at head_dim 64, 16 at 128
+    __shared__ __attribute__((aligned(16))) float so[S][G][HD];
+    __shared__ float sm[G][S], sl[G][S], se[G][S], sML[G][2];
+    const int st = wv * TPW + slot;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      f32x4* dst = reinterpret_cast<f32x4*>(&so[st][g][part_i * 8]);
+      dst[0] = f32x4{o[g][0], o[g][1], o[g][2], o[g][3]};
+      dst[1] = f32x4{o[g][4], o[g][5], o[g][6], o[g][7]};
+      if (part_i == 0) { sm[g][st] = m[g]; sl[g][st] = l[g]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < G * S) {                            // (G x S <= 128 threads: whole rows of 16 lanes per head)
+      const int g = threadIdx.x / S, i = threadIdx.x - g * S;
+      const float mi = sm[g][i], li = sl[g][i];
+      float M = mi;
+      M = fmaxf(M, dpp_mov<0xB1, 0xf>(M)); M = fmaxf(M, dpp_mov<0x4E, 0xf>(M)); M = fmaxf(M, dpp_mov<0x141, 0xf>(M)); M = fmaxf(M, dpp_mov<0x140, 0xf>(M));
+      if constexpr (S == 32) M = fmaxf(M, __shfl_xor(M, 16, 64));
+      const float e = (mi == -INFINITY) ? 0.f : exp2f(mi - M);      // a stream without keys (m = -inf) weighs nothing
+      float L = li * e;
+      L = row_group_sum<16>(L);
+      if constexpr (S == 32) L += __shfl_xor(L, 16, 64);
+      se[g][i] = e;
+      if (i == 0) { sML[g][0] = M; sML[g][1] = L; }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < G * HD; idx += 64 * NW) {
+      const int g = idx / HD, d = idx - g * HD;
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < S; i++) acc = fmaf(so[i][g][d], se[g][i], acc);
+      if (!head_live(g)) continue;
+      const float M = sML[g][0], L = sML[g][1];
+      if (a.direct) {   // the only split: softmax normalisation here, straight into the o_proj input (fp32 rows, or 16-bit split terms for a batched step)
+        const size_t oi = blockIdx.y * a.q_stride + (size_t)head_of(g) * HD + d;
+        if constexpr (DT != DT_F32) {
+          if (a.out_hi) {          // x = hi + lo, hi = round16(x), lo = round16(x - hi)  (prefill.h split16)
+            const float v = acc / L;
+            const E h = f32_to_elem<DT>(v);
+            a.out_hi[oi] = h; a.out_lo[oi] = f32_to_elem<DT>(v - elem_to_f32<DT>(h));
+            continue;
+          }
+        }
+        a.out[oi] = acc / L;
+        continue;
+      }
+      float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);
+      dst[d] = acc;
+      if (d == 0) { dst[HD] = M; dst[HD + 1] = L; }
+    }
     return;
   }
 #pragma unroll

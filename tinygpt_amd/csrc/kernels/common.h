@@ -140,14 +140,11 @@ __device__ __forceinline__ float head_rms_inv(float ss, int hd, float eps) { ret
 
 // ---- the residual stream in fixed point (kernels/oproj_sliced.h): 2^-32 units in a 64-bit integer — range +-2^31, resolution 2.3e-10 (below the
 // fp32 ulp of any |x| > 4e-3).  Integer adds commute, so a sum of contributions from many workgroups does not depend on their arrival order.
-// f32 -> fixed: v * 2^32 is exact in fp32 (a power-of-two scale), the conversion rounds to nearest.  fixed -> f32: integer part and fraction converted
-// separately and joined by one FMA (three VALU instructions; within ~1 ulp of the correctly rounded value, and a pure function of the accumulator).
+// f32 -> fixed: v * 2^32 is exact in fp32 (a power-of-two scale), the conversion rounds to nearest.  fixed -> f32: the correctly rounded int64 -> float
+// conversion (sign, leading-zero count, shift, round: ~10 VALU instructions) and an exact scale.  (A cheaper hi / lo split was tried first: its error is
+// ABSOLUTE, 2^-25, and small negative values — -1 + 0.9999 — lost four digits: logits 3e-5 off at a one-token context.)
 __device__ __forceinline__ long long f32_to_fix(float v) { return __float2ll_rn(v * 4294967296.0f); }
-__device__ __forceinline__ float fix_to_f32(long long a) {
-  const int hi = (int)(a >> 32);
-  const unsigned lo = (unsigned)a;
-  return fmaf((float)lo, 1.0f / 4294967296.0f, (float)hi);
-}
+__device__ __forceinline__ float fix_to_f32(long long a) { return (float)a * (1.0f / 4294967296.0f); }
 
 // ---- cross-lane reductions ----------------------------------------------------------------------
 // 64-lane sum on the DPP crossbar (no LDS traffic): quad butterflies, half-row / row mirrors, then the two

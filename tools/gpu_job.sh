@@ -30,6 +30,6 @@ job_trace() {
 }
 
 job_atomic_probe() { timeout 120 tools/probes/build/atomic_probe > $O/atomic_probe.log 2>&1; cat $O/atomic_probe.log; }
-job_lab() { for g in ${LAB_GEOMS:-1b}; do timeout 300 tools/probes/build/layer_lab $g ${LAB_POS:-2064}; done > $O/lab.log 2>&1; cat $O/lab.log; }
+job_lab() { for g in ${LAB_GEOMS:-1b}; do for ns in ${LAB_NSPLIT:-0}; do timeout 300 tools/probes/build/layer_lab $g ${LAB_POS:-2064} 16 $([ $ns -gt 0 ] && echo $ns); done; done > $O/lab.log 2>&1; cat $O/lab.log; }
 
 for j in "$@"; do echo "=== job $j"; job_$j; done

@@ -2,6 +2,38 @@
 #pragma once
 #include "kernels/oproj_sliced.h"
 
+// experiment: a plain K-sliced GEMV tile (no merge): workgroup = RB rows x SW columns, partial sums into fixed-point accumulators
+struct SlicedArgs { const void* W; int ldw; const float* x; long long* acc; int N; };
+template <int LPR, int NL>
+__global__ __launch_bounds__(256) void gemv_sliced_kernel(const SlicedArgs a) {
+  constexpr int SW = LPR * 8, RPL = 64 / LPR, RPW = NL * RPL, RB = 4 * RPW;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int slice = blockIdx.y, row0 = blockIdx.x * RB + wv * RPW;
+  const int rl = lane / LPR, cl = lane % LPR;
+  Slice8<DT_BF16> w[NL];
+  const unsigned short* Wp = static_cast<const unsigned short*>(a.W) + (size_t)slice * SW;
+#pragma unroll
+  for (int i = 0; i < NL; i++) w[i] = load_slice_nt<DT_BF16>(Wp + (size_t)min(row0 + i * RPL + rl, a.N - 1) * a.ldw, cl);
+  const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + (size_t)slice * SW + cl * 8);
+  const f32x4 xa = xp[0], xb = xp[1];
+  float mine = 0.f;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    float s = dot8<DT_BF16>(0.f, w[i], xa, xb);
+    if constexpr (LPR == 64) s = wave_sum(s);
+    else { s = row_group_sum<16>(s); if constexpr (LPR == 32) s += __shfl_xor(s, 16, 64); }
+#pragma unroll
+    for (int r = 0; r < RPL; r++) { const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), r * LPR)); if (lane == i * RPL + r) mine = t; }
+  }
+  if (lane < RPW && row0 + lane < a.N) __hip_atomic_fetch_add(a.acc + row0 + lane, f32_to_fix(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int LPR, int NL>
+static void v_sliced(Lab& b, const void* W, int N, int K, const float* x, long long* acc) {
+  SlicedArgs a{W, K, x, acc, N};
+  constexpr int RB = 4 * NL * (64 / LPR);
+  hipLaunchKernelGGL((gemv_sliced_kernel<LPR, NL>), dim3((N + RB - 1) / RB, K / (LPR * 8)), dim3(256), 0, b.st, a);
+}
+
 static int g_ops_dbg = 0;
 static void v_oproj_sliced(Lab& b, int l, long long* acc, const float* resid) {
   const LayerBuf& w = b.lb[(size_t)l];
@@ -34,7 +66,20 @@ static void v_down_acc(Lab& b, int l, long long* acc, float* resid) {
 
 __global__ void acc_to_f32(const long long* acc, float* out, int n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) out[i] = fix_to_f32(acc[i]); }
 
+template <int G, int NW, int UNR>
+static void v_attn(Lab& b, int l) {
+  AttnArgs a = attn_args(b, l);
+  const int ngroups = (a.gfull + G - 1) / G;
+  const dim3 grid(a.kv_heads * a.nsplit, 1, ngroups), blk(64 * NW);
+  hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 64, G, NW, false, false, UNR>), grid, blk, 0, b.st, a);
+}
+
 static void lab_variants_main(Lab& b) {
+  if (b.g.hd == 64) {
+#define TA(G_, NW_, U_) { const float t = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn<G_, NW_, U_>(b, l); }, b.L); printf("  attn split form: %d heads per workgroup, %2d waves x %d wave-loads (%3d keys per workgroup): %.2f us\n", G_, NW_, U_, NW_ * 8 * U_, t); }
+    TA(2, 4, 4) TA(1, 4, 4) TA(4, 4, 4) TA(3, 4, 4) TA(2, 4, 2) TA(1, 4, 2) TA(4, 4, 2) TA(2, 4, 8)
+#undef TA
+  }
   long long* acc; CK(hipMalloc(&acc, (size_t)b.H * 8));
   float *x_a, *x_b; CK(hipMalloc(&x_a, (size_t)b.H * 4)); CK(hipMalloc(&x_b, (size_t)b.H * 4));
   // numerics: one layer, product chain vs sliced chain from the same residual
@@ -59,6 +104,18 @@ static void lab_variants_main(Lab& b) {
   CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
   const float tl = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); p_attn_only(b, l, nullptr); v_oproj_sliced(b, l, acc, b.x); v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x); } }, b.L);
   printf("gate_up reading the fixed-point residual %.2f us, down adding to it %.2f us; the layer as 5 launches {qkv, attn, o_proj sliced, gate_up, down}: %.2f us per layer\n", tg, td, tl);
+  {
+    const float t1 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<32, 8>(b, b.lb[(size_t)l].wdown, b.H, b.I, b.h, acc); }, b.L);
+    const float t2 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<64, 8>(b, b.lb[(size_t)l].wdown, b.H, b.I, b.h, acc); }, b.L);
+    const float t3 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<32, 16>(b, b.lb[(size_t)l].wdown, b.H, b.I, b.h, acc); }, b.L);
+    const float t4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<64, 16>(b, b.lb[(size_t)l].wdown, b.H, b.I, b.h, acc); }, b.L);
+    printf("down as K-sliced tiles + fixed-point atomics: 64 rows x 256 cols %.2f us, 32 x 512 %.2f, 128 x 256 %.2f, 64 x 512 %.2f   (product down %s)\n", t1, t2, t3, t4, "above");
+    const float g1 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<32, 8>(b, b.lb[(size_t)l].wgu, 2 * b.I, b.H, b.x, acc); }, b.L);
+    const float g2 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<64, 16>(b, b.lb[(size_t)l].wgu, 2 * b.I, b.H, b.x, acc); }, b.L);
+    const float q1 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<32, 8>(b, b.lb[(size_t)l].wqkv, b.NQ, b.H, b.x, acc); }, b.L);
+    const float q2 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<64, 8>(b, b.lb[(size_t)l].wqkv, b.NQ, b.H, b.x, acc); }, b.L);
+    printf("the same stream shape on gate_up's weights (no norm / silu; accumulators wrap: timing only) 64 x 256: %.2f, 64 x 512: %.2f; on qkv's weights 64 x 256: %.2f, 32 x 512: %.2f\n", g1, g2, q1, q2);
+  }
 #ifdef LAB_DISSECT
   for (int d : {1, 2, 3, 4, 5, 6, 7}) {
     g_ops_dbg = d;

@@ -3,7 +3,7 @@
 // class (one class back-to-back over all layers, what tgx_profile_decode measures).  Compiles in seconds — the place where kernel variants are tried
 // against the product kernels on identical data before they enter tgx_mi355x.hip.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -I../../tinygpt_amd/csrc layer_lab.hip -o build/layer_lab
-// Run:   layer_lab [geom=1b|0.5b|3b|7b] [pos=2064] [layers=16]
+// Run:   layer_lab [geom=1b|0.5b|3b|7b] [pos=2064] [layers=16] [nsplit=CUs / kv heads, <= 32]
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -63,13 +63,14 @@ static void p_qkv(Lab& b, int l, float* resid) {
   k.heads = b.g.heads; k.kv_heads = b.g.kv; k.hd = b.g.hd; k.max_ctx = b.max_ctx;
   LAUNCH_GEMV(b, PRO_RMSNORM, EPI_QKV_ROPE, b.H, ks, k);
 }
+static int g_attn_dbg = 0;
 static AttnArgs attn_args(Lab& b, int l) {
   const LayerBuf& w = b.lb[(size_t)l];
   AttnArgs a{};
   a.q = b.q; a.k_cache = w.kc; a.v_cache = w.vc; a.pos = b.pos; a.part = b.part; a.out = b.attn;
   a.heads = b.g.heads; a.kv_heads = b.g.kv; a.max_ctx = b.max_ctx; a.nsplit = b.nsplit; a.scale = 1.0f / sqrtf((float)b.g.hd);
   a.q_stride = b.qd; a.kv_stride = 0; a.part_stride = (long long)b.part_row;
-  a.gfull = b.g.heads / b.g.kv;
+  a.gfull = b.g.heads / b.g.kv; a.dbg = g_attn_dbg;
   return a;
 }
 static void p_attn_only(Lab& b, int l, float*) {
@@ -156,7 +157,7 @@ int main(int argc, char** argv) {
   b.max_ctx = 4096;
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   b.G = prop.multiProcessorCount;
-  b.nsplit = std::min(32, std::max(1, b.G / b.g.kv));
+  b.nsplit = argc > 4 ? atoi(argv[4]) : std::min(32, std::max(1, b.G / b.g.kv));
   b.part_row = (size_t)b.g.heads * b.nsplit * (b.g.hd + 4);
   printf("device %s, %d CUs; geometry %s H=%d I=%d heads=%d kv=%d hd=%d; %d layers, context %d, nsplit %d\n", prop.name, b.G, gname, b.H, b.I, b.g.heads, b.g.kv, b.g.hd, b.L, b.pos_h, b.nsplit);
   CK(hipStreamCreateWithFlags(&b.st, hipStreamNonBlocking));
@@ -200,6 +201,14 @@ int main(int argc, char** argv) {
   printf("  %-10s %7.2f\n", "sum", sum);
   const float whole = time_graph(b, [&] { for (int l = 0; l < b.L; l++) for (const Class& c : cls) c.fn(b, l, b.scratch_x); }, b.L);
   printf("product layer as one graph (6 launches per layer, residual into a scratch vector): %.2f us per layer\n", whole);
+#if TGX_DISSECT
+  for (int d : {1, 2, 3, 4}) {
+    g_attn_dbg = d;
+    const float t = time_graph(b, [&] { for (int l = 0; l < b.L; l++) p_attn_only(b, l, nullptr); }, b.L);
+    printf("  attn dissect %d (1 no K/V loop, 2 no merge, 4 exit at once): %.2f us\n", d, t);
+  }
+  g_attn_dbg = 0;
+#endif
 #ifdef LAB_VARIANTS
   lab_variants_main(b);
 #endif
