@@ -121,7 +121,7 @@ struct tgx_ctx {
   unsigned long long graph_clock = 0;
   int graph_cur = -1;
   bool mirror_to_host = true;             // finalize / pick kernels also store the token into the pinned host ring (tgx_fetch_token)
-  int graph_steps = 8;                    // measured: 1 -> 1389 tok/s, 8 -> 1396, 16 -> 1399 (the gap between two graph launches is ~4 us)
+  int graph_steps = 16;                   // measured: 1 -> 1389 tok/s, 8 -> 1396, 16 -> 1399 (the gap between two graph launches is ~4 us)
   unsigned long long* seed_dev = nullptr;
   unsigned long long seed_on_dev = 0;         // value last copied to seed_dev: an unchanged seed costs no copy and no stream sync
   bool seed_valid = false;

@@ -180,8 +180,9 @@ __device__ __forceinline__ void unit_rows(const GemvArgs& a, int u, int& ra, int
 }
 
 // XACC: see GemvArgs.x_acc / res_acc (R == 1 only)
+// (four workgroups per CU — 128 registers — wherever the plain form is within a few registers of it: the lm_head form came out at 130)
 template <int DT, int PRO, int EPI, int NX, int R, bool XACC = false>
-__global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a) {
+__global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void gemv_kernel(const GemvArgs a) {
   typedef elem_t<DT> E;
   static_assert(!XACC || R == 1, "fixed-point residual: batch 1");
   if (TGX_DBG(a, 4)) return;
