@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--model", default="llama-3.2-1b", help="key of tinygpt_amd.desc.KNOWN_CONFIGS")
+    ap.add_argument("--model-dir", default=None, help="a real HF directory (config.json + model.safetensors or its sharded form, ModelLoader.cpp:18-89): "
+                    "its hyper-parameters and weights replace the synthetic ones; `data` then reads \"checkpoint\"")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"], help="storage dtype of parameters and KV cache (the headline is bf16)")
     ap.add_argument("--prompt", type=int, default=2048, help="prefill length before the timed decode")
     ap.add_argument("--profile-reps", type=int, default=8)
@@ -132,6 +134,16 @@ def cpu_baseline(desc, tensors, seconds, prompt_len, prompt_seed, max_prefill_s=
                       f"spread min/max in legs"}
 
 
+def kernel_source_sha256():
+    """sha256 over the sources of the roofline kernel (the GEMV and the helpers it is built from): what ties profiles/pmc_traffic.json to a build"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemv.h", "common.h"):
+        with open(os.path.join(ROOT, "tinygpt_amd", "csrc", "kernels", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def timed_region(run_steps, sync, dist=None, torch=None):
     """The contract's timed region, used by the real run below and (with a stand-in `run_steps`) by tests/test_replicas_gloo.py:
     barrier + synchronize | EXACTLY the K steps of this rank | synchronize; then barrier + MAX over ranks.  No collective sits inside the
@@ -183,16 +195,23 @@ def main():
     from tinygpt_amd import known_desc, synth
     from tinygpt_amd.ffi import GREEDY, Model, product_backend
 
-    desc = known_desc(args.model, args.dtype)
+    if args.model_dir:
+        from tinygpt_amd.checkpoint import iter_checkpoint
+        from tinygpt_amd.desc import load_desc
+        desc = load_desc(args.model_dir, args.dtype)
+        if not desc.name:
+            desc.name = os.path.basename(os.path.normpath(args.model_dir))
+    else:
+        desc = known_desc(args.model, args.dtype)
     need_ctx = args.prompt + args.warmup + args.steps + 8
     if need_ctx > desc.max_ctx:
         sys.exit(f"prompt+warmup+steps = {need_ctx} exceeds contextSize {desc.max_ctx}")
-    tensors = list(synth.synth_checkpoint(desc, 1234, 0.02))
+    tensors = list(iter_checkpoint(args.model_dir)) if args.model_dir else list(synth.synth_checkpoint(desc, 1234, 0.02))
     model = Model(desc, product_backend(), device=local_rank)       # raises if the HIP library is missing
     if args.no_graph:
         model.set_option("graph", 0)
     for name, bits in tensors:
-        model.upload(name, bits)
+        model.upload(name, bits, strict=not args.model_dir)          # a real checkpoint may hold keys the path does not use (non-strict load, GPTModel.h:96)
     model.finalize()
 
     # the library switches attention forms at a context limit and re-captures its graphs when a decode call crosses it: keep the warm-up and
@@ -246,12 +265,18 @@ def main():
     if os.path.exists(pmc_path):
         try:
             rec = json.load(open(pmc_path))
-            ent = rec.get("by_config", {}).get(f"{args.model}:{args.dtype}")
+            ent = rec.get("by_config", {}).get(f"{args.model}:{args.dtype}") if not args.model_dir else None
             if ent is None and args.model == "llama-3.2-1b" and args.dtype == "bf16" and "gateup_bytes_per_launch" in rec:
                 ent = {"gateup_bytes_per_launch": rec["gateup_bytes_per_launch"], "source": rec.get("source", "profiles/r01_bench_pmc.txt")}
             if ent:
-                traffic = ent["gateup_bytes_per_launch"]
-                traffic_source = f"static: {ent.get('source', 'profiles/pmc_traffic.json')} (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction), not collected in this run"
+                have = kernel_source_sha256()
+                if ent.get("kernel_src_sha256") == have:
+                    traffic = ent["gateup_bytes_per_launch"]
+                    traffic_source = (f"static: {ent.get('source', 'profiles/pmc_traffic.json')} (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction), not collected in this run; "
+                                      f"taken with the same kernel source (sha256 {have[:12]} of csrc/kernels/gemv.h + common.h)")
+                else:
+                    traffic_source = (f"a rocprofv3 --pmc FETCH_SIZE figure is on record ({ent['gateup_bytes_per_launch']} B per launch) but it was taken with another build of the "
+                                      f"kernel (source sha256 {str(ent.get('kernel_src_sha256'))[:12]} vs {have[:12]} now): re-run tools/bench_configs.sh")
         except Exception as e:
             traffic_source = f"profiles/pmc_traffic.json unreadable: {e}"
     kname = "gemv_kernel<PRO_LAYERNORM,EPI_GELU> (ln_2 + c_fc + gelu)" if desc.family == "gpt2" else "gemv_kernel<PRO_RMSNORM,EPI_SILU_MUL> (gate_up)"
@@ -288,7 +313,7 @@ def main():
                    else f"decode tokens/sec (and % HBM roofline), {desc.name} {args.dtype} batch=1, 1 GPU"),
         "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "checkpoint" if args.model_dir else "synthetic",
         "config": {"workload": f"{desc.name} {args.dtype}, batch 1 per GPU: {args.prompt}-token prefill then greedy decode "
                                f"(one step = one token, context {T0}..{T0 + args.steps - 1})",
                    "replicas": world, "prompt_tokens": args.prompt, "prefill_ms": round(prefill_ms, 2),

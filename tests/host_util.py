@@ -135,6 +135,8 @@ def write_model_dir(path, cfg, seed, std, shards=1, dtype="bf16", eos=None):
     for name, bits in synth.synth_checkpoint(d, seed, std):
         if dtype == "bf16":      # reinterpret the bit patterns: no float round trip (matters at full model size)
             tensors[name] = torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(torch.bfloat16)
+        elif dtype == "fp16":
+            tensors[name] = torch.from_numpy(synth.bf16_bits_to_f32(bits).copy()).to(torch.float16)
         else:
             tensors[name] = torch.from_numpy(synth.bf16_bits_to_f32(bits).copy())
     if shards == 1:
