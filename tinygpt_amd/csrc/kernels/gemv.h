@@ -223,21 +223,61 @@ __global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void ge
     for (int j = 0; j < NX; j++) { ta[j] = load_slice_nt<DT>(pa, cidx[j]); tb[j] = load_slice_nt<DT>(pb, cidx[j]); }
   };
 
+#ifndef TGX_XFIRST
+#define TGX_XFIRST 0
+#endif
+  constexpr bool XFIRST = TGX_XFIRST && R == 1 && !XACC;     // experiment (tools/probes/layer_lab.hip): the activation slices leave ahead of the weight tile
+  float xr[R][NX][8];
+  auto load_x = [&]() {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const f32x4* xg = reinterpret_cast<const f32x4*>(a.x + (size_t)r * a.x_stride);
+#pragma unroll
+      for (int j = 0; j < NX; j++) {
+        f32x4 v0 = xg[2 * cidx[j]], v1 = xg[2 * cidx[j] + 1];
+        if (!cok[j]) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+#pragma unroll
+        for (int t = 0; t < 4; t++) { xr[r][j][t] = v0[t]; xr[r][j][4 + t] = v1[t]; }
+      }
+    }
+  };
+  if constexpr (XFIRST) { load_x(); __builtin_amdgcn_sched_barrier(0); }
+  // 0. XACC: this thread's eight accumulators of the residual stream leave FIRST — loads return in order, so behind the weight tile their conversion,
+  //    the LDS hand-over and its barrier would all sit between the tile's arrival and the first FMA (gate_up 12.8 -> 13.4 us); ahead of it they are done
+  //    by the time the tile lands
+  ulonglong2 xacc0[(XACC && PRO == PRO_RMSNORM) ? 4 : 1];
+  if constexpr (XACC && PRO == PRO_RMSNORM) {
+    const ulonglong2* ag = reinterpret_cast<const ulonglong2*>(a.x_acc + (size_t)min((int)threadIdx.x, nchunk - 1) * 8);
+#pragma unroll
+    for (int q = 0; q < 4; q++) xacc0[q] = ag[q];
+    __builtin_amdgcn_sched_barrier(0);
+  }
   // 1. the first unit's weights are in flight before anything else is touched
   int ub = blockIdx.x * UPB;
   if (ub < a.units && !(TGX_DBG(a, 2))) load_unit(ub, wa, wb);
+  // (XACC: the norm weights too — behind the hand-over's barrier they would be one more memory round trip)
+  Slice8<DT> nw_x[(XACC && PRO == PRO_RMSNORM) ? NX : 1];
+  if constexpr (XACC && PRO == PRO_RMSNORM) {
+#pragma unroll
+    for (int j = 0; j < NX; j++) nw_x[j] = load_slice<DT>(static_cast<const E*>(a.norm_w), cidx[j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 
   // 2. this wave's slice of every row's activation vector -> registers (zero outside the range)
-  float xr[R][NX][8];
   if constexpr (XACC && PRO == PRO_RMSNORM) {
     // x = fp32(acc), converted ONCE per workgroup and handed to the waves through LDS (dynamic, K floats): every wave converting its own copy cost
     // 16 KB of accumulator reads and 32 conversions per lane ahead of the first FMA (+2.2 us on the gate_up launch, tools/probes/layer_lab.hip)
     extern __shared__ __attribute__((aligned(16))) float xs[];
     for (int cs = threadIdx.x; cs < nchunk; cs += 256) {
-      const ulonglong2* ag = reinterpret_cast<const ulonglong2*>(a.x_acc + (size_t)cs * 8);
       ulonglong2 t[4];
+      if (cs == (int)threadIdx.x) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) t[q] = ag[q];
+        for (int q = 0; q < 4; q++) t[q] = xacc0[q];
+      } else {       // hidden sizes beyond 2048: the later chunks
+        const ulonglong2* ag = reinterpret_cast<const ulonglong2*>(a.x_acc + (size_t)cs * 8);
+#pragma unroll
+        for (int q = 0; q < 4; q++) t[q] = ag[q];
+      }
       float f[8];
 #pragma unroll
       for (int q = 0; q < 4; q++) { f[2 * q] = fix_to_f32((long long)t[q].x); f[2 * q + 1] = fix_to_f32((long long)t[q].y); }
@@ -253,18 +293,8 @@ __global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void ge
 #pragma unroll
       for (int t = 0; t < 4; t++) { xr[0][j][t] = v0[t]; xr[0][j][4 + t] = v1[t]; }
     }
-  } else {
-#pragma unroll
-  for (int r = 0; r < R; r++) {
-    const f32x4* xg = reinterpret_cast<const f32x4*>(a.x + (size_t)r * a.x_stride);
-#pragma unroll
-    for (int j = 0; j < NX; j++) {
-      f32x4 v0 = xg[2 * cidx[j]], v1 = xg[2 * cidx[j] + 1];
-      if (!cok[j]) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
-#pragma unroll
-      for (int t = 0; t < 4; t++) { xr[r][j][t] = v0[t]; xr[r][j][4 + t] = v1[t]; }
-    }
-  }
+  } else if constexpr (!XFIRST) {
+    load_x();
   }
   // sum of one value per batch row over the KS waves that share a unit, in wave order (every wave of the workgroup takes part)
   auto ks_sum = [&](float* v) {
@@ -330,7 +360,7 @@ __global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void ge
     const E* wg = static_cast<const E*>(a.norm_w);
     Slice8<DT> nw[NX];
 #pragma unroll
-    for (int j = 0; j < NX; j++) nw[j] = load_slice<DT>(wg, cidx[j]);        // in flight together with x
+    for (int j = 0; j < NX; j++) { if constexpr (XACC) nw[j] = nw_x[j]; else nw[j] = load_slice<DT>(wg, cidx[j]); }       // in flight together with x
     float ssq[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
