@@ -186,6 +186,7 @@ struct tgx_ctx {
   int gemm_dma = 15 | (1 << 4) | (2 << 8);
   int wide_8k_max = 8;       // option prefill.wide_8k_max: ... while its tiles number at most this many half-chips (8 = 4 tiles per CU: everything below the 256 x 256 kernel's range;
                              // 3 / 8: Llama-3.2-1B S = 512 3.62 / 3.44 ms, 768 5.06 / 4.94; Mistral-7B S = 256 11.16 / 10.81, 512 22.5 / 21.4)
+  int xcd_tiles = 1;         // option prefill.xcd_tiles: the eight-wave GEMMs hand every XCD a 2 x 4 cut of the tile grid (gemm_dma.h xcd_tile)
   int wide_8k = 1;           // option prefill.wide_8k: gate_up of 129-384-row prompts on the eight-wave 128 x 128 kernel
   int hidden_256 = 1;        // option prefill.hidden_256: o_proj / down on the 256 x 256 eight-wave kernel when their tiles fill the chip
   int debug_attn = 0;        // experiment: AttnArgs.dbg

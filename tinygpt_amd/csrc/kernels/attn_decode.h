@@ -193,7 +193,8 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
       for (int j = 0; j < 8; j++) {
         const float v = w[j] * (x[j] * inv);
         const float other = __shfl_xor(v, HL, 64);
-        x[j] = second ? (v * cs[j] + other * sn[j]) : (v * cs[j] - other * sn[j]);
+        // == rope_rotate_pair (common.h) from the view of one partner: first half v cs - other sn, second half v cs + other sn
+        x[j] = second ? fmaf(v, cs[j], __fmul_rn(other, sn[j])) : fmaf(v, cs[j], -__fmul_rn(other, sn[j]));
       }
     };
 #pragma unroll

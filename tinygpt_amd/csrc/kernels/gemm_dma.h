@@ -204,6 +204,21 @@ __global__ __launch_bounds__(256) void gemm_dma_qkv_kernel(const GemmArgs a) {
   }
 }
 
+// XCD-aware tile order (round 4).  Workgroup `linear id` runs on XCD `linear id % 8` (tools/probes/xcc_map_probe.hip) and each XCD has its own 4 MB L2.  With
+// blockIdx.x = N tile fastest, XCD j owned the N tiles j (mod 8) of EVERY row block: all eight L2s streamed their own copy of the whole activation
+// matrix (gate_up at S = 2048: 373 MB fetched for 84 MB of operands, profiles/r03_prefill_mfma.txt).  Here the tile grid is cut into 2 x 4 rectangles, one
+// per XCD, walked M-fastest inside: an XCD's co-resident workgroups share 1/2 of the row blocks and 1/4 of the weight tiles.  Falls back to the plain order
+// when the grid does not divide.  Performance only: any bijection is correct.
+__device__ __forceinline__ void xcd_tile(const GemmArgs& a, int& tm, int& tn) {
+  const int gn = (int)gridDim.x, gm = (int)gridDim.y;
+  tm = (int)blockIdx.y; tn = (int)blockIdx.x;
+  if (!a.xcd_tiles || (gm & 1) || (gn & 3)) return;
+  const int id = tn + gn * tm, xcd = id & 7, l = id >> 3;
+  const int sm = gm >> 1, sn = gn >> 2;          // the XCD's rectangle: sm x sn tiles
+  const int xm = xcd >> 2, xn = xcd & 3;
+  tm = xm * sm + l % sm; tn = xn * sn + l / sm;
+}
+
 // ---- 256 x 256 tile, 8 waves, three-stage LDS-DMA ring (the wide products: gate_up / c_fc) -------------------------------------------
 // Why a bigger tile and a deeper ring: one stage of the 128² kernel holds 0.2-0.4 µs of MFMA work per wave, an LDS-DMA piece takes 1-2 µs
 // to land — the two-stage ring stalls on every stage and only co-resident workgroups hide it.  Here a stage (k = 32) is 48 KB
@@ -218,7 +233,9 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 2, wn = wv & 3;
-  const int m0 = blockIdx.y * TMN, n0 = blockIdx.x * TMN;
+  int tile_m, tile_n;
+  xcd_tile(a, tile_m, tile_n);
+  const int m0 = tile_m * TMN, n0 = tile_n * TMN;
   const unsigned lds_base = (unsigned)(size_t)dma_lds;
   const bool inter = EPI == GEMM_SILU;
 
@@ -354,7 +371,9 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kh = wv >> 2, wm = (wv >> 1) & 1, wn = wv & 1;
-  const int m0 = blockIdx.y * TMN, n0 = blockIdx.x * TMN;
+  int tile_m, tile_n;
+  xcd_tile(a, tile_m, tile_n);
+  const int m0 = tile_m * TMN, n0 = tile_n * TMN;
   const unsigned lds_base = (unsigned)(size_t)dma_lds;
 
   f32x16 acc[2][2];

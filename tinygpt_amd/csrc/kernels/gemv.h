@@ -475,9 +475,7 @@ __global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void ge
           }
           if (!a.raw_qk && (is_q || is_k)) {   // rotate-half RoPE at absolute position pos
             const float cs = e0[r], sn = e1[r];
-            const float ra_ = va * cs - vb * sn;
-            const float rb_ = vb * cs + va * sn;
-            va = ra_; vb = rb_;
+            rope_rotate_pair(va, vb, cs, sn);       // one spelling of the rotation in every RoPE + append site (common.h)
           }
           if (is_q) {
             float* q = a.q_out + (size_t)r * a.q_stride + hh * a.hd;
@@ -560,7 +558,8 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(QkNormArgs a) {
   x1 = elem_to_f32<DT>(w[p + half]) * (x1 * inv);
   const int pos = *a.pos;
   const float cs = a.rope_cos[(size_t)pos * half + p], sn = a.rope_sin[(size_t)pos * half + p];
-  const float r0 = x0 * cs - x1 * sn, r1 = x1 * cs + x0 * sn;
+  float r0 = x0, r1 = x1;
+  rope_rotate_pair(r0, r1, cs, sn);
   if (is_q) { a.q[hh * a.hd + p] = r0; a.q[hh * a.hd + p + half] = r1; }
   else {
     E* dst = static_cast<E*>(a.k_cache) + ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd;

@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) 
       const f32x4 cs = *reinterpret_cast<const f32x4*>(a.rope_cos + (size_t)pos * half + p), sn = *reinterpret_cast<const f32x4*>(a.rope_sin + (size_t)pos * half + p);
 #pragma unroll
       for (int t = 0; t < 4; t++) {
-        const float r0 = x0[t] * cs[t] - x1[t] * sn[t], r1 = x1[t] * cs[t] + x0[t] * sn[t];
+        float r0 = x0[t], r1 = x1[t];
+        rope_rotate_pair(r0, r1, cs[t], sn[t]);         // one spelling of the rotation in every RoPE + append site (common.h): the paths append identical rows
         x0[t] = r0; x1[t] = r1;
       }
     }
@@ -295,6 +296,7 @@ struct GemmArgs {
   // gemm_x2_kernel with A_lo2: tile columns below three_from take two terms only.  The third term exists for results that are rounded
   // to 16 bits again — the K / V columns of the QKV product; its Q columns (the first heads*head_dim) stay fp32.
   int three_from;
+  int xcd_tiles;          // 1: gemm_dma8 / gemm_dma8k map workgroups to tiles per XCD (gemm_dma.h xcd_tile; option prefill.xcd_tiles)
 };
 
 // GEMM_SILU epilogue of one 32 x 32 accumulator block (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)): even lanes hold

@@ -52,7 +52,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
   tgx::GemmArgs g{};
   g.A_hi = a_hi ? a_hi : c->ws_ah; g.A_lo = a_lo ? a_lo : c->ws_al; g.A_lo2 = three_terms ? c->ws_al2 : nullptr;
   g.inter = N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
-  g.B = B; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc; g.three_from = three_from;
+  g.B = B; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc; g.three_from = three_from; g.xcd_tiles = c->xcd_tiles;
   // few column tiles (N = hidden) -> 64-row tiles, so that at least two workgroups share a CU
   const bool few = ((N + tgx::GBN - 1) / tgx::GBN) * ((M + tgx::GBM - 1) / tgx::GBM) < 2 * c->num_cus;
   // measured (tools/prefill_bench.py --gemm-tm, Llama-3.2-1B, S = 2048): this policy 15.0 ms, 64-row tiles also for the three-term

@@ -32,4 +32,22 @@ job_trace() {
 job_atomic_probe() { timeout 120 tools/probes/build/atomic_probe > $O/atomic_probe.log 2>&1; cat $O/atomic_probe.log; }
 job_lab() { for g in ${LAB_GEOMS:-1b}; do for ns in ${LAB_NSPLIT:-0}; do timeout 300 tools/probes/build/layer_lab $g ${LAB_POS:-2064} 16 $([ $ns -gt 0 ] && echo $ns); done; done > $O/lab.log 2>&1; cat $O/lab.log; }
 
+# launch-geometry axes of the GEMV classes on one model (tools/sweep.py): SWEEP_MODEL, SWEEP_PROMPT
+job_sweep() {
+  for g in "qkv.ks=1,2,4" "qkv.bpc=2,4,8" "oproj.ks=1,2,4" "oproj.bpc=1,2,4" "gateup.ks=1,2" "gateup.bpc=2,4,8" "down.ks=1,2,4" "down.bpc=1,2,4,8"; do
+    echo "== $g"; python tools/sweep.py --model ${SWEEP_MODEL:-qwen2.5-0.5b} --prompt ${SWEEP_PROMPT:-16} --steps 64 --grid "$g" 2>&1 | tail -4
+  done > $O/sweep.log 2>&1; cat $O/sweep.log
+}
+
+# prefill GEMMs: FETCH_SIZE (x2 on gfx950) and duration with / without the XCD-aware tile order (option prefill.xcd_tiles)
+job_prefill_xcd() {
+  cd /tmp
+  for o in 0 1; do
+    rm -rf /tmp/px$o; rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/px$o -o p -- python $R/tools/prefill_bench.py --reps 3 --opts "prefill.xcd_tiles=$o" > $O/prefill_xcd$o.log 2>&1
+    echo "== prefill.xcd_tiles=$o  FETCH_SIZE (KiB, x2 for bytes on gfx950)"; python $R/tools/rocpd_pmc.py $(find /tmp/px$o -name "*.db" | head -1) 2>&1 | head -12
+    rm -rf /tmp/pm$o; rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm$o -o p -- python $R/tools/prefill_bench.py --reps 3 --opts "prefill.xcd_tiles=$o" >> $O/prefill_xcd$o.log 2>&1
+    echo "== prefill.xcd_tiles=$o  MFMA busy"; python $R/tools/rocpd_pmc.py $(find /tmp/pm$o -name "*.db" | head -1) 2>&1 | head -16
+  done > $O/prefill_xcd.txt 2>&1; cat $O/prefill_xcd.txt; cd $R
+}
+
 for j in "$@"; do echo "=== job $j"; job_$j; done

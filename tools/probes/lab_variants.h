@@ -110,11 +110,6 @@ static void lab_variants_main(Lab& b) {
     const float t3 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<32, 16>(b, b.lb[(size_t)l].wdown, b.H, b.I, b.h, acc); }, b.L);
     const float t4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<64, 16>(b, b.lb[(size_t)l].wdown, b.H, b.I, b.h, acc); }, b.L);
     printf("down as K-sliced tiles + fixed-point atomics: 64 rows x 256 cols %.2f us, 32 x 512 %.2f, 128 x 256 %.2f, 64 x 512 %.2f   (product down %s)\n", t1, t2, t3, t4, "above");
-    const float g1 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<32, 8>(b, b.lb[(size_t)l].wgu, 2 * b.I, b.H, b.x, acc); }, b.L);
-    const float g2 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<64, 16>(b, b.lb[(size_t)l].wgu, 2 * b.I, b.H, b.x, acc); }, b.L);
-    const float q1 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<32, 8>(b, b.lb[(size_t)l].wqkv, b.NQ, b.H, b.x, acc); }, b.L);
-    const float q2 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_sliced<64, 8>(b, b.lb[(size_t)l].wqkv, b.NQ, b.H, b.x, acc); }, b.L);
-    printf("the same stream shape on gate_up's weights (no norm / silu; accumulators wrap: timing only) 64 x 256: %.2f, 64 x 512: %.2f; on qkv's weights 64 x 256: %.2f, 32 x 512: %.2f\n", g1, g2, q1, q2);
   }
 #ifdef LAB_DISSECT
   for (int d : {1, 2, 3, 4, 5, 6, 7}) {
