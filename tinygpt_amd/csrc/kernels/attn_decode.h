@@ -368,6 +368,78 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
     }
     return;
   }
+#ifndef TGX_OLD_DIRECT_MERGE
+#define TGX_OLD_DIRECT_MERGE 0      // experiments (tools/probes/layer_lab.hip): 1 keeps the butterfly + per-wave-record merge of the 8 / 16-wave forms
+#endif
+  if constexpr (NW > 4 && G == 1 && !TGX_OLD_DIRECT_MERGE) {
+    // Direct forms with 8 / 16 waves and one head per workgroup (batch 1, contexts of a few hundred keys): the same single LDS meeting of all NW x TPW
+    // streams as above instead of a register butterfly per wave plus an NW-record merge whose cost grows with NW (16 records: ~2 us).  Wave 0 derives
+    // the weights (1-2 streams per lane, wave reductions); HD x PARTS threads sum their quarter of the streams, HD threads add the quarters in order.
+    constexpr int S = NW * TPW, KPL = (S + 63) / 64, PARTS = NW / 4, SPP = S / PARTS;
+    __shared__ __attribute__((aligned(16))) float so[S][HD];
+    __shared__ float sm[S], sl[S], se[S], sML[2], spart[PARTS][HD];
+    const int st = wv * TPW + slot;
+    {
+      f32x4* dst = reinterpret_cast<f32x4*>(&so[st][part_i * 8]);
+      dst[0] = f32x4{o[0][0], o[0][1], o[0][2], o[0][3]};
+      dst[1] = f32x4{o[0][4], o[0][5], o[0][6], o[0][7]};
+      if (part_i == 0) { sm[st] = m[0]; sl[st] = l[0]; }
+    }
+    __syncthreads();
+    if (wv == 0) {
+      float mi[KPL], li[KPL], M = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < KPL; k++) {
+        const int i = lane + 64 * k;
+        mi[k] = i < S ? sm[i] : -INFINITY; li[k] = i < S ? sl[i] : 0.f;
+        M = fmaxf(M, mi[k]);
+      }
+      M = group_max<64>(M);
+      float L = 0.f;
+#pragma unroll
+      for (int k = 0; k < KPL; k++) {
+        const float e = (mi[k] == -INFINITY) ? 0.f : exp2f(mi[k] - M);      // a stream without keys weighs nothing
+        L = fmaf(li[k], e, L);
+        if (lane + 64 * k < S) se[lane + 64 * k] = e;
+      }
+      L = wave_sum(L);
+      if (lane == 0) { sML[0] = M; sML[1] = L; }
+    }
+    __syncthreads();
+    if (threadIdx.x < HD * PARTS) {
+      const int d = threadIdx.x % HD, pt = threadIdx.x / HD;
+      float acc = 0.f;
+#pragma unroll 8
+      for (int i = pt * SPP; i < (pt + 1) * SPP; i++) acc = fmaf(so[i][d], se[i], acc);
+      spart[pt][d] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < HD && head_live(0)) {
+      const int d = threadIdx.x;
+      float acc = spart[0][d];
+#pragma unroll
+      for (int pt = 1; pt < PARTS; pt++) acc += spart[pt][d];
+      const float M = sML[0], L = sML[1];
+      if (a.direct) {
+        const size_t oi = blockIdx.y * a.q_stride + (size_t)head_of(0) * HD + d;
+        bool done = false;
+        if constexpr (DT != DT_F32) {
+          if (a.out_hi) {
+            const float v = acc / L;
+            const E h = f32_to_elem<DT>(v);
+            a.out_hi[oi] = h; a.out_lo[oi] = f32_to_elem<DT>(v - elem_to_f32<DT>(h));
+            done = true;
+          }
+        }
+        if (!done) a.out[oi] = acc / L;
+      } else {
+        float* dst = part_row + ((size_t)head_of(0) * a.nsplit + sp) * (HD + 4);
+        dst[d] = acc;
+        if (d == 0) { dst[HD] = M; dst[HD + 1] = L; }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int g = 0; g < G; g++) {
     float M = m[g];

@@ -74,7 +74,27 @@ static void v_attn(Lab& b, int l) {
   hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 64, G, NW, false, false, UNR>), grid, blk, 0, b.st, a);
 }
 
+// direct forms (short contexts): one workgroup per (kv head, query head), normalised output, no records
+template <int NW>
+static void v_attn_direct(Lab& b, int l) {
+  AttnArgs a = attn_args(b, l);
+  a.direct = 1;
+  const dim3 grid(a.kv_heads, 1, a.gfull), blk(64 * NW);
+  hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 64, 1, NW>), grid, blk, 0, b.st, a);
+}
+
 static void lab_variants_main(Lab& b) {
+  if (b.g.hd == 64 && b.pos_h < 1024) {
+    const float d4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_direct<4>(b, l); }, b.L);
+    const float d8 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_direct<8>(b, l); }, b.L);
+    const float d16 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_direct<16>(b, l); }, b.L);
+    // numerics: 16 waves vs 4 waves on layer 2
+    std::vector<float> oa((size_t)b.qd), ob((size_t)b.qd);
+    v_attn_direct<4>(b, 2); CK(hipStreamSynchronize(b.st)); CK(hipMemcpy(oa.data(), b.attn, (size_t)b.qd * 4, hipMemcpyDeviceToHost));
+    v_attn_direct<16>(b, 2); CK(hipStreamSynchronize(b.st)); CK(hipMemcpy(ob.data(), b.attn, (size_t)b.qd * 4, hipMemcpyDeviceToHost));
+    double mx = 0, ref = 0; for (int i = 0; i < b.qd; i++) { mx = std::max(mx, (double)fabsf(oa[(size_t)i] - ob[(size_t)i])); ref = std::max(ref, (double)fabsf(oa[(size_t)i])); }
+    printf("attention direct form at context %d: 4 waves %.2f us, 8 waves %.2f, 16 waves %.2f   (16 vs 4 waves: rel diff %.2g)\n", b.pos_h, d4, d8, d16, mx / ref);
+  }
   if (b.g.hd == 64) {
 #define TA(G_, NW_, U_) { const float t = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn<G_, NW_, U_>(b, l); }, b.L); printf("  attn split form: %d heads per workgroup, %2d waves x %d wave-loads (%3d keys per workgroup): %.2f us\n", G_, NW_, U_, NW_ * 8 * U_, t); }
     TA(2, 4, 4) TA(1, 4, 4) TA(4, 4, 4) TA(3, 4, 4) TA(2, 4, 2) TA(1, 4, 2) TA(4, 4, 2) TA(2, 4, 8)
