@@ -216,10 +216,10 @@ def main():
 
     # the library switches attention forms at a context limit and re-captures its graphs when a decode call crosses it: keep the warm-up and
     # the timed region on the same form (the split one) when the timed region would cross
-    limit = 768 if desc.head_dim == 64 else 384
+    limit = (576 if desc.kv_heads >= 8 else 832) if desc.head_dim == 64 else 384          # == tgx_create's attn.direct_max
     if args.prompt + 1 + args.warmup <= limit < args.prompt + 1 + args.warmup + args.steps:
         model.set_option("attn.direct_max", 0)
-    nw4 = 256 if desc.head_dim == 64 else 0           # the four-wave form of very short contexts: same rule (a crossing would capture a graph inside the timed region)
+    nw4 = 192 if desc.head_dim == 64 else 0           # the four-wave form of very short contexts: same rule (a crossing would capture a graph inside the timed region)
     if nw4 and args.prompt + 1 + args.warmup <= nw4 < args.prompt + 1 + args.warmup + args.steps:
         model.set_option("attn.direct_nw4", 0)
     prompt = synth.synth_prompt(desc.vocab, args.prompt, 1234 + rank)[None, :]

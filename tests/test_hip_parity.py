@@ -554,7 +554,7 @@ def test_k_sliced_o_proj_with_the_attention_merge_equals_combine_plus_o_proj(nam
 
 
 def test_one_long_decode_call_equals_single_steps_across_the_attention_form_limits(hip):
-    """A decode call that crosses the limits of the attention forms (four-wave direct <= 256 keys, sixteen-wave direct <= 768, split + combine beyond)
+    """A decode call that crosses the limits of the attention forms (four-wave direct <= 192 keys, sixteen-wave direct <= 576 at head_dim 64 with 8 kv heads, split form — merged by the K-sliced o_proj — beyond)
     is issued in chunks, each on the form of its own contexts, from the cache of captured graphs (round 3): its ids and final logits must be
     bit-identical to the same generation issued one step at a time, and a second generation (graphs re-used) must repeat them."""
     import copy
@@ -563,7 +563,7 @@ def test_one_long_decode_call_equals_single_steps_across_the_attention_form_limi
     d = copy.deepcopy(known_desc("llama-3.2-1b"))
     d.layers, d.vocab, d.max_ctx = 2, 4096, 1024
     m = Model(d, hip).load_synthetic(1234, 0.02).finalize()
-    prompt = synth.synth_prompt(d.vocab, 200, 9)[None, :]
+    prompt = synth.synth_prompt(d.vocab, 150, 9)[None, :]
     runs = []
     for mode in ("one call", "single steps", "one call again"):
         m.reset_cache(); m.forward(prompt)
@@ -571,7 +571,7 @@ def test_one_long_decode_call_equals_single_steps_across_the_attention_form_limi
         if mode == "single steps":
             ids = np.concatenate([m.decode(1, GREEDY) for _ in range(620)])
         else:
-            ids = m.decode(620, GREEDY).copy()               # contexts 201 .. 820: crosses 256 and 768
+            ids = m.decode(620, GREEDY).copy()               # contexts 151 .. 770: crosses 192 and 576
         runs.append((first, ids, m.logits(rounded=False).copy()))
     for k in (1, 2):
         np.testing.assert_array_equal(runs[0][0], runs[k][0])

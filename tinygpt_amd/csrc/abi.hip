@@ -319,6 +319,7 @@ static int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t see
     } else {
       for (int i = 0; i < m; i++) launch_decode_step(c, cfg);
       HIP_OK(c, hipGetLastError());
+      if (c->launch_fault) { (void)hipStreamSynchronize(c->stream); c->poisoned = true; }      // the kernels issued before the fault advanced the device-side state
       LAUNCH_OK(c);
     }
     c->past += m;
@@ -388,9 +389,11 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   if (const char* e = getenv("TGX_NO_GRAPH")) c->use_graph = !(e[0] == '1');
   // measured crossover of the direct and the split attention (tools/sweep.py --grid attn.direct_max=0,100000): context ~850-1100 at
   // head_dim 64 (Qwen2.5-0.5B, Llama-3.2-1B), ~500 at 128 (Mistral-7B: half the tokens per wave-load)
-  c->attn_direct_max = d.head_dim == 64 ? 768 : 384;
+  // round 4 (the split form lost its combine launch to the K-sliced o_proj, the 16-wave direct form its per-wave merge): Llama-3.2-1B 0.652 / 0.654 ms/token
+  // split / direct at context 700, 0.654 / 0.667 at 1000; Qwen2.5-0.5B (2 kv heads: few split workgroups) 0.591 / 0.586 at 700, 0.591 / 0.600 at 1000
+  c->attn_direct_max = d.head_dim == 64 ? (d.kv_heads >= 8 ? 576 : 832) : 384;
   // four waves per head up to 256 keys at head_dim 64 (Qwen2.5-0.5B 16-token prompt 0.579 -> 0.565 ms/token, Llama-3.2-1B 0.648 -> 0.634; from ~256 keys and at head_dim 128 the sixteen-wave form is ahead)
-  c->attn_direct_nw4 = d.head_dim == 64 ? 256 : 0;
+  c->attn_direct_nw4 = d.head_dim == 64 ? 192 : 0;      // (round 4: equal at ~220 keys, the sixteen-wave form ahead from ~300)
   // very short prompts: ONE pass through the batched decode kernels (4 positions) still beats the skinny MFMA prefill on small models
   // (Llama-3.2-1B: S = 4 1.00 vs 1.07 ms, S = 5 1.55 vs 1.07; Mistral-7B S = 4 4.65 vs 4.09) — tools/prefill_crossover.py, profiles/r02_prefill_short.txt
   c->prefill_min_rows = d.hidden > 2048 ? 4 : 5;
@@ -627,6 +630,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
   if (!c || !ids) return c ? set_err(c, TGX_ERR_INVALID, "null argument") : TGX_ERR_INVALID;
   if (!c->finalized) return set_err(c, TGX_ERR_STATE, "forward before finalize");
   if (batch < 1 || batch > c->d.max_batch || seq < 1) return set_err(c, TGX_ERR_INVALID, "batch/seq out of range");
+  if (c->poisoned) return set_err(c, TGX_ERR_STATE, "an earlier pass failed half-way: call tgx_reset_cache first");
   if (seq > 1 && c->past > 0) return set_err(c, TGX_ERR_INVALID, "seq>1 with pastLength>0");
   if (c->past + seq > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded: %lld + %d > %d", (long long)c->past, seq, c->d.max_ctx);
   for (int64_t i = 0; i < (int64_t)batch * seq; i++)
@@ -678,7 +682,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     }
   }
   HIP_OK(c, hipGetLastError());
-  if (c->launch_fault) (void)hipStreamSynchronize(c->stream);   // nothing of a failed pass stays in flight (the prompt copies read the caller's buffer)
+  if (c->launch_fault) { (void)hipStreamSynchronize(c->stream); c->poisoned = true; }   // nothing of a failed pass stays in flight (the prompt copies read the caller's buffer); the caches hold a partial pass
   LAUNCH_OK(c);
   HIP_OK(c, hipStreamSynchronize(c->stream));   // host `ids` may be pageable and reused by the caller
   c->past += seq;
@@ -728,6 +732,7 @@ int tgx_sample(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* o
 
 int tgx_decode(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int n_steps, int64_t* out_ids) {
   if (!c || !cfg || n_steps < 0) return TGX_ERR_INVALID;
+  if (c->poisoned) return set_err(c, TGX_ERR_STATE, "an earlier pass failed half-way: call tgx_reset_cache first");
   if (!c->have_token) return set_err(c, TGX_ERR_STATE, "decode needs a current token: call tgx_sample after tgx_forward");
   if (c->past + n_steps > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded: %lld + %d > %d", (long long)c->past, n_steps, c->d.max_ctx);
   if (n_steps > c->log_cap) return set_err(c, TGX_ERR_INVALID, "n_steps exceeds the token log capacity %d", c->log_cap);
@@ -753,6 +758,7 @@ int tgx_decode(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int n_step
 
 int tgx_step_async(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* out_ticket) {
   if (!c || !cfg || !out_ticket) return TGX_ERR_INVALID;
+  if (c->poisoned) return set_err(c, TGX_ERR_STATE, "an earlier pass failed half-way: call tgx_reset_cache first");
   if (!c->have_token) return set_err(c, TGX_ERR_STATE, "step needs a current token: call tgx_sample after tgx_forward");
   if (c->past + 1 > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded");
   HIP_OK(c, hipSetDevice(c->device));
@@ -784,6 +790,7 @@ int tgx_reset_cache(tgx_ctx* c) {
   HIP_OK(c, hipStreamSynchronize(c->stream));
   c->past = 0;
   c->have_logits = c->have_token = false;
+  c->poisoned = false;
   return TGX_OK;
 }
 

@@ -139,6 +139,7 @@ struct tgx_ctx {
   bf16_t *ws_qh = nullptr, *ws_ql = nullptr;          // [S][qd] rotated queries (hi, lo)
   bf16_t *ws_hh = nullptr, *ws_hl = nullptr;          // [S][I] siluMul output (hi, lo): the down product's A operand
   float* ws_part = nullptr; size_t ws_part_bytes = 0;   // split-K slabs of the short-prompt GEMMs
+  bool poisoned = false;                                // a pass failed after some of its kernels were issued (device-side position / cache / counters may have moved): every entry point refuses until tgx_reset_cache
   const char* launch_fault = nullptr;                   // a launcher could not issue a kernel (a combination that is not instantiated): the issuing entry point fails with it
   int* ws_pos = nullptr;                                // fp32 prefill: [rows] positions of the prompt rows
   float* ws_attn_part = nullptr;                        // fp32 prefill: split-attention partials of one block of rows
