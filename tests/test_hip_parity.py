@@ -232,7 +232,7 @@ def test_batches_beyond_four_rows_run_on_the_matrix_cores(family, dtype, rows, h
                 # one ulp of the LARGER of the two (a flip across a power of two is one ulp of the upper binade).  Layer 1's inputs differ by
                 # layer 0's flips, an ABSOLUTE difference of ~1e-4 of the largest entry: entries near zero get the wider floor there
                 # (rows 35 / 39 of the 40- and 70-row qwen2_tiny batches: PREFILL entries of layer 1 up to 5.6e-4 of the largest entry away, the same on
-                #  every step form including round 2's — tools/dbg_rows64.py lists them: floor 5e-2 ulp-units there)
+                #  every step form including round 2's — listed in round 3 with a since-deleted debug script: floor 5e-2 ulp-units there)
                 fl = floor if layer == 0 else max(floor, 5e-2 if (family == "qwen2_tiny" and row in (35, 39)) else 2e-2)
                 bad = np.abs(g_ - r_) > tol * (np.maximum(np.abs(g_), np.abs(r_)) + fl * np.abs(r_).max())
                 assert not bad.any(), (row, layer, int(bad.sum()), float(np.abs(g_ - r_).max()))

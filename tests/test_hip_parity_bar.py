@@ -121,7 +121,7 @@ def test_full_depth_vs_oracle(name, oracle_lib):
             if step:
                 # the step's OWN appended row cannot be injected (it is computed inside the step): where its fp32 values straddle a bf16 boundary
                 # the token attends to a key / value one ulp off, often with a large weight (itself) — measured 2e-5 .. 2.7e-4 per step over
-                # 28 layers (tools/dbg_inject.py prints the per-layer row differences), against 1.3-1.7e-3 end to end
+                # 28 layers (test_full_depth_flip_floor_oracle_vs_reordered_oracle measures the same effect with no GPU code involved), against 1.3-1.7e-3 end to end
                 assert inj[-1] < 5e-4, (step, inj)
             top2 = np.sort(lr[0])[-2:]
             gap = (top2[1] - top2[0]) / np.abs(lr).max()

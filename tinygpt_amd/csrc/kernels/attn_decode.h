@@ -53,6 +53,14 @@ struct AttnArgs {
   // direct forms: when set, the normalised rows leave as exact 16-bit split terms (row stride q_stride) — the o_proj product of a batched step then takes
   // stored terms (kernels/skinny_dma.h) instead of splitting fp32 rows while staging
   unsigned short *out_hi, *out_lo;
+  // direct form with the o_proj product in its epilogue (kernel template OPJ, batch 1, short contexts; round 4): the workgroup of query head h multiplies
+  // its normalised output by W_o[:, h * hd .. + hd) and adds the H partial sums to the fixed-point residual accumulators (kernels/oproj_sliced.h has the
+  // long-context twin).  blockIdx.z = head-in-group * oj_rsplit + row part: oj_rsplit workgroups share a head, each repeats its attention and takes
+  // H / oj_rsplit rows of the product.  No attention output touches memory and the o_proj launch disappears.
+  const void* oj_w;       // [H][heads * hd] storage dtype
+  const float* oj_x;      // [H] residual input (added once, by head 0)
+  long long* oj_acc;      // [H] fixed-point accumulators, zero on entry
+  int oj_H, oj_ldw, oj_rsplit;
 };
 
 template <int HD>
@@ -63,8 +71,9 @@ __device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, fl
 // RAW (direct forms of a batched step): the workgroup first finishes its own slice of the QKV product (AttnArgs.raw_*: slab sums + bias, q / k norm at
 // head_dim 128, RoPE, cache append by the kv head's first head group) — q, k and v of this position go through LDS, the row-wise rope_kv_rows launch
 // disappears; the same arithmetic in the same order (common.h rope_rotate_pair / head_rms_inv): bit-identical to it.  See attn_decode_mfma.h for the MFMA twin.
-template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool RAW = false, int UNR_ = 4>
+template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool RAW = false, int UNR_ = 4, bool OPJ = false>
 __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) {
+  static_assert(!OPJ || (G == 1 && NW > 4 && !QKN && !RAW && DT != DT_F32), "OPJ: one head per workgroup, 8 / 16 waves, 16-bit storage");
   typedef elem_t<DT> E;
   constexpr int LPT = HD / 8;         // lanes per token row
   constexpr int TPW = 64 / LPT;       // tokens per wave-load
@@ -83,7 +92,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
   const int nsp = a.direct ? 1 : a.nsplit;
   const int kvh = blockIdx.x / nsp, sp = blockIdx.x - kvh * nsp;
   const int part_i = lane % LPT, slot = lane / LPT;
-  const int g_base = blockIdx.z * G;                                   // first head (within the kv group) of this workgroup
+  const int g_base = (OPJ ? (int)blockIdx.z / a.oj_rsplit : (int)blockIdx.z) * G;      // first head (within the kv group) of this workgroup
   auto head_of = [&](int g) { return kvh * a.gfull + min(g_base + g, a.gfull - 1); };   // clamped: a short last group reloads its last head
   auto head_live = [&](int g) { return g_base + g < a.gfull; };
   // Token blocks of STEP = NW waves x UNR wave-loads are dealt round-robin to the splits: split sp owns blocks sp,
@@ -159,6 +168,28 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
 #pragma unroll
     for (int j = 0; j < 4; j++) { qf[g][j] = q0[j]; qf[g][4 + j] = q1[j]; }
   }
+  // OPJ: this wave's rows of the o_proj strip W_o[rows, head columns]: LPT lanes per row (one 16-byte slice each), TPW rows per wave-load, OJC wave-loads
+  // per chunk.  Chunk 0 leaves now, behind the first K / V block (loads return in order: the attention's waits are not held up by it) and behind q, and lands while the
+  // attention runs; chunk 1 leaves when the key loop is done.
+  constexpr int OJC = 8;
+  static_assert(!OPJ || LPT == OJC, "OPJ: head_dim 64 (a chunk's OJC row sums go to the LPT lanes of a row group)");
+  Slice8<DT> ow0[OPJ ? OJC : 1], ow1[OPJ ? OJC : 1];
+  int oj_row0 = 0, oj_rend = 0, oj_rounds = 0;
+  const E* oj_wp = nullptr;
+  float oj_res[2] = {0.f, 0.f};
+  if constexpr (OPJ) {
+    const int rs = (int)blockIdx.z % a.oj_rsplit, rwg = a.oj_H / a.oj_rsplit;
+    const int rw = ((rwg + NW * TPW - 1) / (NW * TPW)) * TPW;            // rows per wave (whole wave-loads)
+    oj_rounds = rw / TPW;
+    oj_rend = (rs + 1) * rwg;
+    oj_row0 = rs * rwg + wv * rw;
+    oj_wp = static_cast<const E*>(a.oj_w) + (size_t)head_of(0) * HD;
+#pragma unroll
+    for (int r = 0; r < OJC; r++) ow0[r] = load_slice_nt<DT>(oj_wp + (size_t)min(oj_row0 + r * TPW + slot, a.oj_H - 1) * a.oj_ldw, part_i);
+#pragma unroll
+    for (int c = 0; c < 2; c++) oj_res[c] = a.oj_x[min(oj_row0 + (c * OJC + part_i) * TPW + slot, a.oj_H - 1)];
+  }
+  if constexpr (OPJ) __builtin_amdgcn_sched_barrier(0);
   const float qscale = a.scale * LOG2E;     // softmax in base 2: exp(x) = exp2(x * log2 e)
   float knew[8];                            // QKN / RAW: this lane group's slice of the current position's key, as the cache will hold it
   float vnew[8];                            // RAW: and of its value row
@@ -233,7 +264,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
     for (int j = 0; j < 8; j++) o[g][j] = 0.f;
   }
 
-  while (!(TGX_DBG(a, 1))) {
+  auto block = [&]() {
     if (t0 < n_keys) {          // wave-uniform: a wave whose whole range lies beyond the context skips the arithmetic
     // the block's UNR scores first (independent dot products), then ONE softmax update per block and head: a maximum over the block, UNR + 1
     // exponentials and one rescale of the running output instead of 2 UNR exponentials and UNR rescales in a serial chain (round 4)
@@ -290,13 +321,27 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
       }
     }
     }
-    t0 += nsp * STEP;                 // this split's next block (contexts beyond nsplit*STEP tokens)
-    if (t0 >= n_keys) break;          // wave-uniform
+  };
+  auto reload = [&]() {
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
       const int tc = min(t0 + r * TPW + slot, n_keys - 1);
       kv[r] = load_slice<DT>(kbase + (size_t)tc * HD, 0);
       vv[r] = load_slice<DT>(vbase + (size_t)tc * HD, 0);
+    }
+  };
+  if constexpr (OPJ) {
+    // the first block outside the loop: a loop header would make its waits the conservative ones of the back edge (all but 3 loads landed), i.e. the
+    // attention would wait for the o_proj strip that was issued behind its K / V block
+    block();
+    t0 += nsp * STEP;
+    while (t0 < n_keys) { reload(); block(); t0 += nsp * STEP; }
+  } else {
+    while (!(TGX_DBG(a, 1))) {
+      block();
+      t0 += nsp * STEP;                 // this split's next block (contexts beyond nsplit*STEP tokens)
+      if (t0 >= n_keys) break;          // wave-uniform
+      reload();
     }
   }
 
@@ -372,6 +417,12 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
 #define TGX_OLD_DIRECT_MERGE 0      // experiments (tools/probes/layer_lab.hip): 1 keeps the butterfly + per-wave-record merge of the 8 / 16-wave forms
 #endif
   if constexpr (NW > 4 && G == 1 && !TGX_OLD_DIRECT_MERGE) {
+    if constexpr (OPJ) {
+      if (oj_rounds > OJC) {
+#pragma unroll
+        for (int r = 0; r < OJC; r++) ow1[r] = load_slice_nt<DT>(oj_wp + (size_t)min(oj_row0 + (OJC + r) * TPW + slot, a.oj_H - 1) * a.oj_ldw, part_i);
+      }
+    }
     // Direct forms with 8 / 16 waves and one head per workgroup (batch 1, contexts of a few hundred keys): the same single LDS meeting of all NW x TPW
     // streams as above instead of a register butterfly per wave plus an NW-record merge whose cost grows with NW (16 records: ~2 us).  Wave 0 derives
     // the weights (1-2 streams per lane, wave reductions); HD x PARTS threads sum their quarter of the streams, HD threads add the quarters in order.
@@ -420,7 +471,8 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
 #pragma unroll
       for (int pt = 1; pt < PARTS; pt++) acc += spart[pt][d];
       const float M = sML[0], L = sML[1];
-      if (a.direct) {
+      if constexpr (OPJ) spart[0][d] = acc / L;                 // the normalised head output stays in LDS: the o_proj strip's activation
+      else if (a.direct) {
         const size_t oi = blockIdx.y * a.q_stride + (size_t)head_of(0) * HD + d;
         bool done = false;
         if constexpr (DT != DT_F32) {
@@ -436,6 +488,50 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
         float* dst = part_row + ((size_t)head_of(0) * a.nsplit + sp) * (HD + 4);
         dst[d] = acc;
         if (d == 0) { dst[HD] = M; dst[HD + 1] = L; }
+      }
+    }
+    if constexpr (OPJ) {
+      // == Attention.h:111-112 o_proj(attn) + the residual add of DecoderLayer.h:40, for this head's HD columns of every row of the part: lane (slot, part_i)
+      // holds 8 activations; a wave-load covers TPW rows; the row sums of a chunk are handed to distinct lanes (round r -> the lanes with part_i == r), so a
+      // chunk ends in ONE atomic instruction per wave over 64 consecutive accumulators.  64-bit fixed point: the sum over heads does not depend on the order
+      // in which the workgroups arrive (common.h f32_to_fix).
+      __syncthreads();
+      const f32x4 xa = *reinterpret_cast<const f32x4*>(&spart[0][part_i * 8]), xb = *reinterpret_cast<const f32x4*>(&spart[0][part_i * 8 + 4]);
+      const bool first_head = head_of(0) == 0;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        if (c * OJC >= oj_rounds) break;
+        float mine = 0.f;
+#pragma unroll
+        for (int r = 0; r < OJC; r++) {
+          float sdot = dot8<DT>(0.f, c == 0 ? ow0[r] : ow1[r], xa, xb);
+          sdot = row_group_sum<LPT>(sdot);
+          if (part_i == r) mine = sdot;
+        }
+        const int row = oj_row0 + (c * OJC + part_i) * TPW + slot;
+        if (c * OJC + part_i < oj_rounds && row < oj_rend) {
+          long long f = f32_to_fix(mine);
+          if (first_head) f += f32_to_fix(oj_res[c]);
+          __hip_atomic_fetch_add(a.oj_acc + row, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      for (int c = 2; c * OJC < oj_rounds; c++) {        // strips taller than 2 chunks x NW waves (hidden > 2048 per part): streamed, latency exposed
+#pragma unroll
+        for (int r = 0; r < OJC; r++) ow0[r] = load_slice_nt<DT>(oj_wp + (size_t)min(oj_row0 + (c * OJC + r) * TPW + slot, a.oj_H - 1) * a.oj_ldw, part_i);
+        const int row = oj_row0 + (c * OJC + part_i) * TPW + slot;
+        const float res = a.oj_x[min(row, a.oj_H - 1)];
+        float mine = 0.f;
+#pragma unroll
+        for (int r = 0; r < OJC; r++) {
+          float sdot = dot8<DT>(0.f, ow0[r], xa, xb);
+          sdot = row_group_sum<LPT>(sdot);
+          if (part_i == r) mine = sdot;
+        }
+        if (c * OJC + part_i < oj_rounds && row < oj_rend) {
+          long long f = f32_to_fix(mine);
+          if (first_head) f += f32_to_fix(res);
+          __hip_atomic_fetch_add(a.oj_acc + row, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     return;

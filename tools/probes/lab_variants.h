@@ -83,7 +83,51 @@ static void v_attn_direct(Lab& b, int l) {
   hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 64, 1, NW>), grid, blk, 0, b.st, a);
 }
 
+// direct form with the o_proj product in its epilogue (AttnArgs.oj_*): {attention, o_proj} as ONE launch at short contexts
+template <int NW>
+static void v_attn_oproj(Lab& b, int l, long long* acc, const float* resid, int rsplit) {
+  AttnArgs a = attn_args(b, l);
+  a.direct = 1;
+  a.oj_w = b.lb[(size_t)l].wo; a.oj_x = resid; a.oj_acc = acc; a.oj_H = b.H; a.oj_ldw = b.qd; a.oj_rsplit = rsplit;
+  const dim3 grid(a.kv_heads, 1, a.gfull * rsplit), blk(64 * NW);
+  hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 64, 1, NW, false, false, 4, true>), grid, blk, 0, b.st, a);
+}
+
+static void lab_fused_short(Lab& b) {
+  long long* acc; CK(hipMalloc(&acc, (size_t)b.H * 8));
+  float *x_a, *x_b; CK(hipMalloc(&x_a, (size_t)b.H * 4)); CK(hipMalloc(&x_b, (size_t)b.H * 4));
+  std::vector<float> ha((size_t)b.H), hb((size_t)b.H);
+  for (int rsplit : {1, 2, 4}) {
+    if ((b.H / rsplit) % 8) continue;
+    CK(hipMemcpyAsync(x_a, b.x, (size_t)b.H * 4, hipMemcpyDeviceToDevice, b.st));
+    CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
+    v_attn_direct<16>(b, 3); p_oproj(b, 3, x_a);
+    v_attn_oproj<16>(b, 3, acc, b.x, rsplit);
+    hipLaunchKernelGGL(acc_to_f32, dim3((b.H + 255) / 256), dim3(256), 0, b.st, (const long long*)acc, x_b, b.H);
+    CK(hipMemcpyAsync(ha.data(), x_a, (size_t)b.H * 4, hipMemcpyDeviceToHost, b.st)); CK(hipMemcpyAsync(hb.data(), x_b, (size_t)b.H * 4, hipMemcpyDeviceToHost, b.st));
+    CK(hipStreamSynchronize(b.st));
+    double mx = 0, ref = 0;
+    for (int i = 0; i < b.H; i++) { mx = std::max(mx, (double)fabsf(ha[(size_t)i] - hb[(size_t)i])); ref = std::max(ref, (double)fabsf(ha[(size_t)i])); }
+    CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
+    const float t16 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_oproj<16>(b, l, acc, b.x, rsplit); }, b.L);
+    const float t8 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_oproj<8>(b, l, acc, b.x, rsplit); }, b.L);
+    printf("attention + o_proj in one launch, %d workgroup(s) per head: 16 waves %.2f us, 8 waves %.2f   (vs {attn direct 16 waves, o_proj}: max |x| %.4g, rel diff %.3g)\n", rsplit, t16, t8, ref, mx / ref);
+  }
+  const float tp = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { v_attn_direct<16>(b, l); p_oproj(b, l, b.scratch_x); } }, b.L);
+  const float tp4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { v_attn_direct<4>(b, l); p_oproj(b, l, b.scratch_x); } }, b.L);
+  printf("{attn direct, o_proj} as two launches: 16 waves %.2f us, 4 waves %.2f\n", tp, tp4);
+  CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
+  const float l5 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); v_attn_direct<16>(b, l); p_oproj(b, l, b.scratch_x); p_gateup(b, l, nullptr); p_down(b, l, b.scratch_x); } }, b.L);
+  for (int rsplit : {1, 2, 4}) {
+    if ((b.H / rsplit) % 8) continue;
+    const float l4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); v_attn_oproj<16>(b, l, acc, b.x, rsplit); v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x); } }, b.L);
+    printf("layer at context %d: 5 launches {qkv, attn direct, o_proj, gate_up, down} %.2f us; 4 launches {qkv, attn + o_proj (x%d), gate_up, down} %.2f us\n", b.pos_h, l5, rsplit, l4);
+  }
+  CK(hipFree(acc)); CK(hipFree(x_a)); CK(hipFree(x_b));
+}
+
 static void lab_variants_main(Lab& b) {
+  if (b.g.hd == 64 && b.pos_h < 1024) { lab_fused_short(b); if (getenv("LAB_SHORT_ONLY")) return; }
   if (b.g.hd == 64 && b.pos_h < 1024) {
     const float d4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_direct<4>(b, l); }, b.L);
     const float d8 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_direct<8>(b, l); }, b.L);

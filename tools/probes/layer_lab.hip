@@ -1,7 +1,7 @@
 // layer_lab.hip — the batch-1 decode layer of the product (kernels/gemv.h, kernels/attn_decode.h) as a standalone harness: the six launches of a layer
 // {qkv, attention, combine, o_proj, gate_up, down} over L layers of distinct weights and caches, as one hipGraph (the product's structure) and class by
 // class (one class back-to-back over all layers, what tgx_profile_decode measures).  Compiles in seconds — the place where kernel variants are tried
-// against the product kernels on identical data before they enter tgx_mi355x.hip.
+// against the product kernels on identical data before they enter csrc/decode.hip.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -I../../tinygpt_amd/csrc layer_lab.hip -o build/layer_lab
 // Run:   layer_lab [geom=1b|0.5b|3b|7b] [pos=2064] [layers=16] [nsplit=CUs / kv heads, <= 32]
 #include <hip/hip_runtime.h>
@@ -52,7 +52,7 @@ struct Lab {
                    case 7: hipLaunchKernelGGL((gemv_kernel<DT_BF16, PRO, EPI, 7, 1>), dim3(gr_), dim3(256), 0, (lab).st, ARGS); break; \
                    default: hipLaunchKernelGGL((gemv_kernel<DT_BF16, PRO, EPI, 8, 1>), dim3(gr_), dim3(256), 0, (lab).st, ARGS); break; } } while (0)
 
-// ---- the product's launches (tgx_mi355x.hip launch_layer_kernel, batch 1, split-form attention) ----
+// ---- the product's launches (csrc/decode.hip launch_layer_kernel, batch 1, split-form attention) ----
 static void p_qkv(Lab& b, int l, float* resid) {
   (void)resid;
   const LayerBuf& w = b.lb[(size_t)l];

@@ -16,7 +16,7 @@ ap.add_argument("--model", default="llama-3.2-1b")
 ap.add_argument("--prompt", type=int, default=64)
 ap.add_argument("--steps", type=int, default=128)
 ap.add_argument("--ctx", type=int, default=0)
-ap.add_argument("--opt", action="append", default=[], help="key=value for tgx_set_option (after finalize), e.g. engine.mode=2")
+ap.add_argument("--opt", action="append", default=[], help="key=value for tgx_set_option (after finalize), e.g. oproj.sliced=0")
 args = ap.parse_args()
 
 d = known_desc(args.model)
