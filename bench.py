@@ -214,14 +214,6 @@ def main():
         model.upload(name, bits, strict=not args.model_dir)          # a real checkpoint may hold keys the path does not use (non-strict load, GPTModel.h:96)
     model.finalize()
 
-    # the library switches attention forms at a context limit and re-captures its graphs when a decode call crosses it: keep the warm-up and
-    # the timed region on the same form (the split one) when the timed region would cross
-    limit = (576 if desc.kv_heads >= 8 else 832) if desc.head_dim == 64 else 384          # == tgx_create's attn.direct_max
-    if args.prompt + 1 + args.warmup <= limit < args.prompt + 1 + args.warmup + args.steps:
-        model.set_option("attn.direct_max", 0)
-    nw4 = 192 if desc.head_dim == 64 else 0           # the four-wave form of very short contexts: same rule (a crossing would capture a graph inside the timed region)
-    if nw4 and args.prompt + 1 + args.warmup <= nw4 < args.prompt + 1 + args.warmup + args.steps:
-        model.set_option("attn.direct_nw4", 0)
     prompt = synth.synth_prompt(desc.vocab, args.prompt, 1234 + rank)[None, :]
     model.forward(prompt)                                           # untimed: allocates the prefill workspace, warms the code objects
     model.synchronize()
@@ -233,6 +225,12 @@ def main():
         model.synchronize()
         prefill_ms = min(prefill_ms, (time.perf_counter() - t0) * 1e3)
     model.sample(GREEDY)
+    # the library switches attention forms at a context limit and re-captures its graphs when a decode call crosses it: keep the warm-up and
+    # the timed region on the same form (the one beyond the limit) when the timed region would cross
+    for key, off in (("attn.direct_limit", "attn.direct_max"), ("attn.nw4_limit", "attn.direct_nw4")):
+        limit = model.get_option(key)                                  # what tgx_create chose for this geometry and batch
+        if limit and args.prompt + 1 + args.warmup <= limit < args.prompt + 1 + args.warmup + args.steps:
+            model.set_option(off, 0)
 
     def sync():
         model.synchronize()

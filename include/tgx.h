@@ -222,6 +222,14 @@ TGX_API int tgx_set_logits(tgx_ctx* ctx, const float* logits, int batch);
  *   "debug.*"      experiment switches (tools/gemv_dissect.py, tools/attn_dissect.py; live only in a -DTGX_DISSECT=1 build) */
 TGX_API int tgx_set_option(tgx_ctx* ctx, const char* key, int value);
 
+/* Reads back what the library would do for the CURRENT batch size (no reference counterpart; callers that time a decode region use it to keep the
+ * region on one attention form instead of mirroring the defaults):
+ *   "attn.direct_limit"  decode steps at contexts up to this many keys run the direct attention form (batch-1 steps at head_dim 64: with the
+ *                        o_proj product in the same launch), beyond it the split form
+ *   "attn.nw4_limit"     ... and up to this many keys its four-wave variant (0 = never)
+ *   "graph.steps"        decode steps per captured multi-step graph */
+TGX_API int tgx_get_option(const tgx_ctx* ctx, const char* key, int* out_value);
+
 /* Algorithmic HBM bytes one decoded token streams at context length T (SURVEY.md §8d formula). */
 TGX_API int64_t tgx_bytes_per_token(const tgx_ctx* ctx, int64_t T);
 

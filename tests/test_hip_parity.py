@@ -553,6 +553,46 @@ def test_k_sliced_o_proj_with_the_attention_merge_equals_combine_plus_o_proj(nam
                 np.testing.assert_array_equal(outs[0][3], outs[1][3])
 
 
+@pytest.mark.parametrize("name,lens,batch,dtype", [("llama-3.2-1b", (1, 30, 191, 192, 447, 448, 449, 600, 1300), 1, "bf16"), ("qwen2.5-0.5b", (5, 270, 500, 900), 1, "bf16"),
+                                                   ("qwen2.5-0.5b", (300,), 1, "fp16"), ("llama-3.2-1b", (130,), 2, "bf16"), ("llama-3.2-1b", (200,), 3, "bf16")])
+def test_o_proj_in_the_direct_attention_launch_equals_attention_plus_o_proj(name, lens, batch, dtype, hip):
+    """Batch-1 steps on the direct attention form at head_dim 64 (round 4, attn_decode_kernel template OPJ; option oproj.fused, on by default): every query
+    head's workgroups multiply the normalised head output by their rows of W_o[:, head columns] and add into the fixed-point residual accumulators
+    (Attention.h:108-112, DecoderLayer.h:40) — no attention output in memory, no o_proj launch.  Against the separate direct attention + row-sliced o_proj
+    launches: the same keys in another stream split (4 / 8 waves instead of 4 / 16), another summation order of the o_proj dot products: one layer within
+    2e-6, two layers within 2e-4 (bf16 cache flips, see above), greedy ids equal; the fused form twice: bit-identical (integer atomics commute, the
+    accumulators rest at zero).  Contexts on both sides of the four-wave limit (448 keys) and far beyond the default limit of the form.  Batches of
+    2 / 3 rows never take it: the option must not change them."""
+    import copy
+    from tinygpt_amd import known_desc, synth
+    from tinygpt_amd.ffi import Model
+    for layers in (1, 2):
+        d = copy.deepcopy(known_desc(name, dtype))
+        d.layers, d.vocab, d.max_ctx, d.max_batch = layers, 4096, 2048, batch
+        tol = 2e-6 if layers == 1 else 2e-4
+        m = Model(d, hip).load_synthetic(1234, 0.02).finalize()
+        m.set_option("attn.direct_max", 100000)             # the direct form at every context
+        for n in lens:
+            prompt = np.stack([synth.synth_prompt(d.vocab, n, 300 + n + 7 * b) for b in range(batch)])
+            outs = []
+            for fused in (0, 1, 1):
+                m.set_option("oproj.fused", fused)
+                m.reset_cache(); m.forward(prompt)
+                first = m.sample(GREEDY).copy()
+                one = m.decode(1, GREEDY).copy()
+                l1 = m.logits(rounded=False).copy()
+                rest = m.decode(4, GREEDY).copy()
+                outs.append((first, np.concatenate([one, rest]), l1, m.logits(rounded=False).copy()))
+            np.testing.assert_array_equal(outs[0][0], outs[1][0])
+            np.testing.assert_array_equal(outs[0][1], outs[1][1])
+            assert rel_err(outs[1][2], outs[0][2]) < tol, (layers, n, rel_err(outs[1][2], outs[0][2]))
+            assert rel_err(outs[1][3], outs[0][3]) < tol, (layers, n, rel_err(outs[1][3], outs[0][3]))
+            for k in (1, 2, 3):
+                np.testing.assert_array_equal(outs[1][k], outs[2][k])
+            if batch > 1:
+                np.testing.assert_array_equal(outs[0][3], outs[1][3])
+
+
 def test_one_long_decode_call_equals_single_steps_across_the_attention_form_limits(hip):
     """A decode call that crosses the limits of the attention forms (four-wave direct <= 192 keys, sixteen-wave direct <= 576 at head_dim 64 with 8 kv heads, split form — merged by the K-sliced o_proj — beyond)
     is issued in chunks, each on the form of its own contexts, from the cache of captured graphs (round 3): its ids and final logits must be

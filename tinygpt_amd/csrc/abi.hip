@@ -4,6 +4,7 @@
 // One context = one GPU = one HIP stream; every call comes from one host thread (the reference's engine is
 // entered by one thread only: examples/inference/main.cpp, server/HttpServer.cpp:118-163).
 // There is NO CPU path in this library: every entry point either runs on the GPU or returns an error.
+#include <climits>
 #include "ctx.h"
 
 static std::string g_create_err;
@@ -185,13 +186,24 @@ static int attn_mfma_threshold(const tgx_ctx* c) {
 // The attention form of the launches about to be issued / captured, from the context the call ends at: direct (one workgroup per head, no
 // combine) for short contexts, the MFMA decode attention for long ones, the VALU split form in between.  One place for all callers
 // (the prefill-by-steps branch used to leave attn_mfma at whatever the previous decode call had chosen).
-static void update_attn_modes(tgx_ctx* c, int n_positions, int rows_per_launch = -1) {   // rows_per_launch: batch rows that share an attention launch (-1: the batch)
+// contexts up to which a decode call of this batch runs the direct form / its four-wave variant: batch-1 steps whose o_proj rides in the attention
+// launch (decode.hip oproj_fused_capable) keep the direct form longer and on fewer waves
+static long long direct_limit(const tgx_ctx* c, int rpl, bool step) {
+  if (step && rpl == 1 && c->batch == 1 && oproj_fused_capable(c)) return c->attn_fused_max;
+  return (long long)c->attn_direct_max * (rpl >= 4 ? rpl : 1);
+}
+static long long nw4_limit(const tgx_ctx* c, int rpl, bool step) {
+  if (rpl >= 4) return 0;
+  if (step && rpl == 1 && c->batch == 1 && oproj_fused_capable(c)) return c->attn_fused_nw4;
+  return c->attn_direct_nw4;
+}
+static void update_attn_modes(tgx_ctx* c, int n_positions, int rows_per_launch = -1, bool step = true) {   // rows_per_launch: batch rows that share an attention launch (-1: the batch); step: a decode step (not the chunk rows of a prefill-by-steps pass)
   // batches (round 3): the rows themselves fill the chip, so the one-workgroup-per-(kv head, row) form stays ahead of the split form far beyond the
   // batch-1 crossover — Llama-3.2-1B at context 2k: B = 8 1.250 -> 1.105 ms/step, B = 32 2.360 -> 1.680; Mistral-7B at 600: B = 32 6.91 -> 5.47
   const int rpl = rows_per_launch < 0 ? c->batch : rows_per_launch;
-  const long long direct_lim = (long long)c->attn_direct_max * (rpl >= 4 ? rpl : 1);
+  const long long direct_lim = direct_limit(c, rpl, step), nw4_lim = nw4_limit(c, rpl, step);
   c->attn_direct = c->past + n_positions <= direct_lim;
-  c->attn_nw4 = c->attn_direct && rpl < 4 && c->attn_direct_nw4 > 0 && c->past + n_positions <= c->attn_direct_nw4;
+  c->attn_nw4 = c->attn_direct && nw4_lim > 0 && c->past + n_positions <= nw4_lim;
   c->attn_mfma = !c->attn_direct && c->past >= attn_mfma_threshold(c) && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
 }
 
@@ -303,7 +315,7 @@ static int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t see
   int remaining = n;
   while (remaining > 0) {
     int m = remaining;
-    const long long lims[2] = {c->batch < 4 ? (long long)c->attn_direct_nw4 : 0LL, (long long)c->attn_direct_max * (c->batch >= 4 ? c->batch : 1)};
+    const long long lims[2] = {nw4_limit(c, c->batch, true), direct_limit(c, c->batch, true)};
     for (long long lim : lims)
       if (lim > 0 && c->past + 1 <= lim && c->past + m > lim) m = (int)(lim - c->past);
     update_attn_modes(c, m);
@@ -667,7 +679,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     // prefill by steps (fp32 storage, GPT-2, prompts shorter than 4 tokens, shapes the GEMM tile does not cover): up to 4 consecutive
     // positions per pass through the decode kernels — the chunk rows share this row's cache (kv_stride 0), each attends the
     // keys up to its own position, so the result equals position-by-position passes at a quarter of the weight traffic
-    update_attn_modes(c, seq, 1);      // the chunk rows of a pass are positions of ONE sequence
+    update_attn_modes(c, seq, 1, /*step=*/false);      // the chunk rows of a pass are positions of ONE sequence
     for (int s0 = 0; s0 < seq;) {
       const int rem = seq - s0, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
       launch_embed_chunk(c, r.prompt + s0, R, (int)c->past + s0);
@@ -872,7 +884,7 @@ int tgx_profile_decode(tgx_ctx* c, int n_reps, int64_t* launches, double* total_
       HIP_OK(c, hipEventRecord(c->prof.ev[0], c->stream));
       int n = 0;
       if (cls == TGX_KERNEL_LMHEAD) { launch_lm_head(c, 0, 1); n = 1; }
-      else for (int l = 0; l < c->d.layers; l++, n++) launch_layer_kernel(c, &c->rows[0], 1, c->prof_same_layer ? 0 : l, cls, c->scratch_x, (long long)c->kv_row_elems);
+      else for (int l = 0; l < c->d.layers; l++) n += launch_layer_kernel(c, &c->rows[0], 1, c->prof_same_layer ? 0 : l, cls, c->scratch_x, (long long)c->kv_row_elems);
       HIP_OK(c, hipEventRecord(c->prof.ev[1], c->stream));
       HIP_OK(c, hipEventSynchronize(c->prof.ev[1]));
       float ms = 0.f;
@@ -916,6 +928,14 @@ int tgx_set_logits(tgx_ctx* c, const float* logits, int batch) {
   return TGX_OK;
 }
 
+int tgx_get_option(const tgx_ctx* c, const char* key, int* out_value) {
+  if (!c || !key || !out_value) return TGX_ERR_INVALID;
+  if (!strcmp(key, "attn.direct_limit")) { *out_value = (int)std::min<long long>(direct_limit(c, c->batch, true), INT_MAX); return TGX_OK; }
+  if (!strcmp(key, "attn.nw4_limit")) { *out_value = (int)nw4_limit(c, c->batch, true); return TGX_OK; }
+  if (!strcmp(key, "graph.steps")) { *out_value = c->graph_steps; return TGX_OK; }
+  return TGX_ERR_INVALID;
+}
+
 int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!c || !key) return TGX_ERR_INVALID;
   static const char* cls_names[TGX_KERNEL_COUNT] = {"qkv", "attn", "oproj", "gateup", "down", "lmhead"};
@@ -928,8 +948,11 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
     if (value < 0 || value > 4) return set_err(c, TGX_ERR_INVALID, "attn.gmax must be 0 (default) or 1..4");
     c->attn_gmax = value; return TGX_OK;
   }
-  if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = value; return TGX_OK; }
-  if (!strcmp(key, "attn.direct_nw4")) { drop_step_graphs(c); c->attn_direct_nw4 = value; return TGX_OK; }
+  if (!strcmp(key, "attn.direct_max")) { c->attn_direct_max = c->attn_fused_max = value; return TGX_OK; }      // (both forms of the limit: an explicit value forces the form)
+  if (!strcmp(key, "attn.direct_nw4")) { drop_step_graphs(c); c->attn_direct_nw4 = c->attn_fused_nw4 = value; return TGX_OK; }
+  if (!strcmp(key, "attn.fused_max")) { c->attn_fused_max = value; return TGX_OK; }
+  if (!strcmp(key, "attn.fused_nw4")) { drop_step_graphs(c); c->attn_fused_nw4 = value; return TGX_OK; }
+  if (!strcmp(key, "oproj.fused")) { drop_step_graphs(c); c->oproj_fused = value != 0; return TGX_OK; }
   if (!strcmp(key, "attn.raw_fuse")) { drop_step_graphs(c); c->attn_raw_fuse = value; return TGX_OK; }
   if (!strcmp(key, "attn.batch_nw8")) { drop_step_graphs(c); c->attn_batch_nw8 = value; return TGX_OK; }
   if (!strcmp(key, "attn.batch_la")) { if (value < -1 || value > 1) return set_err(c, TGX_ERR_INVALID, "attn.batch_la is -1, 0 or 1"); drop_step_graphs(c); c->attn_batch_la = value; return TGX_OK; }

@@ -215,6 +215,9 @@ struct tgx_ctx {
   // option oproj.sliced (default 1): batch-1 decode steps on the split attention form run o_proj K-sliced with the merge of the attention splits in its
   // prologue (kernels/oproj_sliced.h): no attn_combine launch; the residual stream between o_proj and down lives in fixed-point accumulators
   int oproj_sliced = 1;
+  // batch-1 steps on the direct attention form (short contexts, head_dim 64): the o_proj product runs in the attention launch's epilogue (attn_decode_kernel
+  // template OPJ) — 4 launches per layer; the direct form then serves contexts up to attn_fused_max keys, with four waves per head up to attn_fused_nw4
+  int oproj_fused = 1, attn_fused_max = 640, attn_fused_nw4 = 448;
   long long* slab_acc = nullptr;   // [max_batch][hidden], resting at zero between layers
   float* scratch_x = nullptr;   // [hidden] residual sink for tgx_profile_decode
   Profiler prof;
@@ -262,7 +265,9 @@ bool is_greedy(const tgx_sampler_cfg* s);   // Sampler.cpp:15-21
 // ---- decode.hip (kernels/gemv.h, kernels/oproj_sliced.h)
 int gemv_grid(const tgx_ctx* c, int units, int ks, int bpc);
 bool oproj_sliced_ok(const tgx_ctx* c, int R, long long kv_stride);
-void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float* resid, long long kv_stride);
+bool oproj_fused_capable(const tgx_ctx* c);                               // static conditions (geometry, dtype, option)
+bool oproj_fused_ok(const tgx_ctx* c, int R, long long kv_stride);       // ... and this launch is a batch-1 step on the direct form
+int launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float* resid, long long kv_stride);   // returns the number of launches issued
 void launch_layers(tgx_ctx* c, RowState* rv, int R, long long kv_stride);
 void launch_layers(tgx_ctx* c, int row0, int R);
 void launch_lm_head(tgx_ctx* c, int row0, int R);

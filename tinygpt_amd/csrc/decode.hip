@@ -110,9 +110,25 @@ bool oproj_sliced_ok(const tgx_ctx* c, int R, long long kv_stride) {
   return qd % 128 == 0 && d.hidden % tgx::oproj_sliced_rows<16>() == 0;
 }
 
+// The direct attention form with the o_proj product in its epilogue (attn_decode_kernel template OPJ, kernels/attn_decode.h): batch-1 steps at short
+// contexts run {qkv, attention + o_proj, gate_up, down}.  Each query head's workgroups (oj_rsplit of them, each repeating the head's attention over the few
+// hundred keys) multiply the normalised head output by their rows of W_o[:, head columns] and add into the fixed-point residual accumulators that gate_up
+// and down already read (see above).  Measured per layer (tools/probes/layer_lab.hip, profiles/r04_attn_oproj_fused.txt): Qwen2.5-0.5B at context 30 / 270 /
+// 600 20.2 / 21.0 / 21.8 -> 18.8 / 19.9 / 21.4 us, Llama-3.2-1B 33.3 / 34.2 / 35.5 -> 30.9 / 32.9 / 34.3; the split form is ahead from ~700 / ~900 keys.
+bool oproj_fused_capable(const tgx_ctx* c) {
+  const tgx_model_desc& d = c->d;
+  if (!c->oproj_fused || c->gpt2 || c->dt == tgx::DT_F32 || !c->slab_acc) return false;
+  return d.head_dim == 64 && !d.qk_norm && d.inter <= 16384 && d.hidden % 8 == 0;
+}
+bool oproj_fused_ok(const tgx_ctx* c, int R, long long kv_stride) {
+  return R == 1 && c->batch == 1 && kv_stride != 0 && c->attn_direct && oproj_fused_capable(c);
+}
+// the residual stream between o_proj and down lives in the fixed-point accumulators (either o_proj form above)
+static bool resid_fixed(const tgx_ctx* c, int R, long long kv_stride) { return oproj_sliced_ok(c, R, kv_stride) || oproj_fused_ok(c, R, kv_stride); }
+
 // One kernel class of one decoder layer for R rows (batch rows of the slabs, or the chunk rows of a prefill-by-steps pass).  `resid` is the residual stream of row0 that the
 // o_proj/down epilogues update (slab_x in the real pass; a scratch vector when tgx_profile_decode replays a class).
-void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float* resid, long long kv_stride) {
+int launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float* resid, long long kv_stride) {
   const tgx_model_desc& d = c->d;
   RowState& r = rv[0];   // R consecutive row views with the slabs' row strides; kv_stride = 0 when the rows are positions of ONE sequence
   const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
@@ -155,10 +171,14 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
         a.k_raw = r.k_raw; a.kraw_stride = kvd; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm;
         a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.eps = d.norm_eps;
       }
+      if (oproj_fused_ok(c, R, kv_stride)) {      // + o_proj and the residual add in the same launch (Attention.h:111-112, DecoderLayer.h:40)
+        a.oj_w = w.wo; a.oj_x = r.x; a.oj_acc = c->slab_acc + (size_t)(&r - c->rows.data()) * H; a.oj_H = H; a.oj_ldw = qd;
+      }
       launch_attn(c, a, R, /*combine=*/!oproj_sliced_ok(c, R, kv_stride));
       break;
     }
     case TGX_KERNEL_OPROJ: { // o_proj + residual                                     (Attention.h:90, DecoderLayer.h:40)
+      if (oproj_fused_ok(c, R, kv_stride)) return 0;       // done by the attention launch
       tgx::GemvArgs a{};
       fill_strides(c, a);
       a.W = w.wo; a.bias = w.bo; a.x = r.attn; a.x_stride = qd; a.N = H; a.K = qd; a.units = (H + 1) / 2; a.out = resid; a.out_stride = H; a.hd = 2;
@@ -186,7 +206,7 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
         break;
       }
       a.N = 2 * I; a.K = H; a.units = I; a.out = r.h; a.out_stride = I; a.hd = 2;
-      if (oproj_sliced_ok(c, R, kv_stride)) a.x_acc = c->slab_acc + (size_t)(&r - c->rows.data()) * H;     // x' = fp32(acc)
+      if (resid_fixed(c, R, kv_stride)) a.x_acc = c->slab_acc + (size_t)(&r - c->rows.data()) * H;     // x' = fp32(acc)
       launch_gemv<tgx::PRO_RMSNORM, tgx::EPI_SILU_MUL>(c, a, TGX_KERNEL_GATEUP, R);
       break;
     }
@@ -205,12 +225,13 @@ void launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float*
         }
         break;
       }
-      if (oproj_sliced_ok(c, R, kv_stride)) a.res_acc = c->slab_acc + (size_t)(&r - c->rows.data()) * H;   // x = fp32(acc) + down(h); acc <- 0
+      if (resid_fixed(c, R, kv_stride)) a.res_acc = c->slab_acc + (size_t)(&r - c->rows.data()) * H;   // x = fp32(acc) + down(h); acc <- 0
       launch_gemv<tgx::PRO_PLAIN, tgx::EPI_RESIDUAL>(c, a, TGX_KERNEL_DOWN, R);
       break;
     }
-    default: break;
+    default: return 0;
   }
+  return 1;
 }
 
 // All decoder layers for R rows: their current tokens' embeddings sit in the x slab, positions in the pos slab.

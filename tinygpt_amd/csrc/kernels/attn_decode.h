@@ -73,7 +73,7 @@ __device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, fl
 // disappears; the same arithmetic in the same order (common.h rope_rotate_pair / head_rms_inv): bit-identical to it.  See attn_decode_mfma.h for the MFMA twin.
 template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool RAW = false, int UNR_ = 4, bool OPJ = false>
 __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) {
-  static_assert(!OPJ || (G == 1 && NW > 4 && !QKN && !RAW && DT != DT_F32), "OPJ: one head per workgroup, 8 / 16 waves, 16-bit storage");
+  static_assert(!OPJ || (G == 1 && !QKN && !RAW && DT != DT_F32), "OPJ: one head per workgroup, 16-bit storage");
   typedef elem_t<DT> E;
   constexpr int LPT = HD / 8;         // lanes per token row
   constexpr int TPW = 64 / LPT;       // tokens per wave-load
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
       }
     return;
   }
-  if constexpr (NW == 4) {
+  if constexpr (NW == 4 && !OPJ) {
     // Split form and four-wave direct form (round 4): the NW x TPW token-slot streams of the workgroup meet ONCE in LDS.  Every lane group writes its
     // (m, l, o[HD]) stream; G x S threads derive each stream's weight 2^(m_i - M) and the sums M, L (one DPP row reduction + one cross-row exchange);
     // G x HD threads then take their output dim over the S weighted streams.  Replaces a 3-step register butterfly per wave (~30 ds_bpermute per
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
 #ifndef TGX_OLD_DIRECT_MERGE
 #define TGX_OLD_DIRECT_MERGE 0      // experiments (tools/probes/layer_lab.hip): 1 keeps the butterfly + per-wave-record merge of the 8 / 16-wave forms
 #endif
-  if constexpr (NW > 4 && G == 1 && !TGX_OLD_DIRECT_MERGE) {
+  if constexpr ((NW > 4 || OPJ) && G == 1 && !TGX_OLD_DIRECT_MERGE) {
     if constexpr (OPJ) {
       if (oj_rounds > OJC) {
 #pragma unroll

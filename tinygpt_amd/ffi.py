@@ -73,6 +73,7 @@ ABI = {
     "write_kv": (c_int, [c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float), c_int64]),
     "profile_decode": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_double)]),
     "set_option": (c_int, [c_void_p, c_char_p, c_int]),
+    "get_option": (c_int, [c_void_p, c_char_p, POINTER(c_int)]),
     "read_probs": (c_int, [c_void_p, POINTER(c_float)]),
     "set_logits": (c_int, [c_void_p, POINTER(c_float), c_int]),
     "bytes_per_token": (c_int64, [c_void_p, c_int64]),
@@ -266,6 +267,11 @@ class Model:
 
     def set_option(self, key: str, value: int):
         self._check(self.be.set_option(self._ctx, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        out = c_int(0)
+        self._check(self.be.get_option(self._ctx, key.encode(), ctypes.byref(out)))
+        return out.value
         return self
 
     def bytes_per_token(self, T: int) -> int:

@@ -97,12 +97,23 @@ static void lab_fused_short(Lab& b) {
   long long* acc; CK(hipMalloc(&acc, (size_t)b.H * 8));
   float *x_a, *x_b; CK(hipMalloc(&x_a, (size_t)b.H * 4)); CK(hipMalloc(&x_b, (size_t)b.H * 4));
   std::vector<float> ha((size_t)b.H), hb((size_t)b.H);
-  for (int rsplit : {1, 2, 4}) {
-    if ((b.H / rsplit) % 8) continue;
+  const float tp = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { v_attn_direct<16>(b, l); p_oproj(b, l, b.scratch_x); } }, b.L);
+  const float tp4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { v_attn_direct<4>(b, l); p_oproj(b, l, b.scratch_x); } }, b.L);
+  printf("context %d: {attn direct, o_proj} as two launches: 16 waves %.2f us, 4 waves %.2f\n", b.pos_h, tp, tp4);
+  const float l5 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); v_attn_direct<16>(b, l); p_oproj(b, l, b.scratch_x); p_gateup(b, l, nullptr); p_down(b, l, b.scratch_x); } }, b.L);
+  const float l5b = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); v_attn_direct<4>(b, l); p_oproj(b, l, b.scratch_x); p_gateup(b, l, nullptr); p_down(b, l, b.scratch_x); } }, b.L);
+  printf("  layer as 5 launches {qkv, attn direct, o_proj, gate_up, down}: 16 waves %.2f us, 4 waves %.2f\n", l5, l5b);
+  {
+    CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
+    const float ls = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); p_attn_only(b, l, nullptr); v_oproj_sliced(b, l, acc, b.x); v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x); } }, b.L);
+    printf("  layer as 5 launches {qkv, attn split form, o_proj sliced, gate_up, down}: %.2f us\n", ls);
+  }
+  for (int rsplit : {4, 8}) {
+    if ((b.H % rsplit) || (b.H / rsplit) % 8) continue;
     CK(hipMemcpyAsync(x_a, b.x, (size_t)b.H * 4, hipMemcpyDeviceToDevice, b.st));
     CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
     v_attn_direct<16>(b, 3); p_oproj(b, 3, x_a);
-    v_attn_oproj<16>(b, 3, acc, b.x, rsplit);
+    v_attn_oproj<4>(b, 3, acc, b.x, rsplit);
     hipLaunchKernelGGL(acc_to_f32, dim3((b.H + 255) / 256), dim3(256), 0, b.st, (const long long*)acc, x_b, b.H);
     CK(hipMemcpyAsync(ha.data(), x_a, (size_t)b.H * 4, hipMemcpyDeviceToHost, b.st)); CK(hipMemcpyAsync(hb.data(), x_b, (size_t)b.H * 4, hipMemcpyDeviceToHost, b.st));
     CK(hipStreamSynchronize(b.st));
@@ -111,23 +122,18 @@ static void lab_fused_short(Lab& b) {
     CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
     const float t16 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_oproj<16>(b, l, acc, b.x, rsplit); }, b.L);
     const float t8 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_oproj<8>(b, l, acc, b.x, rsplit); }, b.L);
-    printf("attention + o_proj in one launch, %d workgroup(s) per head: 16 waves %.2f us, 8 waves %.2f   (vs {attn direct 16 waves, o_proj}: max |x| %.4g, rel diff %.3g)\n", rsplit, t16, t8, ref, mx / ref);
-  }
-  const float tp = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { v_attn_direct<16>(b, l); p_oproj(b, l, b.scratch_x); } }, b.L);
-  const float tp4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { v_attn_direct<4>(b, l); p_oproj(b, l, b.scratch_x); } }, b.L);
-  printf("{attn direct, o_proj} as two launches: 16 waves %.2f us, 4 waves %.2f\n", tp, tp4);
-  CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
-  const float l5 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); v_attn_direct<16>(b, l); p_oproj(b, l, b.scratch_x); p_gateup(b, l, nullptr); p_down(b, l, b.scratch_x); } }, b.L);
-  for (int rsplit : {1, 2, 4}) {
-    if ((b.H / rsplit) % 8) continue;
-    const float l4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); v_attn_oproj<16>(b, l, acc, b.x, rsplit); v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x); } }, b.L);
-    printf("layer at context %d: 5 launches {qkv, attn direct, o_proj, gate_up, down} %.2f us; 4 launches {qkv, attn + o_proj (x%d), gate_up, down} %.2f us\n", b.pos_h, l5, rsplit, l4);
+    const float t4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_oproj<4>(b, l, acc, b.x, rsplit); }, b.L);
+    CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
+    const float l8 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); v_attn_oproj<8>(b, l, acc, b.x, rsplit); v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x); } }, b.L);
+    CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
+    const float l4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); v_attn_oproj<4>(b, l, acc, b.x, rsplit); v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x); } }, b.L);
+    printf("  attn + o_proj in one launch, %2d workgroups per head: 16 waves %.2f us, 8 waves %.2f, 4 waves %.2f (rel diff %.2g); layer as 4 launches: 8 waves %.2f, 4 waves %.2f\n", rsplit, t16, t8, t4, mx / ref, l8, l4);
   }
   CK(hipFree(acc)); CK(hipFree(x_a)); CK(hipFree(x_b));
 }
 
 static void lab_variants_main(Lab& b) {
-  if (b.g.hd == 64 && b.pos_h < 1024) { lab_fused_short(b); if (getenv("LAB_SHORT_ONLY")) return; }
+  if (b.g.hd == 64 && (b.pos_h < 1024 || getenv("LAB_SHORT_ONLY"))) { lab_fused_short(b); if (getenv("LAB_SHORT_ONLY")) return; }
   if (b.g.hd == 64 && b.pos_h < 1024) {
     const float d4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_direct<4>(b, l); }, b.L);
     const float d8 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_direct<8>(b, l); }, b.L);
