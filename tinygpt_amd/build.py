@@ -36,6 +36,8 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=()):
     """hipcc -c every translation unit (one process each, all at once: the longest is the GEMV instantiations of decode.hip, ~80 s), then link."""
     if os.environ.get("TGX_DISSECT") == "1":      # experiment build: the debug.gemv / debug.attn switches become live
         extra_flags = list(extra_flags) + ["-DTGX_DISSECT=1"]
+    if os.environ.get("TGX_EXTRA_FLAGS"):         # experiment builds (e.g. -DTGX_GEMM_TERMS=1, tools/probes/README.md); never the shipped library
+        extra_flags = list(extra_flags) + os.environ["TGX_EXTRA_FLAGS"].split()
     cflags = [f for f in FLAGS if f != "-shared"] + list(extra_flags)
     # the flag set is part of the staleness test (a stamp next to the library): toggling TGX_VGPR_FORM / TGX_DISSECT / extra_flags rebuilds
     stamp, want = LIB + ".flags", " ".join([HIPCC] + cflags)

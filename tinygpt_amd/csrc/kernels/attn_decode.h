@@ -171,8 +171,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
   // OPJ: this wave's rows of the o_proj strip W_o[rows, head columns]: LPT lanes per row (one 16-byte slice each), TPW rows per wave-load, OJC wave-loads
   // per chunk.  Chunk 0 leaves now, behind the first K / V block (loads return in order: the attention's waits are not held up by it) and behind q, and lands while the
   // attention runs; chunk 1 leaves when the key loop is done.
-  constexpr int OJC = 8;
-  static_assert(!OPJ || LPT == OJC, "OPJ: head_dim 64 (a chunk's OJC row sums go to the LPT lanes of a row group)");
+  constexpr int OJC = LPT;        // wave-loads per chunk: a chunk's OJC row sums go to the LPT lanes of a row group (8 at head_dim 64, 16 at 128)
   Slice8<DT> ow0[OPJ ? OJC : 1], ow1[OPJ ? OJC : 1];
   int oj_row0 = 0, oj_rend = 0, oj_rounds = 0;
   const E* oj_wp = nullptr;

@@ -226,8 +226,12 @@ __device__ __forceinline__ void xcd_tile(const GemmArgs& a, int& tm, int& tn) {
 // stages are in flight while the third is consumed: the waits are counted (vmcnt(6): this wave's six pieces of the NEXT stage may still
 // fly), never a drain.  A wave owns 128 x 64 of the output (4 x 2 MFMA tiles): 10 fragment reads per 16 MFMAs, double-buffered in
 // registers (see the pipeline note at the loop).
+#ifndef TGX_GEMM_TERMS
+#define TGX_GEMM_TERMS 2      // experiment (profiles/r04_act16_cost.txt): 1 = the eight-wave GEMMs multiply A_hi only, i.e. activations rounded to the storage dtype — the
+#endif                        // reference's own bf16-module contract for a Linear's input — to price what the fp32-activation contract costs the prefill; never shipped
 template <int DT, int EPI>
 __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
+  constexpr bool LO = TGX_GEMM_TERMS >= 2;
   constexpr int DBK = 32, CPR = 4, RPP = 16, TMN = 256, NS = 3;
   constexpr int STAGE = 3 * TMN * DBK;                    // 16-bit elements per stage
   extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
   const int klast = (nk - 1) * DBK;
   // stage s (stages past the end reload the last real one into a free buffer: every wait below then counts the same six pieces)
   auto issue_piece = [&](int q, int s) {
+    if (!LO && q % 3 == 1) return;
     dma_1k(gsrc[q] + min(s * DBK, klast), lds_base + (unsigned)((s % NS) * STAGE * 2) + ldst[q]);
   };
   // fragment addresses: the swizzle term depends on the lane only (tile rows are 32-aligned per MFMA block)
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       fa[2 * i] = *reinterpret_cast<const bf16x8*>(st + arow + i * 32 * DBK + ko);
-      fa[2 * i + 1] = *reinterpret_cast<const bf16x8*>(st + TMN * DBK + arow + i * 32 * DBK + ko);
+      if (LO) fa[2 * i + 1] = *reinterpret_cast<const bf16x8*>(st + TMN * DBK + arow + i * 32 * DBK + ko);
     }
   };
 
@@ -297,7 +302,8 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
 #pragma unroll
   for (int q = 0; q < 3; q++) issue_piece(q, 2);
   bf16x8 fa0[8], fb0[2], fa1[8], fb1[2];
-  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // stage 0 landed (this wave's pieces); stage 1 and half of stage 2 may fly
+  if (LO) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // stage 0 landed (this wave's pieces); stage 1 and half of stage 2 may fly
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_frags(0, 0, fa0, fb0);
   for (int k = 0; k < nk; k++) {
@@ -307,13 +313,14 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
     for (int i = 0; i < 4; i++) {
 #pragma unroll
       for (int j = 0; j < 2; j++) {
-        acc[i][j] = mfma16<DT>(fa0[2 * i + 1], fb0[j], acc[i][j]);   // small term first
+        if (LO) acc[i][j] = mfma16<DT>(fa0[2 * i + 1], fb0[j], acc[i][j]);   // small term first
         acc[i][j] = mfma16<DT>(fa0[2 * i], fb0[j], acc[i][j]);
       }
       if (i < 3) issue_piece(3 + i, k + 2);                           // one DMA per four MFMAs
       __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // stage k+1 landed; this wave's reads of stage k are complete
+    if (LO) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // stage k+1 landed; this wave's reads of stage k are complete
+    else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                             // ... for every wave: the buffer of stage k is free
     read_frags(k + 1, 0, fa0, fb0);                           // (after the last step: a harmless read of a reloaded stage)
     __builtin_amdgcn_sched_barrier(0);
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
     for (int i = 0; i < 4; i++) {
 #pragma unroll
       for (int j = 0; j < 2; j++) {
-        acc[i][j] = mfma16<DT>(fa1[2 * i + 1], fb1[j], acc[i][j]);
+        if (LO) acc[i][j] = mfma16<DT>(fa1[2 * i + 1], fb1[j], acc[i][j]);
         acc[i][j] = mfma16<DT>(fa1[2 * i], fb1[j], acc[i][j]);
       }
       if (i < 3) issue_piece(i, k + 3);
@@ -397,7 +404,8 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
     gsrc[3 * p] = a.A_hi + g; gsrc[3 * p + 1] = a.A_lo + g; gsrc[3 * p + 2] = a.B + brow * a.K + chunk * 8;
     ldst[3 * p] = (unsigned)(piece * 1024); ldst[3 * p + 1] = ldst[3 * p] + (unsigned)(TMN * DBK * 2); ldst[3 * p + 2] = ldst[3 * p] + (unsigned)(2 * TMN * DBK * 2);
   }
-  auto issue_piece = [&](int q, int k0, int stage) { dma_1k(gsrc[q] + k0, lds_base + (unsigned)(stage * STAGE * 2) + ldst[q]); };
+  constexpr bool LO = TGX_GEMM_TERMS >= 2;
+  auto issue_piece = [&](int q, int k0, int stage) { if (!LO && q % 3 == 1) return; dma_1k(gsrc[q] + k0, lds_base + (unsigned)(stage * STAGE * 2) + ldst[q]); };
   auto frag = [&](const bf16_t* tile, int row, int kchunk) -> bf16x8 {
     return *reinterpret_cast<const bf16x8*>(tile + row * DBK + ((kchunk ^ ((row >> 1) & 7)) << 3));
   };
@@ -410,7 +418,8 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
     for (int q = 0; q < 6; q++) issue_piece(q, DBK, 1);
   }
   for (int k = 0; k < nk; k++) {
-    if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (k + 1 < nk) { if (LO) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const bool more = k + 2 < nk;
     const int nk0 = (k + 2) * DBK, nst = (k + 2) % NS;
@@ -426,13 +435,13 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
       for (int i = 0; i < 2; i++) {
         const int row = wm * 64 + i * 32 + (lane & 31);
         fah[i] = frag(tAh, row, kchunk);
-        fal[i] = frag(tAl, row, kchunk);
+        if (LO) fal[i] = frag(tAl, row, kchunk);
       }
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-          acc[i][j] = mfma16<DT>(fal[i], fb[j], acc[i][j]);   // small term first
+          if (LO) acc[i][j] = mfma16<DT>(fal[i], fb[j], acc[i][j]);   // small term first
           acc[i][j] = mfma16<DT>(fah[i], fb[j], acc[i][j]);
           if (more && (kl * 4 + i * 2 + j) < 6) issue_piece(kl * 4 + i * 2 + j, nk0, nst);     // one DMA per two MFMAs
         }

@@ -50,4 +50,12 @@ job_prefill_xcd() {
   done > $O/prefill_xcd.txt 2>&1; cat $O/prefill_xcd.txt; cd $R
 }
 
+# per-kernel durations of the batched prefill (rocprofv3 --kernel-trace; PREFILL_ARGS e.g. "--seq 2048")
+job_prefill_trace() {
+  cd /tmp; rm -rf /tmp/pt
+  rocprofv3 --kernel-trace --stats -d /tmp/pt -o p -- python $R/tools/prefill_bench.py --reps 4 ${PREFILL_ARGS:-} > $O/prefill_trace.log 2>&1
+  python $R/tools/rocpd_stats.py $(find /tmp/pt -name "*.db" | head -1) > $O/prefill_kernels.txt 2>&1
+  tail -4 $O/prefill_trace.log; head -14 $O/prefill_kernels.txt | cut -c1-180; cd $R
+}
+
 for j in "$@"; do echo "=== job $j"; job_$j; done

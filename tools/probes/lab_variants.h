@@ -52,6 +52,8 @@ static void v_gateup_acc(Lab& b, int l, long long* acc) {
   const int nx = b.nx_of(b.H, 1), gr = b.grid_of(u.units, 1);
   switch (nx) { case 2: hipLaunchKernelGGL((gemv_kernel<DT_BF16, PRO_RMSNORM, EPI_SILU_MUL, 2, 1, true>), dim3(gr), dim3(256), (size_t)b.H * 4, b.st, u); break;
                 case 4: hipLaunchKernelGGL((gemv_kernel<DT_BF16, PRO_RMSNORM, EPI_SILU_MUL, 4, 1, true>), dim3(gr), dim3(256), (size_t)b.H * 4, b.st, u); break;
+                case 6: hipLaunchKernelGGL((gemv_kernel<DT_BF16, PRO_RMSNORM, EPI_SILU_MUL, 6, 1, true>), dim3(gr), dim3(256), (size_t)b.H * 4, b.st, u); break;
+                case 8: hipLaunchKernelGGL((gemv_kernel<DT_BF16, PRO_RMSNORM, EPI_SILU_MUL, 8, 1, true>), dim3(gr), dim3(256), (size_t)b.H * 4, b.st, u); break;
                 default: printf("lab: nx %d not instantiated\n", nx); }
 }
 static void v_down_acc(Lab& b, int l, long long* acc, float* resid) {
@@ -61,6 +63,7 @@ static void v_down_acc(Lab& b, int l, long long* acc, float* resid) {
   const int nx = b.nx_of(b.I, 4), gr = b.grid_of(d.units, 4);
   switch (nx) { case 3: hipLaunchKernelGGL((gemv_kernel<DT_BF16, PRO_PLAIN, EPI_RESIDUAL, 3, 1, true>), dim3(gr), dim3(256), 0, b.st, d); break;
                 case 4: hipLaunchKernelGGL((gemv_kernel<DT_BF16, PRO_PLAIN, EPI_RESIDUAL, 4, 1, true>), dim3(gr), dim3(256), 0, b.st, d); break;
+                case 7: hipLaunchKernelGGL((gemv_kernel<DT_BF16, PRO_PLAIN, EPI_RESIDUAL, 7, 1, true>), dim3(gr), dim3(256), 0, b.st, d); break;
                 default: printf("lab: nx %d not instantiated\n", nx); }
 }
 
@@ -80,7 +83,8 @@ static void v_attn_direct(Lab& b, int l) {
   AttnArgs a = attn_args(b, l);
   a.direct = 1;
   const dim3 grid(a.kv_heads, 1, a.gfull), blk(64 * NW);
-  hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 64, 1, NW>), grid, blk, 0, b.st, a);
+  if (b.g.hd == 64) hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 64, 1, NW>), grid, blk, 0, b.st, a);
+  else hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 128, 1, NW>), grid, blk, 0, b.st, a);
 }
 
 // direct form with the o_proj product in its epilogue (AttnArgs.oj_*): {attention, o_proj} as ONE launch at short contexts
@@ -90,7 +94,8 @@ static void v_attn_oproj(Lab& b, int l, long long* acc, const float* resid, int 
   a.direct = 1;
   a.oj_w = b.lb[(size_t)l].wo; a.oj_x = resid; a.oj_acc = acc; a.oj_H = b.H; a.oj_ldw = b.qd; a.oj_rsplit = rsplit;
   const dim3 grid(a.kv_heads, 1, a.gfull * rsplit), blk(64 * NW);
-  hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 64, 1, NW, false, false, 4, true>), grid, blk, 0, b.st, a);
+  if (b.g.hd == 64) hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 64, 1, NW, false, false, 4, true>), grid, blk, 0, b.st, a);
+  else hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 128, 1, NW, false, false, 4, true>), grid, blk, 0, b.st, a);
 }
 
 static void lab_fused_short(Lab& b) {
@@ -108,7 +113,7 @@ static void lab_fused_short(Lab& b) {
     const float ls = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); p_attn_only(b, l, nullptr); v_oproj_sliced(b, l, acc, b.x); v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x); } }, b.L);
     printf("  layer as 5 launches {qkv, attn split form, o_proj sliced, gate_up, down}: %.2f us\n", ls);
   }
-  for (int rsplit : {4, 8}) {
+  for (int rsplit : {2, 4, 8}) {
     if ((b.H % rsplit) || (b.H / rsplit) % 8) continue;
     CK(hipMemcpyAsync(x_a, b.x, (size_t)b.H * 4, hipMemcpyDeviceToDevice, b.st));
     CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
@@ -133,7 +138,7 @@ static void lab_fused_short(Lab& b) {
 }
 
 static void lab_variants_main(Lab& b) {
-  if (b.g.hd == 64 && (b.pos_h < 1024 || getenv("LAB_SHORT_ONLY"))) { lab_fused_short(b); if (getenv("LAB_SHORT_ONLY")) return; }
+  if (b.pos_h < 1024 || getenv("LAB_SHORT_ONLY")) { lab_fused_short(b); if (getenv("LAB_SHORT_ONLY")) return; }
   if (b.g.hd == 64 && b.pos_h < 1024) {
     const float d4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_direct<4>(b, l); }, b.L);
     const float d8 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_direct<8>(b, l); }, b.L);
