@@ -219,6 +219,10 @@ TGX_API int tgx_set_logits(tgx_ctx* ctx, const float* logits, int batch);
  *   "prefill.min_rows"  prompts shorter than this take passes through the decode kernels instead of the batched prefill (default 7)
  *   "prefill.splitk" 0/1  split K over workgroups when a prompt gives the GEMMs few row tiles (default 1)
  *   "prefill.mfma" 0/1  batched matrix-core prefill vs passes through the decode kernels; "prefill.gemm_tm" 64/128 row tile
+ *   "act.round16" 0/1  (default 0) numerics contract: 1 = the input of every Linear is rounded to the storage dtype (round-to-nearest-even) before the
+ *                  product — what a module constructed in config.torch_dtype sees (ModelLlama.h:62) — instead of entering in fp32.  The matrix-core
+ *                  products of the prefill and of batched steps then take one 16-bit term per activation instead of two or three;
+ *                  fp32 storage: no effect.  Set it before the first tgx_forward of a sequence: the cache of a sequence must be filled under one contract
  *   "debug.*"      experiment switches (tools/gemv_dissect.py, tools/attn_dissect.py; live only in a -DTGX_DISSECT=1 build) */
 TGX_API int tgx_set_option(tgx_ctx* ctx, const char* key, int value);
 

@@ -23,6 +23,7 @@ ORACLE_EXTRA = {
     "set_logits": (c_int, [c_void_p, POINTER(c_float), c_int]),
     "set_threads": (c_int, [c_int]),
     "set_reorder": (c_int, [c_void_p, c_int]),
+    "set_act16": (c_int, [c_void_p, c_int]),
 }
 
 
@@ -57,6 +58,11 @@ class OracleModel(Model):
     def set_reorder(self, on: bool = True):
         """every reduction from the last element to the first: a second fp32 schedule of the same arithmetic (test hook)"""
         self._check(self.be.set_reorder(self._ctx, 1 if on else 0))
+        return self
+
+    def set_act16(self, on: bool = True):
+        """the input of every Linear rounded to the storage dtype first: the counterpart of the library's option act.round16"""
+        self._check(self.be.set_act16(self._ctx, 1 if on else 0))
         return self
 
     def rope_tables(self, n_pos: int):

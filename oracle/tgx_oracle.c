@@ -84,6 +84,7 @@ typedef struct tgxo_ctx {
   int bf16;
   int f16;                       /* compute_dtype fp16: parameters and KV cache hold half-rounded values */
   int round_act;
+  int act16;                     /* tgxo_set_act16: the input of every Linear is rounded to the storage dtype first (the reference's bf16 modules see bf16 tensors, ModelLlama.h:62) */
   int reorder;                   /* tgxo_set_reorder: every reduction runs in the REVERSE element order (a second, equally valid fp32 schedule) */
   mat_t embed, wpe, lm_head;
   vec_t final_norm;
@@ -431,6 +432,12 @@ static inline float dot_row(const tgxo_ctx* c, const mat_t* m, int64_t row, cons
  * product is the same dot_row() in the same element order, i.e. the results are bit-identical to the row-by-row order. */
 static void linear(const tgxo_ctx* c, const mat_t* m, const float* x, int S, float* y, int raw) {
   int64_t N = m->rows, K = m->cols;
+  float* xr = NULL;
+  if (c->act16 && (c->bf16 || c->f16)) {      /* option act.round16 of the MI355X library: x := storage_dtype(x), RNE, once per Linear input */
+    xr = (float*)malloc((size_t)S * K * sizeof(float));
+    for (int64_t i = 0; i < (int64_t)S * K; i++) xr[i] = RKV(c, x[i]);
+    x = xr;
+  }
 #pragma omp parallel for schedule(static)
   for (int64_t nb = 0; nb < N; nb += 8) {
     int64_t ne = nb + 8 < N ? nb + 8 : N;
@@ -440,6 +447,7 @@ static void linear(const tgxo_ctx* c, const mat_t* m, const float* x, int S, flo
         y[(int64_t)s * N + n] = raw ? a : R(c, a);
       }
   }
+  free(xr);
 }
 
 static void rmsnorm(const tgxo_ctx* c, const float* x, const float* w, int n, float* y) {
@@ -751,6 +759,8 @@ TGXO_EXPORT int tgxo_set_logits(tgxo_ctx* c, const float* logits, int batch) {
  * last element to the first.  Same products, another fp32 summation order: the distance between the two schedules is the floor any OTHER correct
  * implementation (the HIP kernels) can be held to. */
 TGXO_EXPORT int tgxo_set_reorder(tgxo_ctx* c, int on) { if (!c) return 1; c->reorder = on != 0; return 0; }
+/* 1 = the Linear-input rounding of the library's option act.round16 (see linear()) */
+TGXO_EXPORT int tgxo_set_act16(tgxo_ctx* c, int on) { if (!c) return 1; c->act16 = on != 0; return 0; }
 
 TGXO_EXPORT int tgxo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
 

@@ -933,6 +933,7 @@ int tgx_get_option(const tgx_ctx* c, const char* key, int* out_value) {
   if (!strcmp(key, "attn.direct_limit")) { *out_value = (int)std::min<long long>(direct_limit(c, c->batch, true), INT_MAX); return TGX_OK; }
   if (!strcmp(key, "attn.nw4_limit")) { *out_value = (int)nw4_limit(c, c->batch, true); return TGX_OK; }
   if (!strcmp(key, "graph.steps")) { *out_value = c->graph_steps; return TGX_OK; }
+  if (!strcmp(key, "act.round16")) { *out_value = c->act16; return TGX_OK; }
   return TGX_ERR_INVALID;
 }
 
@@ -952,6 +953,8 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.direct_nw4")) { drop_step_graphs(c); c->attn_direct_nw4 = c->attn_fused_nw4 = value; return TGX_OK; }
   if (!strcmp(key, "attn.fused_max")) { c->attn_fused_max = value; return TGX_OK; }
   if (!strcmp(key, "attn.fused_nw4")) { drop_step_graphs(c); c->attn_fused_nw4 = value; return TGX_OK; }
+  if (!strcmp(key, "act.round16")) { drop_step_graphs(c); c->act16 = value != 0; return TGX_OK; }
+  if (!strcmp(key, "act.one_term_kernels")) { c->act16_kernels = value != 0; return TGX_OK; }      // 0: the two-term kernels on the all-zero second term (bit-identical; tests)      // (the all-zero term buffer is allocated with the next workspace check)
   if (!strcmp(key, "oproj.fused")) { drop_step_graphs(c); c->oproj_fused = value != 0; return TGX_OK; }
   if (!strcmp(key, "attn.raw_fuse")) { drop_step_graphs(c); c->attn_raw_fuse = value; return TGX_OK; }
   if (!strcmp(key, "attn.batch_nw8")) { drop_step_graphs(c); c->attn_batch_nw8 = value; return TGX_OK; }

@@ -215,6 +215,11 @@ struct tgx_ctx {
   // option oproj.sliced (default 1): batch-1 decode steps on the split attention form run o_proj K-sliced with the merge of the attention splits in its
   // prologue (kernels/oproj_sliced.h): no attn_combine launch; the residual stream between o_proj and down lives in fixed-point accumulators
   int oproj_sliced = 1;
+  // option act.round16 (default 0): the input of every Linear is rounded to the storage dtype — the part of the reference's 16-bit-module contract
+  // (ModelLlama.h:62) that has a price: the matrix-core products then take ONE 16-bit term per activation.  ws_zero: the "lo term"
+  // every stored-term product reads in this mode
+  int act16 = 0, act16_kernels = 1;
+  bf16_t* ws_zero = nullptr; size_t ws_zero_elems = 0;
   // batch-1 steps on the direct attention form (short contexts, head_dim 64): the o_proj product runs in the attention launch's epilogue (attn_decode_kernel
   // template OPJ) — 4 launches per layer; the direct form then serves contexts up to attn_fused_max keys, with four waves per head up to attn_fused_nw4
   int oproj_fused = 1, attn_fused_max = 640, attn_fused_nw4 = 448;

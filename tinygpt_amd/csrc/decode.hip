@@ -90,6 +90,7 @@ static void fill_strides(const tgx_ctx* c, tgx::GemvArgs& a) {
   a.x_stride = 0; a.out_stride = 0;       // set per call site (x and out come from different slabs)
   a.q_stride = (long long)d.heads * d.head_dim; a.kraw_stride = (long long)d.kv_heads * d.head_dim;
   a.kv_stride = (long long)c->kv_row_elems; a.logits_stride = d.vocab; a.part_stride = c->lm_grid;
+  a.act16 = c->act16;
 }
 
 // Qwen3: independent batch rows (each its own cache) take the q/k norm inside the attention launch; the positions of one sequence that a
@@ -172,7 +173,7 @@ int launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float* 
         a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.eps = d.norm_eps;
       }
       if (oproj_fused_ok(c, R, kv_stride)) {      // + o_proj and the residual add in the same launch (Attention.h:111-112, DecoderLayer.h:40)
-        a.oj_w = w.wo; a.oj_x = r.x; a.oj_acc = c->slab_acc + (size_t)(&r - c->rows.data()) * H; a.oj_H = H; a.oj_ldw = qd;
+        a.oj_w = w.wo; a.oj_x = r.x; a.oj_acc = c->slab_acc + (size_t)(&r - c->rows.data()) * H; a.oj_H = H; a.oj_ldw = qd; a.oj_act16 = c->act16;
       }
       launch_attn(c, a, R, /*combine=*/!oproj_sliced_ok(c, R, kv_stride));
       break;
@@ -185,7 +186,7 @@ int launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float* 
       if (oproj_sliced_ok(c, R, kv_stride)) {   // split-form attention, batch 1: K-sliced product, the split records merged in its prologue, partial sums into
         // the row's fixed-point accumulators (kernels/oproj_sliced.h); the residual x is added by K slice 0; gate_up reads the accumulators, down empties them
         tgx::OprojSlicedArgs o{};
-        o.W = w.wo; o.ldw = qd; o.part = r.attn_part; o.nsplit = c->attn_nsplit; o.x = r.x; o.acc = c->slab_acc + (size_t)(&r - c->rows.data()) * H; o.H = H;
+        o.W = w.wo; o.ldw = qd; o.part = r.attn_part; o.nsplit = c->attn_nsplit; o.x = r.x; o.acc = c->slab_acc + (size_t)(&r - c->rows.data()) * H; o.H = H; o.act16 = c->act16;
         const dim3 blk(256);
         TGX_DT16_SWITCH(c->dt,
           if (qd % 256 == 0) hipLaunchKernelGGL((tgx::oproj_sliced_kernel<DT, 64, 32>), dim3(H / tgx::oproj_sliced_rows<32>(), qd / 256), blk, 0, c->stream, o);

@@ -61,6 +61,7 @@ struct AttnArgs {
   const float* oj_x;      // [H] residual input (added once, by head 0)
   long long* oj_acc;      // [H] fixed-point accumulators, zero on entry
   int oj_H, oj_ldw, oj_rsplit;
+  int oj_act16;           // option act.round16: the head output is rounded to the storage dtype before the product
 };
 
 template <int HD>
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
 #pragma unroll
       for (int pt = 1; pt < PARTS; pt++) acc += spart[pt][d];
       const float M = sML[0], L = sML[1];
-      if constexpr (OPJ) spart[0][d] = acc / L;                 // the normalised head output stays in LDS: the o_proj strip's activation
+      if constexpr (OPJ) { const float on = acc / L; spart[0][d] = a.oj_act16 ? elem_to_f32<DT>(f32_to_elem<DT>(on)) : on; }     // the normalised head output stays in LDS: the o_proj strip's activation
       else if (a.direct) {
         const size_t oi = blockIdx.y * a.q_stride + (size_t)head_of(0) * HD + d;
         bool done = false;

@@ -226,12 +226,10 @@ __device__ __forceinline__ void xcd_tile(const GemmArgs& a, int& tm, int& tn) {
 // stages are in flight while the third is consumed: the waits are counted (vmcnt(6): this wave's six pieces of the NEXT stage may still
 // fly), never a drain.  A wave owns 128 x 64 of the output (4 x 2 MFMA tiles): 10 fragment reads per 16 MFMAs, double-buffered in
 // registers (see the pipeline note at the loop).
-#ifndef TGX_GEMM_TERMS
-#define TGX_GEMM_TERMS 2      // experiment (profiles/r04_act16_cost.txt): 1 = the eight-wave GEMMs multiply A_hi only, i.e. activations rounded to the storage dtype — the
-#endif                        // reference's own bf16-module contract for a Linear's input — to price what the fp32-activation contract costs the prefill; never shipped
-template <int DT, int EPI>
+// LO = false (option act.round16: the Linear's input is rounded to the storage dtype, so A_hi IS the activation): the A_lo tile is neither staged nor
+// multiplied — 4 DMA pieces per stage instead of 6, half the MFMAs (gate_up at S = 2048: 232 -> 130 us, profiles/r04_act16_cost.txt)
+template <int DT, int EPI, bool LO = true>
 __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
-  constexpr bool LO = TGX_GEMM_TERMS >= 2;
   constexpr int DBK = 32, CPR = 4, RPP = 16, TMN = 256, NS = 3;
   constexpr int STAGE = 3 * TMN * DBK;                    // 16-bit elements per stage
   extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
@@ -371,7 +369,7 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
 // waves w and w + 4 own the same 64 x 64 quadrant and take alternate halves of every stage's k range (two of its four k16 steps each), so
 // a SIMD holds two waves, a stage is 48 KB with three stages in the ring, and the two partial accumulators meet once, through LDS, after
 // the K loop (fixed order: lower half + upper half).
-template <int DT, int EPI>
+template <int DT, int EPI, bool LO = true>
 __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
   constexpr int DBK = 64, CPR = 8, RPP = 8, TMN = 128, NS = 3;
   constexpr int STAGE = 3 * TMN * DBK;                    // 16-bit elements per stage (A_hi | A_lo | B)
@@ -404,7 +402,6 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
     gsrc[3 * p] = a.A_hi + g; gsrc[3 * p + 1] = a.A_lo + g; gsrc[3 * p + 2] = a.B + brow * a.K + chunk * 8;
     ldst[3 * p] = (unsigned)(piece * 1024); ldst[3 * p + 1] = ldst[3 * p] + (unsigned)(TMN * DBK * 2); ldst[3 * p + 2] = ldst[3 * p] + (unsigned)(2 * TMN * DBK * 2);
   }
-  constexpr bool LO = TGX_GEMM_TERMS >= 2;
   auto issue_piece = [&](int q, int k0, int stage) { if (!LO && q % 3 == 1) return; dma_1k(gsrc[q] + k0, lds_base + (unsigned)(stage * STAGE * 2) + ldst[q]); };
   auto frag = [&](const bf16_t* tile, int row, int kchunk) -> bf16x8 {
     return *reinterpret_cast<const bf16x8*>(tile + row * DBK + ((kchunk ^ ((row >> 1) & 7)) << 3));

@@ -132,6 +132,7 @@ struct GemvArgs {
   int ldw;                // elements between weight rows (== K unless the launch covers a K range of wider rows; 0 = K)
   int units;              // number of row pairs
   int ks;                 // waves per unit (1, 2, 4)
+  int act16;              // option act.round16: the Linear's input (after its norm) is rounded to the storage dtype — the reference's bf16 modules see bf16 tensors (ModelLlama.h:62)
   int dbg;                // experiments only ("debug.gemv"): 1 skip the norm arithmetic, 2 skip the weight stream, 4 exit at once, 8 skip the epilogue
   long long x_stride, out_stride, q_stride, kv_stride, logits_stride, part_stride, kraw_stride;   // elements between batch rows
   // EPI_QKV_ROPE
@@ -382,6 +383,17 @@ __global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void ge
 #pragma unroll
         for (int t = 0; t < 8; t++) xr[r][j][t] = w[t] * (xr[r][j][t] * inv);
       }
+    }
+  }
+
+  if constexpr (DT != DT_F32) {
+    if (a.act16) {          // (kernel-uniform) x := storage_dtype(x), round-to-nearest-even: what a 16-bit module hands to its Linear
+#pragma unroll
+      for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int j = 0; j < NX; j++)
+#pragma unroll
+          for (int t = 0; t < 8; t++) xr[r][j][t] = elem_to_f32<DT>(f32_to_elem<DT>(xr[r][j][t]));
     }
   }
 

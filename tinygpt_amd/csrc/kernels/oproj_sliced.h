@@ -34,6 +34,7 @@ struct OprojSlicedArgs {
   const float* x;       // [H] residual stream (fp32), added by K slice 0
   long long* acc;       // [H] fixed-point accumulators, zero when the launch starts
   int H;
+  int act16;            // option act.round16: the merged attention output is rounded to the storage dtype before the product
   int dbg;              // experiments only (tools/probes/layer_lab.hip -DLAB_DISSECT): 1 no atomics (plain stores), 2 no record merge, 4 no weight loads
 };
 
@@ -114,8 +115,11 @@ __global__ __launch_bounds__(256) void oproj_sliced_kernel(const OprojSlicedArgs
     }
     if (sl == 0) {
       f32x4* dst = reinterpret_cast<f32x4*>(&xs[wv * HD + dg * 8]);
-      dst[0] = f32x4{o[0] / L, o[1] / L, o[2] / L, o[3] / L};
-      dst[1] = f32x4{o[4] / L, o[5] / L, o[6] / L, o[7] / L};
+      float on[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) { on[j] = o[j] / L; if (a.act16) on[j] = elem_to_f32<DT>(f32_to_elem<DT>(on[j])); }
+      dst[0] = f32x4{on[0], on[1], on[2], on[3]};
+      dst[1] = f32x4{on[4], on[5], on[6], on[7]};
     }
   }
   if (OPS_DBG(a, 2)) { if (threadIdx.x < SW) xs[threadIdx.x] = 1.0f; }

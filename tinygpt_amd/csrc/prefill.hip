@@ -10,15 +10,16 @@ bool prefill_shapes_ok(const tgx_model_desc& d) {
 }
 
 int ensure_prefill_ws(tgx_ctx* c, int S) {
-  if (S <= c->ws_rows) return TGX_OK;
+  if (S <= c->ws_rows && (!c->act16 || c->ws_zero || c->dt == tgx::DT_F32)) return TGX_OK;
+  S = std::max(S, c->ws_rows);
   const tgx_model_desc& d = c->d;
   const size_t H = (size_t)d.hidden, qd = (size_t)d.heads * d.head_dim, kvd = (size_t)d.kv_heads * d.head_dim, I = (size_t)d.inter;
   const size_t wout = qd + 2 * kvd, wa = std::max(H, qd);   // the gate_up product leaves no fp32 intermediate (GEMM_SILU)
   drop_step_graphs(c);                                       // a captured batched decode step holds pointers into the old workspace
   HIP_OK(c, hipStreamSynchronize(c->stream));
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl);
-  c->ws_al2 = nullptr;
+  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl); fr(c->ws_zero);
+  c->ws_al2 = nullptr; c->ws_zero = nullptr; c->ws_zero_elems = 0;
   c->ws_x = nullptr; c->ws_out = nullptr; c->ws_ah = c->ws_al = c->ws_qh = c->ws_ql = c->ws_hh = c->ws_hl = nullptr; c->ws_rows = 0;
   const size_t rows = (size_t)S;
   // fp32 storage: ws_ah / ws_qh / ws_hh hold fp32 rows (the fp32 GEMM's A operands, the rotated queries); the lo terms are unused
@@ -32,6 +33,11 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
   HIP_OK(c, hipMalloc((void**)&c->ws_ql, rows * qd * 2 * lo + 16));
   HIP_OK(c, hipMalloc((void**)&c->ws_hh, rows * I * te));
   HIP_OK(c, hipMalloc((void**)&c->ws_hl, rows * I * 2 * lo + 16));
+  if (c->act16 && lo) {      // option act.round16: the all-zero "lo term" of every stored-term product (any A operand fits: rows x max(H, qd, I))
+    c->ws_zero_elems = rows * std::max(wa, I) + 8;
+    HIP_OK(c, hipMalloc((void**)&c->ws_zero, c->ws_zero_elems * 2));
+    HIP_OK(c, hipMemset(c->ws_zero, 0, c->ws_zero_elems * 2));
+  }
   if (c->dt == tgx::DT_F32) {
     if (c->ws_pos) (void)hipFree(c->ws_pos);
     c->ws_pos = nullptr;
@@ -47,10 +53,13 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
 static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float* C, int M, int N, int K, int ldc, bool three_terms = false,
                  const bf16_t* a_hi = nullptr, const bf16_t* a_lo = nullptr, int three_from = 0, int* defer = nullptr) {
   if (defer) *defer = 1;
+  const bool one = c->act16 && c->ws_zero;       // option act.round16: A_hi is the (rounded) activation; every other term reads zeros, the eight-wave kernels skip it
+  if (one) { three_terms = false; three_from = 0; }
+  const bool one_k = one && c->act16_kernels;    // ... in kernels that have a one-term form
   const bf16_t* B = reinterpret_cast<const bf16_t*>(B_);   // 16-bit storage (bf16 or fp16 bit patterns); fp32 storage never gets here
   const bf16_t* bias = reinterpret_cast<const bf16_t*>(bias_);
   tgx::GemmArgs g{};
-  g.A_hi = a_hi ? a_hi : c->ws_ah; g.A_lo = a_lo ? a_lo : c->ws_al; g.A_lo2 = three_terms ? c->ws_al2 : nullptr;
+  g.A_hi = a_hi ? a_hi : c->ws_ah; g.A_lo = one ? c->ws_zero : (a_lo ? a_lo : c->ws_al); g.A_lo2 = three_terms ? c->ws_al2 : nullptr;
   g.inter = N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
   g.B = B; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc; g.three_from = three_from; g.xcd_tiles = c->xcd_tiles;
   // few column tiles (N = hidden) -> 64-row tiles, so that at least two workgroups share a CU
@@ -113,7 +122,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
     const dim3 g8((N + 255) / 256, (M + 255) / 256), b8(512);
     const size_t lds8 = (size_t)3 * 3 * 256 * 32 * 2;
     TGX_DT16_SWITCH(c->dt,
-      if (epi == tgx::GEMM_SILU) hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_SILU>), g8, b8, lds8, c->stream, g);
+      if (epi == tgx::GEMM_SILU) { if (one_k) hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_SILU, false>), g8, b8, lds8, c->stream, g); else hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_SILU>), g8, b8, lds8, c->stream, g); }
       else hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_GELU>), g8, b8, lds8, c->stream, g);)
     return;
   }
@@ -124,8 +133,8 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
     const dim3 g8((N + 255) / 256, (M + 255) / 256), b8(512);
     const size_t lds8 = (size_t)3 * 3 * 256 * 32 * 2;
     TGX_DT16_SWITCH(c->dt,
-      if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_RESIDUAL>), g8, b8, lds8, c->stream, g);
-      else hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_STORE>), g8, b8, lds8, c->stream, g);)
+      if (epi == tgx::GEMM_RESIDUAL) { if (one_k) hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_RESIDUAL, false>), g8, b8, lds8, c->stream, g); else hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_RESIDUAL>), g8, b8, lds8, c->stream, g); }
+      else { if (one_k) hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_STORE, false>), g8, b8, lds8, c->stream, g); else hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_STORE>), g8, b8, lds8, c->stream, g); })
     return;
   }
   if ((c->gemm_dma & 8) && c->wide_8k && K % 64 == 0 && !three_terms && epi == tgx::GEMM_SILU) {
@@ -135,7 +144,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
     if (2 * t128 >= c->num_cus && 2 * t128 <= c->wide_8k_max * c->num_cus) {
       const dim3 g8((N + 127) / 128, (M + 127) / 128), b8(512);
       const size_t lds8 = (size_t)3 * 3 * 128 * 64 * 2;
-      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_SILU>), g8, b8, lds8, c->stream, g))
+      TGX_DT16_SWITCH(c->dt, if (one_k) hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_SILU, false>), g8, b8, lds8, c->stream, g); else hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_SILU>), g8, b8, lds8, c->stream, g);)
       return;
     }
   }
@@ -146,8 +155,8 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
       const dim3 g8((N + 127) / 128, (M + 127) / 128), b8(512);
       const size_t lds8 = (size_t)3 * 3 * 128 * 64 * 2;
       TGX_DT16_SWITCH(c->dt,
-        if (epi == tgx::GEMM_RESIDUAL) hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_RESIDUAL>), g8, b8, lds8, c->stream, g);
-        else hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_STORE>), g8, b8, lds8, c->stream, g);)
+        if (epi == tgx::GEMM_RESIDUAL) { if (one_k) hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_RESIDUAL, false>), g8, b8, lds8, c->stream, g); else hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_RESIDUAL>), g8, b8, lds8, c->stream, g); }
+        else { if (one_k) hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_STORE, false>), g8, b8, lds8, c->stream, g); else hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_STORE>), g8, b8, lds8, c->stream, g); })
       return;
     }
   }
@@ -319,6 +328,19 @@ int prefill_set_attrs(tgx_ctx* c) {
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_BF16, tgx::GEMM_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_F16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_F16, tgx::GEMM_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
+  // option act.round16: the one-term forms
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_SILU, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_BF16, tgx::GEMM_SILU, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_RESIDUAL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_BF16, tgx::GEMM_RESIDUAL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_STORE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_BF16, tgx::GEMM_STORE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_F16, tgx::GEMM_SILU, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_F16, tgx::GEMM_SILU, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_F16, tgx::GEMM_RESIDUAL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_F16, tgx::GEMM_RESIDUAL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_F16, tgx::GEMM_STORE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_F16, tgx::GEMM_STORE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
 #define TGX_DMA_ATTR_P(DT_) TGX_DMA_ATTR1(DT_, tgx::GEMM_PARTIAL, 1, 64, 2) TGX_DMA_ATTR1(DT_, tgx::GEMM_PARTIAL, 2, 64, 2) TGX_DMA_ATTR1(DT_, tgx::GEMM_PARTIAL, 2, 32, 2)
   TGX_DMA_ATTR_P(tgx::DT_BF16) TGX_DMA_ATTR_P(tgx::DT_F16)
 #undef TGX_DMA_ATTR_P

@@ -97,6 +97,11 @@ struct SkinnyCall {
 static int launch_skinny(tgx_ctx* c, const SkinnyCall& k) {
   tgx::GemmArgs g{};
   g.A_hi = k.a_hi; g.A_lo = k.a_lo; g.A_lo2 = k.a_lo2; g.A_f32 = k.a_f32; g.lda = k.lda;
+  if (c->act16 && c->ws_zero) {      // option act.round16: stored lo terms read zeros, fp32 rows are rounded once while staging
+    g.one_term = 1;
+    if (g.A_lo) g.A_lo = c->ws_zero;
+    if (g.A_lo2) g.A_lo2 = c->ws_zero;
+  }
   g.norm_w = reinterpret_cast<const bf16_t*>(k.norm_w); g.ssq_part = k.ssq_in; g.ssq_ncb = tgx::SK_NCB; g.eps = c->d.norm_eps;
   g.inter = k.N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
   g.B = reinterpret_cast<const bf16_t*>(k.W); g.bias = reinterpret_cast<const bf16_t*>(k.bias); g.C = k.C; g.M = k.M; g.N = k.N; g.K = k.K; g.ldc = k.ldc;
@@ -208,7 +213,7 @@ static bool ksplit_ok(const tgx_ctx* c, int M, int N, int K) {
 }
 static void launch_ksplit(tgx_ctx* c, int epi, const ebyte* W, float* C, int ldc, int M, int N, int K) {
   tgx::GemmArgs g{};
-  g.A_hi = c->ws_ah; g.A_lo = c->ws_al; g.B = reinterpret_cast<const bf16_t*>(W); g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.A_hi = c->ws_ah; g.A_lo = (c->act16 && c->ws_zero) ? c->ws_zero : c->ws_al; g.B = reinterpret_cast<const bf16_t*>(W); g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.inter = N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
   const dim3 grid((N + 63) / 64), blk(256);
 #define TGX_KS(E_, K_) do { if (M > 16) hipLaunchKernelGGL((tgx::skinny_ksplit_kernel<DT, E_, K_, 2>), grid, blk, 0, c->stream, g); \
