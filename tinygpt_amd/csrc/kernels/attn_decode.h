@@ -62,10 +62,11 @@ struct AttnArgs {
   long long* oj_acc;      // [H] fixed-point accumulators, zero on entry
   int oj_H, oj_ldw, oj_rsplit;
   int oj_act16;           // option act.round16: the head output is rounded to the storage dtype before the product
+  int out_act16;          // ... and so is the fp32 output row of every form that feeds a separate o_proj launch (0 off, 1 bf16, 2 fp16)
 };
 
 template <int HD>
-__device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, float* out_head, float (*sm_o)[HD + 4]);   // below
+__device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, float* out_head, float (*sm_o)[HD + 4], int round_mode = 0);   // below
 
 // NW = waves per workgroup: 4 for the split form; 16 for the direct form (short contexts), where ONE workgroup covers a block of
 // NW * TPW * UNR tokens (512 at head_dim 64, 256 at 128) per pass over the load -> softmax chain.
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
             continue;
           }
         }
-        a.out[oi] = acc / L;
+        a.out[oi] = round_storage_if<DT>(acc / L, a.out_act16);
         continue;
       }
       float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
 #pragma unroll
       for (int pt = 1; pt < PARTS; pt++) acc += spart[pt][d];
       const float M = sML[0], L = sML[1];
-      if constexpr (OPJ) { const float on = acc / L; spart[0][d] = a.oj_act16 ? elem_to_f32<DT>(f32_to_elem<DT>(on)) : on; }     // the normalised head output stays in LDS: the o_proj strip's activation
+      if constexpr (OPJ) spart[0][d] = round_storage_if<DT>(acc / L, a.oj_act16);     // the normalised head output stays in LDS: the o_proj strip's activation
       else if (a.direct) {
         const size_t oi = blockIdx.y * a.q_stride + (size_t)head_of(0) * HD + d;
         bool done = false;
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
             done = true;
           }
         }
-        if (!done) a.out[oi] = acc / L;
+        if (!done) a.out[oi] = round_storage_if<DT>(acc / L, a.out_act16);
       } else {
         float* dst = part_row + ((size_t)head_of(0) * a.nsplit + sp) * (HD + 4);
         dst[d] = acc;
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
           continue;
         }
       }
-      a.out[o] = acc / L;
+      a.out[o] = round_storage_if<DT>(acc / L, a.out_act16);
       continue;
     }
     float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
 // of independent 16-byte loads; each wave folds its splits in registers (butterfly over the lane bits above DG, fixed order), the four waves
 // meet once in LDS.  `nsplit` records are read; sm_o is [4][HD + 4] floats of LDS.  Shared by attn_combine_kernel and the in-kernel fold.
 template <int HD>
-__device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, float* out_head, float (*sm_o)[HD + 4]) {
+__device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, float* out_head, float (*sm_o)[HD + 4], int round_mode) {
   constexpr int DG = HD / 8;            // lanes per split (dim groups of 8)
   constexpr int SPB = 256 / DG;         // splits per pass (32 for hd 64, 16 for hd 128)
   constexpr int NPASS = 32 / SPB;       // 1 or 2 passes cover the 32 possible splits
@@ -663,7 +664,7 @@ __device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, fl
     acc = fmaf(sm_o[1][tid], s1, acc); acc = fmaf(sm_o[2][tid], s2, acc); acc = fmaf(sm_o[3][tid], s3, acc);
     float LL = sm_o[0][HD + 1] * s0;
     LL = fmaf(sm_o[1][HD + 1], s1, LL); LL = fmaf(sm_o[2][HD + 1], s2, LL); LL = fmaf(sm_o[3][HD + 1], s3, LL);
-    out_head[tid] = acc / LL;
+    out_head[tid] = round_storage_mode(acc / LL, round_mode);       // option act.round16 (AttnArgs.out_act16: 1 bf16, 2 fp16): the o_proj input
   }
 }
 
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sm_o[4][HD + 4];   // per wave: o[HD], M, L
   const int h = blockIdx.x;
   const float* p = a.part + blockIdx.y * a.part_stride + (size_t)h * a.nsplit * (HD + 4);
-  attn_combine_head<HD>(p, a.nsplit, a.out + blockIdx.y * a.q_stride + (size_t)h * HD, sm_o);
+  attn_combine_head<HD>(p, a.nsplit, a.out + blockIdx.y * a.q_stride + (size_t)h * HD, sm_o, a.out_act16);
 }
 
 }  // namespace tgx

@@ -386,8 +386,11 @@ __global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void ge
     }
   }
 
-  if constexpr (DT != DT_F32) {
-    if (a.act16) {          // (kernel-uniform) x := storage_dtype(x), round-to-nearest-even: what a 16-bit module hands to its Linear
+  // option act.round16: a Linear's input is rounded to the storage dtype.  Norm-fused inputs are rounded here, after their norm; the inputs of the PLAIN products
+  // (attention output, siluMul / gelu output) are rounded by the kernel that writes them (below, kernels/attn_decode.h): nothing but loads stands between a
+  // PLAIN product's launch and its weight stream
+  if constexpr (DT != DT_F32 && PRO != PRO_PLAIN) {
+    if (a.act16) {          // (kernel-uniform)
 #pragma unroll
       for (int r = 0; r < R; r++)
 #pragma unroll
@@ -504,11 +507,11 @@ __global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void ge
           if (rb_valid) o[rb] = e1[r] + vb;
           if constexpr (XACC) { a.res_acc[ra] = 0; if (rb_valid) a.res_acc[rb] = 0; }     // this lane is the only reader / writer of its rows' accumulators
         } else if (EPI == EPI_SILU_MUL) {
-          a.out[(size_t)r * a.out_stride + u] = (va / (1.0f + expf(-va))) * vb;
+          a.out[(size_t)r * a.out_stride + u] = round_storage_if<DT>((va / (1.0f + expf(-va))) * vb, a.act16);        // (the down product's input)
         } else if (EPI == EPI_GELU) {
           float* o = a.out + (size_t)r * a.out_stride;
-          o[ra] = gelu_new(va);
-          if (rb_valid) o[rb] = gelu_new(vb);
+          o[ra] = round_storage_if<DT>(gelu_new(va), a.act16);                 // (c_proj's input)
+          if (rb_valid) o[rb] = round_storage_if<DT>(gelu_new(vb), a.act16);
         }
       }
     }

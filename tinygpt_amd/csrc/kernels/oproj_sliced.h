@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void oproj_sliced_kernel(const OprojSlicedArgs
       f32x4* dst = reinterpret_cast<f32x4*>(&xs[wv * HD + dg * 8]);
       float on[8];
 #pragma unroll
-      for (int j = 0; j < 8; j++) { on[j] = o[j] / L; if (a.act16) on[j] = elem_to_f32<DT>(f32_to_elem<DT>(on[j])); }
+      for (int j = 0; j < 8; j++) on[j] = round_storage_if<DT>(o[j] / L, a.act16);
       dst[0] = f32x4{on[0], on[1], on[2], on[3]};
       dst[1] = f32x4{on[4], on[5], on[6], on[7]};
     }
