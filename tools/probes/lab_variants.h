@@ -137,7 +137,159 @@ static void lab_fused_short(Lab& b) {
   CK(hipFree(acc)); CK(hipFree(x_a)); CK(hipFree(x_b));
 }
 
+
+// ---- experiment: gate_up + down as ONE launch (small models).  Workgroup w owns the intermediate elements i in [w IPW, (w + 1) IPW): it computes
+// h_i = silu(gate_i . x') * (up_i . x') (rows i and I + i of W_gu) and adds h_i * W_down[:, i] into its H column sums — W_down is read TRANSPOSED
+// ([I][H]: column i is a contiguous row), so both products stream.  No cross-workgroup dependency: the H partial sums per workgroup go to the fixed-point
+// residual accumulators with atomics.
+struct MlpFusedArgs { const unsigned short *wgu, *wdT, *norm_w; const float* x; long long* acc; int H, I, ipw; float eps; };
+template <int NX, int NWV>     // NX: 16-byte slices of an H-vector per lane (H <= 512 NX); NWV: waves per workgroup
+__global__ __launch_bounds__(64 * NWV) void mlp_fused_kernel(const MlpFusedArgs a) {
+  extern __shared__ float red_[];
+  float (*red)[NX * 512] = reinterpret_cast<float (*)[NX * 512]>(red_);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nsl = a.H / 8;                                      // slices per row
+  int cidx[NX]; bool cok[NX];
+#pragma unroll
+  for (int j = 0; j < NX; j++) { cidx[j] = min(lane + 64 * j, nsl - 1); cok[j] = lane + 64 * j < nsl; }
+  const int i0 = blockIdx.x * a.ipw, i1 = min(i0 + a.ipw, a.I);
+  // first unit's weights leave before the norm
+  Slice8<DT_BF16> wg[NX], wu[NX], wd[NX], ng[NX], nu[NX], nd[NX];
+  auto load_unit = [&](int i, Slice8<DT_BF16>* g, Slice8<DT_BF16>* u, Slice8<DT_BF16>* d) {
+    const int ic = min(i, a.I - 1);
+#pragma unroll
+    for (int j = 0; j < NX; j++) {
+      g[j] = load_slice_nt<DT_BF16>(a.wgu + (size_t)ic * a.H, cidx[j]);
+      u[j] = load_slice_nt<DT_BF16>(a.wgu + (size_t)(a.I + ic) * a.H, cidx[j]);
+      d[j] = load_slice_nt<DT_BF16>(a.wdT + (size_t)ic * a.H, cidx[j]);
+    }
+  };
+  load_unit(i0 + wv, wg, wu, wd);
+  float xr[NX][8];
+  Slice8<DT_BF16> nw[NX];
+#pragma unroll
+  for (int j = 0; j < NX; j++) {
+    const f32x4* xp = reinterpret_cast<const f32x4*>(a.x + cidx[j] * 8);
+    const f32x4 x0 = xp[0], x1 = xp[1];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { xr[j][t] = cok[j] ? x0[t] : 0.f; xr[j][4 + t] = cok[j] ? x1[t] : 0.f; }
+    nw[j] = load_slice<DT_BF16>(a.norm_w, cidx[j]);
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < NX; j++)
+#pragma unroll
+    for (int t = 0; t < 8; t++) ss = fmaf(xr[j][t], xr[j][t], ss);
+  ss = wave_sum(ss);
+  const float inv = 1.0f / sqrtf(ss / (float)a.H + a.eps);
+#pragma unroll
+  for (int j = 0; j < NX; j++) {
+    float w[8];
+    slice_unpack<DT_BF16>(nw[j], w);
+#pragma unroll
+    for (int t = 0; t < 8; t++) xr[j][t] = w[t] * (xr[j][t] * inv);
+  }
+  float out[NX][8];
+#pragma unroll
+  for (int j = 0; j < NX; j++)
+#pragma unroll
+    for (int t = 0; t < 8; t++) out[j][t] = 0.f;
+  for (int i = i0 + wv; i < i1; i += NWV) {
+    const bool more = i + NWV < i1;
+    if (more) load_unit(i + NWV, ng, nu, nd);
+    float g = 0.f, u = 0.f;
+#pragma unroll
+    for (int j = 0; j < NX; j++) {
+      float fg[8], fu[8];
+      slice_unpack<DT_BF16>(wg[j], fg); slice_unpack<DT_BF16>(wu[j], fu);
+#pragma unroll
+      for (int t = 0; t < 8; t++) { g = fmaf(fg[t], xr[j][t], g); u = fmaf(fu[t], xr[j][t], u); }
+    }
+    g = wave_sum(g); u = wave_sum(u);
+    const float h = (g / (1.0f + expf(-g))) * u;
+#pragma unroll
+    for (int j = 0; j < NX; j++) {
+      float fd[8];
+      slice_unpack<DT_BF16>(wd[j], fd);
+#pragma unroll
+      for (int t = 0; t < 8; t++) out[j][t] = fmaf(h, fd[t], out[j][t]);
+    }
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < NX; j++) { wg[j] = ng[j]; wu[j] = nu[j]; wd[j] = nd[j]; }
+    }
+  }
+  // the four waves' column sums meet in LDS, then one fixed-point add per column
+#pragma unroll
+  for (int j = 0; j < NX; j++) {
+    f32x4* dst = reinterpret_cast<f32x4*>(&red[wv][(lane + 64 * j) * 8]);
+    dst[0] = f32x4{out[j][0], out[j][1], out[j][2], out[j][3]}; dst[1] = f32x4{out[j][4], out[j][5], out[j][6], out[j][7]};
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.H; c += 64 * NWV) {
+    float v = red[0][c];
+#pragma unroll
+    for (int w = 1; w < NWV; w++) v += red[w][c];
+    long long f = f32_to_fix(v);
+    if (blockIdx.x == 0) f += f32_to_fix(a.x[c]);          // the residual, once
+    __hip_atomic_fetch_add(a.acc + c, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__global__ void transpose_bf16(const unsigned short* src, unsigned short* dst, int rows, int cols) {      // dst[c][r] = src[r][c]
+  const size_t n = (size_t)rows * cols;
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = idx / cols, c = idx - r * cols;
+    dst[c * rows + r] = src[idx];
+  }
+}
+template <int NWV>
+static void v_mlp_fused(Lab& b, int l, const unsigned short* wdT, long long* acc, int nwg) {
+  const LayerBuf& w = b.lb[(size_t)l];
+  MlpFusedArgs a{w.wgu, wdT, w.post_norm, b.x, acc, b.H, b.I, (b.I + nwg - 1) / nwg, b.eps};
+  if (b.H <= 1024) {
+    const size_t lds = (size_t)NWV * 2 * 512 * 4;
+    static bool set = false; if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<2, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+    hipLaunchKernelGGL((mlp_fused_kernel<2, NWV>), dim3(nwg), dim3(64 * NWV), lds, b.st, a);
+  } else {
+    constexpr int W = NWV > 8 ? 8 : NWV;
+    const size_t lds = (size_t)W * 4 * 512 * 4;
+    static bool set = false; if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<4, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+    hipLaunchKernelGGL((mlp_fused_kernel<4, W>), dim3(nwg), dim3(64 * W), lds, b.st, a);
+  }
+}
+static void lab_mlp_fused(Lab& b) {
+  if (b.H > 2048) return;
+  std::vector<unsigned short*> wdT((size_t)b.L);
+  for (int l = 0; l < b.L; l++) {
+    CK(hipMalloc(&wdT[(size_t)l], (size_t)b.H * b.I * 2));
+    hipLaunchKernelGGL(transpose_bf16, dim3(1024), dim3(256), 0, b.st, (const unsigned short*)b.lb[(size_t)l].wdown, wdT[(size_t)l], b.H, b.I);
+  }
+  long long* acc; CK(hipMalloc(&acc, (size_t)b.H * 8));
+  float *x_a, *x_b; CK(hipMalloc(&x_a, (size_t)b.H * 4)); CK(hipMalloc(&x_b, (size_t)b.H * 4));
+  std::vector<float> ha((size_t)b.H), hb((size_t)b.H);
+  CK(hipMemcpyAsync(x_a, b.x, (size_t)b.H * 4, hipMemcpyDeviceToDevice, b.st));
+  p_gateup(b, 3, nullptr); p_down(b, 3, x_a);
+  const float tp = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_gateup(b, l, nullptr); p_down(b, l, b.scratch_x); } }, b.L);
+  printf("{gate_up, down} as two launches: %.2f us\n", tp);
+  for (int nwg : {64, 128, 192, 256, 512}) {
+    CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
+    v_mlp_fused<4>(b, 3, wdT[3], acc, nwg);
+    hipLaunchKernelGGL(acc_to_f32, dim3((b.H + 255) / 256), dim3(256), 0, b.st, (const long long*)acc, x_b, b.H);
+    CK(hipMemcpyAsync(ha.data(), x_a, (size_t)b.H * 4, hipMemcpyDeviceToHost, b.st)); CK(hipMemcpyAsync(hb.data(), x_b, (size_t)b.H * 4, hipMemcpyDeviceToHost, b.st));
+    CK(hipStreamSynchronize(b.st));
+    double mx = 0, ref = 0;
+    for (int i = 0; i < b.H; i++) { mx = std::max(mx, (double)fabsf(ha[(size_t)i] - hb[(size_t)i])); ref = std::max(ref, (double)fabsf(ha[(size_t)i])); }
+    const float t = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_mlp_fused<4>(b, l, wdT[(size_t)l], acc, nwg); }, b.L);
+    const float t8 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_mlp_fused<8>(b, l, wdT[(size_t)l], acc, nwg); }, b.L);
+    const float t16 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_mlp_fused<16>(b, l, wdT[(size_t)l], acc, nwg); }, b.L);
+    printf("  gate_up + down in one launch (W_down transposed, fixed-point column sums), %3d workgroups: 4 waves %.2f us, 8 waves %.2f, 16 waves (8 at hidden > 1024) %.2f   (rel diff vs two launches %.2g)\n", nwg, t, t8, t16, mx / ref);
+  }
+  for (int l = 0; l < b.L; l++) CK(hipFree(wdT[(size_t)l]));
+  CK(hipFree(acc)); CK(hipFree(x_a)); CK(hipFree(x_b));
+}
+
 static void lab_variants_main(Lab& b) {
+  if (getenv("LAB_MLP")) { lab_mlp_fused(b); return; }
   if (b.pos_h < 1024 || getenv("LAB_SHORT_ONLY")) { lab_fused_short(b); if (getenv("LAB_SHORT_ONLY")) return; }
   if (b.g.hd == 64 && b.pos_h < 1024) {
     const float d4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_direct<4>(b, l); }, b.L);
