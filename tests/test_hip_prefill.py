@@ -130,3 +130,23 @@ def test_real_layer_shapes_33_to_64_row_prompts_skinny_equals_tiled(name, S, dty
     ulp = {"bf16": 8e-3, "fp16": 1e-3}[dtype]
     for (k1, v1), (k0, v0) in zip(res[64][3], res[32][3]):
         assert rel_err(k1, k0) < ulp and rel_err(v1, v0) < ulp
+
+
+@pytest.mark.parametrize("name,S,dtype", [("llama-3.2-1b", 300, "bf16"), ("llama-3.2-1b", 1024, "bf16"), ("llama-3.2-1b", 700, "fp16"), ("mistral-7b-v0.3", 400, "bf16"), ("qwen2.5-0.5b", 600, "bf16")])
+def test_n_hidden_products_as_k_slabs_on_the_eight_wave_kernel(name, S, dtype):
+    """Round 4 (option prefill.splitk_8k, on by default): the o_proj / down products of a 129-1500-row prompt, whose 128 x 128 tiles number less than a chip, run as
+    2-4 K slabs on the eight-wave LDS-DMA kernel (gemm_dma8k_kernel<.., GEMM_PARTIAL>; slabs summed in z order by the next row-wise kernel or the reducer).
+    Against the same prompt without it (64-row register-staged slabs below 256 tiles, a half-empty chip above): the same products in another summation
+    order — ONE layer (no cache row has a schedule-dependent input): logits within 2e-5, the same first token; and bit-identical on a second run."""
+    d = copy.deepcopy(known_desc(name, dtype))
+    d.layers, d.vocab, d.max_ctx = 1, 4096, S + 16
+    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    prompt = synth.synth_prompt(d.vocab, S, 78)[None, :]
+    outs = []
+    for on in (0, 1, 1):
+        m.set_option("prefill.splitk_8k", on)
+        m.reset_cache(); m.forward(prompt)
+        outs.append((m.logits(rounded=False).copy(), m.sample(GREEDY).copy()))
+    assert rel_err(outs[1][0], outs[0][0]) < 2e-5, rel_err(outs[1][0], outs[0][0])
+    np.testing.assert_array_equal(outs[1][1], outs[0][1])
+    np.testing.assert_array_equal(outs[1][0], outs[2][0])

@@ -219,6 +219,7 @@ struct tgx_ctx {
   // (ModelLlama.h:62) that has a price: the matrix-core products then take ONE 16-bit term per activation.  ws_zero: the "lo term"
   // every stored-term product reads in this mode
   int act16 = 0, act16_kernels = 1;
+  int splitk_8k = 1;         // option prefill.splitk_8k: N = hidden products of 129-1500-row prompts as 2-4 K slabs on the eight-wave LDS-DMA kernel
   bf16_t* ws_zero = nullptr; size_t ws_zero_elems = 0;
   // batch-1 steps on the direct attention form (short contexts, head_dim 64): the o_proj product runs in the attention launch's epilogue (attn_decode_kernel
   // template OPJ) — 4 launches per layer; the direct form then serves contexts up to attn_fused_max keys, with four waves per head up to attn_fused_nw4

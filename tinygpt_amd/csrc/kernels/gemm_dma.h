@@ -390,6 +390,10 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int prow = lane / CPR, pslot = lane % CPR;
+  // EPI == GEMM_PARTIAL (round 4): split-K slab blockIdx.z of a prompt whose 128 x 128 tiles alone leave CUs idle (129-1500 rows at hidden 2048): this workgroup's
+  // share of K is [k_begin, k_end); the slabs are summed in z order by gemm_splitk_reduce_kernel or the next row-wise kernel
+  const int k_begin = EPI == GEMM_PARTIAL ? (int)blockIdx.z * a.k_per : 0;
+  const int k_end = EPI == GEMM_PARTIAL ? min(a.K, k_begin + a.k_per) : a.K;
   const bf16_t* gsrc[6];
   unsigned ldst[6];
 #pragma unroll
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
     const size_t g = (size_t)min(m0 + row, a.M - 1) * a.K + chunk * 8;
     const int nb = min(n0 + row, a.N - 1);
     const size_t brow = EPI == GEMM_SILU ? (size_t)((nb & 1) ? a.inter : 0) + (size_t)(nb >> 1) : (size_t)nb;     // gate / up rows interleaved as tile columns
-    gsrc[3 * p] = a.A_hi + g; gsrc[3 * p + 1] = a.A_lo + g; gsrc[3 * p + 2] = a.B + brow * a.K + chunk * 8;
+    gsrc[3 * p] = a.A_hi + g + k_begin; gsrc[3 * p + 1] = a.A_lo + g + k_begin; gsrc[3 * p + 2] = a.B + brow * a.K + chunk * 8 + k_begin;
     ldst[3 * p] = (unsigned)(piece * 1024); ldst[3 * p + 1] = ldst[3 * p] + (unsigned)(TMN * DBK * 2); ldst[3 * p + 2] = ldst[3 * p] + (unsigned)(2 * TMN * DBK * 2);
   }
   auto issue_piece = [&](int q, int k0, int stage) { if (!LO && q % 3 == 1) return; dma_1k(gsrc[q] + k0, lds_base + (unsigned)(stage * STAGE * 2) + ldst[q]); };
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
     return *reinterpret_cast<const bf16x8*>(tile + row * DBK + ((kchunk ^ ((row >> 1) & 7)) << 3));
   };
 
-  const int nk = a.K / DBK;
+  const int nk = (k_end - k_begin) / DBK;
 #pragma unroll
   for (int q = 0; q < 6; q++) issue_piece(q, 0, 0);
   if (nk > 1) {
@@ -475,6 +479,14 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
         continue;
       }
       if (col >= a.N) continue;
+      if (EPI == GEMM_PARTIAL) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < a.M) a.part[((size_t)blockIdx.z * a.M + row) * a.N + col] = acc[i][j][r];
+        }
+        continue;
+      }
       const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r++) {

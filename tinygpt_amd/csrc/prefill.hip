@@ -75,6 +75,14 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
   const int ntiles = (int)(grid.x * grid.y), ktiles = K / tgx::GBK;
   int nsplit = 1;
   if (c->gemm_splitk && ntiles < c->num_cus && K % tgx::GBK == 0) nsplit = std::min(std::min(16, ktiles), (2 * c->num_cus + ntiles - 1) / ntiles);
+  // N = hidden products of a 129-1500-row prompt (round 4, option prefill.splitk_8k): their 128 x 128 tiles number less than a chip (Llama-3.2-1B S = 1024: 128 tiles on 256
+  // CUs, 84 us per product against 104 at twice the rows) — the eight-wave LDS-DMA kernel over 2-4 K slabs instead of 64-row register-staged slabs or a half-empty chip
+  bool part_8k = false;
+  if (c->gemm_splitk && c->splitk_8k && (c->gemm_dma & 8) && K % 64 == 0 && !three_terms && (epi == tgx::GEMM_RESIDUAL || epi == tgx::GEMM_STORE) && M > 128) {
+    const int t128 = ((N + 127) / 128) * ((M + 127) / 128);
+    const int z = std::min(4, c->num_cus / std::max(1, t128));
+    if (z >= 2 && K / 64 >= 4 * z) { part_8k = true; nsplit = z; }
+  }
   if (nsplit > 1) {
     const size_t need = (size_t)nsplit * M * N * 4;
     if (need > c->ws_part_bytes) {
@@ -87,7 +95,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
   }
   if (nsplit > 1) {
     g.part = c->ws_part; g.nsplit = nsplit; g.interleave = epi == tgx::GEMM_SILU ? 1 : 0;
-    g.k_per = ((ktiles + nsplit - 1) / nsplit) * tgx::GBK;
+    g.k_per = part_8k ? ((K / 64 + nsplit - 1) / nsplit) * 64 : ((ktiles + nsplit - 1) / nsplit) * tgx::GBK;
     const dim3 gz(grid.x, grid.y, nsplit);
     const size_t nout = (size_t)M * (epi == tgx::GEMM_SILU ? N / 2 : N);
     const dim3 rg((unsigned)((nout + 255) / 256));
@@ -95,7 +103,12 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
     // 1-2 TB/s (S = 48: gate_up 32 us for 67 MB); 64-row tiles whenever the prompt fits them, k = 64 per stage (32 for the 128-row three-term tile)
     // measured (Llama-3.2-1B, ms per prompt, DMA vs register-staged slabs): S = 40 1.61 / 1.79, 48 1.65 / 1.76, 64 1.71 / 1.87; 96 2.08 / 1.99, 128 2.12 / 2.09,
     // 256 2.65 / 2.68; Mistral-7B S = 48 5.40 / 6.23 — the 64-row tile wins, the 128-row one does not: prompts of <= 64 rows only (value 2 = always)
-    const bool dma_part = c->splitk_dma && (M <= 64 || c->splitk_dma == 2) && (c->gemm_dma & 3) && g.k_per % 64 == 0 && K % 64 == 0;
+    if (part_8k) {
+      const dim3 g8((N + 127) / 128, (M + 127) / 128, nsplit), b8(512);
+      const size_t lds8 = (size_t)3 * 3 * 128 * 64 * 2;
+      TGX_DT16_SWITCH(c->dt, if (one_k) hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_PARTIAL, false>), g8, b8, lds8, c->stream, g); else hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_PARTIAL>), g8, b8, lds8, c->stream, g);)
+    }
+    const bool dma_part = !part_8k && c->splitk_dma && (M <= 64 || c->splitk_dma == 2) && (c->gemm_dma & 3) && g.k_per % 64 == 0 && K % 64 == 0;
     if (dma_part) {
       const int mi = (small || M <= 64) ? 1 : 2;
       const int dbk = (mi == 2 && three_terms) ? 32 : 64;
@@ -107,7 +120,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
         else hipLaunchKernelGGL((tgx::gemm_dma_kernel<DT, tgx::GEMM_PARTIAL, 2, 32, 2>), gd, blk, lds, c->stream, g);)
     }
     TGX_DT16_SWITCH(c->dt,
-      if (dma_part) {}
+      if (dma_part || part_8k) {}
       else if (small) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_PARTIAL, 1>), gz, blk, dyn, c->stream, g);
       else hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_PARTIAL, 2>), gz, blk, dyn, c->stream, g);
       if (defer && c->defer_reduce && M >= c->defer_min_rows && (epi == tgx::GEMM_RESIDUAL || epi == tgx::GEMM_STORE)) { *defer = nsplit; }   // with few rows the row-wise consumers are too few workgroups to sum 16 slabs quickly (round 2, S = 64: 1.82 -> 1.87 ms; S = 256: 2.80 -> 2.70)
@@ -328,6 +341,11 @@ int prefill_set_attrs(tgx_ctx* c) {
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_BF16, tgx::GEMM_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_F16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_F16, tgx::GEMM_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
+  // split-K slabs on the eight-wave kernel
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_PARTIAL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_PARTIAL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_F16, tgx::GEMM_PARTIAL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_F16, tgx::GEMM_PARTIAL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
   // option act.round16: the one-term forms
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_SILU, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8_kernel<tgx::DT_BF16, tgx::GEMM_SILU, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 256 * 32 * 2));
