@@ -168,13 +168,13 @@ int launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float* 
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
       a.scale = 1.0f / sqrtf((float)hd);
       a.q_stride = qd; a.kv_stride = kv_stride; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
-      a.out_act16 = c->act16 ? (c->dt == tgx::DT_BF16 ? 1 : (c->dt == tgx::DT_F16 ? 2 : 0)) : 0;
+      a.act16 = c->act16 ? (c->dt == tgx::DT_BF16 ? 1 : (c->dt == tgx::DT_F16 ? 2 : 0)) : 0;
       if (qk_fused(c, kv_stride)) {
         a.k_raw = r.k_raw; a.kraw_stride = kvd; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm;
         a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.eps = d.norm_eps;
       }
       if (oproj_fused_ok(c, R, kv_stride)) {      // + o_proj and the residual add in the same launch (Attention.h:111-112, DecoderLayer.h:40)
-        a.oj_w = w.wo; a.oj_x = r.x; a.oj_acc = c->slab_acc + (size_t)(&r - c->rows.data()) * H; a.oj_H = H; a.oj_ldw = qd; a.oj_act16 = c->act16;
+        a.oj_w = w.wo; a.oj_x = r.x; a.oj_acc = c->slab_acc + (size_t)(&r - c->rows.data()) * H; a.oj_H = H; a.oj_ldw = qd;
       }
       launch_attn(c, a, R, /*combine=*/!oproj_sliced_ok(c, R, kv_stride));
       break;

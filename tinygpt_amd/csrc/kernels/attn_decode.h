@@ -61,12 +61,21 @@ struct AttnArgs {
   const float* oj_x;      // [H] residual input (added once, by head 0)
   long long* oj_acc;      // [H] fixed-point accumulators, zero on entry
   int oj_H, oj_ldw, oj_rsplit;
-  int oj_act16;           // option act.round16: the head output is rounded to the storage dtype before the product
-  int out_act16;          // ... and so is the fp32 output row of every form that feeds a separate o_proj launch (0 off, 1 bf16, 2 fp16)
+  int act16;              // option act.round16 (0 off, 1 bf16, 2 fp16): the normalised output — the o_proj input, in this launch (OPJ) or the next — is rounded to the
+                          // storage dtype.  (ONE field for both uses: with a second one the split form's kernel, which executes neither, measured 5.02 -> 5.26 us)
 };
 
 template <int HD>
 __device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, float* out_head, float (*sm_o)[HD + 4], int round_mode = 0);   // below
+
+// the normalised output value of a direct form; option act.round16 rounds it to the storage dtype (the o_proj input).  A branch, not a select: these stores sit
+// at the end of the kernel (no loads in flight), and the select form made the SPLIT form's kernel 0.24 us slower although it never executes this code
+template <int DT>
+__device__ __forceinline__ float attn_out_value(float acc, float L, int round16) {
+  float v = acc / L;
+  if constexpr (DT != DT_F32) { if (round16) v = elem_to_f32<DT>(f32_to_elem<DT>(v)); }
+  return v;
+}
 
 // NW = waves per workgroup: 4 for the split form; 16 for the direct form (short contexts), where ONE workgroup covers a block of
 // NW * TPW * UNR tokens (512 at head_dim 64, 256 at 128) per pass over the load -> softmax chain.
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
             continue;
           }
         }
-        a.out[oi] = round_storage_if<DT>(acc / L, a.out_act16);
+        a.out[oi] = attn_out_value<DT>(acc, L, a.act16);
         continue;
       }
       float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);
@@ -472,7 +481,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
 #pragma unroll
       for (int pt = 1; pt < PARTS; pt++) acc += spart[pt][d];
       const float M = sML[0], L = sML[1];
-      if constexpr (OPJ) spart[0][d] = round_storage_if<DT>(acc / L, a.oj_act16);     // the normalised head output stays in LDS: the o_proj strip's activation
+      if constexpr (OPJ) spart[0][d] = round_storage_if<DT>(acc / L, a.act16);     // the normalised head output stays in LDS: the o_proj strip's activation
       else if (a.direct) {
         const size_t oi = blockIdx.y * a.q_stride + (size_t)head_of(0) * HD + d;
         bool done = false;
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
             done = true;
           }
         }
-        if (!done) a.out[oi] = round_storage_if<DT>(acc / L, a.out_act16);
+        if (!done) a.out[oi] = attn_out_value<DT>(acc, L, a.act16);
       } else {
         float* dst = part_row + ((size_t)head_of(0) * a.nsplit + sp) * (HD + 4);
         dst[d] = acc;
@@ -589,7 +598,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
           continue;
         }
       }
-      a.out[o] = round_storage_if<DT>(acc / L, a.out_act16);
+      a.out[o] = attn_out_value<DT>(acc, L, a.act16);
       continue;
     }
     float* dst = part_row + ((size_t)head_of(g) * a.nsplit + sp) * (HD + 4);
@@ -664,7 +673,7 @@ __device__ __forceinline__ void attn_combine_head(const float* p, int nsplit, fl
     acc = fmaf(sm_o[1][tid], s1, acc); acc = fmaf(sm_o[2][tid], s2, acc); acc = fmaf(sm_o[3][tid], s3, acc);
     float LL = sm_o[0][HD + 1] * s0;
     LL = fmaf(sm_o[1][HD + 1], s1, LL); LL = fmaf(sm_o[2][HD + 1], s2, LL); LL = fmaf(sm_o[3][HD + 1], s3, LL);
-    out_head[tid] = round_storage_mode(acc / LL, round_mode);       // option act.round16 (AttnArgs.out_act16: 1 bf16, 2 fp16): the o_proj input
+    out_head[tid] = round_storage_mode(acc / LL, round_mode);       // option act.round16 (AttnArgs.act16: 1 bf16, 2 fp16): the o_proj input
   }
 }
 
@@ -673,7 +682,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sm_o[4][HD + 4];   // per wave: o[HD], M, L
   const int h = blockIdx.x;
   const float* p = a.part + blockIdx.y * a.part_stride + (size_t)h * a.nsplit * (HD + 4);
-  attn_combine_head<HD>(p, a.nsplit, a.out + blockIdx.y * a.q_stride + (size_t)h * HD, sm_o, a.out_act16);
+  attn_combine_head<HD>(p, a.nsplit, a.out + blockIdx.y * a.q_stride + (size_t)h * HD, sm_o, a.act16);
 }
 
 }  // namespace tgx

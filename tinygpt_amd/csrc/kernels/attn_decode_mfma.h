@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_mfma_kernel(const AttnArg
     if (a.direct) {      // the only "split": softmax normalisation here (a row always holds its own key: L > 0)
       const size_t o = blockIdx.y * a.q_stride + (size_t)(kvh * G + g) * HD + d;
       if (a.out_hi) split16<DT>(acc / L, a.out_hi[o], a.out_lo[o]);
-      else a.out[o] = round_storage_if<DT>(acc / L, a.out_act16);
+      else a.out[o] = round_storage_if<DT>(acc / L, a.act16);
       continue;
     }
     float* out = part_row + ((size_t)(kvh * G + g) * a.nsplit + sp) * (HD + 4);

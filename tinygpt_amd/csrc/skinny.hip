@@ -276,7 +276,7 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
       a.scale = 1.0f / sqrtf((float)hd);
       a.q_stride = qd; a.kv_stride = (long long)c->kv_row_elems; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
-      a.out_act16 = c->act16 ? (c->dt == tgx::DT_BF16 ? 1 : (c->dt == tgx::DT_F16 ? 2 : 0)) : 0;
+      a.act16 = c->act16 ? (c->dt == tgx::DT_BF16 ? 1 : (c->dt == tgx::DT_F16 ? 2 : 0)) : 0;
       if (raw_fuse) {
         if (qs > 1) { a.raw_part = c->ws_part; a.raw_nsplit = qs; a.raw_bias = w.bqkv; } else a.raw_qkv = c->ws_out;
         a.raw_rows = M; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.eps = d.norm_eps;
