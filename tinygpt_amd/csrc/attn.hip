@@ -94,15 +94,15 @@ static void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R, bool combine) {
       const dim3 gridg(a.kv_heads, R, gfull / dg), blkg(1024);
       if constexpr (!QKN && DT != tgx::DT_F32) {
         if (raw && !(c->debug_skip & 1)) {
-          if (dg == 2) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 16, false, true>), gridg, blkg, 0, c->stream, a);
-          else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 16, false, true>), gridg, blkg, 0, c->stream, a);
+          if (dg == 2) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 16, false, true, 2>), gridg, blkg, 0, c->stream, a);
+          else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 16, false, true, 1>), gridg, blkg, 0, c->stream, a);
           return;
         }
       }
       if constexpr (!QKN) {
         if (!(c->debug_skip & 1)) {
-          if (dg == 2) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 16, false>), gridg, blkg, 0, c->stream, a);
-          else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 16, false>), gridg, blkg, 0, c->stream, a);
+          if (dg == 2) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 16, false, false, 2>), gridg, blkg, 0, c->stream, a);
+          else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 16, false, false, 1>), gridg, blkg, 0, c->stream, a);
         }
       }
       return;
