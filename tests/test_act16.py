@@ -134,7 +134,7 @@ def test_act16_every_linear_rounds_its_input_first_cache_rows_of_layer_two_exact
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fam,rows", [("llama_tiny", 2), ("llama_tiny", 5), ("qwen2_tiny", 7), ("mistral_tiny", 20), ("llama_tiny", 40), ("qwen2_tiny", 70)])
+@pytest.mark.parametrize("fam,rows", [("llama_tiny", 2), ("llama_tiny", 3), ("qwen2_tiny", 4), ("llama_tiny", 5), ("qwen2_tiny", 7), ("mistral_tiny", 20), ("llama_tiny", 40), ("qwen2_tiny", 70)])
 def test_act16_batched_steps_vs_oracle(fam, rows, hip, oracle_lib):
     """batch rows share the weight pass (GEMV groups up to 2 rows; skinny MFMA products from 3 rows: fp32 rows rounded ONCE while staging, stored terms with
     an all-zero second term, the LDS-DMA ring kernel from 17 rows): every row vs the oracle in the same mode, teacher-forced through the captured step"""

@@ -268,7 +268,6 @@ __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) 
 enum { GEMM_STORE = 0, GEMM_RESIDUAL = 1, GEMM_SILU = 2, GEMM_PARTIAL = 3, GEMM_GELU = 4 };   // PARTIAL: split-K slab, finished by gemm_splitk_reduce_kernel
 // GEMM_GELU (GPT-2's c_fc, ModelGPT2.h:96-107): out_hi / out_lo [M][N] = the 16-bit terms of gelu_new(acc + bias) — the c_proj product's A operand
 struct GemmArgs {
-  int one_term;                // option act.round16: kernels that split fp32 rows while staging keep the first term only (the row rounded to the storage dtype)
   const bf16_t *A_hi, *A_lo;   // [M][K]
   const bf16_t* A_lo2;         // optional third term (nullptr: two-term product)
   const bf16_t* B;             // [N][K] (torch Linear weight)

@@ -147,9 +147,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const GemmArgs a) {
           }
           const bf16_t h = f32_to_elem<DT>(y);
           const float r1 = y - elem_to_f32<DT>(h);
-          const bf16_t l = a.one_term ? (bf16_t)0 : f32_to_elem<DT>(r1);          // act.round16: the activation IS h
+          const bf16_t l = f32_to_elem<DT>(r1);
           bf16_t terms[3] = {h, l, 0};
-          if (NT == 3 && !a.one_term) terms[2] = f32_to_elem<DT>(r1 - elem_to_f32<DT>(l));
+          if (NT == 3) terms[2] = f32_to_elem<DT>(r1 - elem_to_f32<DT>(l));
 #pragma unroll
           for (int t = 0; t < NT; t++) {
             if (e & 1) o[t][e >> 1] |= (unsigned int)terms[t] << 16; else o[t][e >> 1] = terms[t];

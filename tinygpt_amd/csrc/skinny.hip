@@ -97,10 +97,11 @@ struct SkinnyCall {
 static int launch_skinny(tgx_ctx* c, const SkinnyCall& k) {
   tgx::GemmArgs g{};
   g.A_hi = k.a_hi; g.A_lo = k.a_lo; g.A_lo2 = k.a_lo2; g.A_f32 = k.a_f32; g.lda = k.lda;
-  if (c->act16 && c->ws_zero) {      // option act.round16: stored lo terms read zeros, fp32 rows are rounded once while staging
-    g.one_term = 1;
+  if (c->act16 && c->ws_zero) {      // option act.round16: the stored lo terms read zeros.  (fp32-row sources: the callers below take the stored-term route for every
+    // norm-fused product in this mode; the attention rows of asrc 1 arrive rounded, so their second term IS zero)
     if (g.A_lo) g.A_lo = c->ws_zero;
     if (g.A_lo2) g.A_lo2 = c->ws_zero;
+    if (k.asrc == 2) { c->launch_fault = "internal: act.round16 needs stored terms for norm-fused skinny products"; return 1; }
   }
   g.norm_w = reinterpret_cast<const bf16_t*>(k.norm_w); g.ssq_part = k.ssq_in; g.ssq_ncb = tgx::SK_NCB; g.eps = c->d.norm_eps;
   g.inter = k.N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
@@ -239,7 +240,7 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
   const bool lm_ks = ksplit_ok(c, M, V, H);
   // 33-64 rows (round 3): four activation blocks; every RMSNorm-fused product takes its activations as 16-bit terms prepared once per product by the
   // row-wise launch that also adds the pending split-K residual (the RMSNorm-on-the-way staging runs out of registers at four blocks)
-  const bool terms = M > 32 || ((c->skinny_terms >= 2 || (c->skinny_dma && c->skinny_dma_qkv && M >= c->skinny_dma_rows && H % 64 == 0)) && M > (c->skinny_dma_qkv >= 2 ? 4 : 16));
+  const bool terms = M > 32 || c->act16 || ((c->skinny_terms >= 2 || (c->skinny_dma && c->skinny_dma_qkv && M >= c->skinny_dma_rows && H % 64 == 0)) && M > (c->skinny_dma_qkv >= 2 ? 4 : 16));      // (act.round16: the row-wise launch's first term IS the rounded input)
   int pend = 0;            // terms form: slabs of the previous layer's down product not yet added to the rows
   // the rows start as embedding rows (the finalize of the previous step gathered them): their sums of squares for the first RMSNorm
   if (!terms) hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
@@ -350,7 +351,7 @@ void launch_prefill_skinny(tgx_ctx* c, int row0, int NB, int S) {
   launch_embed_rows(c, (const long long*)c->rows[(size_t)row0].prompt, c->ws_x, M, S);
   // 33-64 rows (four activation blocks): RMSNorm + the 16-bit terms once per product in a row-wise launch (which also takes the pending split-K
   // residual), the panel kernel stages stored terms — its RMSNorm-on-the-way form runs out of registers at four blocks
-  const bool terms = M > 32;
+  const bool terms = M > 32 || c->act16;
   int pend = 0;             // slabs of the previous layer's down product not yet added to ws_x (terms form)
   if (!terms) hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)c->ws_x, (long long)H, H, ssq);
   for (int l = 0; l < d.layers; l++) {
