@@ -953,6 +953,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.direct_nw4")) { drop_step_graphs(c); c->attn_direct_nw4 = c->attn_fused_nw4 = value; return TGX_OK; }
   if (!strcmp(key, "attn.fused_max")) { c->attn_fused_max = value; return TGX_OK; }
   if (!strcmp(key, "attn.fused_nw4")) { drop_step_graphs(c); c->attn_fused_nw4 = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.terms_rows")) { c->prefill_terms_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk_8k")) { c->splitk_8k = value; return TGX_OK; }
   if (!strcmp(key, "act.round16")) { drop_step_graphs(c); c->act16 = value != 0; return TGX_OK; }
   if (!strcmp(key, "act.one_term_kernels")) { c->act16_kernels = value != 0; return TGX_OK; }      // 0: the two-term kernels on the all-zero second term (bit-identical; tests)      // (the all-zero term buffer is allocated with the next workspace check)

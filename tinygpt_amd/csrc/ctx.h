@@ -219,6 +219,7 @@ struct tgx_ctx {
   // (ModelLlama.h:62) that has a price: the matrix-core products then take ONE 16-bit term per activation.  ws_zero: the "lo term"
   // every stored-term product reads in this mode
   int act16 = 0, act16_kernels = 1;
+  int prefill_terms_rows = 16;   // option prefill.terms_rows: skinny prompts with more rows than this take their norm-fused products on stored 16-bit terms (round 4: from 17 rows instead of 33 — Mistral-7B S = 20 / 32 4.47 / 4.67 -> 3.94 / 4.30 ms, Llama-3.2-1B within noise)
   int splitk_8k = 1;         // option prefill.splitk_8k: N = hidden products of 129-1500-row prompts as 2-4 K slabs on the eight-wave LDS-DMA kernel
   bf16_t* ws_zero = nullptr; size_t ws_zero_elems = 0;
   // batch-1 steps on the direct attention form (short contexts, head_dim 64): the o_proj product runs in the attention launch's epilogue (attn_decode_kernel

@@ -351,7 +351,7 @@ void launch_prefill_skinny(tgx_ctx* c, int row0, int NB, int S) {
   launch_embed_rows(c, (const long long*)c->rows[(size_t)row0].prompt, c->ws_x, M, S);
   // 33-64 rows (four activation blocks): RMSNorm + the 16-bit terms once per product in a row-wise launch (which also takes the pending split-K
   // residual), the panel kernel stages stored terms — its RMSNorm-on-the-way form runs out of registers at four blocks
-  const bool terms = M > 32 || c->act16;
+  const bool terms = M > c->prefill_terms_rows || c->act16;      // (option prefill.terms_rows)
   int pend = 0;             // slabs of the previous layer's down product not yet added to ws_x (terms form)
   if (!terms) hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)c->ws_x, (long long)H, H, ssq);
   for (int l = 0; l < d.layers; l++) {

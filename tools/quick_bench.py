@@ -16,10 +16,11 @@ ap.add_argument("--model", default="llama-3.2-1b")
 ap.add_argument("--prompt", type=int, default=64)
 ap.add_argument("--steps", type=int, default=128)
 ap.add_argument("--ctx", type=int, default=0)
+ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--opt", action="append", default=[], help="key=value for tgx_set_option (after finalize), e.g. oproj.sliced=0")
 args = ap.parse_args()
 
-d = known_desc(args.model)
+d = known_desc(args.model, args.dtype)
 if args.ctx:
     d.max_ctx = args.ctx
 t0 = time.time()
