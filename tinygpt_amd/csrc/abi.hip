@@ -953,6 +953,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.direct_nw4")) { drop_step_graphs(c); c->attn_direct_nw4 = c->attn_fused_nw4 = value; return TGX_OK; }
   if (!strcmp(key, "attn.fused_max")) { c->attn_fused_max = value; return TGX_OK; }
   if (!strcmp(key, "attn.fused_nw4")) { drop_step_graphs(c); c->attn_fused_nw4 = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.qkv_nosplit")) { c->qkv_nosplit = value; return TGX_OK; }
   if (!strcmp(key, "prefill.terms_rows")) { c->prefill_terms_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk_8k")) { c->splitk_8k = value; return TGX_OK; }
   if (!strcmp(key, "act.round16")) { drop_step_graphs(c); c->act16 = value != 0; return TGX_OK; }
@@ -986,6 +987,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.skinny_hidden_max_wide")) { c->prefill_skinny_hidden_max_wide = value; return TGX_OK; }
   if (!strcmp(key, "prefill.skinny_hidden_max")) { c->prefill_skinny_hidden_max = value; return TGX_OK; }
   if (!strcmp(key, "prefill.skinny_rows")) { if (value < 0 || value > 128) return set_err(c, TGX_ERR_INVALID, "prefill.skinny_rows is 0..128"); c->prefill_skinny_rows = value; return TGX_OK; }
+  if (!strcmp(key, "prefill.wide_8k_eff")) { c->wide_8k_eff = value; return TGX_OK; }
   if (!strcmp(key, "prefill.wide_8k_max")) { c->wide_8k_max = value; return TGX_OK; }
   if (!strcmp(key, "prefill.xcd_tiles")) { c->xcd_tiles = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.wide_8k")) { c->wide_8k = value != 0; return TGX_OK; }

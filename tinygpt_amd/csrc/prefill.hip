@@ -74,14 +74,24 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
   // split K over blockIdx.z until ~2 workgroups per CU exist; the slabs are summed in z order by a second launch (deterministic)
   const int ntiles = (int)(grid.x * grid.y), ktiles = K / tgx::GBK;
   int nsplit = 1;
-  if (c->gemm_splitk && ntiles < c->num_cus && K % tgx::GBK == 0) nsplit = std::min(std::min(16, ktiles), (2 * c->num_cus + ntiles - 1) / ntiles);
+  // (the balanced QKV launch below fills the chip by itself from 1024 rows on at hidden 2048: 128 + 128 workgroups of equal work; Llama-3.2-1B S = 1024 5.16 -> 5.06 ms — no slabs then; option prefill.qkv_nosplit)
+  const bool qkv_bal = (c->gemm_dma & 3) && c->qkv_balanced && three_terms && epi == tgx::GEMM_STORE && three_from > 0 && three_from % tgx::GBN == 0 && N > three_from && K % 64 == 0 && M >= 128;
+  const int qkv_wgs = qkv_bal ? (three_from / tgx::GBN) * ((M + 127) / 128) + ((N - three_from + tgx::GBN - 1) / tgx::GBN) * ((M + 63) / 64) : 0;
+  const bool qkv_nosplit = qkv_bal && c->qkv_nosplit && qkv_wgs >= c->num_cus;
+  if (c->gemm_splitk && ntiles < c->num_cus && K % tgx::GBK == 0 && !qkv_nosplit) nsplit = std::min(std::min(16, ktiles), (2 * c->num_cus + ntiles - 1) / ntiles);
   // N = hidden products of a 129-1500-row prompt (round 4, option prefill.splitk_8k): their 128 x 128 tiles number less than a chip (Llama-3.2-1B S = 1024: 128 tiles on 256
   // CUs, 84 us per product against 104 at twice the rows) — the eight-wave LDS-DMA kernel over 2-4 K slabs instead of 64-row register-staged slabs or a half-empty chip
   bool part_8k = false;
   if (c->gemm_splitk && c->splitk_8k && (c->gemm_dma & 8) && K % 64 == 0 && !three_terms && (epi == tgx::GEMM_RESIDUAL || epi == tgx::GEMM_STORE) && M > 128) {
     const int t128 = ((N + 127) / 128) * ((M + 127) / 128);
-    const int z = std::min(4, c->num_cus / std::max(1, t128));
-    if (z >= 2 && K / 64 >= 4 * z) { part_8k = true; nsplit = z; }
+    // slabs z = 2..4 that shorten the critical path: rounds of workgroups x 1 / z of the K loop against one round of whole tiles (160 tiles on 256 CUs: z = 3 -> 2 rounds of a
+    // third = 0.67; 128 tiles: z = 2 -> 0.5); taken from 0.8 down (the slabs cost a pass over z x M x N floats)
+    int z = 1; double best = 0.8001;
+    for (int zz = 2; zz <= 4; zz++) {
+      const double cost = (double)((zz * t128 + c->num_cus - 1) / c->num_cus) / zz;
+      if (t128 < c->num_cus && cost < best - 1e-9 && K / 64 >= 4 * zz) { best = cost; z = zz; }
+    }
+    if (z >= 2) { part_8k = true; nsplit = z; }
   }
   if (nsplit > 1) {
     const size_t need = (size_t)nsplit * M * N * 4;
@@ -130,7 +140,11 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
       else hipLaunchKernelGGL((tgx::gemm_splitk_reduce_kernel<DT, tgx::GEMM_STORE>), rg, blk, 0, c->stream, g);)
     return;
   }
-  if ((c->gemm_dma & 4) && K % 64 == 0 && !three_terms && (epi == tgx::GEMM_SILU || epi == tgx::GEMM_GELU) && ((N + 255) / 256) * ((M + 255) / 256) >= c->num_cus) {
+  // (a prompt whose 256 x 256 tiles leave the last round of workgroups mostly empty — 1152 rows at intermediate 8192: 320 tiles = 1.25 rounds, the time of 2048 rows — takes the
+  //  128 x 128 kernel below instead: 1152 tiles = 4.5 rounds; option prefill.wide_8k_eff = per cent of the last round's fill below which that happens)
+  const int t256 = ((N + 255) / 256) * ((M + 255) / 256), r256 = (t256 + c->num_cus - 1) / c->num_cus;
+  const bool ragged256 = c->wide_8k && c->wide_8k_eff > 0 && epi == tgx::GEMM_SILU && (c->gemm_dma & 8) && t256 >= c->num_cus && 100 * t256 < c->wide_8k_eff * r256 * c->num_cus;
+  if ((c->gemm_dma & 4) && K % 64 == 0 && !three_terms && (epi == tgx::GEMM_SILU || epi == tgx::GEMM_GELU) && t256 >= c->num_cus && !ragged256) {
     // the wide product (gate_up / c_fc) with enough 256 x 256 tiles to fill the chip: 8 waves, three-stage LDS-DMA ring
     const dim3 g8((N + 255) / 256, (M + 255) / 256), b8(512);
     const size_t lds8 = (size_t)3 * 3 * 256 * 32 * 2;
@@ -154,7 +168,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
     // the wide product of a prompt too short for 256 x 256 tiles (129-384 rows: 128-384 tiles of 128 x 128): the eight-wave kernel with the K step split between
     // wave pairs instead of the four-wave one (option prefill.wide_8k: Llama-3.2-1B S = 256 gate_up 61 us per layer)
     const int t128 = ((N + 127) / 128) * ((M + 127) / 128);
-    if (2 * t128 >= c->num_cus && 2 * t128 <= c->wide_8k_max * c->num_cus) {
+    if (2 * t128 >= c->num_cus && (2 * t128 <= c->wide_8k_max * c->num_cus || ragged256)) {
       const dim3 g8((N + 127) / 128, (M + 127) / 128), b8(512);
       const size_t lds8 = (size_t)3 * 3 * 128 * 64 * 2;
       TGX_DT16_SWITCH(c->dt, if (one_k) hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_SILU, false>), g8, b8, lds8, c->stream, g); else hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_SILU>), g8, b8, lds8, c->stream, g);)
