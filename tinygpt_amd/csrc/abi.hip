@@ -190,7 +190,9 @@ static int attn_mfma_threshold(const tgx_ctx* c) {
 // launch (decode.hip oproj_fused_capable) keep the direct form longer and on fewer waves
 static long long direct_limit(const tgx_ctx* c, int rpl, bool step) {
   if (step && rpl == 1 && c->batch == 1 && oproj_fused_capable(c)) return c->attn_fused_max;
-  return (long long)c->attn_direct_max * (rpl >= 4 ? rpl : 1);
+  // (2-3 rows, round 4: the direct form stays ahead to ~2x / ~3x the batch-1 limit — Llama-3.2-1B B = 3 at context 600 0.888 -> 0.820 ms per step, at 1200 0.959 -> 0.856;
+  //  crossovers measured at ~2000 / ~2800 keys there, ~900 / ~1600 on Mistral-7B, ~1400 / > 1500 on Qwen2.5-0.5B)
+  return (long long)c->attn_direct_max * (rpl >= 2 ? rpl : 1);
 }
 static long long nw4_limit(const tgx_ctx* c, int rpl, bool step) {
   if (rpl >= 4) return 0;
