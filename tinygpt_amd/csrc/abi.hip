@@ -955,6 +955,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.direct_nw4")) { drop_step_graphs(c); c->attn_direct_nw4 = c->attn_fused_nw4 = value; return TGX_OK; }
   if (!strcmp(key, "attn.fused_max")) { c->attn_fused_max = value; return TGX_OK; }
   if (!strcmp(key, "attn.fused_nw4")) { drop_step_graphs(c); c->attn_fused_nw4 = value; return TGX_OK; }
+  if (!strcmp(key, "skinny.terms_above")) { drop_step_graphs(c); c->skinny_terms_above = value; return TGX_OK; }
   if (!strcmp(key, "prefill.qkv_nosplit")) { c->qkv_nosplit = value; return TGX_OK; }
   if (!strcmp(key, "prefill.terms_rows")) { c->prefill_terms_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk_8k")) { c->splitk_8k = value; return TGX_OK; }

@@ -221,6 +221,7 @@ struct tgx_ctx {
   int act16 = 0, act16_kernels = 1;
   int prefill_terms_rows = 16;   // option prefill.terms_rows: skinny prompts with more rows than this take their norm-fused products on stored 16-bit terms (round 4: from 17 rows instead of 33 — Mistral-7B S = 20 / 32 4.47 / 4.67 -> 3.94 / 4.30 ms, Llama-3.2-1B within noise)
   int wide_8k_eff = 76;      // (Llama-3.2-1B S = 1152 7.28 -> 6.78 ms, 1280 7.52 -> 6.95, 1400 8.45 -> 8.14; at 87 % fill the 256 x 256 tiles win again) option prefill.wide_8k_eff (per cent): gate_up on 128 x 128 tiles when the 256 x 256 tiling's rounds are filled less than this
+  int skinny_terms_above = 2;  // (round 4: 2 instead of 4 — Llama-3.2-1B B = 3 / 4 0.822 / 0.823 -> 0.794 / 0.798 ms per step) option skinny.terms_above: batched steps with more rows than this prepare stored terms for the norm-fused products (with skinny.dma_qkv 2)
   int qkv_nosplit = 1;       // option prefill.qkv_nosplit: the balanced QKV launch instead of K slabs when it alone covers 3/4 of the chip
   int splitk_8k = 1;         // option prefill.splitk_8k: N = hidden products of 129-1500-row prompts as 2-4 K slabs on the eight-wave LDS-DMA kernel
   bf16_t* ws_zero = nullptr; size_t ws_zero_elems = 0;

@@ -240,7 +240,7 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
   const bool lm_ks = ksplit_ok(c, M, V, H);
   // 33-64 rows (round 3): four activation blocks; every RMSNorm-fused product takes its activations as 16-bit terms prepared once per product by the
   // row-wise launch that also adds the pending split-K residual (the RMSNorm-on-the-way staging runs out of registers at four blocks)
-  const bool terms = M > 32 || c->act16 || ((c->skinny_terms >= 2 || (c->skinny_dma && c->skinny_dma_qkv && M >= c->skinny_dma_rows && H % 64 == 0)) && M > (c->skinny_dma_qkv >= 2 ? 4 : 16));      // (act.round16: the row-wise launch's first term IS the rounded input)
+  const bool terms = M > 32 || c->act16 || ((c->skinny_terms >= 2 || (c->skinny_dma && c->skinny_dma_qkv && M >= c->skinny_dma_rows && H % 64 == 0)) && M > (c->skinny_dma_qkv >= 2 ? c->skinny_terms_above : 16));      // (act.round16: the row-wise launch's first term IS the rounded input)
   int pend = 0;            // terms form: slabs of the previous layer's down product not yet added to the rows
   // the rows start as embedding rows (the finalize of the previous step gathered them): their sums of squares for the first RMSNorm
   if (!terms) hipLaunchKernelGGL(tgx::row_ssq_kernel, dim3(M, tgx::SK_NCB), dim3(256), 0, c->stream, (const float*)r.x, (long long)H, H, ssq);
