@@ -12,7 +12,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 d = copy.deepcopy(known_desc(name)); d.max_ctx = 4096; d.max_batch = 128
 m = Model(d).load_synthetic(1234, 0.02).finalize()
 bad = 0
-for S in (2048, 3200, 300, 40, 12):
+for S in (2048, 3200, 1024, 1280, 700, 300, 40, 24, 12):      # (1024 / 1280 / 700: round 4's K slabs on the eight-wave kernel and 128 x 128 gate_up tiles)
     ids = synth.synth_prompt(d.vocab, S, 7)[None, :]
     ref = None
     t0 = time.time()
@@ -72,5 +72,17 @@ for S in (33, 48, 64, 100, 128):
         if ref is None: ref = lg
         elif not np.array_equal(ref, lg): bad += 1; print(f"MISMATCH prefill S={S} rep {r}", flush=True)
     print(f"prefill S={S}: {3 * reps} repetitions", flush=True)
+# round 4: batch-1 steps — fixed-point atomic sums (attention + o_proj in one launch up to 640 keys, K-sliced o_proj beyond): a generation that crosses both form limits, 3 x
+for opt in (0, 1):
+    m.set_option("act.round16", opt)
+    ids = synth.synth_prompt(d.vocab, 200, 5)[None, :]
+    outs = []
+    for r in range(3):
+        m.reset_cache(); m.forward(ids); m.sample(GREEDY)
+        outs.append((m.decode(900, GREEDY).copy(), m.logits(False).copy()))
+    ok = all(np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]) for o in outs)
+    if not ok: bad += 1
+    print(f"decode B=1 act.round16={opt}: 3 x 900 steps from context 200 (ids and final logits) equal: {ok}", flush=True)
+m.set_option("act.round16", 0)
 print("SOAK", "FAILED" if bad else "OK", bad)
 sys.exit(1 if bad else 0)
