@@ -553,7 +553,7 @@ def test_k_sliced_o_proj_with_the_attention_merge_equals_combine_plus_o_proj(nam
                 np.testing.assert_array_equal(outs[0][3], outs[1][3])
 
 
-@pytest.mark.parametrize("name,lens,batch,dtype", [("llama-3.2-1b", (1, 30, 191, 192, 447, 448, 449, 600, 1300), 1, "bf16"), ("qwen2.5-0.5b", (5, 270, 500, 900), 1, "bf16"),
+@pytest.mark.parametrize("name,lens,batch,dtype", [("llama-3.2-1b", (1, 30, 191, 192, 383, 384, 385, 600, 1300), 1, "bf16"), ("qwen2.5-0.5b", (5, 270, 500, 900), 1, "bf16"),
                                                    ("qwen2.5-0.5b", (300,), 1, "fp16"), ("llama-3.2-1b", (130,), 2, "bf16"), ("llama-3.2-1b", (200,), 3, "bf16")])
 def test_o_proj_in_the_direct_attention_launch_equals_attention_plus_o_proj(name, lens, batch, dtype, hip):
     """Batch-1 steps on the direct attention form at head_dim 64 (round 4, attn_decode_kernel template OPJ; option oproj.fused, on by default): every query
@@ -561,7 +561,7 @@ def test_o_proj_in_the_direct_attention_launch_equals_attention_plus_o_proj(name
     (Attention.h:108-112, DecoderLayer.h:40) — no attention output in memory, no o_proj launch.  Against the separate direct attention + row-sliced o_proj
     launches: the same keys in another stream split (4 / 8 waves instead of 4 / 16), another summation order of the o_proj dot products: one layer within
     2e-6, two layers within 2e-4 (bf16 cache flips, see above), greedy ids equal; the fused form twice: bit-identical (integer atomics commute, the
-    accumulators rest at zero).  Contexts on both sides of the four-wave limit (448 keys) and far beyond the default limit of the form.  Batches of
+    accumulators rest at zero).  Contexts on both sides of the block-size limit (384 keys) and far beyond the default limit of the form.  Batches of
     2 / 3 rows never take it: the option must not change them."""
     import copy
     from tinygpt_amd import known_desc, synth

@@ -41,7 +41,7 @@ static void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R, bool combine) {
     // B = 17 1.247 / 1.159, B = 20 1.293 / 1.200, context 2k B = 17 1.553 / 1.340; Mistral-7B B = 16 3.92 / 4.07, B = 17 4.89 / 4.78: from 17 rows.
     // With AttnArgs.raw_* set the launch also finishes the QKV product (attn.raw_fuse: B = 32 1.335 -> 1.326, B = 8 1.000 -> 0.978)
     if constexpr (!QKN && DT != tgx::DT_F32 && HD == 64) {
-      if (a.oj_w) {     // batch-1 step: + the o_proj product and the residual add (AttnArgs.oj_*, template OPJ); 4 waves per head up to attn_fused_nw4 keys, 8 beyond
+      if (a.oj_w) {     // batch-1 step: + the o_proj product and the residual add (AttnArgs.oj_*, template OPJ); 4 waves per head; 4 wave-loads per softmax block up to attn_fused_nw4 keys, 8 beyond
         // workgroups per head: as many as keep heads x parts within one round of CUs (each repeats the head's attention and takes hidden / parts rows of the
         // strip) — layer_lab: Llama-3.2-1B at context 30 31.4 / 30.9 us per layer with 4 / 8 parts, 34.9 with 2; Qwen2.5-0.5B 18.7 / 18.8
         int rs = 8;
@@ -50,7 +50,7 @@ static void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R, bool combine) {
         const dim3 grid(a.kv_heads, 1, gfull * rs);
         if (c->debug_skip & 1) return;
         if (c->attn_nw4) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, false, false, 4, true>), grid, dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 8, false, false, 4, true>), grid, dim3(512), 0, c->stream, a);
+        else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, false, false, 8, true>), grid, dim3(256), 0, c->stream, a);      // beyond: four waves x EIGHT wave-loads per block (layer_lab, 600 keys: 7.33 vs 7.57 us for eight waves x four on Llama-3.2-1B, 6.60 vs 6.85 on Qwen2.5-0.5B)
         return;
       }
     }

@@ -226,8 +226,8 @@ struct tgx_ctx {
   int splitk_8k = 1;         // option prefill.splitk_8k: N = hidden products of 129-1500-row prompts as 2-4 K slabs on the eight-wave LDS-DMA kernel
   bf16_t* ws_zero = nullptr; size_t ws_zero_elems = 0;
   // batch-1 steps on the direct attention form (short contexts, head_dim 64): the o_proj product runs in the attention launch's epilogue (attn_decode_kernel
-  // template OPJ) — 4 launches per layer; the direct form then serves contexts up to attn_fused_max keys, with four waves per head up to attn_fused_nw4
-  int oproj_fused = 1, attn_fused_max = 640, attn_fused_nw4 = 448;
+  // template OPJ) — 4 launches per layer; the direct form then serves contexts up to attn_fused_max keys, with four wave-loads per softmax block up to attn_fused_nw4 keys and eight beyond (four waves per head either way); was: four / eight waves up to attn_fused_nw4
+  int oproj_fused = 1, attn_fused_max = 640, attn_fused_nw4 = 384;
   long long* slab_acc = nullptr;   // [max_batch][hidden], resting at zero between layers
   float* scratch_x = nullptr;   // [hidden] residual sink for tgx_profile_decode
   Profiler prof;

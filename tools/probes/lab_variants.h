@@ -88,13 +88,13 @@ static void v_attn_direct(Lab& b, int l) {
 }
 
 // direct form with the o_proj product in its epilogue (AttnArgs.oj_*): {attention, o_proj} as ONE launch at short contexts
-template <int NW>
+template <int NW, int UNR = 4>
 static void v_attn_oproj(Lab& b, int l, long long* acc, const float* resid, int rsplit) {
   AttnArgs a = attn_args(b, l);
   a.direct = 1;
   a.oj_w = b.lb[(size_t)l].wo; a.oj_x = resid; a.oj_acc = acc; a.oj_H = b.H; a.oj_ldw = b.qd; a.oj_rsplit = rsplit;
   const dim3 grid(a.kv_heads, 1, a.gfull * rsplit), blk(64 * NW);
-  if (b.g.hd == 64) hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 64, 1, NW, false, false, 4, true>), grid, blk, 0, b.st, a);
+  if (b.g.hd == 64) hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 64, 1, NW, false, false, UNR, true>), grid, blk, 0, b.st, a);
   else hipLaunchKernelGGL((attn_decode_kernel<DT_BF16, 128, 1, NW, false, false, 4, true>), grid, blk, 0, b.st, a);
 }
 
@@ -128,6 +128,10 @@ static void lab_fused_short(Lab& b) {
     const float t16 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_oproj<16>(b, l, acc, b.x, rsplit); }, b.L);
     const float t8 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_oproj<8>(b, l, acc, b.x, rsplit); }, b.L);
     const float t4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_oproj<4>(b, l, acc, b.x, rsplit); }, b.L);
+    const float t4u8 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_oproj<4, 8>(b, l, acc, b.x, rsplit); }, b.L);
+    const float t4u2 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_oproj<4, 2>(b, l, acc, b.x, rsplit); }, b.L);
+    const float t8u2 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_oproj<8, 2>(b, l, acc, b.x, rsplit); }, b.L);
+    printf("    (4 waves x 8 wave-loads per block %.2f, x 2: %.2f; 8 waves x 2: %.2f)\n", t4u8, t4u2, t8u2);
     CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
     const float l8 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); v_attn_oproj<8>(b, l, acc, b.x, rsplit); v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x); } }, b.L);
     CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
