@@ -795,3 +795,23 @@ def test_qkv_finish_inside_the_valu_attention_launch_is_bit_identical(family, dt
     for step in range(5):
         ref.forward(res[2][1][step - 1][:, None] if step else res[2][0][:, None]); ref.sample(GREEDY)
     assert rel_err(res[2][2], ref.logits(rounded=False)) < (TOL_ORACLE if dtype == "fp16" or family != "mistral_tiny" else 3e-3)
+
+
+def test_get_option_reports_the_form_limits_of_the_current_batch(hip):
+    """tgx_get_option (round 4): what bench.py reads to keep its timed region on one attention form.  Llama-3.2-1B geometry: batch 1 runs attention + o_proj in one launch
+    up to 640 keys (softmax blocks of 4 wave-loads up to 384); batches of 2-3 rows keep the direct form to rows x 576, 4+ rows likewise; unknown keys are refused."""
+    import copy
+    from tinygpt_amd import known_desc, synth
+    from tinygpt_amd.ffi import Model, TgxError
+    d = copy.deepcopy(known_desc("llama-3.2-1b"))
+    d.layers, d.vocab, d.max_ctx, d.max_batch = 1, 4096, 256, 4
+    m = Model(d, hip).load_synthetic(1234, 0.02).finalize()
+    for rows, limit, nw4 in ((1, 640, 384), (2, 2 * 576, 192), (3, 3 * 576, 192), (4, 4 * 576, 0)):
+        m.reset_cache(); m.forward(np.stack([synth.synth_prompt(d.vocab, 8, b) for b in range(rows)]))
+        assert m.get_option("attn.direct_limit") == limit and m.get_option("attn.nw4_limit") == nw4, rows
+    m.set_option("oproj.fused", 0)
+    m.reset_cache(); m.forward(synth.synth_prompt(d.vocab, 8, 0)[None, :])
+    assert m.get_option("attn.direct_limit") == 576 and m.get_option("attn.nw4_limit") == 192
+    assert m.get_option("act.round16") == 0 and m.get_option("graph.steps") == 16
+    with pytest.raises(TgxError):
+        m.get_option("no.such.key")
