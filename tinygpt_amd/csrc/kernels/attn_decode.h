@@ -423,10 +423,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
     }
     return;
   }
-#ifndef TGX_OLD_DIRECT_MERGE
-#define TGX_OLD_DIRECT_MERGE 0      // experiments (tools/probes/layer_lab.hip): 1 keeps the butterfly + per-wave-record merge of the 8 / 16-wave forms
-#endif
-  if constexpr ((NW > 4 || OPJ) && G == 1 && !TGX_OLD_DIRECT_MERGE) {
+  if constexpr ((NW > 4 || OPJ) && G == 1) {
     if constexpr (OPJ) {
       if (oj_rounds > OJC) {
 #pragma unroll

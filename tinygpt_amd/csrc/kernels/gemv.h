@@ -224,10 +224,6 @@ __global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void ge
     for (int j = 0; j < NX; j++) { ta[j] = load_slice_nt<DT>(pa, cidx[j]); tb[j] = load_slice_nt<DT>(pb, cidx[j]); }
   };
 
-#ifndef TGX_XFIRST
-#define TGX_XFIRST 0
-#endif
-  constexpr bool XFIRST = TGX_XFIRST && R == 1 && !XACC;     // experiment (tools/probes/layer_lab.hip): the activation slices leave ahead of the weight tile
   float xr[R][NX][8];
   auto load_x = [&]() {
 #pragma unroll
@@ -242,7 +238,6 @@ __global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void ge
       }
     }
   };
-  if constexpr (XFIRST) { load_x(); __builtin_amdgcn_sched_barrier(0); }
   // 0. XACC: this thread's eight accumulators of the residual stream leave FIRST — loads return in order, so behind the weight tile their conversion,
   //    the LDS hand-over and its barrier would all sit between the tile's arrival and the first FMA (gate_up 12.8 -> 13.4 us); ahead of it they are done
   //    by the time the tile lands
@@ -294,8 +289,8 @@ __global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void ge
 #pragma unroll
       for (int t = 0; t < 4; t++) { xr[0][j][t] = v0[t]; xr[0][j][4 + t] = v1[t]; }
     }
-  } else if constexpr (!XFIRST) {
-    load_x();
+  } else {
+    load_x();          // (activation loads ahead of the weight tile measured no different: tools/probes/README.md round 4)
   }
   // sum of one value per batch row over the KS waves that share a unit, in wave order (every wave of the workgroup takes part)
   auto ks_sum = [&](float* v) {
