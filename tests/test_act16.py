@@ -86,6 +86,9 @@ def test_act16_prefill_and_teacher_forced_steps_vs_oracle(fam, dtype, hip, oracl
     ids = g["ids_bf16"]
     gpu.forward(g["prompt"]); ref.forward(g["prompt"])
     assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_TINY
+    if dtype == "bf16":       # against HF itself: inside the bounds the fp32-activation contract is held to (tests/test_hip_parity.py: 2e-2 / 8e-2), fp32 golden a little wider
+        assert rel_err(gpu.logits(rounded=False), g["logits_bf16"][:, 0]) < 8e-2
+        assert rel_err(gpu.logits(rounded=False), g["logits_fp32"][:, 0]) < 3e-2
     for i in range(1, ids.shape[1]):
         gpu.forward(ids[:, i - 1:i]); ref.forward(ids[:, i - 1:i])
         assert rel_err(gpu.logits(rounded=False), ref.logits(rounded=False)) < TOL_TINY, f"step {i}"
