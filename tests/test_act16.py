@@ -204,13 +204,14 @@ def test_act16_long_prompts_on_the_one_term_kernels_vs_oracle(name, plen, hip, o
 
 
 @pytest.mark.gpu
-def test_act16_flip_floor_and_full_depth_vs_oracle(hip, oracle_lib):
-    """Llama-3.2-1B at FULL depth and vocabulary, 320-token prompt + 4 steps: (a) the floor of the mode — the oracle against its own reordered schedule,
+@pytest.mark.parametrize("name", ["llama-3.2-1b", "llama-3.2-3b"])
+def test_act16_flip_floor_and_full_depth_vs_oracle(name, hip, oracle_lib):
+    """Llama-3.2-1B (16 layers) and Llama-3.2-3B (28 layers, head_dim 128) at FULL depth and vocabulary, 320-token prompt + 4 steps: (a) the floor of the mode — the oracle against its own reordered schedule,
     both rounding every Linear input; (b) the HIP path against the oracle, granted 2.5x that floor (and never more than 3e-2).  Printed for
     profiles/r04_act16.txt."""
     from oracle.oracle_ffi import OracleModel
     from tinygpt_amd.ffi import Model
-    d = copy.deepcopy(known_desc("llama-3.2-1b"))
+    d = copy.deepcopy(known_desc(name))
     d.max_ctx, d.max_batch = 384, 1
     oracle_lib.set_threads(32)
     try:
@@ -230,6 +231,6 @@ def test_act16_flip_floor_and_full_depth_vs_oracle(hip, oracle_lib):
                 m.forward(tok[None, :])
     finally:
         oracle_lib.set_threads(8)
-    print("act.round16, Llama-3.2-1B full depth: oracle vs reordered oracle", ["%.2e" % e for e in floor], " HIP vs oracle", ["%.2e" % e for e in err])
+    print(f"act.round16, {name} full depth: oracle vs reordered oracle", ["%.2e" % e for e in floor], " HIP vs oracle", ["%.2e" % e for e in err])
     assert max(floor) > 5e-4                       # the floor of this contract is well above the fp32-activation contract's (3-5e-4 end to end at this depth)
     assert max(err) < min(3e-2, 2.5 * max(floor)), (floor, err)
