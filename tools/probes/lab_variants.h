@@ -292,8 +292,24 @@ static void lab_mlp_fused(Lab& b) {
   CK(hipFree(acc)); CK(hipFree(x_a)); CK(hipFree(x_b));
 }
 
+static void v_oproj_sliced16(Lab& b, int l, long long* acc, const float* resid) {
+  const LayerBuf& w = b.lb[(size_t)l];
+  OprojSlicedArgs a{};
+  a.W = w.wo; a.ldw = b.qd; a.part = b.part; a.nsplit = b.nsplit; a.x = resid; a.acc = acc; a.H = b.H;
+  const dim3 grid(b.H / oproj_sliced_rows<16>(), b.qd / 128); hipLaunchKernelGGL((oproj_sliced_kernel<DT_BF16, 64, 16>), grid, dim3(256), 0, b.st, a);
+}
+static void lab_oproj_shapes(Lab& b) {
+  long long* acc; CK(hipMalloc(&acc, (size_t)b.H * 8)); CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
+  const float t32 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_oproj_sliced(b, l, acc, b.x); }, b.L);
+  const float t16 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_oproj_sliced16(b, l, acc, b.x); }, b.L);
+  const float p32 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_attn_only(b, l, nullptr); v_oproj_sliced(b, l, acc, b.x); } }, b.L);
+  const float p16 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_attn_only(b, l, nullptr); v_oproj_sliced16(b, l, acc, b.x); } }, b.L);
+  printf("o_proj sliced alone: 256-column slices (4 heads) %.2f us, 128-column slices (2 heads) %.2f; with the attention launch in front: %.2f / %.2f\n", t32, t16, p32, p16);
+  CK(hipFree(acc));
+}
 static void lab_variants_main(Lab& b) {
   if (getenv("LAB_MLP")) { lab_mlp_fused(b); return; }
+  if (getenv("LAB_OPROJ")) { lab_oproj_shapes(b); return; }
   if (b.pos_h < 1024 || getenv("LAB_SHORT_ONLY")) { lab_fused_short(b); if (getenv("LAB_SHORT_ONLY")) return; }
   if (b.g.hd == 64 && b.pos_h < 1024) {
     const float d4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn_direct<4>(b, l); }, b.L);
