@@ -150,3 +150,26 @@ def test_n_hidden_products_as_k_slabs_on_the_eight_wave_kernel(name, S, dtype):
     assert rel_err(outs[1][0], outs[0][0]) < 2e-5, rel_err(outs[1][0], outs[0][0])
     np.testing.assert_array_equal(outs[1][1], outs[0][1])
     np.testing.assert_array_equal(outs[1][0], outs[2][0])
+
+
+@pytest.mark.parametrize("name,S", [("llama-3.2-1b", 1200), ("llama-3.2-1b", 1500), ("mistral-7b-v0.3", 600)])
+def test_gate_up_on_128_tiles_where_the_256_tiling_is_ragged(name, S):
+    """Round 4 (option prefill.wide_8k_eff, 76): a prompt whose 256 x 256 gate_up tiles would fill their last round of workgroups to less than 76 % (1152-1536 rows at
+    intermediate 8192) takes the eight-wave 128 x 128 kernel instead — the kernel of the 129-384-row prompts on a larger grid.  Against the 256 x 256 tiling of the
+    same prompt (option 0): the same products, the same siluMul epilogue, another tile shape: ONE layer, logits within 2e-5, same first token; the balanced QKV launch
+    against K slabs (option prefill.qkv_nosplit) within 2e-4 (its results are rounded into this layer's cache)."""
+    d = copy.deepcopy(known_desc(name, "bf16"))
+    d.layers, d.vocab, d.max_ctx = 1, 4096, S + 16
+    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    prompt = synth.synth_prompt(d.vocab, S, 79)[None, :]
+    outs = []
+    for eff, nosplit in ((0, 1), (76, 1), (76, 1), (76, 0)):
+        m.set_option("prefill.wide_8k_eff", eff); m.set_option("prefill.qkv_nosplit", nosplit)
+        m.reset_cache(); m.forward(prompt)
+        outs.append((m.logits(rounded=False).copy(), m.sample(GREEDY).copy()))
+    assert rel_err(outs[1][0], outs[0][0]) < 2e-5, rel_err(outs[1][0], outs[0][0])        # tile shape of gate_up only: no cache row changes
+    np.testing.assert_array_equal(outs[1][1], outs[0][1])
+    np.testing.assert_array_equal(outs[1][0], outs[2][0])
+    # another schedule of the QKV product moves K / V entries across 16-bit rounding boundaries in THIS layer's cache: the two-layer bound of the form tests
+    assert rel_err(outs[3][0], outs[1][0]) < 2e-4, rel_err(outs[3][0], outs[1][0])
+    np.testing.assert_array_equal(outs[3][1], outs[1][1])
