@@ -415,6 +415,12 @@ int tgx_create(const tgx_model_desc* desc, int device_ordinal, tgx_ctx** out_ctx
   // qkv is the most latency-bound launch (few rows): 4 waves per row pair shorten every wave's load -> reduce chain; measured
   // ks 1 -> 4: Llama-3.2-1B 1395 -> 1411 tok/s, 3B 628 -> 637, Mistral-7B 341 -> 347; hidden 896 (Qwen2.5-0.5B) loses 2 %
   c->tune[TGX_KERNEL_QKV].ks = d.hidden >= 2048 ? 4 : 1;
+  // fp32 storage (round 4, tools/sweep.py --dtype fp32): a row pair is twice the bytes — two waves per pair for gate_up / c_fc and o_proj: GPT-2 124M 0.3205 -> 0.3133 ms per
+  // token (with qkv as well: 0.3104), Llama-3.2-1B 1.145 -> 1.124, Qwen2.5-0.5B 0.752 -> 0.739; 16-bit storage: no gain
+  if (c->dt == tgx::DT_F32) {
+    c->tune[TGX_KERNEL_GATEUP].ks = 2; c->tune[TGX_KERNEL_OPROJ].ks = 2;
+    if (c->gpt2) c->tune[TGX_KERNEL_QKV].ks = 2;
+  }
 
   const int H = d.hidden, I = d.inter, V = d.vocab, qd = d.heads * d.head_dim, kvd = d.kv_heads * d.head_dim;
   int rc;

@@ -14,11 +14,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="llama-3.2-1b")
 ap.add_argument("--prompt", type=int, default=256)
 ap.add_argument("--steps", type=int, default=96)
+ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--grid", default="", help="e.g. 'down.ks=1,2,4;gateup.bpc=4,8' (cartesian product)")
 ap.add_argument("--pre", default="", help="options set before finalize, e.g. 'attn.nsplit=16;lmhead.bpc=8'")
 args = ap.parse_args()
 
-d = known_desc(args.model)
+d = known_desc(args.model, args.dtype)
 m = Model(d)
 for kv in filter(None, args.pre.split(";")):
     k, v = kv.split("=")
