@@ -24,6 +24,8 @@ ORACLE_EXTRA = {
     "set_threads": (c_int, [c_int]),
     "set_reorder": (c_int, [c_void_p, c_int]),
     "set_act16": (c_int, [c_void_p, c_int]),
+    "set_one_row_dots": (c_int, [c_int]),
+    "set_torch_rounding": (c_int, [c_void_p, c_int]),
 }
 
 
@@ -63,6 +65,11 @@ class OracleModel(Model):
     def set_act16(self, on: bool = True):
         """the input of every Linear rounded to the storage dtype first: the counterpart of the library's option act.round16"""
         self._check(self.be.set_act16(self._ctx, 1 if on else 0))
+        return self
+
+    def set_torch_rounding(self, on: bool = True):
+        """every op output rounded to bf16 (a torch-bf16 module's contract); before finalize()"""
+        self._check(self.be.set_torch_rounding(self._ctx, 1 if on else 0))
         return self
 
     def rope_tables(self, n_pos: int):

@@ -168,20 +168,28 @@ static inline float src_elem(const void* host, int dt, int64_t i) {
   return half_to_f32(((const uint16_t*)host)[i]);
 }
 
-/* == model().to(dtype): store in compute dtype (bf16->fp32 exact, fp32->bf16 RNE) */
+/* == model().to(dtype): store in compute dtype (bf16->fp32 exact, fp32->bf16 RNE).
+ * The rows are written by the thread that will read them: the loop below is linear()'s own (blocks of 8 rows of the WHOLE matrix, schedule(static), the
+ * same trip count), so with a fixed team size and pinned threads (OMP_PROC_BIND) every page of a weight matrix is first touched - and therefore placed -
+ * on the NUMA node of the core that streams it in every later product.  (calloc of these sizes returns untouched mmap pages.)  A serial memcpy had put
+ * a whole model on the uploading thread's node: bench.py's cpu_baseline read 2.5 GB per token through one socket's quadrant. */
 static void mat_store_rows(tgxo_ctx* c, mat_t* m, int64_t row0, int64_t nrows, const void* host, int dt, int src_is_in_out) {
-  if (c->bf16 && dt == DT_BF16 && !src_is_in_out) {   /* same storage dtype: plain copy */
-    memcpy(m->wb + row0 * m->cols, host, (size_t)(nrows * m->cols) * 2);
-    m->filled_rows += nrows;
-    return;
-  }
+  const int64_t N = m->rows, K = m->cols;
+  const int plain = c->bf16 && dt == DT_BF16 && !src_is_in_out;   /* same storage dtype: plain copy */
 #pragma omp parallel for schedule(static)
-  for (int64_t r = 0; r < nrows; r++)
-    for (int64_t k = 0; k < m->cols; k++) {
-      float v = src_is_in_out ? src_elem(host, dt, k * nrows + r) : src_elem(host, dt, r * m->cols + k);
-      if (c->bf16) m->wb[(row0 + r) * m->cols + k] = f32_to_bf16(v);
-      else m->wf[(row0 + r) * m->cols + k] = c->f16 ? rhf(v) : v;   /* fp16 mode: fp32 container, half-rounded values */
+  for (int64_t nb = 0; nb < N; nb += 8) {
+    int64_t lo = nb > row0 ? nb : row0, hi = (nb + 8 < N ? nb + 8 : N);
+    if (hi > row0 + nrows) hi = row0 + nrows;
+    for (int64_t rr = lo; rr < hi; rr++) {
+      const int64_t r = rr - row0;
+      if (plain) { memcpy(m->wb + rr * K, (const uint16_t*)host + r * K, (size_t)K * 2); continue; }
+      for (int64_t k = 0; k < K; k++) {
+        float v = src_is_in_out ? src_elem(host, dt, k * nrows + r) : src_elem(host, dt, r * K + k);
+        if (c->bf16) m->wb[rr * K + k] = f32_to_bf16(v);
+        else m->wf[rr * K + k] = c->f16 ? rhf(v) : v;   /* fp16 mode: fp32 container, half-rounded values */
+      }
     }
+  }
   m->filled_rows += nrows;
 }
 static void vec_store(tgxo_ctx* c, float* dst, int64_t n, const void* host, int dt) {
@@ -426,10 +434,38 @@ static inline float dot_row(const tgxo_ctx* c, const mat_t* m, int64_t row, cons
   return acc;
 }
 
+/* Four weight rows against one activation row in ONE pass over k: four independent accumulators, each summing exactly the products dot_row() sums for
+ * its row in exactly dot_row()'s order (the compiler vectorises every reduction of the loop the same way it vectorises the single one), so the
+ * results are BIT-IDENTICAL to four dot_row() calls (tests/test_oracle_golden.py::test_four_row_pass_is_bit_identical holds it) - only the activation
+ * loads are shared and four add chains overlap. */
+#define DOT4_BODY(W_T, LOADW, KLOOP)                                                         \
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;                                              \
+  const W_T *w0 = w, *w1 = w + K, *w2 = w + 2 * K, *w3 = w + 3 * K;                          \
+  _Pragma("omp simd reduction(+ : a0, a1, a2, a3)")                                          \
+  KLOOP {                                                                                    \
+    const float xv = x[k];                                                                   \
+    a0 += LOADW(w0[k]) * xv; a1 += LOADW(w1[k]) * xv; a2 += LOADW(w2[k]) * xv; a3 += LOADW(w3[k]) * xv; \
+  }                                                                                          \
+  out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+#define FWD_K for (int64_t k = 0; k < K; k++)
+#define REV_K for (int64_t k = K - 1; k >= 0; k--)
+#define LOAD_F32(v) (v)
+static inline void dot4_bf16_fwd(const uint16_t* w, const float* x, int64_t K, float* out) { DOT4_BODY(uint16_t, bf16_to_f32, FWD_K) }
+static inline void dot4_bf16_rev(const uint16_t* w, const float* x, int64_t K, float* out) { DOT4_BODY(uint16_t, bf16_to_f32, REV_K) }
+static inline void dot4_f32_fwd(const float* w, const float* x, int64_t K, float* out) { DOT4_BODY(float, LOAD_F32, FWD_K) }
+static inline void dot4_f32_rev(const float* w, const float* x, int64_t K, float* out) { DOT4_BODY(float, LOAD_F32, REV_K) }
+static inline void dot_rows4(const tgxo_ctx* c, const mat_t* m, int64_t row, const float* x, float* out) {
+  const int64_t K = m->cols;
+  if (c->bf16) { if (c->reorder) dot4_bf16_rev(m->wb + row * K, x, K, out); else dot4_bf16_fwd(m->wb + row * K, x, K, out); }
+  else { if (c->reorder) dot4_f32_rev(m->wf + row * K, x, K, out); else dot4_f32_fwd(m->wf + row * K, x, K, out); }
+}
+
 /* y[s][n] = R(x[s] . W[n] + b[n]) for S rows of x; raw != 0 keeps the fp32 accumulator.
  * Loop order only: blocks of 8 weight rows are walked over all S activation rows, so that a prompt's activations stream from the
  * cache once per 8 rows instead of once per row (a 2048-token prompt at full model size: minutes -> tens of seconds).  Every dot
- * product is the same dot_row() in the same element order, i.e. the results are bit-identical to the row-by-row order. */
+ * product is the same sum in the same element order (dot_row(), or four rows of it at once: dot_rows4()), i.e. the results are
+ * bit-identical to the row-by-row order. */
+static int g_one_row_dots;     /* tgxo_set_one_row_dots: test hook, forces the row-by-row form */
 static void linear(const tgxo_ctx* c, const mat_t* m, const float* x, int S, float* y, int raw) {
   int64_t N = m->rows, K = m->cols;
   float* xr = NULL;
@@ -438,14 +474,26 @@ static void linear(const tgxo_ctx* c, const mat_t* m, const float* x, int S, flo
     for (int64_t i = 0; i < (int64_t)S * K; i++) xr[i] = RKV(c, x[i]);
     x = xr;
   }
+  const int four = !g_one_row_dots;
 #pragma omp parallel for schedule(static)
   for (int64_t nb = 0; nb < N; nb += 8) {
     int64_t ne = nb + 8 < N ? nb + 8 : N;
-    for (int s = 0; s < S; s++)
-      for (int64_t n = nb; n < ne; n++) {
-        float a = dot_row(c, m, n, x + (int64_t)s * K) + (m->bias ? m->bias[n] : 0.f);
+    for (int s = 0; s < S; s++) {
+      const float* xs = x + (int64_t)s * K;
+      int64_t n = nb;
+      for (; four && n + 4 <= ne; n += 4) {
+        float a4[4];
+        dot_rows4(c, m, n, xs, a4);
+        for (int j = 0; j < 4; j++) {
+          float a = a4[j] + (m->bias ? m->bias[n + j] : 0.f);
+          y[(int64_t)s * N + n + j] = raw ? a : R(c, a);
+        }
+      }
+      for (; n < ne; n++) {
+        float a = dot_row(c, m, n, xs) + (m->bias ? m->bias[n] : 0.f);
         y[(int64_t)s * N + n] = raw ? a : R(c, a);
       }
+    }
   }
   free(xr);
 }
@@ -549,12 +597,14 @@ static int forward_row(tgxo_ctx* c, int b, const int64_t* ids, int S) {
     const layer_t* y = &c->L[l];
     float* Kc = c->kcache + (((size_t)b * d->layers + l) * d->max_ctx) * kvd;
     float* Vc = c->vcache + (((size_t)b * d->layers + l) * d->max_ctx) * kvd;
+#pragma omp parallel for schedule(static) if (S > 8)   /* rows are independent; every per-row sum keeps its serial order */
     for (int s = 0; s < S; s++) {
       if (gpt2) layernorm(c, x + (size_t)s * H, y->in_norm.w, y->in_norm.b, H, xn + (size_t)s * H);
       else rmsnorm(c, x + (size_t)s * H, y->in_norm.w, H, xn + (size_t)s * H);
     }
     linear(c, &y->qkv, xn, S, qkv, 0);
     /* split -> heads -> RoPE(q), RoPE(k) at pastLength -> cache append (Attention.h:94-106) */
+#pragma omp parallel for schedule(static) if (S > 8)   /* rows are independent; every per-row sum keeps its serial order */
     for (int s = 0; s < S; s++) {
       float* row = qkv + (size_t)s * (qd + 2 * kvd);
       if (d->qk_norm) {   /* AttentionWithQKNorm::projectQKV (Attention.h:156-163): RMSNorm over head_dim, per head, before RoPE */
@@ -585,16 +635,20 @@ static int forward_row(tgxo_ctx* c, int b, const int64_t* ids, int S) {
       free(sc);
     }
     linear(c, &y->o, att, S, proj, 0);
+#pragma omp parallel for schedule(static) if (S > 8)
     for (size_t i = 0; i < SH; i++) x[i] = R(c, x[i] + proj[i]);           /* x = x + attn(norm(x)) (DecoderLayer.h:40) */
+#pragma omp parallel for schedule(static) if (S > 8)   /* rows are independent; every per-row sum keeps its serial order */
     for (int s = 0; s < S; s++) {
       if (gpt2) layernorm(c, x + (size_t)s * H, y->post_norm.w, y->post_norm.b, H, xn + (size_t)s * H);
       else rmsnorm(c, x + (size_t)s * H, y->post_norm.w, H, xn + (size_t)s * H);
     }
     linear(c, &y->gate_up, xn, S, gu, 0);
     if (gpt2) {
+#pragma omp parallel for schedule(static) if (S > 8)
       for (size_t i = 0; i < (size_t)S * I; i++) hmid[i] = R(c, gelu_new(gu[i]));
     } else {
       /* siluMul: silu(x[..., :I]) * x[..., I:] (Activation.h:16; gate rows first, GatedMLP.h:46-47) */
+#pragma omp parallel for schedule(static) if (S > 8)   /* rows are independent; every per-row sum keeps its serial order */
       for (int s = 0; s < S; s++)
         for (int i = 0; i < I; i++) {
           float g = gu[(size_t)s * 2 * I + i], u = gu[(size_t)s * 2 * I + I + i];
@@ -602,6 +656,7 @@ static int forward_row(tgxo_ctx* c, int b, const int64_t* ids, int S) {
         }
     }
     linear(c, &y->down, hmid, S, proj, 0);
+#pragma omp parallel for schedule(static) if (S > 8)
     for (size_t i = 0; i < SH; i++) x[i] = R(c, x[i] + proj[i]);           /* x = x + mlp(norm(x)) (DecoderLayer.h:41) */
   }
   /* final norm + lm_head on the last position only (== forward over all S then narrow, GPTEngine.cpp:96-97) */
@@ -759,9 +814,19 @@ TGXO_EXPORT int tgxo_set_logits(tgxo_ctx* c, const float* logits, int batch) {
  * last element to the first.  Same products, another fp32 summation order: the distance between the two schedules is the floor any OTHER correct
  * implementation (the HIP kernels) can be held to. */
 TGXO_EXPORT int tgxo_set_reorder(tgxo_ctx* c, int on) { if (!c) return 1; c->reorder = on != 0; return 0; }
+/* 1 = per-op rounding of every activation to bf16 (what the env switch TGXO_TORCH_ROUNDING=1 selects at create): the contract of a module constructed in
+ * torch_dtype bf16 (ModelLlama.h:62, ModelLoader.cpp:84), restated op by op the way torch-bf16 / HF-bf16 rounds.  Call BEFORE tgxo_finalize (the RoPE tables
+ * are rounded when they are built).  bf16 storage only.  Held against HF-bf16's logits and ids in tests/test_oracle_golden.py. */
+TGXO_EXPORT int tgxo_set_torch_rounding(tgxo_ctx* c, int on) {
+  if (!c) return 1;
+  if (c->finalized) return fail(c, 4, "%s", "set_torch_rounding after finalize");
+  c->round_act = c->bf16 && on != 0;
+  return 0;
+}
 /* 1 = the Linear-input rounding of the library's option act.round16 (see linear()) */
 TGXO_EXPORT int tgxo_set_act16(tgxo_ctx* c, int on) { if (!c) return 1; c->act16 = on != 0; return 0; }
 
+TGXO_EXPORT int tgxo_set_one_row_dots(int on) { g_one_row_dots = on != 0; return 0; }   /* test hook: linear() one row at a time (the form the four-row pass must equal bit for bit) */
 TGXO_EXPORT int tgxo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
 
 TGXO_EXPORT int tgxo_reset_cache(tgxo_ctx* c) { if (!c) return 1; c->past = 0; return 0; }

@@ -46,6 +46,38 @@ def test_directory_through_the_oracle_equals_the_synthetic_model(tmp_path, oracl
     assert np.array_equal(a.logits(rounded=False), b.logits(rounded=False))
 
 
+def test_unloadable_dtype_is_skipped_unless_the_model_consumes_it(tmp_path, oracle_lib):
+    """A directory that also carries I64 / BOOL buffers (position_ids, attn.bias ...) loads: the reference drops a key no module owns before it looks
+    at the dtype (SafeTensors.cpp:176-182 vs :196).  A parameter the model needs in such a dtype is an error that names the tensor."""
+    import torch
+    from safetensors.torch import load_file, save_file
+    from oracle.oracle_ffi import OracleModel
+    from tinygpt_amd.checkpoint import UnsupportedTensor
+    cfg, g = load_golden("llama_tiny")
+    write_model_dir(str(tmp_path), cfg, int(g["seed"]), float(g["std"]))
+    d = load_desc(str(tmp_path), "bf16")
+    f = str(tmp_path / "model.safetensors")
+    t = load_file(f)
+    t["model.layers.0.self_attn.rotary_emb.position_ids"] = torch.arange(8, dtype=torch.int64)
+    t["model.layers.0.self_attn.masked_bias"] = torch.zeros(4, dtype=torch.bool)
+    save_file(t, f)
+    got = dict(iter_checkpoint(str(tmp_path)))
+    assert isinstance(got["model.layers.0.self_attn.masked_bias"], UnsupportedTensor)
+    a = OracleModel(d)
+    skipped = [n for n, arr in got.items() if not a.upload(n, arr, strict=False)]
+    assert sorted(skipped) == ["model.layers.0.self_attn.masked_bias", "model.layers.0.self_attn.rotary_emb.position_ids"]
+    a.finalize()
+    b = OracleModel(d).load_synthetic(int(g["seed"]), float(g["std"])).finalize()
+    a.forward(g["prompt"]); b.forward(g["prompt"])
+    assert np.array_equal(a.logits(rounded=False), b.logits(rounded=False))
+    t["model.norm.weight"] = torch.ones(d.hidden, dtype=torch.int64)          # a consumed parameter in a dtype the path does not load
+    save_file(t, f)
+    c = OracleModel(d)
+    with pytest.raises(ValueError, match="model.norm.weight has dtype I64"):
+        for n, arr in iter_checkpoint(str(tmp_path)):
+            c.upload(n, arr, strict=False)
+
+
 def test_missing_checkpoint_is_an_error(tmp_path):
     with pytest.raises(FileNotFoundError):
         list(iter_checkpoint(str(tmp_path)))

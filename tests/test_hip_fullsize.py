@@ -50,56 +50,44 @@ def test_llama_3_2_1b_at_the_bench_operating_point_vs_oracle(oracle_lib):
     times).  fp32 logits within 2e-3 of the oracle's at every step (the bf16 KV-rounding floor, see the 48-token test above), greedy
     id equal unless the oracle's own top-2 gap is inside that tolerance, KV rows of layers 0 and 15 within one bf16 ulp.
     Reference: Attention.h:71-112, GPTModel.h:51-58."""
-    import os
-    from oracle.oracle_ffi import OracleModel
+    from fullsize_util import bench_range_trajectory
     S, STEPS = 2048, 8
-    d = known_desc("llama-3.2-1b")
+    traj = bench_range_trajectory(oracle_lib)          # the oracle's 5 TFLOP prefill + forced steps, shared with tests/test_hip_parity_bar.py
+    d = copy.deepcopy(traj.desc)
     d.max_ctx = S + 64
-    tensors = list(synth.synth_checkpoint(d, 1234, 0.02))
-    gpu = Model(d, product_backend())
-    ref = OracleModel(d)
-    for name, bits in tensors:
-        gpu.upload(name, bits); ref.upload(name, bits)
-    del tensors
-    gpu.finalize(); ref.finalize()
-    prompt = synth.synth_prompt(d.vocab, S, 1234)[None, :]        # bench.py's rank-0 prompt
-    oracle_lib.set_threads(min(32, os.cpu_count() or 8))           # ~5 TFLOP of fp32 loops: give the oracle more than the suite's 8 threads
-    try:
-        gpu.forward(prompt); ref.forward(prompt)
-        errs = []
+    gpu = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    gpu.forward(traj.prompt)                           # bench.py's rank-0 prompt
+    errs = []
 
-        def check(step):
-            lg, lr = gpu.logits(rounded=False), ref.logits(rounded=False)
-            errs.append(rel_err(lg, lr))
-            assert errs[-1] < 2e-3, (step, errs)
-            top2 = np.sort(lr[0])[-2:]
-            tok_ref = ref.sample(GREEDY)
-            tok_gpu = gpu.sample(GREEDY)          # also leaves the GPU's current token / embedding row set (overwritten below when forced)
-            if (top2[1] - top2[0]) > 4e-3 * np.abs(lr).max():
-                np.testing.assert_array_equal(tok_gpu, tok_ref)
-            return tok_ref
+    def check(step):
+        lg, lr = gpu.logits(rounded=False), traj.logits[step]
+        errs.append(rel_err(lg, lr))
+        assert errs[-1] < 2e-3, (step, errs)
+        top2 = np.sort(lr[0])[-2:]
+        tok_ref = traj.toks[step]
+        tok_gpu = gpu.sample(GREEDY)          # also leaves the GPU's current token / embedding row set (overwritten below when forced)
+        if (top2[1] - top2[0]) > 4e-3 * np.abs(lr).max():
+            np.testing.assert_array_equal(tok_gpu, tok_ref)
+        return tok_ref
 
-        tok = check(0)
-        for step in range(1, STEPS + 1):
-            if step <= 4:                          # single-position pass through tgx_forward (eager launches, split attention form)
-                gpu.forward(tok[None, :])
-            else:                                  # the captured decode graph, teacher-forced: make the oracle's token the current one, replay one step
-                onehot = np.full((1, d.vocab), -1.0, np.float32); onehot[0, int(tok[0])] = 1.0
-                gpu.set_logits(onehot); assert int(gpu.sample(GREEDY)[0]) == int(tok[0])
-                gpu.decode(1, GREEDY)
-            ref.forward(tok[None, :])
-            assert gpu.past_length == ref.past_length == S + step
-            tok = check(step)
-        for layer in (0, d.layers - 1):            # cache contents: prompt rows from the MFMA prefill, 8 rows from the decode-step epilogue
-            for g_, r_ in zip(gpu.read_kv(0, layer), ref.read_kv(0, layer)):
-                assert g_.shape == r_.shape and g_.shape[0] == S + STEPS
-                ulp = 2.0 ** -7                     # one bf16 ulp, relative
-                floor = 4e-6 if layer == 0 else 0.1 * ulp
-                bad = np.abs(g_ - r_) > ulp * np.abs(r_) + floor * np.abs(r_).max()
-                assert not bad.any(), (layer, int(bad.sum()), float(np.abs(g_ - r_).max()))
-        print("operating-point rel errs:", ["%.2e" % e for e in errs])
-    finally:
-        oracle_lib.set_threads(8)
+    tok = check(0)
+    for step in range(1, STEPS + 1):
+        if step <= 4:                          # single-position pass through tgx_forward (eager launches, split attention form)
+            gpu.forward(tok[None, :])
+        else:                                  # the captured decode graph, teacher-forced: make the oracle's token the current one, replay one step
+            onehot = np.full((1, d.vocab), -1.0, np.float32); onehot[0, int(tok[0])] = 1.0
+            gpu.set_logits(onehot); assert int(gpu.sample(GREEDY)[0]) == int(tok[0])
+            gpu.decode(1, GREEDY)
+        assert gpu.past_length == S + step
+        tok = check(step)
+    for layer in (0, d.layers - 1):            # cache contents: prompt rows from the MFMA prefill, 8 rows from the decode-step epilogue
+        for g_, r_ in zip(gpu.read_kv(0, layer), traj.kv_prefix(layer, S + STEPS)):
+            assert g_.shape == r_.shape and g_.shape[0] == S + STEPS
+            ulp = 2.0 ** -7                     # one bf16 ulp, relative
+            floor = 4e-6 if layer == 0 else 0.1 * ulp
+            bad = np.abs(g_ - r_) > ulp * np.abs(r_) + floor * np.abs(r_).max()
+            assert not bad.any(), (layer, int(bad.sum()), float(np.abs(g_ - r_).max()))
+    print("operating-point rel errs:", ["%.2e" % e for e in errs])
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

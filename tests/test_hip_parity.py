@@ -197,10 +197,16 @@ def test_batches_beyond_four_rows_run_on_the_matrix_cores(family, dtype, rows, h
     fp16) — 37 / 40 / 64 rows = one four-block pass, 70 / 100 / 128 rows = one eight-block pass (kernels/skinny_dma.h), 135 rows = a 128-row pass + a 7-row pass.
     Every row must equal the oracle's row: greedy ids exactly over 6 steps, logits within 1e-3, cache rows within one ulp of the storage dtype."""
     gpu, ref, g = make_pair(family, hip, oracle_lib, max_batch=rows, dtype=dtype)
+    # The floor of this comparison is MEASURED here, not granted by name: a second oracle context sums every reduction last-to-first
+    # (tgxo_set_reorder, tests/test_oracle_reorder.py) and runs the same batch and the same forced tokens.  Whatever distance the two schedules of
+    # the SAME code land at (K / V entries that straddle a storage-dtype rounding boundary flip by one ulp and feed the next layer) is what a correct
+    # third schedule cannot be expected to beat; the HIP path is granted twice that, never less than the static bound.
+    from oracle.oracle_ffi import OracleModel
+    ref2 = OracleModel(ref.desc).load_synthetic(int(g["seed"]), float(g["std"])).set_reorder(True).finalize()
     p = g["prompt"]
     V = gpu.desc.vocab
     ids = np.concatenate([(p + 3 * b) % V for b in range(rows)])
-    gpu.forward(ids); ref.forward(ids)
+    gpu.forward(ids); ref.forward(ids); ref2.forward(ids)
     tok = ref.sample(GREEDY)
     np.testing.assert_array_equal(gpu.sample(GREEDY), tok)
     # teacher-forced through the captured batched step: the oracle's token of every row becomes the GPU's current token (one-hot logits ->
@@ -210,11 +216,13 @@ def test_batches_beyond_four_rows_run_on_the_matrix_cores(family, dtype, rows, h
         onehot = np.full((rows, V), -1.0, np.float32); onehot[np.arange(rows), tok] = 1.0
         gpu.set_logits(onehot); np.testing.assert_array_equal(gpu.sample(GREEDY), tok)
         tg = gpu.decode(1, GREEDY)[0]
+        ref2.set_next_token(tok); ref2.decode(1, GREEDY)
         tr = ref.decode(1, GREEDY)[0]
         lg, lr = gpu.logits(rounded=False), ref.logits(rounded=False)
-        # the maximum runs over rows x vocabulary logits: with 64+ rows the bf16 cache-flip floor alone reaches 3.4-7.1e-4 on this fixture (the oracle against
-        # its own reordered schedule, 100 rows: tests/test_oracle_reorder.py's method), and the split-term arithmetic of the matrix-core path sits a few 1e-4 on top
-        assert rel_err(lg, lr) < (TOL_ORACLE if rows < 64 else 1.5e-3), (step, rel_err(lg, lr))
+        # the maximum runs over rows x vocabulary logits, so the flip floor grows with the row count (oracle vs reordered oracle: 1.6e-4 at 5 rows,
+        # 3-9e-4 at 128 on these fixtures); the split-term arithmetic of the matrix-core path sits a few 1e-4 on top
+        floor_l = rel_err(ref2.logits(rounded=False), lr)
+        assert rel_err(lg, lr) < max(TOL_ORACLE, 2 * floor_l), (step, rel_err(lg, lr), floor_l)
         top2 = np.sort(lr, axis=1)[:, -2:]
         clear = (top2[:, 1] - top2[:, 0]) > 2e-3 * np.abs(lr).max()
         assert clear.sum() >= rows // 2
@@ -225,17 +233,24 @@ def test_batches_beyond_four_rows_run_on_the_matrix_cores(family, dtype, rows, h
     # schedules' absolute difference instead); layer 1's inputs already differ by layer 0's rounding flips, which fp16's 11-bit
     # significand resolves: a few ulps there
     ulp, floor = (2.0 ** -7, 1e-3) if dtype == "bf16" else (2.0 ** -10, 2e-2)
-    for row in sorted({0, 4, rows // 2, rows - 1}):
+
+    def excess(a_, r_, tol):
+        """how far |a - r| exceeds `tol` ulp-units of the larger entry, in units of tol * (largest entry): the `fl` below that would just accept it"""
+        return float(((np.abs(a_ - r_) - tol * np.maximum(np.abs(a_), np.abs(r_))) / (tol * np.abs(r_).max())).max())
+
+    # one ulp of the LARGER of the two (a flip across a power of two is one ulp of the upper binade).  Layer 1's inputs differ by layer 0's flips, an
+    # ABSOLUTE difference of ~1e-4 of the largest entry, so entries near zero need a floor there.  Its size is the measured one: the worst excess of
+    # the reordered oracle over ALL rows of the batch (x 2), not a per-row literal.
+    tols = {layer: (1 if layer == 0 or dtype == "bf16" else 4) * ulp for layer in (0, 1)}
+    measured = {layer: max(excess(a_, r_, tols[layer]) for row in range(rows) for a_, r_ in zip(ref2.read_kv(row, layer), ref.read_kv(row, layer)))
+                for layer in (0, 1)}
+    for row in sorted({0, 4, rows // 2, rows - 1} | ({35, 39} if rows > 39 else set())):
         for layer in (0, 1):
             for g_, r_ in zip(gpu.read_kv(row, layer), ref.read_kv(row, layer)):
-                tol = (1 if layer == 0 or dtype == "bf16" else 4) * ulp
-                # one ulp of the LARGER of the two (a flip across a power of two is one ulp of the upper binade).  Layer 1's inputs differ by
-                # layer 0's flips, an ABSOLUTE difference of ~1e-4 of the largest entry: entries near zero get the wider floor there
-                # (rows 35 / 39 of the 40- and 70-row qwen2_tiny batches: PREFILL entries of layer 1 up to 5.6e-4 of the largest entry away, the same on
-                #  every step form including round 2's — listed in round 3 with a since-deleted debug script: floor 5e-2 ulp-units there)
-                fl = floor if layer == 0 else max(floor, 5e-2 if (family == "qwen2_tiny" and row in (35, 39)) else 2e-2)
+                tol = tols[layer]
+                fl = max(floor if layer == 0 else 2e-2, 2 * measured[layer])
                 bad = np.abs(g_ - r_) > tol * (np.maximum(np.abs(g_), np.abs(r_)) + fl * np.abs(r_).max())
-                assert not bad.any(), (row, layer, int(bad.sum()), float(np.abs(g_ - r_).max()))
+                assert not bad.any(), (row, layer, int(bad.sum()), float(np.abs(g_ - r_).max()), excess(g_, r_, tol), measured)
     # a free-running multi-step graph replay (8-step graphs + single steps) stays consistent with single-step replays of the same path
     gpu.reset_cache(); gpu.forward(ids); t0 = gpu.sample(GREEDY).copy(); a = gpu.decode(11, GREEDY).copy()
     gpu.reset_cache(); gpu.forward(ids); gpu.sample(GREEDY); b = np.concatenate([gpu.decode(1, GREEDY) for _ in range(11)])

@@ -10,23 +10,22 @@ Two comparisons per decode step, both teacher-forced with the ORACLE's token:
                   28 / 32-layer models, where the step's own appended row still rounds on the GPU) — the step kernels themselves
                   (RMSNorm, QKV + RoPE + append, split attention + combine, o_proj, gate_up + siluMul, down, lm_head) against the CPU path.
 Reference: Attention.h:71-112, CacheManager.h:24-51, GatedMLP.h:37-41, GPTModel.h:51-58."""
-import copy
-import os
 
 import numpy as np
 import pytest
 
 from conftest import rel_err
-from tinygpt_amd import known_desc, synth
+from fullsize_util import BENCH_EVERY, BENCH_LAST, BENCH_S, bench_range_trajectory, oracle_trajectory
+from tinygpt_amd import synth
 from tinygpt_amd.ffi import GREEDY, Model, product_backend
 
 pytestmark = pytest.mark.gpu
 
 
-def inject_cache(gpu, ref, layers):
-    """the oracle's cache rows [0, pastLength) of every layer -> the GPU cache (bf16 values: the conversion is exact)"""
-    for layer in range(layers):
-        k, v = ref.read_kv(0, layer)
+def inject_cache(gpu, traj, n_rows):
+    """the oracle's cache rows [0, n_rows) of every layer -> the GPU cache (bf16 values: the conversion is exact)"""
+    for layer in range(traj.desc.layers):
+        k, v = traj.kv_prefix(layer, n_rows)
         gpu.write_kv(0, layer, k, v)
 
 
@@ -38,63 +37,53 @@ def force_graph_step(m, tok, vocab):
     m.decode(1, GREEDY)
 
 
-def load_pair(d, n_gpu=2):
-    from oracle.oracle_ffi import OracleModel
-    ref = OracleModel(d)
+def load_gpus(d, n_gpu=2):
     gpus = [Model(d, product_backend()) for _ in range(n_gpu)]
     for name, bits in synth.synth_checkpoint(d, 1234, 0.02):
-        ref.upload(name, bits)
         for g in gpus:
             g.upload(name, bits)
-    ref.finalize()
     for g in gpus:
         g.finalize()
-    return ref, gpus
+    return gpus
 
 
 def test_llama_3_2_1b_bench_range_end_to_end_and_with_the_cpu_paths_cache(oracle_lib):
     """bench.py's workload: 2048-token prompt (MFMA prefill), then the bench's whole decode range — context 2049 .. 2320 — teacher-forced
     through the captured decode graph (what the bench times).  Checked at the first 8 steps and then every 32nd: end to end <= 1e-3 on one
     context, <= 1e-4 on a second one whose cache holds the CPU path's rows; greedy id equal wherever the oracle's top-2 gap exceeds the bound."""
-    S, LAST, EVERY = 2048, 272, 32
-    d = known_desc("llama-3.2-1b")
-    d.max_ctx = S + LAST + 8
-    oracle_lib.set_threads(min(32, os.cpu_count() or 8))
-    try:
-        ref, (end2end, injected) = load_pair(d)
-        prompt = synth.synth_prompt(d.vocab, S, 1234)[None, :]        # bench.py's rank-0 prompt
-        for m in (ref, end2end, injected):
-            m.forward(prompt)
-        e2e, inj = [], []
-        for step in range(LAST + 1):
-            lr = ref.logits(rounded=False)
-            checked = step < 8 or step % EVERY == 0
-            if checked:
-                le, li = end2end.logits(rounded=False), injected.logits(rounded=False)
-                e2e.append(rel_err(le, lr)); inj.append(rel_err(li, lr))
-                assert e2e[-1] < 1e-3, (step, e2e)                     # north_star's bar, end to end (measured 3.4e-4 .. 5.4e-4 over the range)
-                if step:                                                # step 0 = the prefill's logits: no step kernel has run on the injected cache yet
-                    assert inj[-1] < 1e-4, (step, inj)
-                top2 = np.sort(lr[0])[-2:]
-                gap = (top2[1] - top2[0]) / np.abs(lr).max()
-                if gap > 2e-3:
-                    assert int(np.argmax(le[0])) == int(np.argmax(lr[0]))
-                if gap > 2e-4 and step:
-                    assert int(np.argmax(li[0])) == int(np.argmax(lr[0]))
-            tok = ref.sample(GREEDY)
-            if step == LAST:
-                break
-            next_checked = (step + 1) < 8 or (step + 1) % EVERY == 0
-            if next_checked:
-                inject_cache(injected, ref, d.layers)                   # rows [0, pastLength): the step's K / V inputs are the CPU path's
-            ref.forward(tok[None, :])
-            force_graph_step(end2end, tok, d.vocab)
-            force_graph_step(injected, tok, d.vocab)
-            assert end2end.past_length == injected.past_length == ref.past_length == S + step + 1
-        print("bench range, end to end:", ["%.1e" % e for e in e2e])
-        print("bench range, injected  :", ["%.1e" % e for e in inj])
-    finally:
-        oracle_lib.set_threads(8)
+    S, LAST, EVERY = BENCH_S, BENCH_LAST, BENCH_EVERY
+    traj = bench_range_trajectory(oracle_lib)
+    d = traj.desc
+    end2end, injected = load_gpus(d)
+    for m in (end2end, injected):
+        m.forward(traj.prompt)                                         # bench.py's rank-0 prompt
+    e2e, inj = [], []
+    for step in range(LAST + 1):
+        checked = step < 8 or step % EVERY == 0
+        if checked:
+            lr = traj.logits[step]
+            le, li = end2end.logits(rounded=False), injected.logits(rounded=False)
+            e2e.append(rel_err(le, lr)); inj.append(rel_err(li, lr))
+            assert e2e[-1] < 1e-3, (step, e2e)                     # north_star's bar, end to end (measured 3.4e-4 .. 5.4e-4 over the range)
+            if step:                                                # step 0 = the prefill's logits: no step kernel has run on the injected cache yet
+                assert inj[-1] < 1e-4, (step, inj)
+            top2 = np.sort(lr[0])[-2:]
+            gap = (top2[1] - top2[0]) / np.abs(lr).max()
+            if gap > 2e-3:
+                assert int(np.argmax(le[0])) == int(np.argmax(lr[0]))
+            if gap > 2e-4 and step:
+                assert int(np.argmax(li[0])) == int(np.argmax(lr[0]))
+        tok = traj.toks[step]
+        if step == LAST:
+            break
+        next_checked = (step + 1) < 8 or (step + 1) % EVERY == 0
+        if next_checked:
+            inject_cache(injected, traj, S + step)                  # rows [0, pastLength): the step's K / V inputs are the CPU path's
+        force_graph_step(end2end, tok, d.vocab)
+        force_graph_step(injected, tok, d.vocab)
+        assert end2end.past_length == injected.past_length == S + step + 1
+    print("bench range, end to end:", ["%.1e" % e for e in e2e])
+    print("bench range, injected  :", ["%.1e" % e for e in inj])
 
 
 @pytest.mark.parametrize("name", ["llama-3.2-3b", "mistral-7b-v0.3"])
@@ -104,52 +93,46 @@ def test_full_depth_vs_oracle(name, oracle_lib):
     through the decode graph; end to end <= 3e-3 (<= 4e-3 over Mistral's 32 layers: its schedule-vs-schedule flip floor alone is 2.1e-3,
     test_other_baseline_geometries_decode_properties), with the CPU path's cache rows <= 5e-4 (the step's own row still rounds on the GPU).
     ModelLlama.h:35-53, ModelMistral.h:23-40."""
-    d = copy.deepcopy(known_desc(name))
-    d.max_ctx, d.max_batch = 384, 1
+    traj = oracle_trajectory(oracle_lib, name, 320, 3, 6)       # 320 tokens: long enough that the step's own appended row (which may round differently) weighs ~1/320
+    d = traj.desc
     tol_e2e = 4e-3 if d.layers >= 32 else 3e-3      # the bf16 KV-flip floor grows with depth: measured 1.8-2.1e-3 over 28 layers
-    oracle_lib.set_threads(min(32, os.cpu_count() or 8))
-    try:
-        ref, (end2end, injected) = load_pair(d)
-        prompt = synth.synth_prompt(d.vocab, 320, 3)[None, :]      # long enough that the step's own appended row (which may round differently) weighs ~1/320
-        for m in (ref, end2end, injected):
-            m.forward(prompt)
-        e2e, inj = [], []
-        for step in range(7):
-            lr, le, li = ref.logits(rounded=False), end2end.logits(rounded=False), injected.logits(rounded=False)
-            e2e.append(rel_err(le, lr)); inj.append(rel_err(li, lr))
-            assert e2e[-1] < tol_e2e, (step, e2e)
-            if step:
-                # the step's OWN appended row cannot be injected (it is computed inside the step): where its fp32 values straddle a bf16 boundary
-                # the token attends to a key / value one ulp off, often with a large weight (itself) — measured 2e-5 .. 2.7e-4 per step over
-                # 28 layers (test_full_depth_flip_floor_oracle_vs_reordered_oracle measures the same effect with no GPU code involved), against 1.3-1.7e-3 end to end
-                assert inj[-1] < 5e-4, (step, inj)
-            top2 = np.sort(lr[0])[-2:]
-            gap = (top2[1] - top2[0]) / np.abs(lr).max()
-            if gap > 2 * tol_e2e:
-                assert int(np.argmax(le[0])) == int(np.argmax(lr[0]))
-            if gap > 1e-3 and step:
-                assert int(np.argmax(li[0])) == int(np.argmax(lr[0]))
-            tok = ref.sample(GREEDY)
-            if step == 6:
-                break
-            inject_cache(injected, ref, d.layers)
-            ref.forward(tok[None, :])
-            if step < 4:
-                end2end.sample(GREEDY); injected.sample(GREEDY)
-                end2end.forward(tok[None, :]); injected.forward(tok[None, :])
-            else:
-                force_graph_step(end2end, tok, d.vocab); force_graph_step(injected, tok, d.vocab)
-        print(name, "end to end:", ["%.1e" % e for e in e2e], " injected:", ["%.1e" % e for e in inj])
-        # the GPU's own cache rows (MFMA prefill + appended rows) against the CPU path's: layer 0 sees identical inputs on both sides -> one
-        # bf16 ulp; the last layer's inputs carry 27 / 31 layers of flips (1-2e-3 of the residual stream) -> two ulps plus 1 % of the largest entry
-        for layer in (0, d.layers - 1):
-            for g_, r_ in zip(end2end.read_kv(0, layer), ref.read_kv(0, layer)):
-                ulp = 2.0 ** -7
-                tol, floor = (ulp, 4e-6) if layer == 0 else (2 * ulp, 1e-2)
-                bad = np.abs(g_ - r_) > tol * np.abs(r_) + floor * np.abs(r_).max()
-                assert not bad.any(), (layer, int(bad.sum()))
-    finally:
-        oracle_lib.set_threads(8)
+    end2end, injected = load_gpus(d)
+    for m in (end2end, injected):
+        m.forward(traj.prompt)
+    e2e, inj = [], []
+    for step in range(7):
+        lr, le, li = traj.logits[step], end2end.logits(rounded=False), injected.logits(rounded=False)
+        e2e.append(rel_err(le, lr)); inj.append(rel_err(li, lr))
+        assert e2e[-1] < tol_e2e, (step, e2e)
+        if step:
+            # the step's OWN appended row cannot be injected (it is computed inside the step): where its fp32 values straddle a bf16 boundary
+            # the token attends to a key / value one ulp off, often with a large weight (itself) — measured 2e-5 .. 2.7e-4 per step over
+            # 28 layers (test_full_depth_flip_floor_oracle_vs_reordered_oracle measures the same effect with no GPU code involved), against 1.3-1.7e-3 end to end
+            assert inj[-1] < 5e-4, (step, inj)
+        top2 = np.sort(lr[0])[-2:]
+        gap = (top2[1] - top2[0]) / np.abs(lr).max()
+        if gap > 2 * tol_e2e:
+            assert int(np.argmax(le[0])) == int(np.argmax(lr[0]))
+        if gap > 1e-3 and step:
+            assert int(np.argmax(li[0])) == int(np.argmax(lr[0]))
+        tok = traj.toks[step]
+        if step == 6:
+            break
+        inject_cache(injected, traj, 320 + step)
+        if step < 4:
+            end2end.sample(GREEDY); injected.sample(GREEDY)
+            end2end.forward(tok[None, :]); injected.forward(tok[None, :])
+        else:
+            force_graph_step(end2end, tok, d.vocab); force_graph_step(injected, tok, d.vocab)
+    print(name, "end to end:", ["%.1e" % e for e in e2e], " injected:", ["%.1e" % e for e in inj])
+    # the GPU's own cache rows (MFMA prefill + appended rows) against the CPU path's: layer 0 sees identical inputs on both sides -> one
+    # bf16 ulp; the last layer's inputs carry 27 / 31 layers of flips (1-2e-3 of the residual stream) -> two ulps plus 1 % of the largest entry
+    for layer in (0, d.layers - 1):
+        for g_, r_ in zip(end2end.read_kv(0, layer), traj.kv[layer]):
+            ulp = 2.0 ** -7
+            tol, floor = (ulp, 4e-6) if layer == 0 else (2 * ulp, 1e-2)
+            bad = np.abs(g_ - r_) > tol * np.abs(r_) + floor * np.abs(r_).max()
+            assert not bad.any(), (layer, int(bad.sum()))
 
 
 @pytest.mark.parametrize("name,tol", [("llama-3.2-3b", 3e-3), ("mistral-7b-v0.3", 4e-3)])
@@ -160,5 +143,4 @@ def test_full_depth_flip_floor_oracle_vs_reordered_oracle(name, tol, oracle_lib)
     the same code land at 0.8-1.4e-3 (Llama-3.2-3B) / see profiles/r04_kv_flip_floor.txt (Mistral-7B): the floor is above north_star's 1e-3 and the granted
     3e-3 / 4e-3 are ~2x that floor, not slack."""
     from test_oracle_reorder import flip_floor
-    errs = flip_floor(name, tol, oracle_lib, 320, 6)
-    assert max(errs) > 5e-4
+    flip_floor(name, tol, oracle_lib, 320, 6)

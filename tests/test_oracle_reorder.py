@@ -8,9 +8,9 @@ context A sums every reduction first-to-last, context B last-to-first (tgxo_set_
 order).  No GPU, no HIP kernel: whatever distance these two land at is the floor a correct third implementation cannot be expected to beat.
 
   * fp32 storage (nothing is rounded into the cache): the two schedules agree to ~1e-6 -> the reorder switch itself is sound;
-  * bf16 storage, same geometry / prompt / steps as test_full_depth_vs_oracle: measured floor in `FLOOR` below; the test asserts the floor is
-    REAL (> 5e-4: a 1e-3 end-to-end bar is not testable at this depth) and that it stays below the tolerances test_hip_parity_bar.py grants
-    (so those tolerances are the floor plus margin, not slack that could hide a kernel error of the same size);
+  * bf16 storage, same geometry / prompt / steps as test_full_depth_vs_oracle: the measured floor is printed (0.8-2.6e-3: a 1e-3 end-to-end bar is not
+    testable at this depth) and must stay below the tolerances test_hip_parity_bar.py grants (so those tolerances are the floor plus margin, not slack
+    that could hide a kernel error of the same size);
   * the fraction of cache entries that differ, and that every difference is exactly one bf16 ulp, is checked on layer 0 and the last layer.
 """
 import copy
@@ -81,15 +81,15 @@ def test_reordered_schedule_agrees_in_fp32(oracle_lib):
 
 
 def flip_floor(name, tol_granted, oracle_lib, prompt_len, steps):
-    """oracle vs reordered oracle, bf16 storage, FULL depth and vocabulary; returns the per-step logits distances"""
-    oracle_lib.set_threads(min(32, os.cpu_count() or 8))
-    try:
-        d = shrink(name)
-        errs, kv = run_pair(d, "bf16", prompt_len, steps)
-    finally:
-        oracle_lib.set_threads(8)
+    """oracle vs reordered oracle, bf16 storage, FULL depth and vocabulary; returns the per-step logits distances.  The forward schedule is the shared
+    trajectory of tests/fullsize_util.py (the GPU comparison of the same geometry reads it too); the reordered one is forced with its tokens."""
+    from fullsize_util import oracle_trajectory
+    a = oracle_trajectory(oracle_lib, name, prompt_len, 3, steps)
+    b = oracle_trajectory(oracle_lib, name, prompt_len, 3, steps, reorder=True, forced=a, kv_layers=(0, a.desc.layers - 1))
+    errs = [rel_err(b.logits[step], a.logits[step]) for step in range(steps + 1)]
     print(f"{name}: oracle vs reordered oracle, bf16, logits rel err per step:", ["%.2e" % e for e in errs])
-    for layer, ka, kb, va, vb in kv:
+    for layer in (0, a.desc.layers - 1):
+        (ka, va), (kb, vb) = a.kv[layer], b.kv[layer]
         fk, fv = float((ka != kb).mean()), float((va != vb).mean())
         # a flip moves an entry by one bf16 ulp OF ITS OWN magnitude; entries near zero (cancelled dot products) may move by several of their tiny ulps,
         # so the size of a difference is measured against the ulp at the row's scale
@@ -99,12 +99,15 @@ def flip_floor(name, tol_granted, oracle_lib, prompt_len, steps):
             assert fk > 0 or fv > 0                        # flips exist already in the first layer, whose inputs are identical on both sides
             assert sk <= 2.0 ** -7 and sv <= 2.0 ** -7     # ... and there each is ONE rounding step (a bf16 ulp is 2^-8 .. 2^-7 of the value)
     floor = max(errs)
-    assert floor > 5e-4, errs                    # the floor is real: 1e-3 end to end is not a testable bar at this depth
-    assert floor < tol_granted, errs             # and the tolerance the GPU test grants sits above it
+    # Recorded, not asserted from below ("floor > 5e-4" would FAIL if numerics improved): the number is the justification of the granted
+    # tolerance and is printed next to it (profiles/r04_kv_flip_floor.txt holds a run's values).  What IS an invariant: the tolerance the GPU test grants
+    # sits above the floor any correct schedule lands on.
+    print(f"  flip floor {floor:.2e} vs granted {tol_granted:.1e} (north_star's 1e-3 is {'below' if floor > 1e-3 else 'above'} this floor)")
+    assert floor < tol_granted, errs
     return errs
 
 
 def test_bf16_kv_flip_floor_at_full_depth(oracle_lib):
     """Llama-3.2-3B at full depth (28 layers) and vocabulary, 64-token prompt + 3 steps (sized for the CPU suite; the flip floor is set by the depth,
-    not by the prompt length): the two fp32 schedules of the SAME code land above 5e-4 and below the 3e-3 the GPU comparison is granted"""
+    not by the prompt length): the two fp32 schedules of the SAME code land (printed: ~1e-3) below the 3e-3 the GPU comparison is granted"""
     flip_floor("llama-3.2-3b", 3e-3, oracle_lib, 64, 3)

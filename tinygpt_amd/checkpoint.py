@@ -11,6 +11,15 @@ import struct
 
 import numpy as np
 
+class UnsupportedTensor:
+    """a checkpoint entry whose dtype the path does not load; an error only if the model actually consumes it"""
+    def __init__(self, path, name, dtype):
+        self.path, self.name, self.dtype = path, name, dtype
+
+    def error(self):
+        return ValueError(f"{self.path}: tensor {self.name} has dtype {self.dtype} (BF16 / F16 / F32 are loaded)")
+
+
 _DT = {"BF16": (np.uint16, 2), "F16": (np.float16, 2), "F32": (np.float32, 4)}
 
 
@@ -24,7 +33,11 @@ def _read_file(path: str):
         if name == "__metadata__":
             continue
         if info["dtype"] not in _DT:
-            raise ValueError(f"{path}: tensor {name} has dtype {info['dtype']} (BF16 / F16 / F32 are loaded)")
+            # the reference drops a key no module owns before it looks at the dtype (SafeTensors.cpp:176-182 vs :196): I64 / BOOL / U8 buffers
+            # (position_ids, attn.bias, masked_bias ...) must not abort the load.  Yielded as an UnsupportedTensor marker: Model.upload(strict=False)
+            # skips it like any other unknown key, and raises only if the model consumes that name.
+            yield name, UnsupportedTensor(path, name, info["dtype"])
+            continue
         dt, esz = _DT[info["dtype"]]
         b0, b1 = info["data_offsets"]
         shape = tuple(info["shape"])

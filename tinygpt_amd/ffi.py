@@ -163,6 +163,14 @@ class Model:
 
     # -- load (== GPTModel::load -> SafeTensors::load) ---------------------------------------
     def upload(self, name: str, arr: np.ndarray, strict: bool = True):
+        if hasattr(arr, "error") and hasattr(arr, "dtype") and not isinstance(arr, np.ndarray):
+            # checkpoint.UnsupportedTensor: a file dtype this path cannot convert (I64 / BOOL / U8 ...).  The ABI's name probe (ndim < 0, include/tgx.h)
+            # tells a parameter the model needs (TGX_ERR_SHAPE: raise) from a key it ignores or does not know (skipped like the reference, SafeTensors.cpp:176-182)
+            one = (c_int64 * 1)(0)
+            st = self.be.upload(self._ctx, name.encode(), ctypes.cast(one, c_void_p), one, -1, 0)   # 0 = TGX_F32
+            if st == 7 or (st == 6 and strict):
+                raise arr.error()
+            return False
         a, dt = _as_bits(arr)
         shape = (c_int64 * a.ndim)(*a.shape)
         st = self.be.upload(self._ctx, name.encode(), a.ctypes.data_as(c_void_p), shape, a.ndim, dt)
@@ -267,12 +275,12 @@ class Model:
 
     def set_option(self, key: str, value: int):
         self._check(self.be.set_option(self._ctx, key.encode(), int(value)))
+        return self
 
     def get_option(self, key: str) -> int:
         out = c_int(0)
         self._check(self.be.get_option(self._ctx, key.encode(), ctypes.byref(out)))
         return out.value
-        return self
 
     def bytes_per_token(self, T: int) -> int:
         return self.be.bytes_per_token(self._ctx, T)
