@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define TGX_ABI_VERSION 2
+/* 3 (round 5): per-row sequence lifecycle (tgx_reset_row / tgx_forward_row / tgx_sample_row / tgx_past_length_row); tgx_get_option added and
+ * tgx_engine_read_stats + the options engine.*, pf.*, attn.fold_*, lmhead.fuse_finalize removed since 2. */
+#define TGX_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define TGX_API __attribute__((visibility("default")))
@@ -162,8 +164,30 @@ TGX_API int tgx_fetch_token(tgx_ctx* ctx, int64_t ticket, int32_t* out_id);
 /* == GPTModel::resetCache() (src/model/GPTModel.h:91-94): pastLength back to 0 for all rows. */
 TGX_API int tgx_reset_cache(tgx_ctx* ctx);
 
-/* == KVCacheManager::pastLength (src/engine/CacheManager.h:44-51). */
+/* == KVCacheManager::pastLength (src/engine/CacheManager.h:44-51).  With rows of different lengths (see the per-row calls below): the LONGEST
+ * row of the batch — the length every capacity check uses. */
 TGX_API int64_t tgx_past_length(const tgx_ctx* ctx);
+
+/* ---- per-row sequence lifecycle (ABI 3) ---------------------------------------------------
+ * The kernel-contract half of the reference's continuous-batching TODO (README.md:33-34): the reference's KVCacheManager holds ONE pastLength for
+ * the whole batch (src/engine/CacheManager.h:44-51) and its engine rebuilds the batch per request (src/engine/GPTEngine.cpp:67-84,180-232), so a
+ * finished sequence blocks its slot until the longest one ends.  Here every row owns its cache slab and its device-resident position, and the
+ * step kernels read the position per row: a row can be retired and another prompt prefilled into it while the other rows keep their state.
+ * What a row keeps is the semantics of a solo sequence (Attention.h:71-112 over its own keys [0, pastLength_row]): its logits equal those of the
+ * same prompt run alone up to the summation-order differences between kernel paths (tests/test_hip_rows.py).
+ *
+ * tgx_reset_row      == resetCache() for ONE row: its pastLength back to 0; the other rows and the batch size are untouched.  A retired row
+ *                       that is not refilled keeps riding in the batch's steps (it decodes from position 0 on its stale token; its output is
+ *                       meaningless and harmless) until tgx_forward / tgx_reset_cache rebuilds the batch.
+ * tgx_forward_row    == GPTModel::forward(inputIds[1,S]) for ONE row of the live batch: `row` < batch (refill) or == batch (the batch grows by
+ *                       one row, up to max_batch); the row's pastLength must be 0 (tgx_reset_row first).  Leaves the row's last-position logits in
+ *                       its slot of tgx_read_logits; the row has no current token until tgx_sample_row (or tgx_sample) ran — tgx_decode refuses until then.
+ * tgx_sample_row     == Sampler::sample on ONE row's logits; the id becomes that row's device-resident next token.
+ * tgx_past_length_row   the row's own pastLength. */
+TGX_API int tgx_reset_row(tgx_ctx* ctx, int row);
+TGX_API int tgx_forward_row(tgx_ctx* ctx, int row, const int64_t* ids, int seq);
+TGX_API int tgx_sample_row(tgx_ctx* ctx, int row, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* out_id);
+TGX_API int64_t tgx_past_length_row(const tgx_ctx* ctx, int row);
 
 /* == GPTModel::contextSize() / numLayers() (src/model/GPTModel.h:97-98). */
 TGX_API int64_t tgx_context_size(const tgx_ctx* ctx);
@@ -177,7 +201,7 @@ TGX_API const char* tgx_last_error(const tgx_ctx* ctx);
 /* Blocks until all work enqueued on the context's stream has finished. */
 TGX_API int tgx_synchronize(tgx_ctx* ctx);
 
-/* Reads back the KV cache of (row, layer) as fp32 into k_out/v_out, each [pastLength][kv_heads][head_dim]
+/* Reads back the KV cache of (row, layer) as fp32 into k_out/v_out, each [pastLength of that row][kv_heads][head_dim]
  * (the BSHD view KVCacheManager::append returns, Attention.h:106).  Test/diagnostic use. */
 TGX_API int tgx_read_kv(tgx_ctx* ctx, int row, int layer, float* k_out, float* v_out);
 

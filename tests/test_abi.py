@@ -20,7 +20,7 @@ def test_header_symbols_all_exported():
     assert len(names) >= 20
     assert sorted("tgx_" + n for n in ABI) == names, "ffi.ABI and include/tgx.h disagree"
     be = Backend(lib, "tgx_")              # resolves every symbol or raises AttributeError
-    assert be.abi_version() == 2
+    assert be.abi_version() == 3
 
 
 def test_no_gpu_is_a_loud_error():

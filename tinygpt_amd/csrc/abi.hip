@@ -337,6 +337,7 @@ static int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t see
       LAUNCH_OK(c);
     }
     c->past += m;
+    for (int b = 0; b < c->batch; b++) c->row_past[(size_t)b] += m;
     c->steps_issued += m;
     remaining -= m;
   }
@@ -622,6 +623,8 @@ int tgx_finalize(tgx_ctx* c) {
   if ((rc = dev_alloc(c, &c->slab_acc, B * (size_t)H))) return rc;
   HIP_OK(c, hipMemset(c->slab_acc, 0, B * (size_t)H * 8));
   c->past = 0;
+  c->row_past.assign(B, 0);
+  c->row_tok.assign(B, 0);
   c->finalized = true;
   return TGX_OK;
 }
@@ -653,6 +656,8 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
   if (c->poisoned) return set_err(c, TGX_ERR_STATE, "an earlier pass failed half-way: call tgx_reset_cache first");
   if (seq > 1 && c->past > 0) return set_err(c, TGX_ERR_INVALID, "seq>1 with pastLength>0");
   if (c->past + seq > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded: %lld + %d > %d", (long long)c->past, seq, c->d.max_ctx);
+  for (int b = 0; b < batch; b++)
+    if (c->row_past[(size_t)b] != c->past) return set_err(c, TGX_ERR_STATE, "tgx_forward on a batch whose rows differ in length (row %d: %lld, longest %lld): use tgx_decode / tgx_forward_row, or tgx_reset_cache", b, (long long)c->row_past[(size_t)b], (long long)c->past);
   for (int64_t i = 0; i < (int64_t)batch * seq; i++)
     if (ids[i] < 0 || ids[i] >= c->d.vocab) return set_err(c, TGX_ERR_INVALID, "token id out of range");
   HIP_OK(c, hipSetDevice(c->device));
@@ -706,6 +711,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
   LAUNCH_OK(c);
   HIP_OK(c, hipStreamSynchronize(c->stream));   // host `ids` may be pageable and reused by the caller
   c->past += seq;
+  for (int b = 0; b < batch; b++) { c->row_past[(size_t)b] = c->past; c->row_tok[(size_t)b] = 0; }
   c->have_logits = true;
   c->have_token = false;
   return TGX_OK;
@@ -745,6 +751,7 @@ int tgx_sample(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* o
     HIP_OK(c, hipMemcpy(&t, c->rows[(size_t)b].tok, 4, hipMemcpyDeviceToHost));
     if (out_ids) out_ids[b] = t;
     if (b == 0) c->last_sampled0 = t;
+    c->row_tok[(size_t)b] = 1;
   }
   c->have_token = true;
   return TGX_OK;
@@ -809,12 +816,127 @@ int tgx_reset_cache(tgx_ctx* c) {
   if (c->slab_acc) HIP_OK(c, hipMemsetAsync(c->slab_acc, 0, (size_t)c->d.max_batch * c->d.hidden * 8, c->stream));
   HIP_OK(c, hipStreamSynchronize(c->stream));
   c->past = 0;
+  std::fill(c->row_past.begin(), c->row_past.end(), 0);
+  std::fill(c->row_tok.begin(), c->row_tok.end(), 0);
   c->have_logits = c->have_token = false;
   c->poisoned = false;
   return TGX_OK;
 }
 
 int64_t tgx_past_length(const tgx_ctx* c) { return c ? c->past : -1; }
+
+// ---- per-row sequence lifecycle (include/tgx.h, ABI 3).  The step kernels read every row's position from its own device word; the host keeps the
+// mirror row_past[] and `past` = the longest row of the batch (capacity checks, attention-form limits: a form chosen for the longest row is valid for
+// the shorter ones — the direct form's pass count and the split form's active splits are derived on the device from each row's position).
+static void refresh_longest(tgx_ctx* c) {
+  int64_t m = 0;
+  for (int b = 0; b < c->batch; b++) m = std::max(m, c->row_past[(size_t)b]);
+  c->past = m;
+  bool all = c->batch > 0;
+  for (int b = 0; b < c->batch; b++) all = all && c->row_tok[(size_t)b];
+  c->have_token = all;
+}
+
+int64_t tgx_past_length_row(const tgx_ctx* c, int row) { return (c && c->finalized && row >= 0 && row < c->d.max_batch) ? c->row_past[(size_t)row] : -1; }
+
+int tgx_reset_row(tgx_ctx* c, int row) {
+  if (!c) return TGX_ERR_INVALID;
+  if (!c->finalized) return set_err(c, TGX_ERR_STATE, "reset before finalize");
+  if (row < 0 || row >= c->d.max_batch) return set_err(c, TGX_ERR_INVALID, "row %d out of range [0,%d)", row, c->d.max_batch);
+  if (c->poisoned) return set_err(c, TGX_ERR_STATE, "an earlier pass failed half-way: call tgx_reset_cache first");
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipMemsetAsync(c->rows[(size_t)row].pos, 0, 4, c->stream));     // stream-ordered behind the steps already enqueued
+  c->row_past[(size_t)row] = 0;
+  c->row_tok[(size_t)row] = 0;
+  refresh_longest(c);
+  return TGX_OK;
+}
+
+int tgx_forward_row(tgx_ctx* c, int row, const int64_t* ids, int seq) {
+  if (!c || !ids) return c ? set_err(c, TGX_ERR_INVALID, "null argument") : TGX_ERR_INVALID;
+  if (!c->finalized) return set_err(c, TGX_ERR_STATE, "forward before finalize");
+  if (c->poisoned) return set_err(c, TGX_ERR_STATE, "an earlier pass failed half-way: call tgx_reset_cache first");
+  if (row < 0 || row >= c->d.max_batch || row > c->batch) return set_err(c, TGX_ERR_INVALID, "row %d: a live row [0,%d) or the next free one (max_batch %d)", row, c->batch, c->d.max_batch);
+  if (seq < 1 || seq > c->d.max_ctx) return set_err(c, seq < 1 ? TGX_ERR_INVALID : TGX_ERR_CONTEXT, "seq %d out of range (context size %d)", seq, c->d.max_ctx);
+  if (c->row_past[(size_t)row] != 0) return set_err(c, TGX_ERR_STATE, "row %d holds %lld positions: tgx_reset_row first", row, (long long)c->row_past[(size_t)row]);
+  for (int i = 0; i < seq; i++)
+    if (ids[i] < 0 || ids[i] >= c->d.vocab) return set_err(c, TGX_ERR_INVALID, "token id out of range");
+  HIP_OK(c, hipSetDevice(c->device));
+  // the prompt runs as a one-row pass of the same prefill paths tgx_forward takes (they address rows by index and read the pass's past from c->past)
+  const int64_t longest = c->past;
+  const int batch_before = c->batch;
+  c->past = 0;
+  const bool f32_path = c->dt == tgx::DT_F32 && seq >= c->prefill_f32_min_rows && c->prefill_mfma;
+  const bool mfma_path = f32_path || (seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && prefill_shapes_ok(c->d));
+  RowState& r = c->rows[(size_t)row];
+  int rc = TGX_OK;
+  hipError_t e = hipMemcpyAsync(r.prompt, ids, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && mfma_path) {
+    const bool skinny = !f32_path && !c->gpt2 && c->prefill_skinny && c->d.vocab >= 128 &&
+                        (seq <= 32 ? c->prefill_skinny_rows >= seq : (seq <= c->prefill_skinny_rows && c->d.hidden <= c->prefill_skinny_hidden_max && (seq <= 64 || (c->skinny_dma && c->d.hidden <= c->prefill_skinny_hidden_max_wide))));
+    rc = skinny ? ensure_skinny_ws(c, seq) : ensure_prefill_ws(c, seq);
+    if (!rc && f32_path) rc = ensure_f32_part(c, seq);
+    if (!rc) {
+      if (f32_path) launch_prefill_f32(c, row, 1, seq);
+      else if (skinny) launch_prefill_skinny(c, row, 1, seq); else launch_prefill(c, row, 1, seq);
+      launch_lm_head(c, row, 1);
+      launch_add_pos(c, r.pos, seq);
+    }
+  } else if (e == hipSuccess) {
+    update_attn_modes(c, seq, 1, /*step=*/false);
+    for (int s0 = 0; s0 < seq;) {
+      const int rem = seq - s0, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
+      launch_embed_chunk(c, r.prompt + s0, R, s0);
+      for (int k = 0; k < R; k++) { c->chunk[k].kcache = r.kcache; c->chunk[k].vcache = r.vcache; }
+      launch_layers(c, c->chunk, R, 0);
+      s0 += R;
+      if (s0 == seq) {
+        (void)hipMemcpyAsync(r.x, c->chunk[R - 1].x, (size_t)c->d.hidden * 4, hipMemcpyDeviceToDevice, c->stream);
+        launch_add_pos(c, r.pos, seq);
+        launch_lm_head(c, row, 1);
+      }
+    }
+  }
+  c->past = longest;
+  if (rc) return rc;
+  HIP_OK(c, e);
+  HIP_OK(c, hipGetLastError());
+  if (c->launch_fault) { (void)hipStreamSynchronize(c->stream); c->poisoned = true; }
+  LAUNCH_OK(c);
+  HIP_OK(c, hipStreamSynchronize(c->stream));   // host `ids` may be pageable and reused by the caller
+  c->batch = std::max(batch_before, row + 1);
+  c->row_past[(size_t)row] = seq;
+  c->row_tok[(size_t)row] = 0;
+  refresh_longest(c);
+  c->have_logits = true;
+  return TGX_OK;
+}
+
+int tgx_sample_row(tgx_ctx* c, int row, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* out_id) {
+  if (!c || !cfg) return TGX_ERR_INVALID;
+  if (!c->have_logits) return set_err(c, TGX_ERR_STATE, "no logits to sample from");
+  if (row < 0 || row >= c->batch) return set_err(c, TGX_ERR_INVALID, "row %d out of range [0,%d)", row, c->batch);
+  HIP_OK(c, hipSetDevice(c->device));
+  if (!is_greedy(cfg)) {
+    if (!c->seed_valid || c->seed_on_dev != (unsigned long long)seed) {
+      HIP_OK(c, hipStreamSynchronize(c->stream));
+      const unsigned long long s = seed;
+      HIP_OK(c, hipMemcpy(c->seed_dev, &s, 8, hipMemcpyHostToDevice));
+      c->seed_on_dev = s; c->seed_valid = true;
+    }
+    c->have_probs = true;
+  }
+  launch_sample(c, row, 1, *cfg, /*advance_pos=*/false, /*log_step=*/false);
+  HIP_OK(c, hipGetLastError());
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  int t = 0;
+  HIP_OK(c, hipMemcpy(&t, c->rows[(size_t)row].tok, 4, hipMemcpyDeviceToHost));
+  if (out_id) *out_id = t;
+  if (row == 0) c->last_sampled0 = t;
+  c->row_tok[(size_t)row] = 1;
+  refresh_longest(c);
+  return TGX_OK;
+}
 int64_t tgx_context_size(const tgx_ctx* c) { return c ? c->d.max_ctx : -1; }
 int32_t tgx_num_layers(const tgx_ctx* c) { return c ? c->d.layers : -1; }
 
@@ -830,7 +952,7 @@ int tgx_read_kv(tgx_ctx* c, int row, int layer, float* k_out, float* v_out) {
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipStreamSynchronize(c->stream));
   const tgx_model_desc& d = c->d;
-  const size_t hd = (size_t)d.head_dim, per_head = (size_t)d.max_ctx * hd, T = (size_t)c->past;
+  const size_t hd = (size_t)d.head_dim, per_head = (size_t)d.max_ctx * hd, T = (size_t)c->row_past[(size_t)row];
   std::vector<unsigned char> tmp(per_head * c->esz);
   for (int which = 0; which < 2; which++) {
     float* out = which ? v_out : k_out;
@@ -852,7 +974,7 @@ int tgx_read_kv(tgx_ctx* c, int row, int layer, float* k_out, float* v_out) {
 }
 
 int tgx_write_kv(tgx_ctx* c, int row, int layer, const float* k_in, const float* v_in, int64_t n_rows) {
-  if (!c || !c->finalized || row < 0 || row >= c->d.max_batch || layer < 0 || layer >= c->d.layers || n_rows < 0 || n_rows > c->past) return c ? set_err(c, TGX_ERR_INVALID, "write_kv: row / layer / n_rows out of range") : TGX_ERR_INVALID;
+  if (!c || !c->finalized || row < 0 || row >= c->d.max_batch || layer < 0 || layer >= c->d.layers || n_rows < 0 || n_rows > c->row_past[(size_t)row]) return c ? set_err(c, TGX_ERR_INVALID, "write_kv: row / layer / n_rows out of range") : TGX_ERR_INVALID;
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipStreamSynchronize(c->stream));
   const tgx_model_desc& d = c->d;

@@ -99,7 +99,9 @@ struct tgx_ctx {
   float *ch_x = nullptr, *ch_q = nullptr, *ch_kraw = nullptr, *ch_attn = nullptr, *ch_h = nullptr, *ch_part = nullptr;
   int* ch_pos = nullptr;
 
-  int64_t past = 0;       // host mirror of every row's device-resident pos
+  int64_t past = 0;       // host mirror of the device-resident pos: the LONGEST row of the batch (all rows, unless the per-row calls made them differ)
+  std::vector<int64_t> row_past;   // host mirror of each row's own pos (tgx_reset_row / tgx_forward_row, include/tgx.h)
+  std::vector<char> row_tok;       // the row has a current token (sampled after its last forward)
   int batch = 0;          // rows used by the last forward
   bool have_logits = false, have_token = false;
 

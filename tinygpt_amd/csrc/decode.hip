@@ -106,6 +106,7 @@ bool oproj_sliced_ok(const tgx_ctx* c, int R, long long kv_stride) {
   const tgx_model_desc& d = c->d;
   if (!c->oproj_sliced || R != 1 || kv_stride == 0 || c->attn_direct || c->attn_mfma || c->gpt2 || c->dt == tgx::DT_F32 || !c->slab_acc) return false;
   if (d.head_dim != 64 || d.qk_norm || d.inter > 16384 || c->attn_nsplit > 32) return false;
+  if (d.hidden > tgx::XACC_HIDDEN_MAX) return false;     // the fixed-point gate_up hands the converted residual to its waves through hidden * 4 bytes of LDS
   const int qd = d.heads * d.head_dim;
   if (qd % 256 == 0) return d.hidden % tgx::oproj_sliced_rows<32>() == 0;
   return qd % 128 == 0 && d.hidden % tgx::oproj_sliced_rows<16>() == 0;
@@ -119,7 +120,7 @@ bool oproj_sliced_ok(const tgx_ctx* c, int R, long long kv_stride) {
 bool oproj_fused_capable(const tgx_ctx* c) {
   const tgx_model_desc& d = c->d;
   if (!c->oproj_fused || c->gpt2 || c->dt == tgx::DT_F32 || !c->slab_acc) return false;
-  return d.head_dim == 64 && !d.qk_norm && d.inter <= 16384 && d.hidden % 8 == 0;
+  return d.head_dim == 64 && !d.qk_norm && d.inter <= 16384 && d.hidden % 8 == 0 && d.hidden <= tgx::XACC_HIDDEN_MAX;
 }
 bool oproj_fused_ok(const tgx_ctx* c, int R, long long kv_stride) {
   return R == 1 && c->batch == 1 && kv_stride != 0 && c->attn_direct && oproj_fused_capable(c);

@@ -143,7 +143,15 @@ __device__ __forceinline__ float head_rms_inv(float ss, int hd, float eps) { ret
 // f32 -> fixed: v * 2^32 is exact in fp32 (a power-of-two scale), the conversion rounds to nearest.  fixed -> f32: the correctly rounded int64 -> float
 // conversion (sign, leading-zero count, shift, round: ~10 VALU instructions) and an exact scale.  (A cheaper hi / lo split was tried first: its error is
 // ABSOLUTE, 2^-25, and small negative values — -1 + 0.9999 — lost four digits: logits 3e-5 off at a one-token context.)
+// Range and non-finite values: |v| >= 2^31 saturates and NaN converts to 0 (v_cvt semantics via __float2ll_rn), so a DIVERGED activation does
+// not propagate as Inf / NaN through the batch-1 fixed-point path the way it does through the fp32 paths (batch >= 2, fp32 storage, prefill).  A residual
+// stream anywhere near 2^31 = 2.1e9 is a broken model (trained checkpoints: 1e1 .. 1e4), the logits of such a step are garbage on every path, and the
+// greedy argmax over garbage is what the caller gets either way; the price of a sticky non-finite flag (a second atomic per contribution) is not paid.
+// Callers that must detect divergence read the logits (tgx_read_logits): a saturated stream shows as logits of ~1e9.
 __device__ __forceinline__ long long f32_to_fix(float v) { return __float2ll_rn(v * 4294967296.0f); }
+// widest hidden size the fixed-point forms serve: gemv_kernel<.., XACC> requests hidden * 4 bytes of dynamic LDS for the hand-over (32 KB here, inside the
+// 64 KB a launch gets without raising the kernel's dynamic-LDS attribute); decode.hip's capability predicates send wider models to the fp32-residual forms
+constexpr int XACC_HIDDEN_MAX = 8192;
 __device__ __forceinline__ float fix_to_f32(long long a) { return (float)a * (1.0f / 4294967296.0f); }
 
 // ---- cross-lane reductions ----------------------------------------------------------------------

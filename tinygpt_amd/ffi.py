@@ -65,6 +65,10 @@ ABI = {
     "fetch_token": (c_int, [c_void_p, c_int64, POINTER(c_int32)]),
     "reset_cache": (c_int, [c_void_p]),
     "past_length": (c_int64, [c_void_p]),
+    "reset_row": (c_int, [c_void_p, c_int]),
+    "forward_row": (c_int, [c_void_p, c_int, POINTER(c_int64), c_int]),
+    "sample_row": (c_int, [c_void_p, c_int, POINTER(SamplerCfg), c_uint64, POINTER(c_int64)]),
+    "past_length_row": (c_int64, [c_void_p, c_int]),
     "context_size": (c_int64, [c_void_p]),
     "num_layers": (c_int32, [c_void_p]),
     "last_error": (c_char_p, [c_void_p]),
@@ -230,6 +234,26 @@ class Model:
     def reset_cache(self):
         self._check(self.be.reset_cache(self._ctx))
 
+    # -- per-row sequence lifecycle (include/tgx.h, ABI 3) ------------------------------------
+    def reset_row(self, row: int):
+        self._check(self.be.reset_row(self._ctx, row))
+        return self
+
+    def forward_row(self, row: int, ids):
+        """prefill one prompt into `row` of the live batch (a retired row, or the next free one); the other rows keep their state"""
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64).reshape(-1))
+        self._check(self.be.forward_row(self._ctx, row, ids.ctypes.data_as(POINTER(c_int64)), len(ids)))
+        self.batch = max(self.batch, row + 1)
+        return self
+
+    def sample_row(self, row: int, cfg: SamplerCfg = GREEDY, seed: int = 0) -> int:
+        out = c_int64()
+        self._check(self.be.sample_row(self._ctx, row, ctypes.byref(cfg), seed, ctypes.byref(out)))
+        return out.value
+
+    def past_length_row(self, row: int) -> int:
+        return self.be.past_length_row(self._ctx, row)
+
     @property
     def past_length(self) -> int:
         return self.be.past_length(self._ctx)
@@ -242,7 +266,7 @@ class Model:
         self._check(self.be.synchronize(self._ctx))
 
     def read_kv(self, row: int, layer: int):
-        T = self.past_length
+        T = self.be.past_length_row(self._ctx, row) if self.be.has("past_length_row") else self.past_length
         shape = (T, self.desc.kv_heads, self.desc.head_dim)
         k = np.empty(shape, dtype=np.float32)
         v = np.empty(shape, dtype=np.float32)

@@ -13,10 +13,10 @@ job_suite()   { (time timeout 2700 python -m pytest tests -m gpu -x -q) > $O/pyt
 job_smoke()   { python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log; }
 job_bench()   { python bench.py > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench_line.json; cut -c1-600 $O/bench_line.json; }
 job_quick()   { python tools/quick_bench.py --prompt 2048 --steps 256 ${QB_ARGS:-} > $O/quick.log 2>&1; cat $O/quick.log; }
-# the attention pair at the bench's operating point: splits per kv head x merge placement
+# the attention pair at the bench's operating point: splits per kv head x o_proj form (K-sliced with the merge in its prologue / combine + row-sliced)
 job_attn_pair() {
   for ns in 4 6 8 12 17 32; do
-    python tools/sweep.py --prompt 2048 --steps 256 --pre "attn.nsplit=$ns" --grid "attn.fold_combine=0,1" 2>&1 | sed "s/^/nsplit=$ns /"
+    python tools/sweep.py --prompt 2048 --steps 256 --pre "attn.nsplit=$ns" --grid "oproj.sliced=0,1" 2>&1 | sed "s/^/nsplit=$ns /"
   done > $O/attn_pair.log 2>&1; cat $O/attn_pair.log
 }
 job_kernarg_probe() { for b in kernarg_probe kernarg_probe_pre; do echo "== $b"; timeout 120 tools/probes/build/$b; done > $O/kernarg_probe.log 2>&1; cat $O/kernarg_probe.log; }
