@@ -32,6 +32,25 @@ import statistics
 import sys
 import time
 
+
+
+def _host_cpu_budget():
+    """(hardware threads this process may run on, CPUs' worth of time its cgroup grants) — read BEFORE any OpenMP runtime starts: with OMP_PROC_BIND set
+    libgomp binds the initial thread to its place, after which sched_getaffinity reports that one core"""
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                 # cgroup v2: "<quota us> <period us>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return usable, quota
+
+
+HOST_USABLE, HOST_CPU_QUOTA = _host_cpu_budget()
+
 # the cpu_baseline leg is OpenMP code: pin its threads, one per core, SPREAD over the places (a team of 64 on a 2 x 64-core host takes every other core
 # of both sockets: all memory channels) — set before anything loads libgomp.  The oracle places every weight row on the NUMA node of the thread that
 # streams it (first touch in the product loop's own partition, oracle/tgx_oracle.c mat_store_rows).
@@ -75,7 +94,7 @@ def cpu_baseline(desc, tensors, seconds, prompt_len, prompt_seed, max_prefill_s=
     from tinygpt_amd.ffi import GREEDY
     build_oracle()
     cores = os.cpu_count() or 1
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
+    usable, quota = HOST_USABLE, HOST_CPU_QUOTA
     be = oracle_backend()
     ids = synth.synth_prompt(desc.vocab, 16, prompt_seed)[None, :]
 
@@ -90,7 +109,10 @@ def cpu_baseline(desc, tensors, seconds, prompt_len, prompt_seed, max_prefill_s=
     # Team size: the port is memory-bound; what a team is worth is decided by where its pages are, so every candidate gets its own upload.  Up to round 4
     # the weights were first-touched by ONE thread (a serial memcpy) and every team streamed them through one socket's quadrant: 78 GB/s at best, and wide
     # teams collapsed (16 threads 40 tok/s, 64 threads 16).  The probe table stays on the line (`legs.probe`).
-    cands = sorted({t for t in (16, 32, 64, 96, 128, 192) if t <= usable} or {usable})
+    # The GPU boxes of this pool grant the container a CFS quota (cpu.max 1600000 100000 = 16 CPUs' worth of time on a 2 x 64-core host): a team wider than
+    # the quota is throttled, not faster — that, not libgomp, is why "all 256 host threads" collapses.  The probe brackets the quota.
+    budget = usable if quota is None else max(1, min(usable, int(round(quota))))
+    cands = sorted({t for t in (max(1, budget // 2), budget, budget + budget // 2, 2 * budget, 64, 128) if t <= usable} or {usable})
     probe, best_n, best_rate, m = {}, 1, 0.0, None
     for n_thr in cands:
         mm = load(n_thr)
@@ -104,7 +126,7 @@ def cpu_baseline(desc, tensors, seconds, prompt_len, prompt_seed, max_prefill_s=
             best_n, best_rate, m, prefill16_s = n_thr, r, mm, p16
         else:
             mm.close()
-        if r < 0.6 * best_rate:          # wider teams only lose from here on
+        if r < 0.6 * best_rate or (quota is not None and n_thr >= 2 * budget):          # wider teams only lose from here on
             break
     be.set_threads(best_n)
 
@@ -137,14 +159,14 @@ def cpu_baseline(desc, tensors, seconds, prompt_len, prompt_seed, max_prefill_s=
     m.close()
     ctx = legs[which]["context"]
     legs["probe"] = probe
-    return {"value": round(value, 3), "unit": "tokens/s", "cores": best_n, "host_cores": cores, "host_cores_usable": usable, "kind": "port",
+    return {"value": round(value, 3), "unit": "tokens/s", "cores": best_n, "host_cores": cores, "host_cores_usable": usable, "cgroup_cpu_quota": quota, "kind": "port",
             "omp": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"), "threads": best_n},
             "legs": legs,
             "sample": f"oracle/liboracle.so (C+OpenMP restatement: an UNTUNED loop nest — plain fp32 loops, no blocking, no SIMD intrinsics; a stated baseline, not a tuned CPU "
                       f"implementation, so the GPU/CPU ratio says nothing about kernel quality), same synthetic {desc.name or 'model'} {desc.compute_dtype}; value = median of 3 samples of "
                       f"{legs[which]['tokens_per_sample']} greedy decode tokens after a {legs[which]['prompt_tokens']}-token prompt (context {ctx[0]}..{ctx[1]}: "
                       + ("the GPU run's own context" if which == "same" else "SHORTER than the GPU run's context — the oracle's prefill of the full prompt was over budget")
-                      + f"), {best_n} of {cores} host threads (best team size of a probe over {cands[0]}..{cands[-1]}, each with its own NUMA-local upload), threads pinned (OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, OMP_PLACES=cores); "
+                      + f"), {best_n} of {cores} host threads (the container's CFS quota grants {quota if quota is not None else 'all'} CPUs; best team size of a probe over {cands[0]}..{cands[-1]}, each with its own NUMA-local upload), threads pinned (OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, OMP_PLACES=cores); "
                       f"spread min/max in legs"}
 
 
