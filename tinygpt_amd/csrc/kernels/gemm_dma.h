@@ -10,6 +10,8 @@
 // chunk c of row r lives in slot c ^ ((r >> 1) & 7): the rows of a ds_read_b128 lane group then fall on distinct bank quads.  The swizzle is
 // applied on the GLOBAL side (each lane fetches the chunk that belongs in its slot) and again in the fragment read address.
 #pragma once
+#include <type_traits>
+
 #include "prefill.h"
 
 namespace tgx {
@@ -224,34 +226,38 @@ __device__ __forceinline__ void xcd_tile(const GemmArgs& a, int& tm, int& tn) {
 // to land — the two-stage ring stalls on every stage and only co-resident workgroups hide it.  Here a stage (k = 32) is 48 KB
 // (A_hi | A_lo | B, 256 rows x 64 bytes each) for 32 MFMAs per wave with two waves per SIMD (~0.85 µs of matrix work per SIMD), and TWO
 // stages are in flight while the third is consumed: the waits are counted (vmcnt(6): this wave's six pieces of the NEXT stage may still
-// fly), never a drain.  A wave owns 128 x 64 of the output (4 x 2 MFMA tiles): 10 fragment reads per 16 MFMAs, double-buffered in
-// registers (see the pipeline note at the loop).
+// fly), never a drain.  The six DMA instructions of a wave and stage are issued ONE AT A TIME between groups of MFMAs so that their issue
+// cost (~100 cycles each) hides under the matrix pipe instead of opening every stage.
+// The wave's output block (round 5): the A operand comes as TWO 16-bit terms (hi, lo), B as one, and an MFMA pair (lo, hi) shares its B fragment — per k16
+// step a wave that owns WI x WJ blocks of 32 x 32 reads 2 WI + WJ fragments for 2 WI WJ MFMAs.  128 x 64 per wave (WI 4, WJ 2: rounds 2-4) = 10 reads per 16
+// MFMAs; 64 x 128 (WI 2, WJ 4) = 8 per 16 and 15 fewer registers: gate_up at S = 2048 235 -> 230 us, same MFMAs per output element in the same order
+// (bit-identical; tools/probes/gemm_lab.hip, profiles/r05_prefill.txt).
 // LO = false (option act.round16: the Linear's input is rounded to the storage dtype, so A_hi IS the activation): the A_lo tile is neither staged nor
 // multiplied — 4 DMA pieces per stage instead of 6, half the MFMAs (gate_up at S = 2048: 232 -> 130 us, profiles/r04_act16_cost.txt)
-template <int DT, int EPI, bool LO = true>
+// DIS (lab only): 1 = no MFMAs, 2 = no DMA after the prologue, 4 = no fragment reads, 8 = no epilogue stores.
+template <int DT, int EPI, bool LO = true, int WJ = 4, int DIS = 0>
 __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
   constexpr int DBK = 32, CPR = 4, RPP = 16, TMN = 256, NS = 3;
+  constexpr int WI = 8 / WJ, NWN = TMN / (32 * WJ);      // 32 x 32 blocks per wave along M / N, waves along N
   constexpr int STAGE = 3 * TMN * DBK;                    // 16-bit elements per stage
   extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv >> 2, wn = wv & 3;
+  const int wm = wv / NWN, wn = wv % NWN;
   int tile_m, tile_n;
   xcd_tile(a, tile_m, tile_n);
   const int m0 = tile_m * TMN, n0 = tile_n * TMN;
   const unsigned lds_base = (unsigned)(size_t)dma_lds;
   const bool inter = EPI == GEMM_SILU;
 
-  f32x16 acc[4][2];
+  f32x16 acc[WI][WJ];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < WI; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < WJ; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int prow = lane / CPR, pslot = lane % CPR;
-  // 48 pieces per stage: wave w takes pieces w, w+8 of each of the three tiles = six DMA instructions, issued ONE AT A TIME between
-  // groups of MFMAs (q = 0..5) so that their issue cost (~100 cycles each) hides under the matrix pipe instead of opening every stage
   const bf16_t* gsrc[6];
   unsigned ldst[6];
 #pragma unroll
@@ -266,89 +272,99 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
   }
   const int nk = a.K / DBK;
   const int klast = (nk - 1) * DBK;
-  // stage s (stages past the end reload the last real one into a free buffer: every wait below then counts the same six pieces)
   auto issue_piece = [&](int q, int s) {
     if (!LO && q % 3 == 1) return;
+    if ((DIS & 2) && s > 2) return;
     dma_1k(gsrc[q] + min(s * DBK, klast), lds_base + (unsigned)((s % NS) * STAGE * 2) + ldst[q]);
   };
-  // fragment addresses: the swizzle term depends on the lane only (tile rows are 32-aligned per MFMA block)
   const int swz = ((lane & 31) >> 2) & 3;
-  const int arow = (wm * 128 + (lane & 31)) * DBK, brow_l = (wn * 64 + (lane & 31)) * DBK;
-  // one k16 step of stage s: 4 x (A_hi, A_lo) + 2 B fragments
+  const int arow = (wm * 32 * WI + (lane & 31)) * DBK, brow_l = (wn * 32 * WJ + (lane & 31)) * DBK;
   auto read_frags = [&](int s, int kk, bf16x8* fa, bf16x8* fb) {
+    if (DIS & 4) return;
     const bf16_t* st = dma_lds + (size_t)(s % NS) * STAGE;
     const int ko = ((kk * 2 + (lane >> 5)) ^ swz) << 3;
 #pragma unroll
-    for (int j = 0; j < 2; j++) fb[j] = *reinterpret_cast<const bf16x8*>(st + 2 * TMN * DBK + brow_l + j * 32 * DBK + ko);
+    for (int j = 0; j < WJ; j++) fb[j] = *reinterpret_cast<const bf16x8*>(st + 2 * TMN * DBK + brow_l + j * 32 * DBK + ko);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < WI; i++) {
       fa[2 * i] = *reinterpret_cast<const bf16x8*>(st + arow + i * 32 * DBK + ko);
       if (LO) fa[2 * i + 1] = *reinterpret_cast<const bf16x8*>(st + TMN * DBK + arow + i * 32 * DBK + ko);
     }
   };
+  // the 16 MFMAs of one k16 step in four groups of four (two blocks x two terms, the B fragment shared by a pair), one DMA piece behind each of the first three
+  auto mfma_step = [&](const bf16x8* fa, const bf16x8* fb, int q0, int s) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        const int idx = 2 * g + p, i = idx / WJ, j = idx % WJ;
+        if (!(DIS & 1)) {
+          if (LO) acc[i][j] = mfma16<DT>(fa[2 * i + 1], fb[j], acc[i][j]);   // small term first
+          acc[i][j] = mfma16<DT>(fa[2 * i], fb[j], acc[i][j]);
+        }
+      }
+      if (g < 3) issue_piece(q0 + g, s);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
 
-  // Software pipeline (one barrier per K step): the fragments of the NEXT k16 step are read into a second register set while the MFMAs of
-  // the current one run, also across the stage boundary — so the barrier that opens stage k+1 sits between the two k16 steps of stage k:
-  //   step k:   read F1 <- (k, kk 1) | MFMA(F0) + DMA pieces 3..5 of stage k+2 | wait: stage k+1 landed, own reads of stage k done | barrier
-  //             read F0 <- (k+1, kk 0) | MFMA(F1) + DMA pieces 0..2 of stage k+3 (into the buffer stage k just left)
-  // Without it both waves of a SIMD read, wait and multiply in lockstep after every barrier (LDS burst, then matrix burst): 4600 cycles per
-  // step against 2048 of MFMA work.
 #pragma unroll
   for (int q = 0; q < 6; q++) issue_piece(q, 0);
 #pragma unroll
   for (int q = 0; q < 6; q++) issue_piece(q, 1);
 #pragma unroll
   for (int q = 0; q < 3; q++) issue_piece(q, 2);
-  bf16x8 fa0[8], fb0[2], fa1[8], fb1[2];
+  bf16x8 fa0[2 * WI], fb0[WJ], fa1[2 * WI], fb1[WJ];
+  if (DIS & 4) {
+#pragma unroll
+    for (int i = 0; i < 2 * WI; i++) { fa0[i] = bf16x8{}; fa1[i] = bf16x8{}; }
+#pragma unroll
+    for (int j = 0; j < WJ; j++) { fb0[j] = bf16x8{}; fb1[j] = bf16x8{}; }
+  }
   if (LO) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // stage 0 landed (this wave's pieces); stage 1 and half of stage 2 may fly
   else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_frags(0, 0, fa0, fb0);
   for (int k = 0; k < nk; k++) {
     read_frags(k, 1, fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);                        // the reads leave first: the scheduler would sink them next to their uses
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        if (LO) acc[i][j] = mfma16<DT>(fa0[2 * i + 1], fb0[j], acc[i][j]);   // small term first
-        acc[i][j] = mfma16<DT>(fa0[2 * i], fb0[j], acc[i][j]);
-      }
-      if (i < 3) issue_piece(3 + i, k + 2);                           // one DMA per four MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (LO) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // stage k+1 landed; this wave's reads of stage k are complete
-    else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                             // ... for every wave: the buffer of stage k is free
-    read_frags(k + 1, 0, fa0, fb0);                           // (after the last step: a harmless read of a reloaded stage)
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        if (LO) acc[i][j] = mfma16<DT>(fa1[2 * i + 1], fb1[j], acc[i][j]);
-        acc[i][j] = mfma16<DT>(fa1[2 * i], fb1[j], acc[i][j]);
-      }
-      if (i < 3) issue_piece(i, k + 3);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    mfma_step(fa0, fb0, 3, k + 2);
+    // stage k+1 landed = only what was issued after its last piece may fly (three pieces of the previous half step, three of this one); this wave's reads of stage k are complete
+    if (DIS & 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else if (LO) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(k + 1, 0, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(fa1, fb1, 0, k + 3);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no DMA may land in this CU's LDS after the workgroup has gone
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+  if (DIS & 8) {            // lab: no epilogue — every accumulator still feeds one value, so no MFMA chain is dead code
+    float t = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+    for (int i = 0; i < WI; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      for (int j = 0; j < WJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) t += acc[i][j][r];
+    if (t == 12345.678f) a.C[0] = t;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < WI; i++)
+#pragma unroll
+    for (int j = 0; j < WJ; j++) {
+      const int col = n0 + wn * 32 * WJ + j * 32 + (lane & 31);
       if (EPI == GEMM_SILU) {
-        silu_block_store<DT>(acc[i][j], lane, col, m0 + wm * 128 + i * 32, a);
+        silu_block_store<DT>(acc[i][j], lane, col, m0 + wm * 32 * WI + i * 32, a);
         continue;
       }
       if (col >= a.N) continue;
       const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = m0 + wm * 32 * WI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= a.M) continue;
         const float v = acc[i][j][r] + bv;
         if (EPI == GEMM_GELU) {
@@ -362,47 +378,46 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
     }
 }
 
-
-// ---- 128 x 128 tile, 8 waves with the K step split between wave pairs, three-stage ring (the N = hidden products: o_proj, down) ---------
+// ---- 128 x 128 tile, 8 waves with the K step split between them, three-stage ring (the N = hidden products: o_proj, down) ---------
 // At S = 2048 these products have only 256 tiles of 128 x 128 — one per CU.  Four waves per tile leave one wave per SIMD (nothing hides a
-// wave's fragment-read latency); 64-row tiles double the workgroups but read a fragment per MFMA.  Here the 128 x 128 tile gets EIGHT waves:
-// waves w and w + 4 own the same 64 x 64 quadrant and take alternate halves of every stage's k range (two of its four k16 steps each), so
-// a SIMD holds two waves, a stage is 48 KB with three stages in the ring, and the two partial accumulators meet once, through LDS, after
-// the K loop (fixed order: lower half + upper half).
-template <int DT, int EPI, bool LO = true>
+// wave's fragment-read latency); 64-row tiles double the workgroups but read a fragment per MFMA.  Here the 128 x 128 tile gets EIGHT waves
+// = 2 row halves x FOUR k quarters (round 5; rounds 2-4: 4 quadrants x 2 k halves, 12 fragment reads per 16 MFMAs): a wave owns 64 x 128 of the
+// output (8 reads per 16 MFMAs) and takes ONE of the four k16 steps of every k64 stage, so a SIMD holds two waves, a stage is 48 KB with three
+// stages in the ring, and the four partial accumulators meet through LDS after the K loop in a fixed order, (q0 + q2) + (q1 + q3); the last
+// exchange hands each of the two surviving wave pairs one column half, so four waves run the epilogue as before.  down at S = 2048 (K = 8192): 161 -> 140 us;
+// o_proj (K = 2048) 52 -> 52 (tools/probes/gemm_lab.hip, profiles/r05_prefill.txt).  Another fp32 summation order than the 4-wave kernel: results differ by ~1e-6.
+template <int DT, int EPI, bool LO = true, int DIS = 0>
 __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
   constexpr int DBK = 64, CPR = 8, RPP = 8, TMN = 128, NS = 3;
-  constexpr int STAGE = 3 * TMN * DBK;                    // 16-bit elements per stage (A_hi | A_lo | B)
+  constexpr int STAGE = 3 * TMN * DBK;
   extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kh = wv >> 2, wm = (wv >> 1) & 1, wn = wv & 1;
+  const int kq = wv >> 1, wm = wv & 1;
   int tile_m, tile_n;
   xcd_tile(a, tile_m, tile_n);
   const int m0 = tile_m * TMN, n0 = tile_n * TMN;
   const unsigned lds_base = (unsigned)(size_t)dma_lds;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < 4; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int prow = lane / CPR, pslot = lane % CPR;
-  // EPI == GEMM_PARTIAL (round 4): split-K slab blockIdx.z of a prompt whose 128 x 128 tiles alone leave CUs idle (129-1500 rows at hidden 2048): this workgroup's
-  // share of K is [k_begin, k_end); the slabs are summed in z order by gemm_splitk_reduce_kernel or the next row-wise kernel
   const int k_begin = EPI == GEMM_PARTIAL ? (int)blockIdx.z * a.k_per : 0;
   const int k_end = EPI == GEMM_PARTIAL ? min(a.K, k_begin + a.k_per) : a.K;
   const bf16_t* gsrc[6];
   unsigned ldst[6];
 #pragma unroll
-  for (int p = 0; p < 2; p++) {       // 16 pieces per tile: wave w takes pieces w, w + 8 of each of the three tiles
+  for (int p = 0; p < 2; p++) {
     const int piece = wv + 8 * p, row = piece * RPP + prow;
     const int chunk = pslot ^ ((row >> 1) & 7);
     const size_t g = (size_t)min(m0 + row, a.M - 1) * a.K + chunk * 8;
     const int nb = min(n0 + row, a.N - 1);
-    const size_t brow = EPI == GEMM_SILU ? (size_t)((nb & 1) ? a.inter : 0) + (size_t)(nb >> 1) : (size_t)nb;     // gate / up rows interleaved as tile columns
+    const size_t brow = EPI == GEMM_SILU ? (size_t)((nb & 1) ? a.inter : 0) + (size_t)(nb >> 1) : (size_t)nb;
     gsrc[3 * p] = a.A_hi + g + k_begin; gsrc[3 * p + 1] = a.A_lo + g + k_begin; gsrc[3 * p + 2] = a.B + brow * a.K + chunk * 8 + k_begin;
     ldst[3 * p] = (unsigned)(piece * 1024); ldst[3 * p + 1] = ldst[3 * p] + (unsigned)(TMN * DBK * 2); ldst[3 * p + 2] = ldst[3 * p] + (unsigned)(2 * TMN * DBK * 2);
   }
@@ -418,64 +433,112 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
 #pragma unroll
     for (int q = 0; q < 6; q++) issue_piece(q, DBK, 1);
   }
+  bf16x8 fah[2], fal[2], fb[4];
+  if (DIS & 4) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) { fah[i] = bf16x8{}; fal[i] = bf16x8{}; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) fb[j] = bf16x8{};
+  }
   for (int k = 0; k < nk; k++) {
-    if (k + 1 < nk) { if (LO) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    // stage k landed = only this wave's pieces of stage k+1 may fly
+    if (k + 1 < nk && !(DIS & 2)) { if (LO) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const bool more = k + 2 < nk;
+    const bool more = k + 2 < nk && !(DIS & 2);
     const int nk0 = (k + 2) * DBK, nst = (k + 2) % NS;
     const bf16_t* st = dma_lds + (size_t)(k % NS) * STAGE;
     const bf16_t *tAh = st, *tAl = st + TMN * DBK, *tB = st + 2 * TMN * DBK;
+    const int kchunk = kq * 2 + (lane >> 5);               // this wave's k16 step of the stage
+    if (!(DIS & 4)) {
 #pragma unroll
-    for (int kl = 0; kl < 2; kl++) {                       // this wave's two k16 steps of the stage
-      const int kchunk = (2 * kh + kl) * 2 + (lane >> 5);
-      bf16x8 fah[2], fal[2], fb[2];
-#pragma unroll
-      for (int j = 0; j < 2; j++) fb[j] = frag(tB, wn * 64 + j * 32 + (lane & 31), kchunk);
+      for (int j = 0; j < 4; j++) fb[j] = frag(tB, j * 32 + (lane & 31), kchunk);
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         const int row = wm * 64 + i * 32 + (lane & 31);
         fah[i] = frag(tAh, row, kchunk);
         if (LO) fal[i] = frag(tAl, row, kchunk);
       }
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          if (LO) acc[i][j] = mfma16<DT>(fal[i], fb[j], acc[i][j]);   // small term first
-          acc[i][j] = mfma16<DT>(fah[i], fb[j], acc[i][j]);
-          if (more && (kl * 4 + i * 2 + j) < 6) issue_piece(kl * 4 + i * 2 + j, nk0, nst);     // one DMA per two MFMAs
-        }
     }
-  }
-
-  // the upper k-half's accumulators -> LDS -> added by the lower half's wave of the same quadrant
-  __builtin_amdgcn_s_barrier();
-  float* red = reinterpret_cast<float*>(dma_lds) + (size_t)(wv & 3) * 4 * 16 * 64;
-  if (kh == 1) {
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int j = 0; j < 2; j++)
+      for (int j = 0; j < 4; j++) {
+        if (!(DIS & 1)) {
+          if (LO) acc[i][j] = mfma16<DT>(fal[i], fb[j], acc[i][j]);   // small term first
+          acc[i][j] = mfma16<DT>(fah[i], fb[j], acc[i][j]);
+        }
+        if (more && (i * 4 + j) < 6) issue_piece(i * 4 + j, nk0, nst);     // one DMA per two MFMAs
+      }
+  }
+
+  // (q0 + q2) + (q1 + q3): quarters 2, 3 -> LDS -> added by quarters 0, 1 (same row half); then q0 / q1 exchange column halves
+  __builtin_amdgcn_s_barrier();
+  float* red = reinterpret_cast<float*>(dma_lds);
+  if (kq >= 2) {
+    float* dst = red + (size_t)(wv - 4) * 8 * 16 * 64;
 #pragma unroll
-        for (int r = 0; r < 16; r++) red[((i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dst[((i * 4 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
   }
   __syncthreads();
-  if (kh == 1) return;
+  if (kq >= 2) return;
+  {
+    const float* src = red + (size_t)wv * 8 * 16 * 64;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] += src[((i * 4 + j) * 16 + r) * 64 + lane];
+  }
+  __syncthreads();                                         // (the four surviving waves) quarters 2, 3 have been read: the buffer is free
+  // q0 finishes columns 0..63 (j 0, 1), q1 columns 64..127 (j 2, 3): each hands the other the half it does not finish.  (Written as two branches with
+  // constant block indices: a run-time index into the accumulator array would send it to scratch memory.)
+  auto put_half = [&](auto J0) {
+    constexpr int j0 = decltype(J0)::value;
+    float* dst = red + (size_t)wv * 4 * 16 * 64;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dst[((i * 2 + jj) * 16 + r) * 64 + lane] = acc[i][j0 + jj][r];
+  };
+  if (kq == 0) put_half(std::integral_constant<int, 2>{}); else put_half(std::integral_constant<int, 0>{});
+  __syncthreads();
+  const float* other = red + (size_t)(wv ^ 2) * 4 * 16 * 64;
+  f32x16 fin[2][2];                                          // the wave's final 64 x 64 half
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int jj = 0; jj < 2; jj++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] += red[((i * 2 + j) * 16 + r) * 64 + lane];
-
+      for (int r = 0; r < 16; r++) {
+        const float o = other[((i * 2 + jj) * 16 + r) * 64 + lane];
+        fin[i][jj][r] = kq == 0 ? acc[i][jj][r] + o : o + acc[i][2 + jj][r];      // (q0 + q2) + (q1 + q3) on both sides
+      }
+  if (DIS & 8) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) t += fin[i][jj][r];
+    if (t == 12345.678f) a.C[0] = t;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-      if (EPI == GEMM_SILU) {          // the gate_up product of a 129-384-row prompt (round 3): siluMul + 16-bit split as in the 256 x 256 kernel
-        silu_block_store<DT>(acc[i][j], lane, col, m0 + wm * 64 + i * 32, a);
+    for (int jj = 0; jj < 2; jj++) {
+      const int col = n0 + kq * 64 + jj * 32 + (lane & 31);
+      if (EPI == GEMM_SILU) {
+        silu_block_store<DT>(fin[i][jj], lane, col, m0 + wm * 64 + i * 32, a);
         continue;
       }
       if (col >= a.N) continue;
@@ -483,7 +546,7 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (row < a.M) a.part[((size_t)blockIdx.z * a.M + row) * a.N + col] = acc[i][j][r];
+          if (row < a.M) a.part[((size_t)blockIdx.z * a.M + row) * a.N + col] = fin[i][jj][r];
         }
         continue;
       }
@@ -492,7 +555,7 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
       for (int r = 0; r < 16; r++) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= a.M) continue;
-        const float v = acc[i][j][r] + bv;
+        const float v = fin[i][jj][r] + bv;
         float* dst = a.C + (size_t)row * a.ldc + col;
         *dst = (EPI == GEMM_RESIDUAL) ? (*dst + v) : v;
       }
