@@ -50,6 +50,9 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
 
 // defer (optional, RESIDUAL / STORE products): when the product is split over K, leave the slabs in ws_part for the consumer kernel to sum
 // (rmsnorm_split_kernel / rope_kv_split_kernel: same z order, one launch and one pass over the rows less) and report the slab count; 1 = done here.
+// -1 (round 5, option prefill.defer_store): the UNSPLIT eight-wave N = hidden product stored its result as ONE slab instead of adding it to the residual
+// stream in its epilogue — a read-modify-write of M x N floats by four waves per CU at the end of a launch that has one tile per CU (nothing left to overlap
+// it: 18-19 of o_proj's 52 us, tools/probes/gemm_lab.hip); the row-wise norm kernel that reads the stream next adds the slab while it streams.
 static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float* C, int M, int N, int K, int ldc, bool three_terms = false,
                  const bf16_t* a_hi = nullptr, const bf16_t* a_lo = nullptr, int three_from = 0, int* defer = nullptr) {
   if (defer) *defer = 1;
@@ -93,7 +96,12 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
     }
     if (z >= 2) { part_8k = true; nsplit = z; }
   }
-  if (nsplit > 1) {
+  // one tile per CU on the eight-wave 128 x 128 kernel, a consumer that can take a pending slab: store the product, let the consumer add it (see `defer` above)
+  const int t128u = ((N + 127) / 128) * ((M + 127) / 128);
+  const bool store_slab = nsplit == 1 && defer && c->defer_store && c->defer_reduce && epi == tgx::GEMM_RESIDUAL && (c->gemm_dma & 8) && K % 64 == 0 && !three_terms &&
+                          2 * t128u >= c->num_cus && 2 * t128u <= 3 * c->num_cus &&
+                          !((c->gemm_dma & 4) && c->hidden_256 && ((N + 255) / 256) * ((M + 255) / 256) >= c->num_cus);
+  if (nsplit > 1 || store_slab) {
     const size_t need = (size_t)nsplit * M * N * 4;
     if (need > c->ws_part_bytes) {
       drop_step_graphs(c);              // a captured batched decode step points into the old slab buffer
@@ -102,6 +110,14 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
       c->ws_part = nullptr; c->ws_part_bytes = 0;
       if (hipMalloc((void**)&c->ws_part, need) == hipSuccess) c->ws_part_bytes = need; else nsplit = 1;
     }
+  }
+  if (store_slab && c->ws_part_bytes >= (size_t)M * N * 4) {
+    g.part = c->ws_part; g.nsplit = 1; g.interleave = 0; g.k_per = K;
+    const dim3 g8((N + 127) / 128, (M + 127) / 128, 1), b8(512);
+    const size_t lds8 = (size_t)3 * 3 * 128 * 64 * 2;
+    TGX_DT16_SWITCH(c->dt, if (one_k) hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_PARTIAL, false>), g8, b8, lds8, c->stream, g); else hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_PARTIAL>), g8, b8, lds8, c->stream, g);)
+    *defer = -1;
+    return;
   }
   if (nsplit > 1) {
     g.part = c->ws_part; g.nsplit = nsplit; g.interleave = epi == tgx::GEMM_SILU ? 1 : 0;
@@ -272,7 +288,7 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
   // GPT-2 (ModelGPT2.h:23-208): wte + wpe rows, LayerNorm with bias ahead of both products, a bias on every Conv1D, c_fc -> gelu_new;
   // its rotation tables are the identity, so the RoPE / cache-append kernel and the attention are the Llama family's
   TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_rows_any_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const long long*)c->rows[(size_t)row0].prompt, (const void*)c->embed, (const void*)(c->gpt2 ? c->wpe : nullptr), c->ws_x, H, S, (long long)d.max_ctx, (int)c->past))
-  int pend = 1;                     // slabs of the previous layer's down product still to be added to ws_x (1: none)
+  int pend = 1;                     // slabs of the previous layer's down product still to be added to ws_x (1: none; -1: one whole-K slab, see launch_gemm)
   const bf16_t* pend_bias = nullptr;
   for (int l = 0; l < d.layers; l++) {
     const LayerW& w = c->L[(size_t)l];
@@ -281,7 +297,7 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
     const bool three = c->dt == tgx::DT_BF16;
     if (c->gpt2) { TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::norm_rows_kernel<DT, 1, 1>), dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const void*)w.in_norm, (const void*)w.in_norm_b, d.norm_eps, H, (float*)nullptr, c->ws_ah, c->ws_al, three ? c->ws_al2 : (bf16_t*)nullptr)) }
     else { TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, c->ws_x, (const bf16_t*)w.in_norm, d.norm_eps, H, c->ws_ah, c->ws_al, three ? c->ws_al2 : (bf16_t*)nullptr,
-                                                  (const float*)(pend > 1 ? c->ws_part : nullptr), pend, (long long)M * H, pend_bias)) }
+                                                  (const float*)(pend != 1 ? c->ws_part : nullptr), std::abs(pend), (long long)M * H, pend_bias)) }
     pend = 1;
     int qsl = 1;
     launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, M, qd + 2 * kvd, H, qd + 2 * kvd, /*three_terms=*/three, nullptr, nullptr, /*three_from=*/qd, &qsl);   // Q columns: two terms
@@ -317,7 +333,7 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
       launch_gemm(c, tgx::GEMM_GELU, w.wgu, w.bfc, nullptr, M, I, H, I);             // c_fc + bias + gelu_new -> ws_hh / ws_hl
     } else {
       TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al, (bf16_t*)nullptr,
-                                                (const float*)(osl > 1 ? c->ws_part : nullptr), osl, (long long)M * H, reinterpret_cast<const bf16_t*>(w.bo)))
+                                                (const float*)(osl != 1 ? c->ws_part : nullptr), std::abs(osl), (long long)M * H, reinterpret_cast<const bf16_t*>(w.bo)))
       launch_gemm(c, tgx::GEMM_SILU, w.wgu, nullptr, nullptr, M, 2 * I, H, 2 * I);      // gate_up + siluMul -> ws_hh / ws_hl
     }
     // the down product's slabs wait for the next layer's input norm (the last layer, and GPT-2's LayerNorm path, finish them here)
