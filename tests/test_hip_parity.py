@@ -530,6 +530,37 @@ def test_direct_attention_equals_split(name, lens, hip):
             assert rel_err(outs[1][3], outs[0][3]) < tol, (layers, n, rel_err(outs[1][3], outs[0][3]))
 
 
+@pytest.mark.parametrize("name,lens,sliced", [("llama-3.2-1b", (200, 900, 2100), 1), ("llama-3.2-1b", (900,), 0), ("qwen2.5-0.5b", (300, 1500), 1), ("mistral-7b-v0.3", (600,), 0)])
+def test_split_attention_heads_per_workgroup_do_not_change_the_result(name, lens, sliced, hip):
+    """The query heads of a kv group go to split-form workgroups 1, 2 or 4 at a time (option attn.gmax; round 5: one per workgroup for a batch-1 step, measured
+    0.4-1.5 % faster on every BASELINE geometry).  Each head's keys, splits and merge are the same whichever workgroup runs it: one layer (no cache entry has a
+    schedule-dependent input) to fp32 rounding, two layers within the bf16 flip floor of a toy; greedy ids equal.  Behind the K-sliced o_proj (head_dim 64) and
+    behind combine + row-sliced o_proj."""
+    import copy
+    from tinygpt_amd import known_desc, synth
+    from tinygpt_amd.ffi import Model
+    for layers in (1, 2):
+        d = copy.deepcopy(known_desc(name))
+        d.layers, d.vocab, d.max_ctx = layers, 4096, 2304
+        tol = 2e-6 if layers == 1 else 2e-4
+        m = Model(d, hip).load_synthetic(1234, 0.02).finalize()
+        m.set_option("oproj.sliced", sliced)
+        m.set_option("attn.direct_max", 0)             # the split form at every context
+        gfull = d.heads // d.kv_heads
+        for n in lens:
+            prompt = synth.synth_prompt(d.vocab, n, 300 + n)[None, :]
+            outs = []
+            for g in [g for g in (1, 2, 4) if g <= max(gfull, 1)]:
+                m.set_option("attn.gmax", g)
+                m.reset_cache(); m.forward(prompt)
+                first = m.sample(GREEDY).copy()
+                ids = m.decode(4, GREEDY).copy()
+                outs.append((first, ids, m.logits(rounded=False).copy()))
+            for o in outs[1:]:
+                np.testing.assert_array_equal(o[0], outs[0][0]); np.testing.assert_array_equal(o[1], outs[0][1])
+                assert rel_err(o[2], outs[0][2]) < tol, (layers, n, rel_err(o[2], outs[0][2]))
+
+
 @pytest.mark.parametrize("name,lens,batch,dtype", [("llama-3.2-1b", (1, 127, 128, 129, 1500, 1536, 2047, 3100), 1, "bf16"), ("llama-3.2-1b", (130, 900), 2, "bf16"),
                                                    ("qwen2.5-0.5b", (63, 300, 1100, 2500), 1, "bf16"), ("qwen2.5-0.5b", (700,), 1, "fp16"), ("llama-3.2-1b", (900,), 3, "bf16")])
 def test_k_sliced_o_proj_with_the_attention_merge_equals_combine_plus_o_proj(name, lens, batch, dtype, hip):

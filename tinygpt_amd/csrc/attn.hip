@@ -17,7 +17,10 @@ static void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R, bool combine) {
   // merges) is what a workgroup's time grows with, while the K/V tile the groups re-read is small and mostly L2-resident.
   // Measured (option attn.gmax; tok/s at 4 / 2 / 1 heads per workgroup): Llama-3.2-1B ctx 2.3k 1364 / 1391 / 1388, ctx 8k
   // 1282 / 1312 / 1295; Qwen2.5-0.5B (7 heads per kv head) 1512 / 1610 / 1621; Mistral-7B 337 / 340 / 339
-  const int gmax = c->attn_gmax > 0 ? c->attn_gmax : 2;
+  // Round 5 (after round 4's single LDS meeting of the token-slot streams; tools/sweep.py --grid attn.gmax=1,2, batch 1, ms per token at 1 / 2 heads per workgroup):
+  // Llama-3.2-1B context 0.9k 0.6559 / 0.6591, 1.2k 0.6546 / 0.6574, 2.2k 0.6525 / 0.6570 (three runs each, spread 0.0002), 4.3k 0.6767 / 0.6847; Qwen2.5-0.5B 2.2k
+  // 0.5935 / 0.5967; Mistral-7B 2.9312 / 2.9370; Llama-3.2-3B 1.6084 / 1.6322 — one head per workgroup for a batch-1 step, two when rows share the launch
+  const int gmax = c->attn_gmax > 0 ? c->attn_gmax : (R == 1 ? 1 : 2);
   const int gfull = a.heads / a.kv_heads, ngroups = gfull > gmax ? (gfull + gmax - 1) / gmax : 1, G = (gfull + ngroups - 1) / ngroups;
   a.gfull = gfull;
   a.direct = c->attn_direct ? 1 : 0;
