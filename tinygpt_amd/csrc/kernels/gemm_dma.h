@@ -235,7 +235,11 @@ __device__ __forceinline__ void xcd_tile(const GemmArgs& a, int& tm, int& tn) {
 // LO = false (option act.round16: the Linear's input is rounded to the storage dtype, so A_hi IS the activation): the A_lo tile is neither staged nor
 // multiplied — 4 DMA pieces per stage instead of 6, half the MFMAs (gate_up at S = 2048: 232 -> 130 us, profiles/r04_act16_cost.txt)
 // DIS (lab only): 1 = no MFMAs, 2 = no DMA after the prologue, 4 = no fragment reads, 8 = no epilogue stores.
-template <int DT, int EPI, bool LO = true, int WJ = 4, int DIS = 0>
+// TEPI (round 5, GEMM_SILU with WJ = 4): the siluMul epilogue goes through LDS.  In the MFMA C layout a lane ends up with ONE (gate, up) result per row pair, so the
+// direct epilogue stores 2 bytes per lane, 32 contiguous bytes per row and instruction — 128 store instructions per wave and term, a quarter of a line each.  Here every wave
+// writes its 64 x 64 results (hi and lo) into its own 18-KB slice of the idle ring ([64 rows][72]: 144-byte rows keep the 16-byte reads aligned and the row pairs off each
+// other's banks), reads them back eight outputs per lane and stores whole 128-byte rows: 16 store instructions per wave.  Same values, same rounding.
+template <int DT, int EPI, bool LO = true, int WJ = 4, int DIS = 0, bool TEPI = true>
 __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
   constexpr int DBK = 32, CPR = 4, RPP = 16, TMN = 256, NS = 3;
   constexpr int WI = 8 / WJ, NWN = TMN / (32 * WJ);      // 32 x 32 blocks per wave along M / N, waves along N
@@ -349,6 +353,46 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) t += acc[i][j][r];
     if (t == 12345.678f) a.C[0] = t;
+    return;
+  }
+  if constexpr (EPI == GEMM_SILU && TEPI && WJ == 4) {
+    constexpr int RS = 72;                                   // 16-bit elements per staged row (64 results + 8 of padding)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the trailing fragment reads of the ring
+    __builtin_amdgcn_s_barrier();                            // ... by every wave: the ring is free
+    bf16_t* sh = dma_lds + (size_t)wv * (2 * 64 * RS);       // this wave's slice: hi rows, then lo rows
+    bf16_t* sl = sh + 64 * RS;
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int i = 0; i < WI; i++)
+#pragma unroll
+      for (int j = 0; j < WJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {                     // as silu_block_store: the even lane finishes row r, the odd lane row r + 1 of the column pair
+          const float a0 = acc[i][j][r], a1 = acc[i][j][r + 1];
+          const float recv = dpp_mov<0xB1, 0xf>(odd ? a0 : a1);
+          const float g = odd ? recv : a0, u = odd ? a1 : recv;
+          const int rl = i * 32 + (r & 3) + (odd ? 1 : 0) + 8 * (r >> 2) + 4 * (lane >> 5);
+          bf16_t hi, lo;
+          split16<DT>(silu_mul_fast(g, u), hi, lo);
+          const int o = rl * RS + j * 16 + ((lane & 31) >> 1);
+          sh[o] = hi; sl[o] = lo;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave reads only what it wrote itself: no workgroup barrier
+    const int oc0 = (n0 + wn * 128) / 2 + (lane & 7) * 8;     // first of this lane's eight outputs
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+      const int rl = p * 8 + (lane >> 3), row = m0 + wm * 64 + rl;
+      const u32x4 vh = *reinterpret_cast<const u32x4*>(sh + rl * RS + (lane & 7) * 8);
+      const u32x4 vl = *reinterpret_cast<const u32x4*>(sl + rl * RS + (lane & 7) * 8);
+      if (row < a.M && 2 * oc0 + 15 < a.N) {
+        *reinterpret_cast<u32x4*>(a.out_hi + (size_t)row * a.inter + oc0) = vh;
+        *reinterpret_cast<u32x4*>(a.out_lo + (size_t)row * a.inter + oc0) = vl;
+      } else if (row < a.M) {                                  // a ragged last tile column: element by element
+        const bf16_t* eh = reinterpret_cast<const bf16_t*>(&vh); const bf16_t* el = reinterpret_cast<const bf16_t*>(&vl);
+        for (int e = 0; e < 8; e++)
+          if (2 * (oc0 + e) + 1 < a.N) { a.out_hi[(size_t)row * a.inter + oc0 + e] = eh[e]; a.out_lo[(size_t)row * a.inter + oc0 + e] = el[e]; }
+      }
+    }
     return;
   }
 #pragma unroll

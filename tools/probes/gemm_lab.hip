@@ -64,6 +64,8 @@ int main(int argc, char** argv) {
   // kernels under test
   auto k8_res = gemm_dma8_kernel<DT_BF16, GEMM_RESIDUAL>; auto k8_silu = gemm_dma8_kernel<DT_BF16, GEMM_SILU>;
   auto w2_silu = gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 2>;          // rounds 2-4: wave = 128 x 64
+  auto k8_silu_direct = gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 0, false>;    // the direct (2 bytes per lane) siluMul epilogue
+  set_lds(k8_silu_direct, LDS8);
   auto k8k_res = gemm_dma8k_kernel<DT_BF16, GEMM_RESIDUAL>;
   set_lds(k8_res, LDS8); set_lds(k8_silu, LDS8); set_lds(w2_silu, LDS8); set_lds(k8k_res, LDS8K);
 #define DISK(name, kern, lds) auto name = kern; set_lds(name, lds);
@@ -109,11 +111,15 @@ int main(int argc, char** argv) {
     auto check = [&](const char* name, auto launch, bool silu) {
       std::vector<float> r(1 << 16), t(1 << 16);
       if (silu) {
-        CK(hipMemset(b.oh, 0, nC)); launch(0, b.C); CK(hipDeviceSynchronize());
+        CK(hipMemset(b.oh, 0, nC)); CK(hipMemset(b.ol, 0, nC)); launch(0, b.C); CK(hipDeviceSynchronize());
         std::vector<uint16_t> x(1 << 16), y(1 << 16);
         CK(hipMemcpy(x.data(), b.oh, x.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(y.data(), (uint16_t*)b.Cref, y.size() * 2, hipMemcpyDeviceToHost));
         size_t bad = 0; for (size_t i = 0; i < x.size(); i++) bad += x[i] != y[i];
-        printf("  check %-52s %zu of %zu hi words differ from the product kernel\n", name, bad, x.size());
+        std::vector<uint16_t> xl(1 << 16), yl(1 << 16);
+        CK(hipMemcpy(xl.data(), (uint16_t*)b.ol + ((size_t)s.M * s.N / 2 - xl.size()), xl.size() * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(yl.data(), (uint16_t*)b.Cref + (size_t)s.M * s.N / 2 + ((size_t)s.M * s.N / 2 - yl.size()), yl.size() * 2, hipMemcpyDeviceToHost));
+        size_t badl = 0; for (size_t i = 0; i < xl.size(); i++) badl += xl[i] != yl[i];
+        printf("  check %-52s %zu of %zu hi words (first rows) + %zu of %zu lo words (last rows) differ from the product kernel\n", name, bad, x.size(), badl, xl.size());
       } else {
         CK(hipMemset(b.C, 0, nC * 4)); launch(0, b.C); CK(hipDeviceSynchronize());
         CK(hipMemcpy(t.data(), b.C, t.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(r.data(), b.Cref, r.size() * 4, hipMemcpyDeviceToHost));
@@ -138,6 +144,9 @@ int main(int argc, char** argv) {
       base(0, b.Cref); CK(hipDeviceSynchronize());
       report("(clock warm-up pass, not a figure)", time_us(reps, [&](int l) { base(l); }));
       report("product: gemm_dma8 (256x256, wave = 64 x 128)", time_us(reps, [&](int l) { base(l); }));
+      check("direct siluMul epilogue (must be bit-identical)", L(k8_silu_direct, g256, LDS8), true);
+      report("gemm_dma8 with the direct siluMul epilogue (2-byte stores)", time_us(reps, [&](int l) { L(k8_silu_direct, g256, LDS8)(l); }));
+      report("product again (LDS-transposed epilogue, 16-byte stores)", time_us(reps, [&](int l) { base(l); }));
       check("wave = 128 x 64 (rounds 2-4; must be bit-identical)", L(w2_silu, g256, LDS8), true);
       report("gemm_dma8 WJ 2 (wave = 128 x 64, rounds 2-4)", time_us(reps, [&](int l) { L(w2_silu, g256, LDS8)(l); }));
       check("gemm_dma8i (full lines: interleaved A, k64 B units)", LI(i_silu), true);
