@@ -33,6 +33,11 @@ struct Backend {
   int64_t (*past_length)(const tgx_ctx*) = nullptr;
   int64_t (*context_size)(const tgx_ctx*) = nullptr;
   const char* (*last_error)(const tgx_ctx*) = nullptr;
+  // per-row sequence lifecycle (include/tgx.h ABI 3; optional: a backend without them serves whole-batch generation only)
+  int (*reset_row)(tgx_ctx*, int) = nullptr;
+  int (*forward_row)(tgx_ctx*, int, const int64_t*, int) = nullptr;
+  int (*sample_row)(tgx_ctx*, int, const tgx_sampler_cfg*, uint64_t, int64_t*) = nullptr;
+  int64_t (*past_length_row)(const tgx_ctx*, int) = nullptr;
 
   bool open(const std::string& path, const std::string& prefix) {
     // RTLD_NODELETE: the shim's runtime owns threads (HIP's signal/event workers; libgomp's team under the CPU oracle) that
@@ -51,6 +56,7 @@ struct Backend {
     TGXH_BIND(forward, true); TGXH_BIND(read_logits, true); TGXH_BIND(sample, true); TGXH_BIND(decode, true);
     TGXH_BIND(step_async, false); TGXH_BIND(fetch_token, false);
     TGXH_BIND(reset_cache, true); TGXH_BIND(past_length, true); TGXH_BIND(context_size, true); TGXH_BIND(last_error, true);
+    TGXH_BIND(reset_row, false); TGXH_BIND(forward_row, false); TGXH_BIND(sample_row, false); TGXH_BIND(past_length_row, false);
 #undef TGXH_BIND
     return ok;
   }
