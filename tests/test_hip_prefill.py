@@ -173,3 +173,26 @@ def test_gate_up_on_128_tiles_where_the_256_tiling_is_ragged(name, S):
     # another schedule of the QKV product moves K / V entries across 16-bit rounding boundaries in THIS layer's cache: the two-layer bound of the form tests
     assert rel_err(outs[3][0], outs[1][0]) < 2e-4, rel_err(outs[3][0], outs[1][0])
     np.testing.assert_array_equal(outs[3][1], outs[1][1])
+
+
+@pytest.mark.parametrize("name,S,dtype", [("llama-3.2-1b", 300, "bf16"), ("llama-3.2-1b", 777, "fp16"), ("qwen2.5-0.5b", 257, "bf16"),
+                                          ("mistral-7b-v0.3", 300, "bf16"), ("llama-3.2-3b", 200, "fp16"), ("qwen3-1.7b", 333, "bf16")])
+def test_prefill_attention_forms_agree(name, S, dtype):
+    """Round 5: the two other schedules of the prompt attention — K / V tiles by LDS-DMA with the next tile's scores under the current softmax (head_dim 64,
+    kernels/attn_prefill_dma.h: the same matrix instructions on the same operands in the same order -> BIT-identical) and the key split inside the workgroup
+    (attn_prefill_kernel KP = 2: the odd tiles' online-softmax stream merged once at the end -> another fp32 summation order, 2e-5 on one layer) — forced on prompts
+    that are ragged in the 128-query blocks and in the 64-key tiles.  The defaults take these forms only for long prompts / head_dim 128."""
+    d = copy.deepcopy(known_desc(name, dtype))
+    d.layers, d.vocab, d.max_ctx = 1, 4096, S + 16
+    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    prompt = synth.synth_prompt(d.vocab, S, 80)[None, :]
+    outs = {}
+    for form, (dma, ks) in {"plain": (0, 0), "dma": (2, 0), "ksplit": (0, 2), "plain2": (0, 0)}.items():
+        m.set_option("prefill.attn_dma", dma); m.set_option("prefill.attn_ksplit", ks)
+        m.reset_cache(); m.forward(prompt)
+        outs[form] = (m.logits(rounded=False).copy(), m.sample(GREEDY).copy())
+    np.testing.assert_array_equal(outs["plain"][0], outs["plain2"][0])
+    if d.head_dim == 64:
+        np.testing.assert_array_equal(outs["dma"][0], outs["plain"][0])
+    assert rel_err(outs["ksplit"][0], outs["plain"][0]) < 2e-5, rel_err(outs["ksplit"][0], outs["plain"][0])
+    np.testing.assert_array_equal(outs["ksplit"][1], outs["plain"][1])

@@ -239,7 +239,7 @@ __device__ __forceinline__ void xcd_tile(const GemmArgs& a, int& tm, int& tn) {
 // direct epilogue stores 2 bytes per lane, 32 contiguous bytes per row and instruction — 128 store instructions per wave and term, a quarter of a line each.  Here every wave
 // writes its 64 x 64 results (hi and lo) into its own 18-KB slice of the idle ring ([64 rows][72]: 144-byte rows keep the 16-byte reads aligned and the row pairs off each
 // other's banks), reads them back eight outputs per lane and stores whole 128-byte rows: 16 store instructions per wave.  Same values, same rounding.
-template <int DT, int EPI, bool LO = true, int WJ = 4, int DIS = 0, bool TEPI = true>
+template <int DT, int EPI, bool LO = true, int WJ = 4, int DIS = 0, bool TEPI = true, int PP = 0>
 __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
   constexpr int DBK = 32, CPR = 4, RPP = 16, TMN = 256, NS = 3;
   constexpr int WI = 8 / WJ, NWN = TMN / (32 * WJ);      // 32 x 32 blocks per wave along M / N, waves along N
@@ -262,6 +262,9 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int prow = lane / CPR, pslot = lane % CPR;
+  // GEMM_PARTIAL: blockIdx.z covers k_per elements of K and stores its fp32 tile to slab z (the N = hidden products with K >> N: `down` as 64 tiles x 4 slabs)
+  const int k_begin = EPI == GEMM_PARTIAL ? (int)blockIdx.z * a.k_per : 0;
+  const int k_end = EPI == GEMM_PARTIAL ? min(a.K, k_begin + a.k_per) : a.K;
   const bf16_t* gsrc[6];
   unsigned ldst[6];
 #pragma unroll
@@ -271,14 +274,14 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
     const size_t g = (size_t)min(m0 + row, a.M - 1) * a.K + chunk * 8;
     const int nb = min(n0 + row, a.N - 1);
     const size_t brow = inter ? (size_t)((nb & 1) ? a.inter : 0) + (size_t)(nb >> 1) : (size_t)nb;
-    gsrc[3 * p] = a.A_hi + g; gsrc[3 * p + 1] = a.A_lo + g; gsrc[3 * p + 2] = a.B + brow * a.K + chunk * 8;
+    gsrc[3 * p] = a.A_hi + g + k_begin; gsrc[3 * p + 1] = a.A_lo + g + k_begin; gsrc[3 * p + 2] = a.B + brow * a.K + chunk * 8 + k_begin;
     ldst[3 * p] = (unsigned)(piece * 1024); ldst[3 * p + 1] = ldst[3 * p] + (unsigned)(TMN * DBK * 2); ldst[3 * p + 2] = ldst[3 * p] + (unsigned)(2 * TMN * DBK * 2);
   }
-  const int nk = a.K / DBK;
+  const int nk = (k_end - k_begin) / DBK;
   const int klast = (nk - 1) * DBK;
   auto issue_piece = [&](int q, int s) {
     if (!LO && q % 3 == 1) return;
-    if ((DIS & 2) && s > 2) return;
+    if ((DIS & 2) && s > ((PP & 1) ? 1 : 2)) return;
     dma_1k(gsrc[q] + min(s * DBK, klast), lds_base + (unsigned)((s % NS) * STAGE * 2) + ldst[q]);
   };
   const int swz = ((lane & 31) >> 2) & 3;
@@ -312,6 +315,70 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
     }
   };
 
+  if constexpr (PP & 1) {
+    // ---- ping-pong form (round 5): the two waves of a SIMD (w and w + 4: a workgroup's waves are dealt to the SIMDs cyclically) work half a stage apart —
+    // while one runs the 32 MFMAs of its k32 stage back to back, the other issues its six DMA pieces of stage s + 2 and reads its sixteen fragments of the next stage.
+    // A phase ends with one workgroup barrier; group 1 (waves 4-7) enters one phase late.  Stage s is read in phases 2s (group 0) and 2s + 1 (group 1); its buffer
+    // is refilled (stage s + 3) from phase 2s + 2 on.  Same MFMAs per accumulator in the same order: bit-identical to the lock-step loop below.
+    const int grp = wv >> 2;
+#pragma unroll
+    for (int q = 0; q < 6; q++) issue_piece(q, 0);
+#pragma unroll
+    for (int q = 0; q < 6; q++) issue_piece(q, 1);
+    bf16x8 fa[2][2 * WI], fb[2][WJ];
+    if (DIS & 4) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int i = 0; i < 2 * WI; i++) fa[h][i] = bf16x8{};
+#pragma unroll
+        for (int j = 0; j < WJ; j++) fb[h][j] = bf16x8{};
+      }
+    }
+    if (LO) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // stage 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    if (PP & 4) { if (grp) __builtin_amdgcn_s_setprio(1); }
+    if (grp) __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < nk; s++) {
+      // memory phase
+      if (PP & 8) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) issue_piece(q, s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      read_frags(s, 0, fa[0], fb[0]);
+      read_frags(s, 1, fa[1], fb[1]);
+      if (!(PP & 8)) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) issue_piece(q, s + 2);
+      }
+      // stage s + 1 landed = only the pieces just issued may fly; this wave's fragment reads are complete (the buffer is refilled two phases on)
+      if (DIS & 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      else if (LO) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // matrix phase
+      if (PP & 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int i = 0; i < WI; i++)
+#pragma unroll
+          for (int j = 0; j < WJ; j++) {
+            if (!(DIS & 1)) {
+              if (LO) acc[i][j] = mfma16<DT>(fa[h][2 * i + 1], fb[h][j], acc[i][j]);   // small term first
+              acc[i][j] = mfma16<DT>(fa[h][2 * i], fb[h][j], acc[i][j]);
+            }
+          }
+      if (PP & 2) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!grp) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
 #pragma unroll
   for (int q = 0; q < 6; q++) issue_piece(q, 0);
 #pragma unroll
@@ -343,6 +410,8 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
     mfma_step(fa1, fb1, 0, k + 3);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  }
 
   if (DIS & 8) {            // lab: no epilogue — every accumulator still feeds one value, so no MFMA chain is dead code
     float t = 0.f;
@@ -405,6 +474,14 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
         continue;
       }
       if (col >= a.N) continue;
+      if (EPI == GEMM_PARTIAL) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + wm * 32 * WI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < a.M) a.part[((size_t)blockIdx.z * a.M + row) * a.N + col] = acc[i][j][r];
+        }
+        continue;
+      }
       const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r++) {

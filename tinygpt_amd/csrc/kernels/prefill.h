@@ -487,6 +487,7 @@ struct AttnPrefillArgs {
   int S, heads, kv_heads, max_ctx, past;
   float scale;                   // hd^-1/2
   int qblk_mirror;               // 1: see the block order in the kernel
+  int heavy_first;               // 1 (the key-split form): grid = (heads, query blocks), blockIdx.y = rank of the block from the heaviest down — see the kernel
 };
 
 // Scores and probabilities never leave the registers (the first version of this round routed them through LDS with four
@@ -503,8 +504,14 @@ struct AttnPrefillArgs {
 #endif
 // LA = K / V tiles of look-ahead.  2 (two register sets) is the faster form while a CU holds two workgroups (S <= ~2k: 61 vs 65 µs per layer at 2048);
 // long prompts give every CU three or more, and the leaner LA = 1 form (162 VGPRs) then runs three waves per SIMD: 251 -> 203 µs per layer at S = 4096, 820 -> 720 at 8192.
-template <int DT, int HD, int LA = 2>
-__global__ __launch_bounds__(256, LA == 1 ? (HD == 64 ? 3 : 2) : 1) void attn_prefill_kernel(const AttnPrefillArgs a) {      // head_dim 128: LA = 1 fits two waves per SIMD (LA = 2 needs 292 registers: one)
+// KP = key split inside the workgroup (round 5).  A wave walks its tiles one after the other (QK^T chain -> softmax -> PV chain: ~2-3 thousand cycles per tile
+// whatever else the CU does), so a workgroup's time is tiles x that latency, and at S = 2048 the grid is ONE round of 512 workgroups whose last query block walks
+// 32 tiles: the launch lasted as long as its heaviest workgroup (56-64 us) although the CUs' average load is half of that.  KP = 2: eight waves — waves 4-7 repeat
+// the query sub-blocks of waves 0-3 on the ODD tiles, 0-3 take the even ones; two tiles are staged per barrier pair; the two online-softmax streams of a
+// query meet once, through LDS, after the loop ((m, l, O) merged as flash-decoding does).  One workgroup per CU instead of two, the same matrix work per CU and
+// cycle, half the chain; blocks are dispatched heaviest first (AttnPrefillArgs.heavy_first) so that the second round fills the CUs as they free up.
+template <int DT, int HD, int LA = 2, int KP = 1>
+__global__ __launch_bounds__(256 * KP, KP == 2 ? 2 : (LA == 1 ? (HD == 64 ? 3 : 2) : 1)) void attn_prefill_kernel(const AttnPrefillArgs a) {      // head_dim 128: LA = 1 fits two waves per SIMD (LA = 2 needs 292 registers: one)
   constexpr int DIS = TGX_ATTN_DIS;
   constexpr int LQ = HD + 8;                  // 16-bit row stride of the K tile (144 / 272 B: conflict-free 16-byte fragment reads)
   constexpr int LV = HD + 32;                 // 16-bit row stride of the V tile ([key][d], 64 B more than a row: the four key rows of a transposing read fall on four bank quarters)
@@ -513,16 +520,18 @@ __global__ __launch_bounds__(256, LA == 1 ? (HD == 64 ? 3 : 2) : 1) void attn_pr
   constexpr int CH = HD / 8;                  // 16-byte chunks per head row
   constexpr int NCH = 64 * CH / 256;          // chunks per thread and tile
   constexpr float LOG2E = 1.4426950408889634f;
-  __shared__ __attribute__((aligned(16))) bf16_t smem[64 * LQ + 64 * LV];     // K tile | V tile; the output rows pass through it at the end
-  bf16_t* const sK = smem;
-  bf16_t* const sV = smem + 64 * LQ;
+  constexpr int REG = 64 * LQ + 64 * LV;      // one K tile | V tile pair, 16-bit elements
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];     // KP x (K tile | V tile); the output rows (and the KP = 2 merge) pass through it at the end
+  const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, kp = tid >> 8, hh = lane >> 5, ql = lane & 31;      // kp: this wave's tile parity (0 when KP == 1)
+  bf16_t* const sK = smem + kp * REG;          // the tile this wave multiplies — and the one its thread group stages
+  bf16_t* const sV = sK + 64 * LQ;
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5, ql = lane & 31;
-  const int h = blockIdx.y, G = a.heads / a.kv_heads, kvh = h / G;
+  const int h = a.heavy_first ? blockIdx.x : blockIdx.y, G = a.heads / a.kv_heads, kvh = h / G;
   const int qd = a.heads * HD;
   // causal work grows with the query block: the upper half of the heads walks the blocks in reverse, so that workgroups b and b + half
-  // the grid (which tend to share a CU) carry complementary amounts
-  const int qblk = (a.qblk_mirror && h >= a.heads / 2) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  // the grid (which tend to share a CU) carry complementary amounts.  heavy_first: every head's last block first (linear workgroup order = dispatch order)
+  const int qblk = a.heavy_first ? (int)gridDim.y - 1 - (int)blockIdx.y
+                                 : ((a.qblk_mirror && h >= a.heads / 2) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
   const int q0 = qblk * 128 + wv * 32;                 // first query of this wave
   const int qi = q0 + ql;                              // this lane's query
   const bool qvalid = qi < a.S;
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(256, LA == 1 ? (HD == 64 ? 3 : 2) : 1) void attn_pr
   const bf16_t* kbase = a.k_cache + (size_t)kvh * a.max_ctx * HD;
   const bf16_t* vbase = a.v_cache + (size_t)kvh * a.max_ctx * HD;
   const int wg_last_pos = a.past + min(qblk * 128 + 127, a.S - 1);   // keys beyond it are never attended by this workgroup
-  const int n_kt = wg_last_pos / 64 + 1;
+  const int n_kt = (wg_last_pos / 64 + 1 + KP - 1) / KP;      // steps of KP tiles
   const int wave_last_pos = a.past + min(q0 + 31, a.S - 1);
   const bool wave_live = q0 < a.S;
   const float qs = a.scale * LOG2E;
@@ -559,11 +568,12 @@ __global__ __launch_bounds__(256, LA == 1 ? (HD == 64 ? 3 : 2) : 1) void attn_pr
   // tile of look-ahead a workgroup's tile time was the load latency itself (~2.4 µs per tile, MfmaUtil 16 %) whatever the arithmetic cost.
   // Keys past the workgroup's range are clamped to its last key (a written cache row: finite values, masked by index below).
   u32x4 kvA[NCH], vvA[NCH], kvB[NCH], vvB[NCH];
+  // (KP = 2: step kt = tiles 2 kt and 2 kt + 1; thread group kp fetches, stages and multiplies tile 2 kt + kp)
   auto fetch_tile = [&](int kt, u32x4* kr, u32x4* vr) {
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
-      const int c = tid + 256 * i, row = c / CH, kc = c - row * CH;
-      const int key = min(kt * 64 + row, wg_last_pos);
+      const int c = (tid & 255) + 256 * i, row = c / CH, kc = c - row * CH;
+      const int key = min((KP * kt + kp) * 64 + row, wg_last_pos);
       kr[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * HD + kc * 8);
       __builtin_amdgcn_sched_barrier(0);       // the same issue order at every call site: the counted vmcnt waits rely on it
       vr[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * HD + kc * 8);
@@ -573,7 +583,7 @@ __global__ __launch_bounds__(256, LA == 1 ? (HD == 64 ? 3 : 2) : 1) void attn_pr
   auto stage_tile = [&](const u32x4* kr, const u32x4* vr) {
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
-      const int c = tid + 256 * i, row = c / CH, kc = c - row * CH;
+      const int c = (tid & 255) + 256 * i, row = c / CH, kc = c - row * CH;
       const u32x4 kv = kr[i], vv = vr[i];
       *reinterpret_cast<u32x4*>(&sK[row * LQ + kc * 8]) = kv;
       *reinterpret_cast<u32x4*>(&sV[row * LV + kc * 8]) = vv;       // V stays [key][d]: the PV step reads it with the transposing LDS read
@@ -584,7 +594,7 @@ __global__ __launch_bounds__(256, LA == 1 ? (HD == 64 ? 3 : 2) : 1) void attn_pr
   for (int r = 0; r < 16; r++) zero16[r] = 0.f;
 
   auto compute_tile = [&](int kt) {
-    const int key0 = kt * 64;
+    const int key0 = (KP * kt + kp) * 64;
     if (!wave_live || key0 > wave_last_pos) return;      // wave-uniform: nothing of this tile is visible to the wave's queries
 
     // S^T sub-tiles: sacc[sub][r] = raw score (q.k) of key key0 + 32 sub + (r&3) + 8 (r>>2) + 4 hh for this lane's query
@@ -716,6 +726,34 @@ __global__ __launch_bounds__(256, LA == 1 ? (HD == 64 ? 3 : 2) : 1) void attn_pr
   // 2-byte writes 4 KB apart (64 cache lines per instruction: ~20 µs of the kernel at S = 2048); instead each wave transposes its 32 x HD block
   // through LDS (rows of 2 HD + 8 bytes: conflict-free 4-byte column writes) and stores whole rows, 16 bytes per lane.
   __syncthreads();                              // every wave is done with the last K / V tile
+  if constexpr (KP == 2) {
+    // the odd-tile stream of every query joins the even-tile one: lane-to-lane (the two waves hold the same queries in the same layout)
+    constexpr int NV = NB * 16 + 2;
+    static_assert(4 * NV * 64 * 4 <= KP * REG * 2, "the merge buffer exceeds the K / V tiles");
+    float* const mo = reinterpret_cast<float*>(smem) + (size_t)wv * NV * 64 + lane;
+    if (kp == 1) {
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) mo[(b * 16 + r) * 64] = oacc[b][r];
+      mo[(NB * 16) * 64] = m_run; mo[(NB * 16 + 1) * 64] = l_run;
+    }
+    __syncthreads();
+    if (kp == 0) {
+      const float m_b = mo[(NB * 16) * 64], l_b = mo[(NB * 16 + 1) * 64];
+      const float m_new = fmaxf(m_run, m_b);
+      const bool dead = m_new == -INFINITY;
+      const float fa = dead ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new), fb = dead ? 1.f : __builtin_amdgcn_exp2f(m_b - m_new);
+      l_run = l_run * fa + l_b * fb;
+      m_run = m_new;
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[b][r] = oacc[b][r] * fa + mo[(b * 16 + r) * 64] * fb;
+    }
+    __syncthreads();                            // the merge buffer is read: the staging rows below reuse it
+    if (kp == 1) return;
+  }
   constexpr int RS = HD + 4;                    // staged row stride in 16-bit elements
   static_assert(4 * 32 * RS <= 64 * LQ + 64 * LV, "output staging exceeds the K / V tiles");
   bf16_t* const wrow = smem + wv * 32 * RS;

@@ -3,6 +3,7 @@
 #include "ctx.h"
 #include "kernels/prefill.h"
 #include "kernels/gemm_dma.h"
+#include "kernels/attn_prefill_dma.h"
 #include "kernels/gemm_f32.h"
 
 bool prefill_shapes_ok(const tgx_model_desc& d) {
@@ -246,14 +247,38 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
 }
 
 // causal GQA flash attention of S prompt positions of one batch row (grid = ceil(S / 128) query blocks x heads)
-void launch_attn_prefill(tgx_ctx* c, const tgx::AttnPrefillArgs& a, bool allow_lean) {
+void launch_attn_prefill(tgx_ctx* c, const tgx::AttnPrefillArgs& a_, bool allow_lean) {
+  tgx::AttnPrefillArgs a = a_;
   const int hd = c->d.head_dim;
-  const dim3 grid((a.S + 127) / 128, a.heads), blk(256);
+  const int nqb = (a.S + 127) / 128, nwg = nqb * a.heads;
+  const size_t lds1 = (size_t)(64 * (hd + 8) + 64 * (hd + 32)) * 2;      // one K tile | V tile pair (kernels/prefill.h)
+  // head_dim 64, three or more workgroups per CU (prompts from ~3k tokens at 32 heads): K / V tiles by LDS-DMA, the next tile's scores under the current tile's
+  // softmax (kernels/attn_prefill_dma.h; bit-identical to attn_prefill_kernel): S = 4096 203 -> 177 us per layer, 8192 730 -> 632; at S = 2048 (one round of 512
+  // workgroups) the launch lasts as long as its heaviest workgroup's chain of tiles in either form (62-63 us).  Option prefill.attn_dma: 0 never, 1 auto, 2 always
+  if (hd == 64 && (c->attn_dma == 2 || (c->attn_dma == 1 && allow_lean && nwg >= 3 * c->num_cus))) {
+    a.heavy_first = 1;
+    const dim3 grid(a.heads, nqb), blk(256);
+    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::attn_prefill_dma_kernel<DT>), grid, blk, (size_t)2 * 3 * 64 * 64 * 2, c->stream, a))
+    return;
+  }
+  // key split inside the workgroup (attn_prefill_kernel KP = 2; option prefill.attn_ksplit: 0 never, 1 auto = head_dim 128, 2 always): eight waves, the odd tiles on
+  // waves 4-7, one merge at the end — half the chain of tiles per wave.  head_dim 128 S = 2048 94 -> 91 us per layer, 4096 401 -> 305, 8192 1284 -> 1086;
+  // head_dim 64 S = 2048 62 -> 56 us in isolation and nothing in the model (tools/probes/README.md round 5): not taken there
+  const bool ksplit = nqb >= 2 && (c->attn_ksplit == 2 || (c->attn_ksplit == 1 && hd == 128));
+  if (ksplit) {
+    a.heavy_first = 1;
+    const dim3 grid(a.heads, nqb), blk(512);
+    TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64, 2, 2>), grid, blk, 2 * lds1, c->stream, a);
+                           else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128, 1, 2>), grid, blk, 2 * lds1, c->stream, a))
+    return;
+  }
+  a.heavy_first = 0;
+  const dim3 grid(nqb, a.heads), blk(256);
   // head_dim 64 with three or more workgroups per CU: the one-tile look-ahead form at three waves per SIMD (prefill.h)
-  const bool lean = allow_lean && hd == 64 && (int)(grid.x * grid.y) >= 3 * c->num_cus;
-  TGX_DT16_SWITCH(c->dt, if (lean) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64, 1>), grid, blk, 0, c->stream, a);
-                         else if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64>), grid, blk, 0, c->stream, a);
-                         else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128, 1>), grid, blk, 0, c->stream, a))     // head_dim 128: two waves per SIMD only in this form (95 vs 138 µs per layer at S = 2048)
+  const bool lean = allow_lean && hd == 64 && nwg >= 3 * c->num_cus;
+  TGX_DT16_SWITCH(c->dt, if (lean) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64, 1>), grid, blk, lds1, c->stream, a);
+                         else if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64>), grid, blk, lds1, c->stream, a);
+                         else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128, 1>), grid, blk, lds1, c->stream, a))     // head_dim 128: two waves per SIMD only in this form (95 vs 138 µs per layer at S = 2048)
 }
 // RoPE + cache append + q split of S prompt rows of one batch row
 void launch_rope_kv_split(tgx_ctx* c, const tgx::RopeKvArgs& a, int S) {
@@ -357,6 +382,8 @@ int prefill_set_attrs(tgx_ctx* c) {
 #define TGX_DMA_ATTR(DT_, EPI_, MI_) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 4) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 4)
 #define TGX_DMA_ATTR_D(DT_) TGX_DMA_ATTR(DT_, tgx::GEMM_SILU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_GELU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 2)
   TGX_DMA_ATTR_D(tgx::DT_BF16) TGX_DMA_ATTR_D(tgx::DT_F16)
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_BF16, 128, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (64 * 136 + 64 * 160) * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_F16, 128, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (64 * 136 + 64 * 160) * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_F16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_RESIDUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));

@@ -77,6 +77,17 @@ int main(int argc, char** argv) {
   DISK(k8_silu_d4, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 4>), LDS8)  DISK(k8_silu_d8, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 8>), LDS8)
   DISK(k8_silu_d6, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 6>), LDS8)  DISK(k8_silu_d7, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 7>), LDS8)
   DISK(k8k_res_d1, (gemm_dma8k_kernel<DT_BF16, GEMM_RESIDUAL, true, 1>), LDS8K)  DISK(k8k_res_d2, (gemm_dma8k_kernel<DT_BF16, GEMM_RESIDUAL, true, 2>), LDS8K)
+  DISK(pp1_silu, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 0, true, 1>), LDS8)  DISK(pp3_silu, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 0, true, 3>), LDS8)
+  DISK(pp5_silu, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 0, true, 5>), LDS8)  DISK(pp1_silu_d2, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 2, true, 1>), LDS8)
+  DISK(pp1_silu_d4, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 4, true, 1>), LDS8)  DISK(pp1_silu_d8, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 8, true, 1>), LDS8)
+  DISK(pp1_silu_d1, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 1, true, 1>), LDS8)  DISK(pp1_silu_d6, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 6, true, 1>), LDS8)
+  DISK(pp9_silu, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 0, true, 9>), LDS8)
+  DISK(ip0_silu, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 0, 0>), LDS8I)  DISK(ip2_silu, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 0, 2>), LDS8I)
+  DISK(ip4_silu, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 0, 4>), LDS8I)  DISK(ip6_silu, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 0, 6>), LDS8I)
+  DISK(ip4_silu_d1, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 1, 4>), LDS8I)  DISK(ip4_silu_d2, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 2, 4>), LDS8I)
+  DISK(ip4_silu_d4, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 4, 4>), LDS8I)  DISK(ip4_silu_d8, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 8, 4>), LDS8I)
+  DISK(k8_part, (gemm_dma8_kernel<DT_BF16, GEMM_PARTIAL>), LDS8)  DISK(k8k_part, (gemm_dma8k_kernel<DT_BF16, GEMM_PARTIAL>), LDS8K)
+  DISK(pp1_res, (gemm_dma8_kernel<DT_BF16, GEMM_RESIDUAL, true, 4, 0, true, 1>), LDS8)
   DISK(k8k_res_d4, (gemm_dma8k_kernel<DT_BF16, GEMM_RESIDUAL, true, 4>), LDS8K)  DISK(k8k_res_d8, (gemm_dma8k_kernel<DT_BF16, GEMM_RESIDUAL, true, 8>), LDS8K)
   DISK(k8k_res_d6, (gemm_dma8k_kernel<DT_BF16, GEMM_RESIDUAL, true, 6>), LDS8K)  DISK(k8k_res_d7, (gemm_dma8k_kernel<DT_BF16, GEMM_RESIDUAL, true, 7>), LDS8K)
 
@@ -137,6 +148,25 @@ int main(int argc, char** argv) {
       report("  DIS 6  (MFMAs on zero operands only)", time_us(reps, [&](int l) { L(k8k_res_d6, g128, LDS8K)(l); }));
       report("  DIS 7  (skeleton: barriers + LDS reduce + epilogue)", time_us(reps, [&](int l) { L(k8k_res_d7, g128, LDS8K)(l); }));
       report("gemm_dma8 (256x256: 64 tiles on 256 CUs)", time_us(reps, [&](int l) { L(k8_res, g256, LDS8)(l); }));
+      if (s.K >= 4096) {
+        float* part; CK(hipMalloc(&part, 4 * nC * 4));
+        auto LP = [&](auto kern, dim3 grid, size_t lds, int z) { return [&, kern, grid, lds, z](int l) { GemmArgs g = make_args(s, b, l, b.C); g.part = part; g.nsplit = z; g.k_per = s.K / z; hipLaunchKernelGGL(kern, dim3(grid.x, grid.y, z), blk, lds, 0, g); }; };
+        for (int rep = 0; rep < 2; rep++) {
+          report("gemm_dma8k one slab (the product's launch: 128x128, store, the next norm launch adds)", time_us(reps, LP(k8k_part, g128, LDS8K, 1)));
+          report("gemm_dma8 256x256 x 4 K slabs (256 workgroups, fp32 slab stores)", time_us(reps, LP(k8_part, g256, LDS8, 4)));
+          report("gemm_dma8 256x256 x 2 K slabs (128 workgroups)", time_us(reps, LP(k8_part, g256, LDS8, 2)));
+          report("gemm_dma8k 128x128 x 2 K slabs (512 workgroups)", time_us(reps, LP(k8k_part, g128, LDS8K, 2)));
+        }
+        // value check: sum of the four slabs against the product kernel's C (C was zero: RESIDUAL adds)
+        CK(hipMemset(b.C, 0, nC * 4)); L(k8k_res, g128, LDS8K)(0, b.C); LP(k8_part, g256, LDS8, 4)(0); CK(hipDeviceSynchronize());
+        std::vector<float> r(1 << 16), t(4 << 16);
+        CK(hipMemcpy(r.data(), b.C, r.size() * 4, hipMemcpyDeviceToHost));
+        for (int z = 0; z < 4; z++) CK(hipMemcpy(t.data() + ((size_t)z << 16), part + (size_t)z * nC, r.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0, mr = 0; for (size_t i = 0; i < r.size(); i++) { const double v = ((double)t[i] + t[i + (1 << 16)]) + ((double)t[i + (2 << 16)] + t[i + (3 << 16)]); md = fmax(md, fabs(v - r[i])); mr = fmax(mr, fabs((double)r[i])); }
+        printf("  check 4 slabs summed vs the 128x128 kernel: max |d| / max |ref| = %.2e\n", md / mr);
+        CK(hipFree(part));
+      }
+      report("gemm_dma8 ping-pong (256x256: 64 tiles on 256 CUs)", time_us(reps, [&](int l) { L(pp1_res, g256, LDS8)(l); }));
     } else {
       auto L = [&](auto kern, dim3 grid, size_t lds) { return [&, kern, grid, lds](int l, float* C = nullptr) { GemmArgs g = make_args(s, b, l, b.C); if (C == b.Cref) { g.out_hi = (bf16_t*)b.Cref; g.out_lo = g.out_hi + (size_t)s.M * s.N / 2; } hipLaunchKernelGGL(kern, grid, blk, lds, 0, g); }; };
       auto LI = [&](auto kern) { return [&, kern](int l, float* C = nullptr) { GemmArgs g = make_args(s, b, l, b.C); g.A_hi = b.Ai; g.A_lo = nullptr; hipLaunchKernelGGL(kern, g256, blk, LDS8I, 0, g); }; };
@@ -144,6 +174,17 @@ int main(int argc, char** argv) {
       base(0, b.Cref); CK(hipDeviceSynchronize());
       report("(clock warm-up pass, not a figure)", time_us(reps, [&](int l) { base(l); }));
       report("product: gemm_dma8 (256x256, wave = 64 x 128)", time_us(reps, [&](int l) { base(l); }));
+      check("ping-pong (must be bit-identical)", L(pp1_silu, g256, LDS8), true);
+      report("gemm_dma8 ping-pong (waves w / w + 4 half a stage apart)", time_us(reps, [&](int l) { L(pp1_silu, g256, LDS8)(l); }));
+      report("  ping-pong + s_setprio 1 around the matrix phase", time_us(reps, [&](int l) { L(pp3_silu, g256, LDS8)(l); }));
+      report("  ping-pong + static s_setprio 1 for waves 4-7", time_us(reps, [&](int l) { L(pp5_silu, g256, LDS8)(l); }));
+      report("  ping-pong, DMA issue ahead of the fragment reads", time_us(reps, [&](int l) { L(pp9_silu, g256, LDS8)(l); }));
+      report("  ping-pong DIS 1  (DMA + reads + barriers only)", time_us(reps, [&](int l) { L(pp1_silu_d1, g256, LDS8)(l); }));
+      report("  ping-pong DIS 2  (no DMA after the prologue)", time_us(reps, [&](int l) { L(pp1_silu_d2, g256, LDS8)(l); }));
+      report("  ping-pong DIS 4  (no fragment reads)", time_us(reps, [&](int l) { L(pp1_silu_d4, g256, LDS8)(l); }));
+      report("  ping-pong DIS 6  (MFMAs on zero operands only)", time_us(reps, [&](int l) { L(pp1_silu_d6, g256, LDS8)(l); }));
+      report("  ping-pong DIS 8  (no epilogue)", time_us(reps, [&](int l) { L(pp1_silu_d8, g256, LDS8)(l); }));
+      report("product again", time_us(reps, [&](int l) { base(l); }));
       check("direct siluMul epilogue (must be bit-identical)", L(k8_silu_direct, g256, LDS8), true);
       report("gemm_dma8 with the direct siluMul epilogue (2-byte stores)", time_us(reps, [&](int l) { L(k8_silu_direct, g256, LDS8)(l); }));
       report("product again (LDS-transposed epilogue, 16-byte stores)", time_us(reps, [&](int l) { base(l); }));
@@ -151,6 +192,19 @@ int main(int argc, char** argv) {
       report("gemm_dma8 WJ 2 (wave = 128 x 64, rounds 2-4)", time_us(reps, [&](int l) { L(w2_silu, g256, LDS8)(l); }));
       check("gemm_dma8i (full lines: interleaved A, k64 B units)", LI(i_silu), true);
       report("gemm_dma8i (full lines: interleaved A, k64 B units, 5 x 32 KB ring)", time_us(reps, [&](int l) { LI(i_silu)(l); }));
+      check("gemm_dma8ip (full lines + ping-pong)", LI(ip0_silu), true);
+      for (int rep = 0; rep < 2; rep++) {
+        report("gemm_dma8i again", time_us(reps, [&](int l) { LI(i_silu)(l); }));
+        report("gemm_dma8ip (full lines + ping-pong)", time_us(reps, [&](int l) { LI(ip0_silu)(l); }));
+        report("  + s_setprio 1 around the matrix phase", time_us(reps, [&](int l) { LI(ip2_silu)(l); }));
+        report("  + static s_setprio 1 for waves 4-7", time_us(reps, [&](int l) { LI(ip4_silu)(l); }));
+        report("  + both", time_us(reps, [&](int l) { LI(ip6_silu)(l); }));
+        report("product (k32 stages, lock step, LDS-transposed epilogue)", time_us(reps, [&](int l) { base(l); }));
+      }
+      report("  dma8ip DIS 1  (DMA + reads + barriers only)", time_us(reps, [&](int l) { LI(ip4_silu_d1)(l); }));
+      report("  dma8ip DIS 2  (no DMA after the prologue)", time_us(reps, [&](int l) { LI(ip4_silu_d2)(l); }));
+      report("  dma8ip DIS 4  (no fragment reads)", time_us(reps, [&](int l) { LI(ip4_silu_d4)(l); }));
+      report("  dma8ip DIS 8  (no epilogue)", time_us(reps, [&](int l) { LI(ip4_silu_d8)(l); }));
       report("  dma8i DIS 1  (DMA + barriers only)", time_us(reps, [&](int l) { LI(i_silu_d1)(l); }));
       report("  dma8i DIS 2  (no DMA after the prologue)", time_us(reps, [&](int l) { LI(i_silu_d2)(l); }));
       report("  dma8i DIS 4  (no fragment reads)", time_us(reps, [&](int l) { LI(i_silu_d4)(l); }));
