@@ -151,7 +151,7 @@ struct tgx_ctx {
   int qkv_balanced = 1;      // option prefill.qkv_balanced: the bf16 QKV product as one launch of equal-work tiles (round 3)
   int attn_mirror = 1;       // experiment: prefill attention block order
   int attn_dma = 1;          // option prefill.attn_dma: head_dim 64 prompts of three or more workgroups per CU take kernels/attn_prefill_dma.h (0 never, 2 always)
-  int attn_ksplit = 1;       // option prefill.attn_ksplit: key split inside the prefill attention workgroup (0 never, 1 at head_dim 128, 2 always)
+  int attn_ksplit = 1;       // option prefill.attn_ksplit: key split inside the prefill attention workgroup (0 never, 1 auto: head_dim 128, and head_dim 64 below three workgroups per CU, 2 always)
   int qk_fuse = 1;           // experiment: 0 keeps Qwen3's separate q/k norm launch
   // option prefill.skinny_rows: prompts of up to this many workspace rows take the skinny GEMMs (32: round 2; 33-64: four activation blocks, round 3).
   // Measured ms per prompt, four-block skinny / tiled split-K: Llama-3.2-1B S = 33 1.48 / 1.51, 48 1.51 / 1.58, 64 1.57 / 1.70; Qwen2.5-0.5B S = 48 1.46 / 1.81;

@@ -261,10 +261,10 @@ void launch_attn_prefill(tgx_ctx* c, const tgx::AttnPrefillArgs& a_, bool allow_
     TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::attn_prefill_dma_kernel<DT>), grid, blk, (size_t)2 * 3 * 64 * 64 * 2, c->stream, a))
     return;
   }
-  // key split inside the workgroup (attn_prefill_kernel KP = 2; option prefill.attn_ksplit: 0 never, 1 auto = head_dim 128, 2 always): eight waves, the odd tiles on
-  // waves 4-7, one merge at the end — half the chain of tiles per wave.  head_dim 128 S = 2048 94 -> 91 us per layer, 4096 401 -> 305, 8192 1284 -> 1086;
-  // head_dim 64 S = 2048 62 -> 56 us in isolation and nothing in the model (tools/probes/README.md round 5): not taken there
-  const bool ksplit = nqb >= 2 && (c->attn_ksplit == 2 || (c->attn_ksplit == 1 && hd == 128));
+  // key split inside the workgroup (attn_prefill_kernel KP = 2; option prefill.attn_ksplit: 0 never, 1 auto, 2 always): eight waves, the odd tiles on waves 4-7,
+  // one merge at the end — half the chain of tiles per wave.  head_dim 128: S = 2048 94 -> 91 us per layer, 4096 401 -> 305, 8192 1284 -> 1086 (always);
+  // head_dim 64 below three workgroups per CU: S = 2048 62 -> 55-56 us in isolation, 68.1 -> 61.3 in the model's trace (profiles/r05_prefill.txt section 5)
+  const bool ksplit = nqb >= 2 && (c->attn_ksplit == 2 || (c->attn_ksplit == 1 && (hd == 128 || nwg < 3 * c->num_cus)));
   if (ksplit) {
     a.heavy_first = 1;
     const dim3 grid(a.heads, nqb), blk(512);
