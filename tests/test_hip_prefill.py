@@ -196,3 +196,22 @@ def test_prefill_attention_forms_agree(name, S, dtype):
         np.testing.assert_array_equal(outs["dma"][0], outs["plain"][0])
     assert rel_err(outs["ksplit"][0], outs["plain"][0]) < 2e-5, rel_err(outs["ksplit"][0], outs["plain"][0])
     np.testing.assert_array_equal(outs["ksplit"][1], outs["plain"][1])
+
+
+@pytest.mark.parametrize("name,S,dtype", [("llama-3.2-1b", 1024, "bf16"), ("llama-3.2-1b", 1900, "bf16"), ("llama-3.2-1b", 2048, "fp16"), ("mistral-7b-v0.3", 1100, "bf16")])
+def test_gate_up_on_full_lines_is_bit_identical(name, S, dtype):
+    """Round 5 (option prefill.full_lines, on by default): where the gate_up product fills the chip with 256 x 256 tiles its activation terms arrive interleaved per k32
+    block (rmsnorm_split_kernel `inter`: one 128-byte line per row and stage) and the weights per k64 block (kernels/gemm_dma.h gemm_dma8i_kernel) — the same matrix
+    instructions on the same operands in the same order as the half-line kernel, the same siluMul epilogue: logits BIT-identical, also with a ragged last row tile."""
+    d = copy.deepcopy(known_desc(name, dtype))
+    d.layers, d.vocab, d.max_ctx = 2, 4096, S + 16
+    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    prompt = synth.synth_prompt(d.vocab, S, 82)[None, :]
+    outs = []
+    for on in (0, 1):
+        m.set_option("prefill.full_lines", on)
+        m.reset_cache(); m.forward(prompt)
+        outs.append((m.logits(rounded=False).copy(), m.read_kv(0, 1)))
+    np.testing.assert_array_equal(outs[1][0], outs[0][0])
+    np.testing.assert_array_equal(outs[1][1][0], outs[0][1][0])
+    np.testing.assert_array_equal(outs[1][1][1], outs[0][1][1])

@@ -221,6 +221,52 @@ __device__ __forceinline__ void xcd_tile(const GemmArgs& a, int& tm, int& tn) {
   tm = xm * sm + l % sm; tn = xn * sn + l / sm;
 }
 
+// The siluMul epilogue of a 256 x 256 tile through LDS (round 5; waves own 64 x 128 blocks: WI 2, WJ 4).  In the MFMA C layout a lane ends up with ONE (gate, up) result per row
+// pair, so the direct epilogue stores 2 bytes per lane, 32 contiguous bytes per row and instruction — 128 store instructions per wave and term, a quarter of a line each.  Here
+// every wave writes its 64 x 64 results (hi and lo) into its own 18-KB slice of the idle ring ([64 rows][72]: 144-byte rows keep the 16-byte reads aligned and the row pairs off
+// each other's banks), reads them back eight outputs per lane and stores whole 128-byte rows: 16 store instructions per wave.  Same values, same rounding.
+template <int DT>
+__device__ __forceinline__ void silu_epilogue_transposed(const f32x16 (&acc)[2][4], bf16_t* dma_lds, const GemmArgs& a, int wv, int lane, int m0, int n0, int wm, int wn) {
+  constexpr int WI = 2, WJ = 4;
+  constexpr int RS = 72;                                   // 16-bit elements per staged row (64 results + 8 of padding)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the trailing fragment reads of the ring
+  __builtin_amdgcn_s_barrier();                            // ... by every wave: the ring is free
+  bf16_t* sh = dma_lds + (size_t)wv * (2 * 64 * RS);       // this wave's slice: hi rows, then lo rows
+  bf16_t* sl = sh + 64 * RS;
+  const bool odd = lane & 1;
+#pragma unroll
+  for (int i = 0; i < WI; i++)
+#pragma unroll
+    for (int j = 0; j < WJ; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {                     // as silu_block_store: the even lane finishes row r, the odd lane row r + 1 of the column pair
+        const float a0 = acc[i][j][r], a1 = acc[i][j][r + 1];
+        const float recv = dpp_mov<0xB1, 0xf>(odd ? a0 : a1);
+        const float g = odd ? recv : a0, u = odd ? a1 : recv;
+        const int rl = i * 32 + (r & 3) + (odd ? 1 : 0) + 8 * (r >> 2) + 4 * (lane >> 5);
+        bf16_t hi, lo;
+        split16<DT>(silu_mul_fast(g, u), hi, lo);
+        const int o = rl * RS + j * 16 + ((lane & 31) >> 1);
+        sh[o] = hi; sl[o] = lo;
+      }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave reads only what it wrote itself: no workgroup barrier
+  const int oc0 = (n0 + wn * 128) / 2 + (lane & 7) * 8;     // first of this lane's eight outputs
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    const int rl = p * 8 + (lane >> 3), row = m0 + wm * 64 + rl;
+    const u32x4 vh = *reinterpret_cast<const u32x4*>(sh + rl * RS + (lane & 7) * 8);
+    const u32x4 vl = *reinterpret_cast<const u32x4*>(sl + rl * RS + (lane & 7) * 8);
+    if (row < a.M && 2 * oc0 + 15 < a.N) {
+      *reinterpret_cast<u32x4*>(a.out_hi + (size_t)row * a.inter + oc0) = vh;
+      *reinterpret_cast<u32x4*>(a.out_lo + (size_t)row * a.inter + oc0) = vl;
+    } else if (row < a.M) {                                  // a ragged last tile column: element by element
+      const bf16_t* eh = reinterpret_cast<const bf16_t*>(&vh); const bf16_t* el = reinterpret_cast<const bf16_t*>(&vl);
+      for (int e = 0; e < 8; e++)
+        if (2 * (oc0 + e) + 1 < a.N) { a.out_hi[(size_t)row * a.inter + oc0 + e] = eh[e]; a.out_lo[(size_t)row * a.inter + oc0 + e] = el[e]; }
+    }
+  }
+}
+
 // ---- 256 x 256 tile, 8 waves, three-stage LDS-DMA ring (the wide products: gate_up / c_fc) -------------------------------------------
 // Why a bigger tile and a deeper ring: one stage of the 128² kernel holds 0.2-0.4 µs of MFMA work per wave, an LDS-DMA piece takes 1-2 µs
 // to land — the two-stage ring stalls on every stage and only co-resident workgroups hide it.  Here a stage (k = 32) is 48 KB
@@ -315,6 +361,17 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
     }
   };
 
+  if constexpr (DIS == 17) {
+    // lab: the tile's whole operand stream issued back to back, no ring discipline (slots overwritten unsynchronised: values are garbage), ONE wait at the end —
+    // what the CU's memory pipeline delivers when nothing limits the bytes in flight
+    for (int s = 0; s < nk; s++) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) dma_1k(gsrc[q] + s * DBK, lds_base + (unsigned)((s % NS) * STAGE * 2) + ldst[q]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nk == 12345) a.C[0] = 1.f;
+    return;
+  }
   if constexpr (PP & 1) {
     // ---- ping-pong form (round 5): the two waves of a SIMD (w and w + 4: a workgroup's waves are dealt to the SIMDs cyclically) work half a stage apart —
     // while one runs the 32 MFMAs of its k32 stage back to back, the other issues its six DMA pieces of stage s + 2 and reads its sixteen fragments of the next stage.
@@ -425,43 +482,7 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
     return;
   }
   if constexpr (EPI == GEMM_SILU && TEPI && WJ == 4) {
-    constexpr int RS = 72;                                   // 16-bit elements per staged row (64 results + 8 of padding)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the trailing fragment reads of the ring
-    __builtin_amdgcn_s_barrier();                            // ... by every wave: the ring is free
-    bf16_t* sh = dma_lds + (size_t)wv * (2 * 64 * RS);       // this wave's slice: hi rows, then lo rows
-    bf16_t* sl = sh + 64 * RS;
-    const bool odd = lane & 1;
-#pragma unroll
-    for (int i = 0; i < WI; i++)
-#pragma unroll
-      for (int j = 0; j < WJ; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {                     // as silu_block_store: the even lane finishes row r, the odd lane row r + 1 of the column pair
-          const float a0 = acc[i][j][r], a1 = acc[i][j][r + 1];
-          const float recv = dpp_mov<0xB1, 0xf>(odd ? a0 : a1);
-          const float g = odd ? recv : a0, u = odd ? a1 : recv;
-          const int rl = i * 32 + (r & 3) + (odd ? 1 : 0) + 8 * (r >> 2) + 4 * (lane >> 5);
-          bf16_t hi, lo;
-          split16<DT>(silu_mul_fast(g, u), hi, lo);
-          const int o = rl * RS + j * 16 + ((lane & 31) >> 1);
-          sh[o] = hi; sl[o] = lo;
-        }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave reads only what it wrote itself: no workgroup barrier
-    const int oc0 = (n0 + wn * 128) / 2 + (lane & 7) * 8;     // first of this lane's eight outputs
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-      const int rl = p * 8 + (lane >> 3), row = m0 + wm * 64 + rl;
-      const u32x4 vh = *reinterpret_cast<const u32x4*>(sh + rl * RS + (lane & 7) * 8);
-      const u32x4 vl = *reinterpret_cast<const u32x4*>(sl + rl * RS + (lane & 7) * 8);
-      if (row < a.M && 2 * oc0 + 15 < a.N) {
-        *reinterpret_cast<u32x4*>(a.out_hi + (size_t)row * a.inter + oc0) = vh;
-        *reinterpret_cast<u32x4*>(a.out_lo + (size_t)row * a.inter + oc0) = vl;
-      } else if (row < a.M) {                                  // a ragged last tile column: element by element
-        const bf16_t* eh = reinterpret_cast<const bf16_t*>(&vh); const bf16_t* el = reinterpret_cast<const bf16_t*>(&vl);
-        for (int e = 0; e < 8; e++)
-          if (2 * (oc0 + e) + 1 < a.N) { a.out_hi[(size_t)row * a.inter + oc0 + e] = eh[e]; a.out_lo[(size_t)row * a.inter + oc0 + e] = el[e]; }
-      }
-    }
+    silu_epilogue_transposed<DT>(acc, dma_lds, a, wv, lane, m0, n0, wm, wn);
     return;
   }
 #pragma unroll
@@ -486,6 +507,176 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int row = m0 + wm * 32 * WI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= a.M) continue;
+        const float v = acc[i][j][r] + bv;
+        if (EPI == GEMM_GELU) {
+          const size_t o = (size_t)row * a.N + col;
+          split16<DT>(gelu_new_fast(v), a.out_hi[o], a.out_lo[o]);
+          continue;
+        }
+        float* dst = a.C + (size_t)row * a.ldc + col;
+        *dst = (EPI == GEMM_RESIDUAL) ? (*dst + v) : v;
+      }
+    }
+}
+
+// ---- 256 x 256 tile on FULL 128-byte lines (round 5) ----------------------------------------------------------------------------------------
+// What bounds the eight-wave kernels above is largely operand delivery, and what bounds delivery is the number of cache LINES asked of the XCD's L2, not bytes
+// (tools/probes/gemm_lab.hip, profiles/r05_prefill.txt: the same 1.6 GB lands in 146 us as 64-byte half-line pieces — k32 stages of row-major operands — and in
+// 84 us as full lines; an extra 4-byte touch per line costs as much as the line).  A k32 stage of a row-major [M][K] operand is half a line per row.  Here
+//   * the A operand arrives INTERLEAVED: Ai[m][K/32][hi 32 | lo 32] — the two terms of one k32 block of a row are one 128-byte line (written that way by the
+//     producing row-wise kernel: same bytes, another address);
+//   * B is staged per k64 block (one full line per weight row) and serves two k32 steps.
+// The ring holds five 32-KB units (160 KB), issued in the order they are freed: block b = [A step 2b | B block b | A step 2b+1]; three units are in flight while
+// two are consumed, as before (96 KB).  Same MFMAs in the same order as gemm_dma8_kernel: bit-identical results.  Wave = 64 x 128 of the output; the siluMul
+// epilogue goes through LDS (silu_epilogue_transposed).  In the product for gate_up of prompts that fill the chip with 256 x 256 tiles (prefill.hip, option
+// prefill.full_lines): 226 -> 213-216 us per launch in the lab (profiles/r05_prefill.txt).
+template <int DT, int EPI, int DIS = 0>
+__global__ __launch_bounds__(512) void gemm_dma8i_kernel(const GemmArgs a) {
+  constexpr int TMN = 256, NSLOT = 5, UNIT = TMN * 64;     // 16-bit elements per unit: 256 rows x 128 bytes
+  constexpr int WI = 2, WJ = 4;
+  extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv >> 1, wn = wv & 1;
+  int tile_m, tile_n;
+  xcd_tile(a, tile_m, tile_n);
+  const int m0 = tile_m * TMN, n0 = tile_n * TMN;
+  const unsigned lds_base = (unsigned)(size_t)dma_lds;
+  const bool inter = EPI == GEMM_SILU;
+
+  f32x16 acc[WI][WJ];
+#pragma unroll
+  for (int i = 0; i < WI; i++)
+#pragma unroll
+    for (int j = 0; j < WJ; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // DMA map: a unit = 32 pieces of 1 KiB = 8 rows x 128 bytes each; wave w takes pieces w, w + 8, w + 16, w + 24; chunk c of row r sits in slot c ^ ((r >> 1) & 7)
+  const int prow = lane >> 3, pslot = lane & 7;
+  const bf16_t *srcA[4], *srcB[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const int row = (wv + 8 * p) * 8 + prow;
+    const int chunk = pslot ^ ((row >> 1) & 7);
+    srcA[p] = a.A_hi + (size_t)min(m0 + row, a.M - 1) * (2 * (size_t)a.K) + chunk * 8;        // interleaved rows are 2 K elements long
+    const int nb = min(n0 + row, a.N - 1);
+    const size_t brow = inter ? (size_t)((nb & 1) ? a.inter : 0) + (size_t)(nb >> 1) : (size_t)nb;
+    srcB[p] = a.B + brow * a.K + chunk * 8;
+  }
+  const int nk = a.K / 32, nblk = a.K / 64;
+  // unit u = 3 b + j: j = 0 the A lines of step 2b, 1 the B lines of block b, 2 the A lines of step 2b + 1 (units past the end reload the last block)
+  auto issue = [&](int b, int j, int p) {
+    if ((DIS & 2) && b > 0) return;
+    const int bb = min(b, nblk - 1);
+    const unsigned dst = lds_base + (unsigned)(((3 * b + j) % NSLOT) * UNIT * 2) + (unsigned)((wv + 8 * p) * 1024);
+    if (j == 1) dma_1k(srcB[p] + (size_t)bb * 64, dst);
+    else dma_1k(srcA[p] + (size_t)(2 * bb + (j >> 1)) * 64, dst);
+  };
+  const int swz = ((lane & 31) >> 1) & 7;
+  const int arow = (wm * 64 + (lane & 31)) * 64, brow_l = (wn * 128 + (lane & 31)) * 64;
+  // fragments of k16 step kk of k32 step s: A chunks (term * 4 + kk * 2 + half), B chunks ((s & 1) * 4 + kk * 2 + half) of the block's lines
+  auto read_frags = [&](int s, int kk, bf16x8* fa, bf16x8* fb) {
+    if (DIS & 4) return;
+    const int b = s >> 1;
+    const bf16_t* ua = dma_lds + (size_t)((3 * b + ((s & 1) << 1)) % NSLOT) * UNIT;
+    const bf16_t* ub = dma_lds + (size_t)((3 * b + 1) % NSLOT) * UNIT;
+    const int ca = kk * 2 + (lane >> 5), cb = (s & 1) * 4 + ca;
+#pragma unroll
+    for (int j = 0; j < WJ; j++) fb[j] = *reinterpret_cast<const bf16x8*>(ub + brow_l + j * 32 * 64 + ((cb ^ swz) << 3));
+#pragma unroll
+    for (int i = 0; i < WI; i++) {
+      fa[2 * i] = *reinterpret_cast<const bf16x8*>(ua + arow + i * 32 * 64 + ((ca ^ swz) << 3));
+      fa[2 * i + 1] = *reinterpret_cast<const bf16x8*>(ua + arow + i * 32 * 64 + (((4 + ca) ^ swz) << 3));
+    }
+  };
+  // the 16 MFMAs of one k16 step in four groups of four, one DMA piece behind each of the first `np` groups: pieces p0 .. of unit (b, j)
+  auto mfma_step = [&](const bf16x8* fa, const bf16x8* fb, int b, int j, int p0, int np) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        const int idx = 2 * g + p, i = idx / WJ, jj = idx % WJ;
+        if (!(DIS & 1)) {
+          acc[i][jj] = mfma16<DT>(fa[2 * i + 1], fb[jj], acc[i][jj]);   // small term first
+          acc[i][jj] = mfma16<DT>(fa[2 * i], fb[jj], acc[i][jj]);
+        }
+      }
+      if (g < np) issue(b, j, p0 + g);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+#pragma unroll
+  for (int u = 0; u < 5; u++)
+#pragma unroll
+    for (int p = 0; p < 4; p++) issue(u / 3, u % 3, p);
+  bf16x8 fa0[2 * WI], fb0[WJ], fa1[2 * WI], fb1[WJ];
+  if (DIS & 4) {
+#pragma unroll
+    for (int i = 0; i < 2 * WI; i++) { fa0[i] = bf16x8{}; fa1[i] = bf16x8{}; }
+#pragma unroll
+    for (int j = 0; j < WJ; j++) { fb0[j] = bf16x8{}; fb1[j] = bf16x8{}; }
+  }
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // units 0, 1 landed (this wave's pieces); units 2, 3, 4 may fly
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, 0, fa0, fb0);
+  for (int b = 0; b < nblk; b++) {
+    const int s = 2 * b;
+    // ---- step 2b
+    read_frags(s, 1, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(fa0, fb0, b + 1, 1, 0, b > 0 ? 4 : 0);             // unit 3b+4 = B of block b+1 (the prologue issued block 1's)
+    // step 2b+1 needs unit 3b+2: behind its last piece only units 3b+3, 3b+4 were issued (8 pieces)
+    if (DIS & 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                               // every wave has read the A lines of step 2b: unit 3b is free
+    read_frags(s + 1, 0, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(fa1, fb1, b + 1, 2, 0, 3);                         // unit 3b+5 = A of step 2b+3, pieces 0..2
+    // ---- step 2b+1
+    read_frags(s + 1, 1, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(fa0, fb0, b + 1, 2, 3, 1);                         // ... piece 3
+    // step 2b+2 needs units 3b+3, 3b+4: behind them only unit 3b+5 (4 pieces)
+    if (DIS & 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                               // units 3b+1 (B) and 3b+2 are free
+    read_frags(s + 2, 0, fa0, fb0);                             // (after the last block: a harmless read of a reloaded unit)
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(fa1, fb1, b + 2, 0, 0, 4);                         // unit 3b+6 = A of step 2b+4
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  if (DIS & 8) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < WI; i++)
+#pragma unroll
+      for (int j = 0; j < WJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) t += acc[i][j][r];
+    if (t == 12345.678f) a.C[0] = t;
+    return;
+  }
+  if constexpr (EPI == GEMM_SILU) {
+    silu_epilogue_transposed<DT>(acc, dma_lds, a, wv, lane, m0, n0, wm, wn);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < WI; i++)
+#pragma unroll
+    for (int j = 0; j < WJ; j++) {
+      const int col = n0 + wn * 128 + j * 32 + (lane & 31);
+      if (EPI == GEMM_SILU) {
+        silu_block_store<DT>(acc[i][j], lane, col, m0 + wm * 64 + i * 32, a);
+        continue;
+      }
+      if (col >= a.N) continue;
+      const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= a.M) continue;
         const float v = acc[i][j][r] + bv;
         if (EPI == GEMM_GELU) {

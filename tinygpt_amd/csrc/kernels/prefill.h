@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const long long* ids, c
 // order exactly as gemm_splitk_reduce_kernel<GEMM_RESIDUAL> does — and is written back: the reduce launch and its pass over x disappear.
 template <int DT>
 __global__ __launch_bounds__(256) void rmsnorm_split_kernel(float* X, const bf16_t* w, float eps, int H, bf16_t* hi, bf16_t* lo, bf16_t* lo2,
-                                                            const float* part = nullptr, int nsplit = 0, long long slab = 0, const bf16_t* bias = nullptr) {
+                                                            const float* part = nullptr, int nsplit = 0, long long slab = 0, const bf16_t* bias = nullptr, int inter = 0) {
+  // inter = 1 (round 5): the two terms leave INTERLEAVED per k32 block — hi[m][H / 32][hi 32 | lo 32], one 128-byte line per row and k32 step — for the consumer
+  // that stages full lines (kernels/gemm_dma.h gemm_dma8i_kernel); `lo` is not written
   // one workgroup per row; a thread owns 8-element slices (two 16-byte loads, one 16-byte store per term), kept in registers between the
   // sum of squares and the scaling for rows up to 8192 elements (H % 8 == 0: checked by the caller)
   __shared__ float sc[4];
@@ -148,6 +150,12 @@ __global__ __launch_bounds__(256) void rmsnorm_split_kernel(float* X, const bf16
       }
     }
     const size_t o = (size_t)blockIdx.x * H + 8 * c;
+    if (inter) {
+      const size_t oi = ((size_t)blockIdx.x * (H >> 5) + (c >> 2)) * 64 + (c & 3) * 8;
+      *reinterpret_cast<u32x4*>(hi + oi) = u32x4{h[0], h[1], h[2], h[3]};
+      *reinterpret_cast<u32x4*>(hi + oi + 32) = u32x4{l[0], l[1], l[2], l[3]};
+      return;
+    }
     *reinterpret_cast<u32x4*>(hi + o) = u32x4{h[0], h[1], h[2], h[3]};
     *reinterpret_cast<u32x4*>(lo + o) = u32x4{l[0], l[1], l[2], l[3]};
     if (lo2) *reinterpret_cast<u32x4*>(lo2 + o) = u32x4{l2[0], l2[1], l2[2], l2[3]};

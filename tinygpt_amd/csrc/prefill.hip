@@ -54,9 +54,29 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
 // -1 (round 5, option prefill.defer_store): the UNSPLIT eight-wave N = hidden product stored its result as ONE slab instead of adding it to the residual
 // stream in its epilogue — a read-modify-write of M x N floats by four waves per CU at the end of a launch that has one tile per CU (nothing left to overlap
 // it: 18-19 of o_proj's 52 us, tools/probes/gemm_lab.hip); the row-wise norm kernel that reads the stream next adds the slab while it streams.
+// The gate_up product on full 128-byte lines (kernels/gemm_dma.h gemm_dma8i_kernel; option prefill.full_lines): taken where the 256 x 256 kernel would be, on the
+// default contract; the producing norm launch then writes the two terms interleaved per k32 block (rmsnorm_split_kernel `inter`) into ws_out, which is idle
+// between the RoPE / cache-append launch and the next layer's QKV product.
+static bool gemm_full_lines(const tgx_ctx* c, int epi, int M, int N, int K) {
+  if (!c->full_lines || epi != tgx::GEMM_SILU || c->gpt2 || (c->act16 && c->ws_zero) || !(c->gemm_dma & 4) || K % 64 != 0 || N % 256 != 0) return false;
+  const tgx_model_desc& d = c->d;
+  if ((size_t)d.heads * d.head_dim + 2 * (size_t)d.kv_heads * d.head_dim < (size_t)K) return false;      // ws_out holds [M][2 K] 16-bit terms
+  const int t256 = ((N + 255) / 256) * ((M + 255) / 256), r256 = (t256 + c->num_cus - 1) / c->num_cus;
+  const bool ragged256 = c->wide_8k && c->wide_8k_eff > 0 && (c->gemm_dma & 8) && t256 >= c->num_cus && 100 * t256 < c->wide_8k_eff * r256 * c->num_cus;
+  return t256 >= c->num_cus && !ragged256;
+}
+
 static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_, float* C, int M, int N, int K, int ldc, bool three_terms = false,
-                 const bf16_t* a_hi = nullptr, const bf16_t* a_lo = nullptr, int three_from = 0, int* defer = nullptr) {
+                 const bf16_t* a_hi = nullptr, const bf16_t* a_lo = nullptr, int three_from = 0, int* defer = nullptr, bool a_inter = false) {
   if (defer) *defer = 1;
+  if (a_inter) {       // A arrives interleaved in a_hi (the caller asked gemm_full_lines first)
+    tgx::GemmArgs g{};
+    g.A_hi = a_hi; g.A_lo = nullptr; g.A_lo2 = nullptr; g.inter = N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
+    g.B = reinterpret_cast<const bf16_t*>(B_); g.bias = nullptr; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc; g.three_from = 1 << 30; g.xcd_tiles = c->xcd_tiles;
+    const dim3 g8((N + 255) / 256, (M + 255) / 256), b8(512);
+    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma8i_kernel<DT, tgx::GEMM_SILU>), g8, b8, (size_t)5 * 256 * 128, c->stream, g))
+    return;
+  }
   const bool one = c->act16 && c->ws_zero;       // option act.round16: A_hi is the (rounded) activation; every other term reads zeros, the eight-wave kernels skip it
   if (one) { three_terms = false; three_from = 0; }
   const bool one_k = one && c->act16_kernels;    // ... in kernels that have a one-term form
@@ -357,9 +377,12 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
       TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::norm_rows_kernel<DT, 1, 1>), dim3(M), dim3(256), 0, c->stream, (const float*)c->ws_x, (const void*)w.post_norm, (const void*)w.post_norm_b, d.norm_eps, H, (float*)nullptr, c->ws_ah, c->ws_al, (bf16_t*)nullptr))
       launch_gemm(c, tgx::GEMM_GELU, w.wgu, w.bfc, nullptr, M, I, H, I);             // c_fc + bias + gelu_new -> ws_hh / ws_hl
     } else {
-      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, c->ws_ah, c->ws_al, (bf16_t*)nullptr,
-                                                (const float*)(osl != 1 ? c->ws_part : nullptr), std::abs(osl), (long long)M * H, reinterpret_cast<const bf16_t*>(w.bo)))
-      launch_gemm(c, tgx::GEMM_SILU, w.wgu, nullptr, nullptr, M, 2 * I, H, 2 * I);      // gate_up + siluMul -> ws_hh / ws_hl
+      const bool fl = gemm_full_lines(c, tgx::GEMM_SILU, M, 2 * I, H);
+      bf16_t* const ai = reinterpret_cast<bf16_t*>(c->ws_out);
+      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rmsnorm_split_kernel<DT>, dim3(M), dim3(256), 0, c->stream, c->ws_x, (const bf16_t*)w.post_norm, d.norm_eps, H, fl ? ai : c->ws_ah, c->ws_al, (bf16_t*)nullptr,
+                                                (const float*)(osl != 1 ? c->ws_part : nullptr), std::abs(osl), (long long)M * H, reinterpret_cast<const bf16_t*>(w.bo), fl ? 1 : 0))
+      if (fl) launch_gemm(c, tgx::GEMM_SILU, w.wgu, nullptr, nullptr, M, 2 * I, H, 2 * I, false, ai, nullptr, 0, nullptr, true);
+      else launch_gemm(c, tgx::GEMM_SILU, w.wgu, nullptr, nullptr, M, 2 * I, H, 2 * I);      // gate_up + siluMul -> ws_hh / ws_hl
     }
     // the down product's slabs wait for the next layer's input norm (the last layer, and GPT-2's LayerNorm path, finish them here)
     const bool can_defer = !c->gpt2 && l + 1 < d.layers;
@@ -382,6 +405,8 @@ int prefill_set_attrs(tgx_ctx* c) {
 #define TGX_DMA_ATTR(DT_, EPI_, MI_) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 4) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 4)
 #define TGX_DMA_ATTR_D(DT_) TGX_DMA_ATTR(DT_, tgx::GEMM_SILU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_GELU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 2)
   TGX_DMA_ATTR_D(tgx::DT_BF16) TGX_DMA_ATTR_D(tgx::DT_F16)
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8i_kernel<tgx::DT_BF16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8i_kernel<tgx::DT_F16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_BF16, 128, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (64 * 136 + 64 * 160) * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_F16, 128, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (64 * 136 + 64 * 160) * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
