@@ -215,3 +215,23 @@ def test_gate_up_on_full_lines_is_bit_identical(name, S, dtype):
     np.testing.assert_array_equal(outs[1][0], outs[0][0])
     np.testing.assert_array_equal(outs[1][1][0], outs[0][1][0])
     np.testing.assert_array_equal(outs[1][1][1], outs[0][1][1])
+
+
+@pytest.mark.parametrize("name,S", [("llama-3.2-1b", 1024), ("llama-3.2-1b", 1900), ("mistral-7b-v0.3", 1100)])
+def test_qkv_on_shared_activation_lines_is_bit_identical(name, S):
+    """Round 5 (option prefill.qkv_shared, on by default): where q_dim = 4 kv_dim the QKV product of a bf16 prompt runs as eight-wave workgroups that own the Q tile AND the
+    K | V tile of a 128-row block and stage the three activation term tiles once for both (kernels/gemm_dma.h gemm_dma_qkv8_kernel) — per accumulator the same matrix
+    instructions in the same order as the balanced two-kind launch: logits and cache rows BIT-identical, also with a ragged last row block."""
+    d = copy.deepcopy(known_desc(name, "bf16"))
+    d.layers, d.vocab, d.max_ctx = 2, 4096, S + 16
+    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    prompt = synth.synth_prompt(d.vocab, S, 83)[None, :]
+    outs = []
+    for on in (0, 1):
+        m.set_option("prefill.qkv_shared", on)
+        m.reset_cache(); m.forward(prompt)
+        outs.append((m.logits(rounded=False).copy(), m.read_kv(0, 0), m.read_kv(0, 1)))
+    np.testing.assert_array_equal(outs[1][0], outs[0][0])
+    for l in (1, 2):
+        np.testing.assert_array_equal(outs[1][l][0], outs[0][l][0])
+        np.testing.assert_array_equal(outs[1][l][1], outs[0][l][1])

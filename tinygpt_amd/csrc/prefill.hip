@@ -224,6 +224,14 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
       return;
     }
   }
+  if ((c->gemm_dma & 3) && c->qkv_balanced && c->qkv_shared && three_terms && epi == tgx::GEMM_STORE && three_from > 0 && three_from % tgx::GBN == 0 && N > three_from && K % 64 == 0 &&
+      (N - three_from) % 64 == 0 && three_from / tgx::GBN == (N - three_from) / 64 && 2 * (three_from / tgx::GBN) * ((M + 127) / 128) >= c->num_cus) {
+    // ... with as many 128-column Q tiles as 64-column K | V tiles (q_dim = 4 kv_dim) and at least half a chip of workgroups: eight waves per workgroup, the Q tile and the
+    // K | V tile of a row block on ONE staging of the activation lines (kernels/gemm_dma.h gemm_dma_qkv8_kernel; option prefill.qkv_shared)
+    const int nwg = (three_from / tgx::GBN) * ((M + 127) / 128);
+    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma_qkv8_kernel<DT>), dim3(nwg), dim3(512), (size_t)2 * (3 * 128 + 128 + 64) * 64 * 2, c->stream, g))
+    return;
+  }
   if ((c->gemm_dma & 3) && c->qkv_balanced && three_terms && epi == tgx::GEMM_STORE && three_from > 0 && three_from % tgx::GBN == 0 && N > three_from && K % 64 == 0 && M >= 128) {
     // the QKV product of a bf16 prompt: Q columns as two-term 128-row tiles, K / V columns as three-term 64-row tiles, ONE launch with
     // equal work per workgroup pair (kernels/gemm_dma.h gemm_dma_qkv_kernel)
@@ -405,6 +413,8 @@ int prefill_set_attrs(tgx_ctx* c) {
 #define TGX_DMA_ATTR(DT_, EPI_, MI_) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 4) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 4)
 #define TGX_DMA_ATTR_D(DT_) TGX_DMA_ATTR(DT_, tgx::GEMM_SILU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_GELU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 2)
   TGX_DMA_ATTR_D(tgx::DT_BF16) TGX_DMA_ATTR_D(tgx::DT_F16)
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma_qkv8_kernel<tgx::DT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * 128 + 128 + 64) * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma_qkv8_kernel<tgx::DT_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * 128 + 128 + 64) * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8i_kernel<tgx::DT_BF16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8i_kernel<tgx::DT_F16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_BF16, 128, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (64 * 136 + 64 * 160) * 2));

@@ -86,6 +86,7 @@ int main(int argc, char** argv) {
   DISK(ip4_silu, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 0, 4>), LDS8I)  DISK(ip6_silu, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 0, 6>), LDS8I)
   DISK(ip4_silu_d1, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 1, 4>), LDS8I)  DISK(ip4_silu_d2, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 2, 4>), LDS8I)
   DISK(ip4_silu_d4, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 4, 4>), LDS8I)  DISK(ip4_silu_d8, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 8, 4>), LDS8I)
+  DISK(i_part, (gemm_dma8i_kernel<DT_BF16, GEMM_PARTIAL>), LDS8I)
   DISK(k8_part, (gemm_dma8_kernel<DT_BF16, GEMM_PARTIAL>), LDS8)  DISK(k8k_part, (gemm_dma8k_kernel<DT_BF16, GEMM_PARTIAL>), LDS8K)
   DISK(k8_silu_d17, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 17>), LDS8)
   DISK(pp1_res, (gemm_dma8_kernel<DT_BF16, GEMM_RESIDUAL, true, 4, 0, true, 1>), LDS8)
@@ -155,6 +156,7 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 2; rep++) {
           report("gemm_dma8k one slab (the product's launch: 128x128, store, the next norm launch adds)", time_us(reps, LP(k8k_part, g128, LDS8K, 1)));
           report("gemm_dma8 256x256 x 4 K slabs (256 workgroups, fp32 slab stores)", time_us(reps, LP(k8_part, g256, LDS8, 4)));
+          report("gemm_dma8i 256x256 x 4 K slabs, full lines (interleaved A)", time_us(reps, [&](int l) { GemmArgs g = make_args(s, b, l, b.C); g.A_hi = b.Ai; g.A_lo = nullptr; g.part = part; g.nsplit = 4; g.k_per = s.K / 4; hipLaunchKernelGGL(i_part, dim3(g256.x, g256.y, 4), blk, LDS8I, 0, g); }));
           report("gemm_dma8 256x256 x 2 K slabs (128 workgroups)", time_us(reps, LP(k8_part, g256, LDS8, 2)));
           report("gemm_dma8k 128x128 x 2 K slabs (512 workgroups)", time_us(reps, LP(k8k_part, g128, LDS8K, 2)));
         }
@@ -165,6 +167,11 @@ int main(int argc, char** argv) {
         for (int z = 0; z < 4; z++) CK(hipMemcpy(t.data() + ((size_t)z << 16), part + (size_t)z * nC, r.size() * 4, hipMemcpyDeviceToHost));
         double md = 0, mr = 0; for (size_t i = 0; i < r.size(); i++) { const double v = ((double)t[i] + t[i + (1 << 16)]) + ((double)t[i + (2 << 16)] + t[i + (3 << 16)]); md = fmax(md, fabs(v - r[i])); mr = fmax(mr, fabs((double)r[i])); }
         printf("  check 4 slabs summed vs the 128x128 kernel: max |d| / max |ref| = %.2e\n", md / mr);
+        { GemmArgs g = make_args(s, b, 0, b.C); g.A_hi = b.Ai; g.A_lo = nullptr; g.part = part; g.nsplit = 4; g.k_per = s.K / 4; CK(hipMemset(part, 0, 4 * nC * 4)); hipLaunchKernelGGL(i_part, dim3(g256.x, g256.y, 4), blk, LDS8I, 0, g); CK(hipDeviceSynchronize());
+          std::vector<float> t2(4 << 16);
+          for (int z = 0; z < 4; z++) CK(hipMemcpy(t2.data() + ((size_t)z << 16), part + (size_t)z * nC, r.size() * 4, hipMemcpyDeviceToHost));
+          size_t bad = 0; for (size_t i = 0; i < t2.size(); i++) bad += t2[i] != t[i];
+          printf("  check full-line 4 slabs vs half-line 4 slabs: %zu of %zu words differ\n", bad, t2.size()); }
         CK(hipFree(part));
       }
       report("gemm_dma8 ping-pong (256x256: 64 tiles on 256 CUs)", time_us(reps, [&](int l) { L(pp1_res, g256, LDS8)(l); }));
