@@ -235,3 +235,23 @@ def test_qkv_on_shared_activation_lines_is_bit_identical(name, S):
     for l in (1, 2):
         np.testing.assert_array_equal(outs[1][l][0], outs[0][l][0])
         np.testing.assert_array_equal(outs[1][l][1], outs[0][l][1])
+
+
+@pytest.mark.parametrize("name,S,dtype", [("llama-3.2-1b", 1024, "bf16"), ("llama-3.2-1b", 1900, "bf16"), ("llama-3.2-1b", 2048, "fp16"), ("mistral-7b-v0.3", 1100, "bf16")])
+def test_down_on_wide_tiles_matches_the_square_tiles(name, S, dtype):
+    """Round 5 (option prefill.wide_n, on by default): the K >> N product (`down`) of a chip-filling prompt runs on 128 x 256 tiles x 2 K slabs (kernels/gemm_dma.h
+    gemm_dma8n_kernel: a third fewer operand lines per output; the slabs are summed in z order by the next norm launch) instead of one slab of 128 x 128 tiles — the same
+    products in another fp32 summation order: TWO layers (the second layer's norm consumes the slabs), logits within 2e-5, the same first token; bit-identical on a rerun."""
+    d = copy.deepcopy(known_desc(name, dtype))
+    d.layers, d.vocab, d.max_ctx = 2, 4096, S + 16
+    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    prompt = synth.synth_prompt(d.vocab, S, 84)[None, :]
+    outs = []
+    m.set_option("prefill.wide_n_min", 1)             # (the default takes the form from two chips' worth of workgroups)
+    for on in (0, 1, 1):
+        m.set_option("prefill.wide_n", on)
+        m.reset_cache(); m.forward(prompt)
+        outs.append((m.logits(rounded=False).copy(), m.sample(GREEDY).copy()))
+    assert rel_err(outs[1][0], outs[0][0]) < 2e-5, rel_err(outs[1][0], outs[0][0])
+    np.testing.assert_array_equal(outs[1][1], outs[0][1])
+    np.testing.assert_array_equal(outs[1][0], outs[2][0])

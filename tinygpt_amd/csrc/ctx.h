@@ -150,6 +150,8 @@ struct tgx_ctx {
   int splitk_dma = 1;        // option prefill.splitk_dma: the split-K slabs of a short prompt through the LDS-DMA GEMM (round 3)
   int qkv_balanced = 1;      // option prefill.qkv_balanced: the bf16 QKV product as one launch of equal-work tiles (round 3)
   int attn_mirror = 1;       // experiment: prefill attention block order
+  int wide_n_min = 2;        // ... from this many chips' worth of its workgroups (option prefill.wide_n_min)
+  int wide_n = 1;            // option prefill.wide_n: K >> N products (`down`) of a chip-filling prompt on 128 x 256 tiles x 2 K slabs (gemm_dma8n_kernel)
   int qkv_shared = 1;        // option prefill.qkv_shared: the QKV product of a bf16 prompt as eight-wave workgroups that stage the activation lines once for their Q and K | V tiles
   int full_lines = 1;        // option prefill.full_lines: gate_up of a chip-filling prompt stages whole 128-byte lines (interleaved activation terms; gemm_dma8i_kernel)
   int attn_dma = 1;          // option prefill.attn_dma: head_dim 64 prompts of three or more workgroups per CU take kernels/attn_prefill_dma.h (0 never, 2 always)

@@ -848,6 +848,120 @@ __global__ __launch_bounds__(512) void gemm_dma8i_kernel(const GemmArgs a) {
     }
 }
 
+// ---- 128 x 256 tile, 8 waves = 2 row halves x 2 column halves x 2 k halves, split-K slabs (the N = hidden products with K >> N: `down`; round 5) -----------------
+// The 128 x 128 kernel below waits for its operands: 48 KB of lines per k64 step and tile, ~1920 cycles of the CU's memory pipeline for 1024 of its matrix pipe
+// (DESIGN.md section 5).  A tile twice as wide shares its activation lines between two column tiles — 64 KB per k64 step for twice the outputs, a third fewer lines per
+// output — at 128 accumulator registers per wave (64 x 128 of the output, as the 256 x 256 kernel's waves); the four wave tiles exist twice, for the first and the
+// second half of every stage's k16 steps, and the two partial accumulators meet once through LDS.  128 tiles at S = 2048: blockIdx.z halves K (two fp32 slabs, summed
+// in z order by the next row-wise launch).  Another fp32 summation order than the 128 x 128 kernel: results differ by ~1e-6.
+template <int DT>
+__global__ __launch_bounds__(512) void gemm_dma8n_kernel(const GemmArgs a) {
+  constexpr int DBK = 64, NS = 2, TM = 128, TN = 256;
+  constexpr int T_A = TM * DBK, T_B = TN * DBK;                           // 16-bit elements of a term tile / the weight tile
+  constexpr int STAGE = 2 * T_A + T_B;                                    // 64 KB
+  extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = wv >> 2, wm = (wv >> 1) & 1, wn = wv & 1;
+  const unsigned lds_base = (unsigned)(size_t)dma_lds;
+  int tile_m, tile_n;
+  xcd_tile(a, tile_m, tile_n);
+  const int m0 = tile_m * TM, n0 = tile_n * TN;
+  const int k_begin = (int)blockIdx.z * a.k_per, k_end = min(a.K, k_begin + a.k_per);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // DMA map: a piece = 8 rows of 128 bytes; lane l -> row (l >> 3), LDS slot l & 7 <- global chunk slot ^ ((row >> 1) & 7).  Wave w: pieces w, w + 8 of each term tile,
+  // pieces w, w + 8, w + 16, w + 24 of the weight tile: eight per stage
+  const int prow = lane >> 3, pslot = lane & 7;
+  const bf16_t* gsrc[8];
+  unsigned ldst[8];
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const int piece = wv + 8 * p, row = piece * 8 + prow;
+    const int chunk = pslot ^ ((row >> 1) & 7);
+    const size_t ga = (size_t)min(m0 + row, a.M - 1) * a.K + k_begin + chunk * 8;
+    gsrc[2 * p] = a.A_hi + ga; gsrc[2 * p + 1] = a.A_lo + ga;
+    ldst[2 * p] = (unsigned)(piece * 1024); ldst[2 * p + 1] = ldst[2 * p] + (unsigned)(T_A * 2);
+  }
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const int piece = wv + 8 * p, row = piece * 8 + prow;
+    const int chunk = pslot ^ ((row >> 1) & 7);
+    gsrc[4 + p] = a.B + (size_t)min(n0 + row, a.N - 1) * a.K + k_begin + chunk * 8;
+    ldst[4 + p] = (unsigned)(2 * T_A * 2 + piece * 1024);
+  }
+  auto frag = [&](const bf16_t* tile, int row, int kchunk) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(tile + row * DBK + ((kchunk ^ ((row >> 1) & 7)) << 3));
+  };
+
+  const int nk = (k_end - k_begin) / DBK;
+#pragma unroll
+  for (int q = 0; q < 8; q++) dma_1k(gsrc[q], lds_base + ldst[q]);
+  for (int k = 0; k < nk; k++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // stage k landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                                      // ... every wave's; and every wave is done reading stage k - 1
+    const bool more = k + 1 < nk;
+    const int nk0 = (k + 1) * DBK;
+    const unsigned nsb = lds_base + (unsigned)(((k + 1) % NS) * STAGE * 2);
+    const bf16_t* st = dma_lds + (size_t)(k % NS) * STAGE;
+    const bf16_t *tAh = st, *tAl = st + T_A, *tB = st + 2 * T_A;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {                                      // this wave's two k16 steps of the stage
+      const int kchunk = (2 * kh + h) * 2 + (lane >> 5);
+      bf16x8 fah[2], fal[2], fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) fb[j] = frag(tB, wn * 128 + j * 32 + (lane & 31), kchunk);
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int row = wm * 64 + i * 32 + (lane & 31);
+        fah[i] = frag(tAh, row, kchunk);
+        fal[i] = frag(tAl, row, kchunk);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          acc[i][j] = mfma16<DT>(fal[i], fb[j], acc[i][j]);   // small term first
+          acc[i][j] = mfma16<DT>(fah[i], fb[j], acc[i][j]);
+          if (more && ((i * 4 + j) & 1)) { const int q = 4 * h + ((i * 4 + j) >> 1); dma_1k(gsrc[q] + nk0, nsb + ldst[q]); }      // one piece of the next stage per two blocks
+        }
+    }
+  }
+
+  // the second k half joins the first through LDS (the ring is idle: 4 x 32 KB = its 128 KB), lane to lane; the first half stores the slab
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  float* red = reinterpret_cast<float*>(dma_lds) + (size_t)(wv & 3) * 8 * 16 * 64 + lane;
+  if (kh == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[((i * 4 + j) * 16 + r) * 64] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (kh == 1) return;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int col = n0 + wn * 128 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float v = acc[i][j][r] + red[((i * 4 + j) * 16 + r) * 64];
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < a.M && col < a.N) a.part[((size_t)blockIdx.z * a.M + row) * a.N + col] = v;
+      }
+    }
+}
+
 // ---- 128 x 128 tile, 8 waves with the K step split between them, three-stage ring (the N = hidden products: o_proj, down) ---------
 // At S = 2048 these products have only 256 tiles of 128 x 128 — one per CU.  Four waves per tile leave one wave per SIMD (nothing hides a
 // wave's fragment-read latency); 64-row tiles double the workgroups but read a fragment per MFMA.  Here the 128 x 128 tile gets EIGHT waves

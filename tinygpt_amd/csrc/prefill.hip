@@ -117,6 +117,27 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
     }
     if (z >= 2) { part_8k = true; nsplit = z; }
   }
+  // K >> N (`down`) on 128 x 256 tiles x 2 K slabs: a third fewer operand lines per output than the 128 x 128 kernel, which waits for them (kernels/gemm_dma.h
+  // gemm_dma8n_kernel; option prefill.wide_n).  Needs a consumer that sums pending slabs (`defer`) and two rounds of workgroups (prefill.wide_n_min, in chips): at one
+  // round (Llama-3.2-1B S = 2048: 256 workgroups) it ties with the one-slab 128 x 128 launch (141 vs 140-146 us) and costs a second slab; Mistral-7B S = 2048 56.1 -> 54.1 ms
+  if (nsplit == 1 && defer && c->wide_n && c->defer_reduce && epi == tgx::GEMM_RESIDUAL && (c->gemm_dma & 8) && !three_terms && !one && K >= 2 * N && K % 128 == 0 && N % 256 == 0 &&
+      2 * (N / 256) * ((M + 127) / 128) >= c->wide_n_min * c->num_cus) {
+    const size_t need = (size_t)2 * M * N * 4;
+    if (need > c->ws_part_bytes) {
+      drop_step_graphs(c);
+      (void)hipStreamSynchronize(c->stream);
+      if (c->ws_part) (void)hipFree(c->ws_part);
+      c->ws_part = nullptr; c->ws_part_bytes = 0;
+      if (hipMalloc((void**)&c->ws_part, need) == hipSuccess) c->ws_part_bytes = need;
+    }
+    if (c->ws_part_bytes >= need) {
+      g.part = c->ws_part; g.nsplit = 2; g.interleave = 0; g.k_per = K / 2;
+      const dim3 g8(N / 256, (M + 127) / 128, 2), b8(512);
+      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma8n_kernel<DT>), g8, b8, (size_t)2 * (2 * 128 + 256) * 64 * 2, c->stream, g))
+      *defer = 2;
+      return;
+    }
+  }
   // one tile per CU on the eight-wave 128 x 128 kernel, a consumer that can take a pending slab: store the product, let the consumer add it (see `defer` above)
   const int t128u = ((N + 127) / 128) * ((M + 127) / 128);
   const bool store_slab = nsplit == 1 && defer && c->defer_store && c->defer_reduce && epi == tgx::GEMM_RESIDUAL && (c->gemm_dma & 8) && K % 64 == 0 && !three_terms &&
@@ -413,6 +434,8 @@ int prefill_set_attrs(tgx_ctx* c) {
 #define TGX_DMA_ATTR(DT_, EPI_, MI_) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 4) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 4)
 #define TGX_DMA_ATTR_D(DT_) TGX_DMA_ATTR(DT_, tgx::GEMM_SILU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_GELU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 2)
   TGX_DMA_ATTR_D(tgx::DT_BF16) TGX_DMA_ATTR_D(tgx::DT_F16)
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8n_kernel<tgx::DT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 128 + 256) * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8n_kernel<tgx::DT_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 128 + 256) * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma_qkv8_kernel<tgx::DT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * 128 + 128 + 64) * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma_qkv8_kernel<tgx::DT_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * 128 + 128 + 64) * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8i_kernel<tgx::DT_BF16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128));
