@@ -426,7 +426,10 @@ __device__ __forceinline__ void silu_epilogue_transposed(const f32x16 (&acc)[2][
 // (bit-identical; tools/probes/gemm_lab.hip, profiles/r05_prefill.txt).
 // LO = false (option act.round16: the Linear's input is rounded to the storage dtype, so A_hi IS the activation): the A_lo tile is neither staged nor
 // multiplied — 4 DMA pieces per stage instead of 6, half the MFMAs (gate_up at S = 2048: 232 -> 130 us, profiles/r04_act16_cost.txt)
-// DIS (lab only): 1 = no MFMAs, 2 = no DMA after the prologue, 4 = no fragment reads, 8 = no epilogue stores.
+// DIS (lab only): 1 = no MFMAs, 2 = no DMA after the prologue, 4 = no fragment reads, 8 = no epilogue stores; 17 = the operand stream free-running (no ring discipline).
+// PP (lab only, tools/probes/gemm_lab.hip): 1 = the two waves of a SIMD half a stage apart (ping-pong), + 2 s_setprio around the matrix phase, + 4 static s_setprio for
+// waves 4-7, + 8 DMA issue ahead of the fragment reads — measured, not adopted (profiles/r05_prefill.txt section 5).  GEMM_PARTIAL (blockIdx.z = K slab) likewise serves the lab's
+// `down` experiment only; the product's slab forms live in gemm_dma8k_kernel / gemm_dma8n_kernel.
 // TEPI (round 5, GEMM_SILU with WJ = 4): the siluMul epilogue goes through LDS.  In the MFMA C layout a lane ends up with ONE (gate, up) result per row pair, so the
 // direct epilogue stores 2 bytes per lane, 32 contiguous bytes per row and instruction — 128 store instructions per wave and term, a quarter of a line each.  Here every wave
 // writes its 64 x 64 results (hi and lo) into its own 18-KB slice of the idle ring ([64 rows][72]: 144-byte rows keep the 16-byte reads aligned and the row pairs off each
