@@ -84,6 +84,7 @@ int main(int argc, char** argv) {
   DISK(pp9_silu, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 0, true, 9>), LDS8)
   DISK(ip0_silu, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 0, 0>), LDS8I)  DISK(ip2_silu, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 0, 2>), LDS8I)
   DISK(ip4_silu, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 0, 4>), LDS8I)  DISK(ip6_silu, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 0, 6>), LDS8I)
+  DISK(ip20_silu, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 0, 20>), LDS8I)
   DISK(ip4_silu_d1, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 1, 4>), LDS8I)  DISK(ip4_silu_d2, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 2, 4>), LDS8I)
   DISK(ip4_silu_d4, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 4, 4>), LDS8I)  DISK(ip4_silu_d8, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 8, 4>), LDS8I)
   DISK(i_part, (gemm_dma8i_kernel<DT_BF16, GEMM_PARTIAL>), LDS8I)
@@ -207,8 +208,18 @@ int main(int argc, char** argv) {
         report("  + s_setprio 1 around the matrix phase", time_us(reps, [&](int l) { LI(ip2_silu)(l); }));
         report("  + static s_setprio 1 for waves 4-7", time_us(reps, [&](int l) { LI(ip4_silu)(l); }));
         report("  + both", time_us(reps, [&](int l) { LI(ip6_silu)(l); }));
+        report("  static prio + one DMA piece per two fragment reads", time_us(reps, [&](int l) { LI(ip20_silu)(l); }));
         report("product (k32 stages, lock step, LDS-transposed epilogue)", time_us(reps, [&](int l) { base(l); }));
       }
+#ifdef LAB_TIMING
+      { long long* tmg; CK(hipMalloc(&tmg, 64 * 8)); CK(hipMemset(tmg, 0, 64 * 8));
+        GemmArgs g = make_args(s, b, 0, b.C); g.A_hi = b.Ai; g.A_lo = nullptr; g.ssq_out = reinterpret_cast<float*>(tmg);
+        hipLaunchKernelGGL(getenv("LAB_IP20") ? ip20_silu : ip4_silu, g256, blk, LDS8I, 0, g); CK(hipDeviceSynchronize());
+        long long ht[64]; CK(hipMemcpy(ht, tmg, 64 * 8, hipMemcpyDeviceToHost));
+        printf("  dma8ip per-phase cycles of one workgroup, per k32 step (%lld k64 blocks): fragment reads | DMA issue | landing wait | barrier | 32 MFMAs | barrier\n", ht[6]);
+        for (int w = 0; w < 8; w++) { printf("    group %d wave %d:", w >> 2, w & 3); for (int i = 0; i < 6; i++) printf(" %6lld", ht[w * 8 + i] / (2 * ht[6])); printf("\n"); }
+        CK(hipFree(tmg)); }
+#endif
       report("  dma8ip DIS 1  (DMA + reads + barriers only)", time_us(reps, [&](int l) { LI(ip4_silu_d1)(l); }));
       report("  dma8ip DIS 2  (no DMA after the prologue)", time_us(reps, [&](int l) { LI(ip4_silu_d2)(l); }));
       report("  dma8ip DIS 4  (no fragment reads)", time_us(reps, [&](int l) { LI(ip4_silu_d4)(l); }));

@@ -65,10 +65,33 @@ __global__ __launch_bounds__(512) void gemm_dma8ip_kernel(const GemmArgs a) {
       fa[2 * i + 1] = *reinterpret_cast<const bf16x8*>(ua + arow + i * 32 * 64 + (((4 + ca) ^ swz) << 3));
     }
   };
+  // two fragments of k16 step kk of k32 step s: part 0, 1 = B blocks (2 part, 2 part + 1); part 2, 3 = both terms of A block part - 2
+  auto read_pair = [&](int s, int kk, int part, bf16x8* fa, bf16x8* fb) __attribute__((always_inline)) {
+    if (DIS & 4) return;
+    const int b = s >> 1;
+    const bf16_t* ua = dma_lds + (size_t)((3 * b + ((s & 1) << 1)) % NSLOT) * UNIT;
+    const bf16_t* ub = dma_lds + (size_t)((3 * b + 1) % NSLOT) * UNIT;
+    const int ca = kk * 2 + (lane >> 5), cb = (s & 1) * 4 + ca;
+    if (part < 2) {
+#pragma unroll
+      for (int j = 2 * part; j < 2 * part + 2; j++) fb[j] = *reinterpret_cast<const bf16x8*>(ub + brow_l + j * 32 * 64 + ((cb ^ swz) << 3));
+    } else {
+      const int i = part - 2;
+      fa[2 * i] = *reinterpret_cast<const bf16x8*>(ua + arow + i * 32 * 64 + ((ca ^ swz) << 3));
+      fa[2 * i + 1] = *reinterpret_cast<const bf16x8*>(ua + arow + i * 32 * 64 + (((4 + ca) ^ swz) << 3));
+    }
+  };
   // ping-pong: waves w and w + 4 (one SIMD) half a k32 step apart; a phase ends with one workgroup barrier; group 1 enters one phase late.  Step s is read in
   // phases 2s (group 0) and 2s + 1 (group 1).  Per k64 block b a wave issues, in its memory phase of step 2b, its pieces of units 3b+3, 3b+4 (A of step 2b+2,
   // B of block b+1: freed by phase 4b-1) and in that of step 2b+1 unit 3b+5 (A of step 2b+3, freed by phase 4b+1); each is read from three phases later.
   const int grp = wv >> 2;
+#ifdef LAB_TIMING
+  long long tm[6] = {0, 0, 0, 0, 0, 0};
+  long long tprev = __builtin_readcyclecounter();
+#define LAB_TICK(i) do { const long long now_ = __builtin_readcyclecounter(); tm[i] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define LAB_TICK(i) do {} while (0)
+#endif
 #pragma unroll
   for (int u = 0; u < 3; u++)
 #pragma unroll
@@ -90,6 +113,7 @@ __global__ __launch_bounds__(512) void gemm_dma8ip_kernel(const GemmArgs a) {
   auto matrix_phase = [&]() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    LAB_TICK(3);
     if (PP & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int h = 0; h < 2; h++)
@@ -104,31 +128,75 @@ __global__ __launch_bounds__(512) void gemm_dma8ip_kernel(const GemmArgs a) {
         }
     if (PP & 2) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    LAB_TICK(4);
     __builtin_amdgcn_s_barrier();
+    LAB_TICK(5);
   };
+#ifdef LAB_TIMING
+  tprev = __builtin_readcyclecounter();
+#endif
   for (int b = 0; b < nblk; b++) {
     // ---- step 2b: memory phase
+    if constexpr (PP & 16) {      // one DMA piece behind every two fragment reads: the wave reaches its next piece when the CU's memory pipeline has taken the others'
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        read_pair(2 * b, q >> 2, q & 3, fa[q >> 2], fb[q >> 2]);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(b + 1, q >> 2, q & 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      LAB_TICK(0);
+    } else {
     read_frags(2 * b, 0, fa[0], fb[0]);
     read_frags(2 * b, 1, fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    LAB_TICK(0);
 #pragma unroll
     for (int p = 0; p < 4; p++) issue(b + 1, 0, p);
 #pragma unroll
     for (int p = 0; p < 4; p++) issue(b + 1, 1, p);
+    __builtin_amdgcn_sched_barrier(0);
+    }
+    LAB_TICK(1);
     if (DIS & 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");      // unit 3b+2 landed
     __builtin_amdgcn_sched_barrier(0);
+    LAB_TICK(2);
     matrix_phase();
     // ---- step 2b+1
+    if constexpr (PP & 16) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        read_pair(2 * b + 1, q >> 2, q & 3, fa[q >> 2], fb[q >> 2]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q & 1) { issue(b + 1, 2, q >> 1); __builtin_amdgcn_sched_barrier(0); }
+      }
+      LAB_TICK(0);
+    } else {
     read_frags(2 * b + 1, 0, fa[0], fb[0]);
     read_frags(2 * b + 1, 1, fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    LAB_TICK(0);
 #pragma unroll
     for (int p = 0; p < 4; p++) issue(b + 1, 2, p);
+    __builtin_amdgcn_sched_barrier(0);
+    }
+    LAB_TICK(1);
     if (DIS & 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");      // units 3b+3, 3b+4 landed
     __builtin_amdgcn_sched_barrier(0);
+    LAB_TICK(2);
     matrix_phase();
   }
   if (!grp) __builtin_amdgcn_s_barrier();
+#ifdef LAB_TIMING
+  if (a.ssq_out && blockIdx.x == 3 && blockIdx.y == 2 && lane == 0) {
+    long long* o = reinterpret_cast<long long*>(a.ssq_out) + wv * 8;
+#pragma unroll
+    for (int i = 0; i < 6; i++) o[i] = tm[i];
+    o[6] = nblk;
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if (DIS & 8) {
