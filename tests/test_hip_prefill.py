@@ -255,3 +255,30 @@ def test_down_on_wide_tiles_matches_the_square_tiles(name, S, dtype):
     assert rel_err(outs[1][0], outs[0][0]) < 2e-5, rel_err(outs[1][0], outs[0][0])
     np.testing.assert_array_equal(outs[1][1], outs[0][1])
     np.testing.assert_array_equal(outs[1][0], outs[2][0])
+
+
+@pytest.mark.parametrize("name,S,dtype", [("llama-3.2-1b", 1024, "bf16"), ("llama-3.2-1b", 1900, "bf16")])
+def test_qkv_epilogue_with_rope_and_cache_append_is_bit_identical(name, S, dtype):
+    """Round 5 (option prefill.qkv_rope, on by default; head_dim 64, one sequence): the shared-line QKV launch also adds the bias, rotates q and k at the row's
+    position, splits q into its two 16-bit terms and rounds k / v into the cache in its epilogue — the arithmetic of rope_kv_split_kernel on the same accumulators:
+    logits and cache rows BIT-identical to the two-launch form, also with a ragged last row block; a second prompt behind a reset as well (the cache rows are rewritten)."""
+    d = copy.deepcopy(known_desc(name, dtype))
+    d.layers, d.vocab, d.max_ctx = 2, 4096, S + 16
+    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
+    outs = []
+    for on in (0, 1):
+        m.set_option("prefill.qkv_rope", on)
+        res = []
+        for seed in (85, 86):
+            prompt = synth.synth_prompt(d.vocab, S - (seed - 85) * 100, seed)[None, :]
+            m.reset_cache(); m.forward(prompt)
+            lg, kv0, kv1 = m.logits(rounded=False).copy(), m.read_kv(0, 0), m.read_kv(0, 1)
+            m.sample(GREEDY)
+            res.append((lg, kv0, kv1, m.decode(3, GREEDY).copy()))
+        outs.append(res)
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a[0], b[0])
+        for l in (1, 2):
+            np.testing.assert_array_equal(a[l][0], b[l][0])
+            np.testing.assert_array_equal(a[l][1], b[l][1])
+        np.testing.assert_array_equal(a[3], b[3])

@@ -1128,6 +1128,7 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.attn_mirror")) { c->attn_mirror = value; return TGX_OK; }
   if (!strcmp(key, "prefill.wide_n_min")) { c->wide_n_min = value; return TGX_OK; }
   if (!strcmp(key, "prefill.wide_n")) { c->wide_n = value != 0; return TGX_OK; }
+  if (!strcmp(key, "prefill.qkv_rope")) { c->qkv_rope = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.qkv_shared")) { c->qkv_shared = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.full_lines")) { c->full_lines = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_dma")) { c->attn_dma = value; return TGX_OK; }

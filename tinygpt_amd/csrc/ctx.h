@@ -70,6 +70,9 @@ struct Profiler {
   double ms[TGX_KERNEL_COUNT] = {};
 };
 
+// where the QKV product of a one-sequence prefill may finish its rows (prefill.hip launch_prefill -> launch_gemm)
+struct QkvEpi { bf16_t *q_hi = nullptr, *q_lo = nullptr, *k = nullptr, *v = nullptr; };
+
 struct tgx_ctx {
   tgx_model_desc d{};
   int device = 0;
@@ -152,6 +155,8 @@ struct tgx_ctx {
   int attn_mirror = 1;       // experiment: prefill attention block order
   int wide_n_min = 2;        // ... from this many chips' worth of its workgroups (option prefill.wide_n_min)
   int wide_n = 1;            // option prefill.wide_n: K >> N products (`down`) of a chip-filling prompt on 128 x 256 tiles x 2 K slabs (gemm_dma8n_kernel)
+  QkvEpi qkv_epi;
+  int qkv_rope = 1;          // option prefill.qkv_rope: ... with RoPE, the cache append and the q split in that launch's epilogue (head_dim 64, one sequence)
   int qkv_shared = 1;        // option prefill.qkv_shared: the QKV product of a bf16 prompt as eight-wave workgroups that stage the activation lines once for their Q and K | V tiles
   int full_lines = 1;        // option prefill.full_lines: gate_up of a chip-filling prompt stages whole 128-byte lines (interleaved activation terms; gemm_dma8i_kernel)
   int attn_dma = 1;          // option prefill.attn_dma: head_dim 64 prompts of three or more workgroups per CU take kernels/attn_prefill_dma.h (0 never, 2 always)

@@ -212,7 +212,10 @@ __global__ __launch_bounds__(256) void gemm_dma_qkv_kernel(const GemmArgs a) {
 // wave) and the g-th 64-column tile of K | V (waves 4-7, three terms, 32 x 64 per wave): the three 16-KB term tiles of a k64 stage are staged once for both, next to the
 // two weight tiles (16 + 8 KB), 72 KB of whole 128-byte lines per stage, two stages.  Needs as many 128-column Q tiles as 64-column K | V tiles (q_dim = 4 kv_dim:
 // Llama-3.2-1B, Mistral-7B); one workgroup per CU at S = 2048, 2 + 1.5 units of work each.  Same MFMAs per accumulator in the same order as gemm_dma_qkv_kernel.
-template <int DT>
+// ROPE (head_dim 64: a Q wave's 64 columns are one query head, a K | V wave's 64 columns one kv head, and the rotation partners (d, d + 32) are the two column blocks
+// of ONE lane): the epilogue adds the bias, rotates q and k at the row's position, splits q into its two 16-bit terms, rounds k and v into the cache — the
+// rope_kv_split launch and the fp32 QKV matrix disappear.  Values pass through the idle ring ([rows][72] 16-bit: 144-byte rows) and leave as whole 128-byte rows.
+template <int DT, bool ROPE = false>
 __global__ __launch_bounds__(512) void gemm_dma_qkv8_kernel(const GemmArgs a) {
   constexpr int DBK = 64, NS = 2;
   constexpr int T_A = 128 * DBK, T_BQ = 128 * DBK, T_BK = 64 * DBK;       // 16-bit elements: a term tile, the Q weight tile, the K | V weight tile
@@ -331,6 +334,72 @@ __global__ __launch_bounds__(512) void gemm_dma_qkv8_kernel(const GemmArgs a) {
     }
   }
 
+  if constexpr (ROPE) {
+    constexpr int RS = 72;                                    // 16-bit elements per staged row
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // every wave is done with the ring
+    bf16_t* const sh = dma_lds + (size_t)wv * (2 * 64 * RS);  // this wave's slice: hi (or the cache image) rows, then lo rows
+    bf16_t* const sl = sh + 64 * RS;
+    const int p = lane & 31, hh = lane >> 5;
+    if (qwave) {
+      const int head = (nq0 + wn * 64) >> 6;
+      const float b0 = a.bias ? elem_to_f32<DT>(a.bias[head * 64 + p]) : 0.f, b1 = a.bias ? elem_to_f32<DT>(a.bias[head * 64 + 32 + p]) : 0.f;
+      float cs[2][16], sn[2][16];
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = min(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, a.M - 1);
+          cs[i][r] = a.rope_cos[(size_t)(a.rope_past + row) * 32 + p]; sn[i][r] = a.rope_sin[(size_t)(a.rope_past + row) * 32 + p];
+        }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          float x0 = acc[i][0][r] + b0, x1 = acc[i][1][r] + b1;
+          rope_rotate_pair(x0, x1, cs[i][r], sn[i][r]);
+          bf16_t h0, l0, h1, l1;
+          split16<DT>(x0, h0, l0); split16<DT>(x1, h1, l1);
+          const int o = (i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * RS + p;
+          sh[o] = h0; sh[o + 32] = h1; sl[o] = l0; sl[o + 32] = l1;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the wave reads only what it wrote itself
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int rl = q * 8 + (lane >> 3), row = m0 + wm * 64 + rl;
+        const u32x4 vh = *reinterpret_cast<const u32x4*>(sh + rl * RS + (lane & 7) * 8);
+        const u32x4 vl = *reinterpret_cast<const u32x4*>(sl + rl * RS + (lane & 7) * 8);
+        if (row < a.M) {
+          const size_t o = (size_t)row * a.three_from + head * 64 + (lane & 7) * 8;
+          *reinterpret_cast<u32x4*>(a.rope_q_hi + o) = vh;
+          *reinterpret_cast<u32x4*>(a.rope_q_lo + o) = vl;
+        }
+      }
+    } else {
+      const bool isk = cg < a.rope_kv_heads;                  // column group cg: key head cg, or value head cg - kv_heads
+      const int kvh = isk ? cg : cg - a.rope_kv_heads;
+      const float b0 = a.bias ? elem_to_f32<DT>(a.bias[nk0 + p]) : 0.f, b1 = a.bias ? elem_to_f32<DT>(a.bias[nk0 + 32 + p]) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh, row = min(m0 + w4 * 32 + rl, a.M - 1);
+        float x0 = acc[0][0][r] + b0, x1 = acc[0][1][r] + b1;
+        if (isk) {
+          const float c = a.rope_cos[(size_t)(a.rope_past + row) * 32 + p], s = a.rope_sin[(size_t)(a.rope_past + row) * 32 + p];
+          rope_rotate_pair(x0, x1, c, s);
+        }
+        sh[rl * RS + p] = f32_to_elem<DT>(x0); sh[rl * RS + 32 + p] = f32_to_elem<DT>(x1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bf16_t* const cache = (isk ? a.rope_k : a.rope_v) + (size_t)kvh * a.rope_max_ctx * 64;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int rl = q * 8 + (lane >> 3), row = m0 + w4 * 32 + rl;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(sh + rl * RS + (lane & 7) * 8);
+        if (row < a.M) *reinterpret_cast<u32x4*>(cache + (size_t)(a.rope_past + row) * 64 + (lane & 7) * 8) = v;
+      }
+    }
+    return;
+  }
   // epilogue: fp32 rows of the QKV matrix (+ bias); C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   auto store_block = [&](const f32x16& v, int row0, int col) __attribute__((always_inline)) {
     if (col >= a.N) return;

@@ -250,6 +250,14 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
     // ... with as many 128-column Q tiles as 64-column K | V tiles (q_dim = 4 kv_dim) and at least half a chip of workgroups: eight waves per workgroup, the Q tile and the
     // K | V tile of a row block on ONE staging of the activation lines (kernels/gemm_dma.h gemm_dma_qkv8_kernel; option prefill.qkv_shared)
     const int nwg = (three_from / tgx::GBN) * ((M + 127) / 128);
+    if (c->qkv_epi.q_hi && c->qkv_rope && c->d.head_dim == 64 && !c->d.qk_norm && defer) {
+      // ... and RoPE + cache append + the q split in its epilogue (one sequence, head_dim 64; option prefill.qkv_rope): no fp32 QKV matrix, no rope_kv_split launch
+      g.rope_q_hi = c->qkv_epi.q_hi; g.rope_q_lo = c->qkv_epi.q_lo; g.rope_k = c->qkv_epi.k; g.rope_v = c->qkv_epi.v;
+      g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.rope_past = (int)c->past; g.rope_max_ctx = c->d.max_ctx; g.rope_kv_heads = c->d.kv_heads;
+      TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma_qkv8_kernel<DT, true>), dim3(nwg), dim3(512), (size_t)2 * (3 * 128 + 128 + 64) * 64 * 2, c->stream, g))
+      *defer = 0;         // the rows are finished: the caller skips its RoPE / cache-append launch
+      return;
+    }
     TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma_qkv8_kernel<DT>), dim3(nwg), dim3(512), (size_t)2 * (3 * 128 + 128 + 64) * 64 * 2, c->stream, g))
     return;
   }
@@ -374,8 +382,15 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
                                                   (const float*)(pend != 1 ? c->ws_part : nullptr), std::abs(pend), (long long)M * H, pend_bias)) }
     pend = 1;
     int qsl = 1;
+    c->qkv_epi = QkvEpi{};
+    if (NB == 1) {      // one sequence: the QKV product may finish its rows itself (launch_gemm: gemm_dma_qkv8_kernel<.., ROPE>)
+      RowState& r0 = c->rows[(size_t)row0];
+      c->qkv_epi.q_hi = c->ws_qh; c->qkv_epi.q_lo = c->ws_ql;
+      c->qkv_epi.k = reinterpret_cast<bf16_t*>(r0.kcache) + (size_t)l * kv_layer; c->qkv_epi.v = reinterpret_cast<bf16_t*>(r0.vcache) + (size_t)l * kv_layer;
+    }
     launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, M, qd + 2 * kvd, H, qd + 2 * kvd, /*three_terms=*/three, nullptr, nullptr, /*three_from=*/qd, &qsl);   // Q columns: two terms
-    for (int b = 0; b < NB; b++) {
+    c->qkv_epi = QkvEpi{};
+    for (int b = 0; b < NB && qsl != 0; b++) {
       RowState& r = c->rows[(size_t)(row0 + b)];
       bf16_t* kc = reinterpret_cast<bf16_t*>(r.kcache);
       bf16_t* vc = reinterpret_cast<bf16_t*>(r.vcache);
@@ -436,6 +451,8 @@ int prefill_set_attrs(tgx_ctx* c) {
   TGX_DMA_ATTR_D(tgx::DT_BF16) TGX_DMA_ATTR_D(tgx::DT_F16)
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8n_kernel<tgx::DT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 128 + 256) * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8n_kernel<tgx::DT_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 128 + 256) * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma_qkv8_kernel<tgx::DT_BF16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * 128 + 128 + 64) * 64 * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma_qkv8_kernel<tgx::DT_F16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * 128 + 128 + 64) * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma_qkv8_kernel<tgx::DT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * 128 + 128 + 64) * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma_qkv8_kernel<tgx::DT_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (3 * 128 + 128 + 64) * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8i_kernel<tgx::DT_BF16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128));
