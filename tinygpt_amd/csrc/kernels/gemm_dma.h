@@ -495,7 +495,7 @@ __device__ __forceinline__ void silu_epilogue_transposed(const f32x16 (&acc)[2][
 // (bit-identical; tools/probes/gemm_lab.hip, profiles/r05_prefill.txt).
 // LO = false (option act.round16: the Linear's input is rounded to the storage dtype, so A_hi IS the activation): the A_lo tile is neither staged nor
 // multiplied — 4 DMA pieces per stage instead of 6, half the MFMAs (gate_up at S = 2048: 232 -> 130 us, profiles/r04_act16_cost.txt)
-// DIS (lab only): 1 = no MFMAs, 2 = no DMA after the prologue, 4 = no fragment reads, 8 = no epilogue stores; 17 = the operand stream free-running (no ring discipline).
+// DIS (lab only): 1 = no MFMAs, 2 = no DMA after the prologue, 4 = no fragment reads, 8 = no epilogue stores; 17 = the operand stream free-running (no ring discipline), 18 = the same through buffer_load ... lds.
 // PP (lab only, tools/probes/gemm_lab.hip): 1 = the two waves of a SIMD half a stage apart (ping-pong), + 2 s_setprio around the matrix phase, + 4 static s_setprio for
 // waves 4-7, + 8 DMA issue ahead of the fragment reads — measured, not adopted (profiles/r05_prefill.txt section 5).  GEMM_PARTIAL (blockIdx.z = K slab) likewise serves the lab's
 // `down` experiment only; the product's slab forms live in gemm_dma8k_kernel / gemm_dma8n_kernel.
@@ -585,6 +585,27 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
     for (int s = 0; s < nk; s++) {
 #pragma unroll
       for (int q = 0; q < 6; q++) dma_1k(gsrc[q] + s * DBK, lds_base + (unsigned)((s % NS) * STAGE * 2) + ldst[q]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nk == 12345) a.C[0] = 1.f;
+    return;
+  }
+  if constexpr (DIS == 18) {
+    // lab: DIS 17 with buffer_load_dwordx4 ... lds (buffer resource + 32-bit offsets) instead of global_load_lds_dwordx4 (64-bit addresses)
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A_hi, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc((void*)a.A_lo, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, 0x7fffffff, 0x00020000);
+    int voff[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) voff[q] = (int)((const char*)gsrc[q] - (const char*)(q % 3 == 0 ? a.A_hi : (q % 3 == 1 ? a.A_lo : a.B)));
+    for (int s = 0; s < nk; s++) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)((char*)dma_lds + (s % NS) * STAGE * 2 + ldst[q]);
+        if (q % 3 == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, dst, 16, voff[q] + s * DBK * 2, 0, 0, 0);
+        else if (q % 3 == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rL, dst, 16, voff[q] + s * DBK * 2, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, dst, 16, voff[q] + s * DBK * 2, 0, 0, 0);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (nk == 12345) a.C[0] = 1.f;

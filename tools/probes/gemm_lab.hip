@@ -89,6 +89,7 @@ int main(int argc, char** argv) {
   DISK(ip4_silu_d4, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 4, 4>), LDS8I)  DISK(ip4_silu_d8, (gemm_dma8ip_kernel<DT_BF16, GEMM_SILU, 8, 4>), LDS8I)
   DISK(i_part, (gemm_dma8i_kernel<DT_BF16, GEMM_PARTIAL>), LDS8I)
   DISK(k8_part, (gemm_dma8_kernel<DT_BF16, GEMM_PARTIAL>), LDS8)  DISK(k8k_part, (gemm_dma8k_kernel<DT_BF16, GEMM_PARTIAL>), LDS8K)
+  DISK(k8_silu_d18, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 18>), LDS8)
   DISK(k8_silu_d17, (gemm_dma8_kernel<DT_BF16, GEMM_SILU, true, 4, 17>), LDS8)
   DISK(pp1_res, (gemm_dma8_kernel<DT_BF16, GEMM_RESIDUAL, true, 4, 0, true, 1>), LDS8)
   DISK(k8k_res_d4, (gemm_dma8k_kernel<DT_BF16, GEMM_RESIDUAL, true, 4>), LDS8K)  DISK(k8k_res_d8, (gemm_dma8k_kernel<DT_BF16, GEMM_RESIDUAL, true, 8>), LDS8K)
@@ -230,6 +231,8 @@ int main(int argc, char** argv) {
       report("  dma8i DIS 8  (no epilogue)", time_us(reps, [&](int l) { LI(i_silu_d8)(l); }));
       report("  dma8 DIS 1  (DMA + barriers only)", time_us(reps, [&](int l) { L(k8_silu_d1, g256, LDS8)(l); }));
       report("  dma8 DIS 17 (the operand stream free-running: no ring discipline, one wait at the end)", time_us(reps, [&](int l) { L(k8_silu_d17, g256, LDS8)(l); }));
+      report("  dma8 DIS 18 (the same through buffer_load_dwordx4 ... lds)", time_us(reps, [&](int l) { L(k8_silu_d18, g256, LDS8)(l); }));
+      report("  dma8 DIS 17 again", time_us(reps, [&](int l) { L(k8_silu_d17, g256, LDS8)(l); }));
       report("  dma8 DIS 2  (no DMA after the prologue: MFMAs + fragment reads)", time_us(reps, [&](int l) { L(k8_silu_d2, g256, LDS8)(l); }));
       report("  dma8 DIS 4  (no fragment reads)", time_us(reps, [&](int l) { L(k8_silu_d4, g256, LDS8)(l); }));
       report("  dma8 DIS 8  (no epilogue)", time_us(reps, [&](int l) { L(k8_silu_d8, g256, LDS8)(l); }));
