@@ -8,13 +8,15 @@ with token id and position resident on the GPU (one hipGraph replay per step).  
 (tinygpt_amd.synth, seed 1234; no checkpoint exists offline) and prompt ids are uniform — timing is
 data-independent; parity is established by tests/.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]                       (N > 1: spawns its own N replica processes)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W                            (the launcher's N processes are the replicas)
 
 N > 1 runs N independent replicas (one process per GPU, distinct prompt seeds, no data-path collective —
-the streams never exchange data); torch.distributed (gloo) only carries the barrier and the
-MAX-over-ranks of the timed region.  Rank 0 prints ONE JSON line.
+the streams never exchange data).  Both invocation shapes work: under a launcher torch.distributed
+(gloo) carries the barrier and the MAX-over-ranks of the timed region; without one (no WORLD_SIZE in the
+environment) `spawn_replicas` starts the N processes itself and a directory of small files carries the same two
+things (`FileGroup`) — replicas need no rendezvous service.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
   roofline     the dominant kernel class (gate_up GEMV: 55 % of a layer's bytes): algorithmic bytes per launch
@@ -180,25 +182,118 @@ def kernel_source_sha256():
     return h.hexdigest()
 
 
-def timed_region(run_steps, sync, dist=None, torch=None):
+class GlooGroup:
+    """barrier + MAX over the launcher's ranks through torch.distributed (gloo): control plane only"""
+
+    def __init__(self, rank, world):
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        self.rank, self.world, self._dist, self._torch = rank, world, dist, torch
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def max(self, v):
+        t = self._torch.tensor([v], dtype=self._torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        self._dist.barrier()
+        self._dist.destroy_process_group()
+
+
+class FileGroup:
+    """The same two operations for replicas that `spawn_replicas` started: a directory the parent created, one small file per (generation, rank).
+    A barrier = write my file of this generation, poll until all `world` files of it exist (200 us poll: the skew it leaves between ranks is
+    three orders below the timed region).  No sockets, no hostname lookups, no torch.distributed."""
+
+    def __init__(self, root, rank, world, timeout_s=1800.0):
+        self.root, self.rank, self.world, self.gen, self.timeout_s = root, rank, world, 0, timeout_s
+
+    def _exchange(self, payload):
+        g = self.gen
+        self.gen += 1
+        mine = os.path.join(self.root, f"g{g}.r{self.rank}")
+        with open(mine + ".tmp", "w") as f:
+            f.write(payload)
+        os.rename(mine + ".tmp", mine)                       # atomic: a reader never sees a half-written value
+        paths = [os.path.join(self.root, f"g{g}.r{r}") for r in range(self.world)]
+        deadline = time.monotonic() + self.timeout_s
+        while not all(os.path.exists(q) for q in paths):
+            if os.path.exists(os.path.join(self.root, "abort")) or time.monotonic() > deadline:
+                raise RuntimeError(f"replica {self.rank}: another replica failed or timed out at barrier {g}")
+            time.sleep(2e-4)
+        return [open(q).read() for q in paths]
+
+    def barrier(self):
+        self._exchange("")
+
+    def max(self, v):
+        return max(float(x) for x in self._exchange(repr(float(v))))
+
+    def close(self):
+        self.barrier()
+
+
+def timed_region(run_steps, sync, group=None):
     """The contract's timed region, used by the real run below and (with a stand-in `run_steps`) by tests/test_replicas_gloo.py:
     barrier + synchronize | EXACTLY the K steps of this rank | synchronize; then barrier + MAX over ranks.  No collective sits inside the
-    timed region — the replicas never exchange data.  Returns (elapsed of the job = slowest replica, this rank's own)."""
+    timed region — the replicas never exchange data.  `group` is a GlooGroup / FileGroup (None at N = 1).
+    Returns (elapsed of the job = slowest replica, this rank's own)."""
     sync()
-    if dist:
-        dist.barrier()
+    if group:
+        group.barrier()
     sync()
     t0 = time.perf_counter()
     run_steps()
     sync()
     mine = time.perf_counter() - t0
     job = mine
-    if dist:
-        dist.barrier()
-        t = torch.tensor([mine], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)                    # MAX over ranks: the job is as slow as its slowest replica
-        job = float(t.item())
+    if group:
+        group.barrier()
+        job = group.max(mine)                                       # MAX over ranks: the job is as slow as its slowest replica
     return job, mine
+
+
+def spawn_replicas(cmd, n, env=None, timeout_s=3600.0):
+    """`python bench.py --gpus N` without a launcher: start the N replica processes (RANK = LOCAL_RANK = r, WORLD_SIZE = N, TGX_BENCH_RDV = a fresh
+    directory for FileGroup), pass rank 0's stdout through (its one JSON line), send the other ranks' stdout to stderr, and return the worst exit code.
+    A replica that dies drops an `abort` file so the others leave their barrier instead of waiting out the timeout."""
+    import shutil
+    import subprocess
+    import tempfile
+    rdv = tempfile.mkdtemp(prefix="tgx_bench_rdv_")
+    procs = []
+    try:
+        for r in range(n):
+            e = dict(os.environ if env is None else env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), TGX_BENCH_RDV=rdv)
+            procs.append(subprocess.Popen(cmd, env=e, stdout=None if r == 0 else sys.stderr))
+        deadline, rc, live = time.monotonic() + timeout_s, 0, set(range(n))
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is not None:
+                    live.discard(r)
+                    if code != 0:
+                        rc = rc or code
+                        open(os.path.join(rdv, "abort"), "w").close()
+            if time.monotonic() > deadline:
+                open(os.path.join(rdv, "abort"), "w").close()
+                rc = rc or 124
+                break
+            time.sleep(0.02)
+        return rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.wait(timeout=10)
+                except Exception:
+                    p.kill()                                        # the exact child this function started
+        shutil.rmtree(rdv, ignore_errors=True)
 
 
 def aggregate_tokens_per_s(world, steps, job_elapsed):
@@ -210,19 +305,17 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:           # no launcher: be the launcher (replicas need no rendezvous service)
+        sys.exit(spawn_replicas([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {args.gpus} "
-                     f"--master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
-        args.gpus = world
+        args.gpus = world                                             # a launcher's process count wins over the flag
 
     import torch
-    dist = None
+    group = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)     # control plane only: barrier + MAX
+        rdv = os.environ.get("TGX_BENCH_RDV")
+        group = FileGroup(rdv, rank, world) if rdv else GlooGroup(rank, world)      # control plane only: barrier + MAX
     if os.environ.get("TGX_BENCH_SHARE_GPU") == "1" and torch.cuda.is_available():   # testing the N > 1 flow on a 1-GPU box: ranks share devices
         local_rank %= torch.cuda.device_count()
     if torch.cuda.is_available():
@@ -242,7 +335,10 @@ def main():
     need_ctx = args.prompt + args.warmup + args.steps + 8
     if need_ctx > desc.max_ctx:
         sys.exit(f"prompt+warmup+steps = {need_ctx} exceeds contextSize {desc.max_ctx}")
-    tensors = list(iter_checkpoint(args.model_dir)) if args.model_dir else list(synth.synth_checkpoint(desc, 1234, 0.02))
+    want_cpu = world == 1 and not args.no_cpu_baseline              # only then is the checkpoint needed twice (GPU upload, then the CPU leg)
+    tensors = iter_checkpoint(args.model_dir) if args.model_dir else synth.synth_checkpoint(desc, 1234, 0.02)
+    if want_cpu:
+        tensors = list(tensors)                                       # otherwise streamed: one tensor in host memory at a time (6.4 GB x 8 ranks for config #5)
     model = Model(desc, product_backend(), device=local_rank)       # raises if the HIP library is missing
     if args.no_graph:
         model.set_option("graph", 0)
@@ -274,10 +370,10 @@ def main():
             torch.cuda.synchronize()
 
     model.decode(args.warmup, GREEDY, fetch=False)                  # untimed warm-up (instantiates the graph)
-    elapsed, _mine = timed_region(lambda: model.decode(args.steps, GREEDY, fetch=False), sync, dist, torch)   # EXACTLY K steps per rank
+    elapsed, _mine = timed_region(lambda: model.decode(args.steps, GREEDY, fetch=False), sync, group)   # EXACTLY K steps per rank
 
     if rank != 0:
-        if dist: dist.barrier(); dist.destroy_process_group()
+        if group: group.close()
         return
 
     T0 = args.prompt + 1 + args.warmup                              # tokens in the cache at the first timed step
@@ -326,7 +422,7 @@ def main():
                 "step_frac": round(bytes_tok * tok_s / world / 1e9 / HBM_PEAK_GBS, 4)}
 
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if want_cpu:
         try:
             cpu = cpu_baseline(desc, tensors, args.cpu_seconds, args.prompt, 1234)
         except Exception as e:     # the GPU number stands on its own; say why the baseline is absent
@@ -362,7 +458,7 @@ def main():
         "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
-    if dist: dist.barrier(); dist.destroy_process_group()
+    if group: group.close()
 
 
 if __name__ == "__main__":

@@ -176,12 +176,15 @@ TGX_API int64_t tgx_past_length(const tgx_ctx* ctx);
  * What a row keeps is the semantics of a solo sequence (Attention.h:71-112 over its own keys [0, pastLength_row]): its logits equal those of the
  * same prompt run alone up to the summation-order differences between kernel paths (tests/test_hip_rows.py).
  *
- * tgx_reset_row      == resetCache() for ONE row: its pastLength back to 0; the other rows and the batch size are untouched.  A retired row
- *                       that is not refilled keeps riding in the batch's steps (it decodes from position 0 on its stale token; its output is
- *                       meaningless and harmless) until tgx_forward / tgx_reset_cache rebuilds the batch.
- * tgx_forward_row    == GPTModel::forward(inputIds[1,S]) for ONE row of the live batch: `row` < batch (refill) or == batch (the batch grows by
- *                       one row, up to max_batch); the row's pastLength must be 0 (tgx_reset_row first).  Leaves the row's last-position logits in
- *                       its slot of tgx_read_logits; the row has no current token until tgx_sample_row (or tgx_sample) ran — tgx_decode refuses until then.
+ * tgx_reset_row      == resetCache() for ONE row: its pastLength back to 0; the other rows and the batch size are untouched.  The row is now
+ *                       RETIRED: tgx_decode / tgx_step_async keep stepping the live rows without waiting for it (a finished sequence with no queued
+ *                       prompt stalls nobody).  It still rides in the steps (it decodes from position 0 on its stale token; its ids and logits in
+ *                       tgx_decode's output / tgx_read_logits are meaningless and harmless) and counts for neither tgx_past_length nor the context
+ *                       check; tgx_past_length_row reports 0 for it.  With every row retired there is nothing to step: tgx_decode refuses.
+ * tgx_forward_row    == GPTModel::forward(inputIds[1,S]) for ONE row of the live batch: a retired `row` < batch (refill) or `row` == batch (the
+ *                       batch grows by one row, up to max_batch); a live row must be retired first (tgx_reset_row).  Leaves the row's last-position
+ *                       logits in its slot of tgx_read_logits; the row is live again but has no current token until tgx_sample_row (or tgx_sample)
+ *                       ran — tgx_decode refuses until then.
  * tgx_sample_row     == Sampler::sample on ONE row's logits; the id becomes that row's device-resident next token.
  * tgx_past_length_row   the row's own pastLength. */
 TGX_API int tgx_reset_row(tgx_ctx* ctx, int row);

@@ -78,12 +78,9 @@ def test_a_row_retired_and_refilled_mid_run_equals_its_solo_run(fam, dtype, rows
     # ---- retire row `at`, prefill the new prompt into it
     gpuB.reset_row(at)
     assert gpuB.past_length_row(at) == 0 and gpuB.past_length == (L0 if rows > 1 else 0)
-    with pytest.raises(TgxError) as ei:                            # the row has no current token: the batch cannot step
-        gpuB.decode(1, GREEDY)
-    assert ei.value.status == 4
     gpuB.forward_row(at, newp)
     assert gpuB.past_length_row(at) == len(newp) and gpuB.past_length == L0
-    with pytest.raises(TgxError) as ei:
+    with pytest.raises(TgxError) as ei:                            # the row is live again and has no current token: the batch cannot step
         gpuB.decode(1, GREEDY)
     assert ei.value.status == 4
     lb = gpuB.logits(rounded=False)
@@ -120,6 +117,66 @@ def test_a_row_retired_and_refilled_mid_run_equals_its_solo_run(fam, dtype, rows
     assert gpuB.past_length == 0 and gpuB.past_length_row(at) == 0
     gpuB.forward(ids); ctrl.reset_cache(); ctrl.forward(ids)      # and the whole-batch path is back to normal afterwards
     np.testing.assert_array_equal(gpuB.logits(rounded=False), ctrl.logits(rounded=False))
+
+
+@pytest.mark.parametrize("rows,retire", [(2, [0]), (4, [3, 1]), (8, [0, 5])])
+@pytest.mark.parametrize("fam", ["llama_tiny", "qwen2_tiny"])
+def test_a_retired_row_stalls_nobody_and_is_refilled_later(fam, rows, retire, hip):
+    """include/tgx.h: a finished sequence with no queued prompt is retired (tgx_reset_row) and the LIVE rows keep decoding — bit-identical to a batch that was
+    never touched; the retired row rides along unnoticed (length 0, no capacity), also when it outruns the longest live row; a prompt prefilled into it several
+    steps later equals its solo run."""
+    IDLE_STEPS, STEPS = 6, 3
+    gpuB, g = make(fam, hip, rows)
+    ctrl, _ = make(fam, hip, rows)
+    p = g["prompt"][0]
+    V = gpuB.desc.vocab
+    ids = np.stack([(p + 5 * b + 1) % V for b in range(rows)])
+    newp = ((p[:4] * 11 + 2) % V).astype(np.int64)
+    solo_toks, solo_logits = solo_run(fam, hip, newp, STEPS, "bf16")
+    for m in (gpuB, ctrl):
+        m.forward(ids); m.sample(GREEDY); m.decode(2, GREEDY)
+    L0 = gpuB.past_length
+    live = [r for r in range(rows) if r not in retire]
+    for r in retire:
+        gpuB.reset_row(r)
+        assert gpuB.past_length_row(r) == 0
+    if not live:                                                   # every row retired: nothing to step
+        assert gpuB.past_length == 0
+        with pytest.raises(TgxError) as ei:
+            gpuB.decode(1, GREEDY)
+        assert ei.value.status == 4
+    else:
+        assert gpuB.past_length == L0
+        tb = gpuB.decode(IDLE_STEPS, GREEDY)                       # no refusal: the live rows step on
+        tc = ctrl.decode(IDLE_STEPS, GREEDY)
+        np.testing.assert_array_equal(tb[:, live], tc[:, live])
+        np.testing.assert_array_equal(gpuB.logits(rounded=False)[live], ctrl.logits(rounded=False)[live])
+        assert gpuB.past_length == L0 + IDLE_STEPS and all(gpuB.past_length_row(r) == 0 for r in retire)
+        tk = gpuB.step_async(GREEDY)                               # the streaming entry point as well
+        ctrl.decode(1, GREEDY)
+        gpuB.fetch_token(tk)
+        np.testing.assert_array_equal(gpuB.logits(rounded=False)[live], ctrl.logits(rounded=False)[live])
+        # retire the live rows too, except one that is re-prefilled SHORT: the rows retired first have now outrun the longest live row
+        keep = live[0]
+        for r in live[1:]:
+            gpuB.reset_row(r)
+        gpuB.reset_row(keep); gpuB.forward_row(keep, newp); gpuB.sample_row(keep, GREEDY)
+        assert gpuB.past_length == len(newp)
+        got = gpuB.decode(STEPS, GREEDY)[:, keep]
+        lk = gpuB.logits(rounded=False)[keep]
+        check_row(lk, got[-1], solo_logits[STEPS], solo_toks[STEPS])
+        assert gpuB.past_length == len(newp) + STEPS
+    # ---- a row that idled is refilled and equals its solo run
+    at = retire[0]
+    gpuB.forward_row(at, newp)
+    assert gpuB.past_length_row(at) == len(newp)
+    check_row(gpuB.logits(rounded=False)[at], gpuB.sample_row(at, GREEDY), solo_logits[0], solo_toks[0])
+    k_at, _ = gpuB.read_kv(at, 0)
+    assert k_at.shape[0] == len(newp)
+    if live:
+        with pytest.raises(TgxError) as ei:
+            gpuB.forward(ids[:, :1])                               # retired rows in the batch: the whole-batch call refuses
+        assert ei.value.status == 4
 
 
 @pytest.mark.parametrize("fam,plen", [("llama_tiny", 40), ("qwen2_tiny", 150), ("gpt2_hd64", 6)])

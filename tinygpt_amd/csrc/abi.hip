@@ -312,6 +312,13 @@ static int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t see
     int rc = ensure_skinny_ws(c, std::min(c->decode_step_rows, c->batch));
     if (rc) return rc;
   }
+  // a retired row rides along from wherever its position word stands (row_past mirrors it); the attention form and the capacity check are chosen for the
+  // longest LIVE row, so an idle row that has outrun it (the longer rows were retired since) restarts from position 0
+  for (int b = 0; b < c->batch; b++)
+    if (c->row_idle[(size_t)b] && c->row_past[(size_t)b] > c->past) {
+      HIP_OK(c, hipMemsetAsync(c->rows[(size_t)b].pos, 0, 4, c->stream));
+      c->row_past[(size_t)b] = 0;
+    }
   // The attention form depends on the context (four-wave direct / sixteen-wave direct / split + combine / matrix cores): a call that crosses a limit is
   // issued in chunks, each on the form of its own contexts, from the cache of captured graphs
   int remaining = n;
@@ -625,6 +632,7 @@ int tgx_finalize(tgx_ctx* c) {
   c->past = 0;
   c->row_past.assign(B, 0);
   c->row_tok.assign(B, 0);
+  c->row_idle.assign(B, 0);
   c->finalized = true;
   return TGX_OK;
 }
@@ -657,7 +665,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
   if (seq > 1 && c->past > 0) return set_err(c, TGX_ERR_INVALID, "seq>1 with pastLength>0");
   if (c->past + seq > c->d.max_ctx) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded: %lld + %d > %d", (long long)c->past, seq, c->d.max_ctx);
   for (int b = 0; b < batch; b++)
-    if (c->row_past[(size_t)b] != c->past) return set_err(c, TGX_ERR_STATE, "tgx_forward on a batch whose rows differ in length (row %d: %lld, longest %lld): use tgx_decode / tgx_forward_row, or tgx_reset_cache", b, (long long)c->row_past[(size_t)b], (long long)c->past);
+    if (c->row_idle[(size_t)b] || c->row_past[(size_t)b] != c->past) return set_err(c, TGX_ERR_STATE, "tgx_forward on a batch whose rows differ in length (row %d: %lld, longest %lld): use tgx_decode / tgx_forward_row, or tgx_reset_cache", b, (long long)c->row_past[(size_t)b], (long long)c->past);
   for (int64_t i = 0; i < (int64_t)batch * seq; i++)
     if (ids[i] < 0 || ids[i] >= c->d.vocab) return set_err(c, TGX_ERR_INVALID, "token id out of range");
   HIP_OK(c, hipSetDevice(c->device));
@@ -711,7 +719,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
   LAUNCH_OK(c);
   HIP_OK(c, hipStreamSynchronize(c->stream));   // host `ids` may be pageable and reused by the caller
   c->past += seq;
-  for (int b = 0; b < batch; b++) { c->row_past[(size_t)b] = c->past; c->row_tok[(size_t)b] = 0; }
+  for (int b = 0; b < batch; b++) { c->row_past[(size_t)b] = c->past; c->row_tok[(size_t)b] = 0; c->row_idle[(size_t)b] = 0; }
   c->have_logits = true;
   c->have_token = false;
   return TGX_OK;
@@ -818,6 +826,7 @@ int tgx_reset_cache(tgx_ctx* c) {
   c->past = 0;
   std::fill(c->row_past.begin(), c->row_past.end(), 0);
   std::fill(c->row_tok.begin(), c->row_tok.end(), 0);
+  std::fill(c->row_idle.begin(), c->row_idle.end(), 0);
   c->have_logits = c->have_token = false;
   c->poisoned = false;
   return TGX_OK;
@@ -828,16 +837,25 @@ int64_t tgx_past_length(const tgx_ctx* c) { return c ? c->past : -1; }
 // ---- per-row sequence lifecycle (include/tgx.h, ABI 3).  The step kernels read every row's position from its own device word; the host keeps the
 // mirror row_past[] and `past` = the longest row of the batch (capacity checks, attention-form limits: a form chosen for the longest row is valid for
 // the shorter ones — the direct form's pass count and the split form's active splits are derived on the device from each row's position).
+// Retired rows (row_idle) are left out of both: nothing waits for them and they bound nothing (run_decode_steps keeps them below the longest live row).
 static void refresh_longest(tgx_ctx* c) {
   int64_t m = 0;
-  for (int b = 0; b < c->batch; b++) m = std::max(m, c->row_past[(size_t)b]);
+  int live = 0;
+  bool all = true;
+  for (int b = 0; b < c->batch; b++) {
+    if (c->row_idle[(size_t)b]) continue;
+    live++;
+    m = std::max(m, c->row_past[(size_t)b]);
+    all = all && c->row_tok[(size_t)b];
+  }
   c->past = m;
-  bool all = c->batch > 0;
-  for (int b = 0; b < c->batch; b++) all = all && c->row_tok[(size_t)b];
-  c->have_token = all;
+  c->have_token = live > 0 && all;
 }
 
-int64_t tgx_past_length_row(const tgx_ctx* c, int row) { return (c && c->finalized && row >= 0 && row < c->d.max_batch) ? c->row_past[(size_t)row] : -1; }
+int64_t tgx_past_length_row(const tgx_ctx* c, int row) {
+  if (!c || !c->finalized || row < 0 || row >= c->d.max_batch) return -1;
+  return c->row_idle[(size_t)row] ? 0 : c->row_past[(size_t)row];        // a retired row holds no sequence, wherever its position word stands
+}
 
 int tgx_reset_row(tgx_ctx* c, int row) {
   if (!c) return TGX_ERR_INVALID;
@@ -848,6 +866,7 @@ int tgx_reset_row(tgx_ctx* c, int row) {
   HIP_OK(c, hipMemsetAsync(c->rows[(size_t)row].pos, 0, 4, c->stream));     // stream-ordered behind the steps already enqueued
   c->row_past[(size_t)row] = 0;
   c->row_tok[(size_t)row] = 0;
+  c->row_idle[(size_t)row] = row < c->batch;                                  // a live slot becomes a retired one: the batch keeps stepping without it
   refresh_longest(c);
   return TGX_OK;
 }
@@ -858,7 +877,7 @@ int tgx_forward_row(tgx_ctx* c, int row, const int64_t* ids, int seq) {
   if (c->poisoned) return set_err(c, TGX_ERR_STATE, "an earlier pass failed half-way: call tgx_reset_cache first");
   if (row < 0 || row >= c->d.max_batch || row > c->batch) return set_err(c, TGX_ERR_INVALID, "row %d: a live row [0,%d) or the next free one (max_batch %d)", row, c->batch, c->d.max_batch);
   if (seq < 1 || seq > c->d.max_ctx) return set_err(c, seq < 1 ? TGX_ERR_INVALID : TGX_ERR_CONTEXT, "seq %d out of range (context size %d)", seq, c->d.max_ctx);
-  if (c->row_past[(size_t)row] != 0) return set_err(c, TGX_ERR_STATE, "row %d holds %lld positions: tgx_reset_row first", row, (long long)c->row_past[(size_t)row]);
+  if (!c->row_idle[(size_t)row] && c->row_past[(size_t)row] != 0) return set_err(c, TGX_ERR_STATE, "row %d holds %lld positions: tgx_reset_row first", row, (long long)c->row_past[(size_t)row]);
   for (int i = 0; i < seq; i++)
     if (ids[i] < 0 || ids[i] >= c->d.vocab) return set_err(c, TGX_ERR_INVALID, "token id out of range");
   HIP_OK(c, hipSetDevice(c->device));
@@ -871,6 +890,10 @@ int tgx_forward_row(tgx_ctx* c, int row, const int64_t* ids, int seq) {
   RowState& r = c->rows[(size_t)row];
   int rc = TGX_OK;
   hipError_t e = hipMemcpyAsync(r.prompt, ids, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && c->row_past[(size_t)row] != 0) {                    // a retired row that rode along since its reset: back to position 0
+    e = hipMemsetAsync(r.pos, 0, 4, c->stream);
+    c->row_past[(size_t)row] = 0;
+  }
   if (e == hipSuccess && mfma_path) {
     const bool skinny = !f32_path && !c->gpt2 && c->prefill_skinny && c->d.vocab >= 128 &&
                         (seq <= 32 ? c->prefill_skinny_rows >= seq : (seq <= c->prefill_skinny_rows && c->d.hidden <= c->prefill_skinny_hidden_max && (seq <= 64 || (c->skinny_dma && c->d.hidden <= c->prefill_skinny_hidden_max_wide))));
@@ -907,6 +930,7 @@ int tgx_forward_row(tgx_ctx* c, int row, const int64_t* ids, int seq) {
   c->batch = std::max(batch_before, row + 1);
   c->row_past[(size_t)row] = seq;
   c->row_tok[(size_t)row] = 0;
+  c->row_idle[(size_t)row] = 0;
   refresh_longest(c);
   c->have_logits = true;
   return TGX_OK;
@@ -952,7 +976,7 @@ int tgx_read_kv(tgx_ctx* c, int row, int layer, float* k_out, float* v_out) {
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipStreamSynchronize(c->stream));
   const tgx_model_desc& d = c->d;
-  const size_t hd = (size_t)d.head_dim, per_head = (size_t)d.max_ctx * hd, T = (size_t)c->row_past[(size_t)row];
+  const size_t hd = (size_t)d.head_dim, per_head = (size_t)d.max_ctx * hd, T = (size_t)tgx_past_length_row(c, row);
   std::vector<unsigned char> tmp(per_head * c->esz);
   for (int which = 0; which < 2; which++) {
     float* out = which ? v_out : k_out;
@@ -974,7 +998,7 @@ int tgx_read_kv(tgx_ctx* c, int row, int layer, float* k_out, float* v_out) {
 }
 
 int tgx_write_kv(tgx_ctx* c, int row, int layer, const float* k_in, const float* v_in, int64_t n_rows) {
-  if (!c || !c->finalized || row < 0 || row >= c->d.max_batch || layer < 0 || layer >= c->d.layers || n_rows < 0 || n_rows > c->row_past[(size_t)row]) return c ? set_err(c, TGX_ERR_INVALID, "write_kv: row / layer / n_rows out of range") : TGX_ERR_INVALID;
+  if (!c || !c->finalized || row < 0 || row >= c->d.max_batch || layer < 0 || layer >= c->d.layers || n_rows < 0 || n_rows > tgx_past_length_row(c, row)) return c ? set_err(c, TGX_ERR_INVALID, "write_kv: row / layer / n_rows out of range") : TGX_ERR_INVALID;
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipStreamSynchronize(c->stream));
   const tgx_model_desc& d = c->d;

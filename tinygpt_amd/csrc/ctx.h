@@ -105,6 +105,7 @@ struct tgx_ctx {
   int64_t past = 0;       // host mirror of the device-resident pos: the LONGEST row of the batch (all rows, unless the per-row calls made them differ)
   std::vector<int64_t> row_past;   // host mirror of each row's own pos (tgx_reset_row / tgx_forward_row, include/tgx.h)
   std::vector<char> row_tok;       // the row has a current token (sampled after its last forward)
+  std::vector<char> row_idle;      // the row was retired (tgx_reset_row) and not refilled: it rides in the steps, nothing waits for it, its output means nothing
   int batch = 0;          // rows used by the last forward
   bool have_logits = false, have_token = false;
 
