@@ -36,6 +36,9 @@ struct OprojSlicedArgs {
   int H;
   int act16;            // option act.round16: the merged attention output is rounded to the storage dtype before the product
   int dbg;              // experiments only (tools/probes/layer_lab.hip -DLAB_DISSECT): 1 no atomics (plain stores), 2 no record merge, 4 no weight loads
+#ifdef LAB_EPOCH
+  unsigned* epoch;      // tools/probes/qkv_attn.h (round 6 lab): the granule tag of the layer's fused qkv || attention launch, advanced here by one thread
+#endif
 };
 
 template <int LPR> constexpr int oproj_sliced_rows() { return 4 * 8 * (64 / LPR); }      // rows per workgroup: 4 waves x 8 wave-loads x rows per wave-load
@@ -148,6 +151,9 @@ __global__ __launch_bounds__(256) void oproj_sliced_kernel(const OprojSlicedArgs
     if (OPS_DBG(a, 1)) { if (slice == 0) a.acc[row0 + lane] = f; }
     else __hip_atomic_fetch_add(a.acc + row0 + lane, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+#ifdef LAB_EPOCH
+  if (a.epoch && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.epoch = *a.epoch + 1;
+#endif
 }
 
 }  // namespace tgx

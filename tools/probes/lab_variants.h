@@ -1,6 +1,8 @@
 // lab_variants.h — kernel variants under test in layer_lab.hip (build with -DLAB_VARIANTS).
 #pragma once
+#include <algorithm>
 #include "kernels/oproj_sliced.h"
+#include "qkv_attn.h"
 
 // experiment: a plain K-sliced GEMV tile (no merge): workgroup = RB rows x SW columns, partial sums into fixed-point accumulators
 struct SlicedArgs { const void* W; int ldw; const float* x; long long* acc; int N; };
@@ -35,10 +37,11 @@ static void v_sliced(Lab& b, const void* W, int N, int K, const float* x, long l
 }
 
 static int g_ops_dbg = 0;
+static unsigned* g_epoch = nullptr;       // set: the o_proj launch advances the granule tag of kernels/qkv_attn.h
 static void v_oproj_sliced(Lab& b, int l, long long* acc, const float* resid) {
   const LayerBuf& w = b.lb[(size_t)l];
   OprojSlicedArgs a{};
-  a.W = w.wo; a.ldw = b.qd; a.part = b.part; a.nsplit = b.nsplit; a.x = resid; a.acc = acc; a.H = b.H; a.dbg = g_ops_dbg;
+  a.W = w.wo; a.ldw = b.qd; a.part = b.part; a.nsplit = b.nsplit; a.x = resid; a.acc = acc; a.H = b.H; a.dbg = g_ops_dbg; a.epoch = g_epoch;
   if (b.g.hd == 64 && b.qd % 256 == 0) { const dim3 grid(b.H / oproj_sliced_rows<32>(), b.qd / 256); hipLaunchKernelGGL((oproj_sliced_kernel<DT_BF16, 64, 32>), grid, dim3(256), 0, b.st, a); }
   else if (b.g.hd == 64) { const dim3 grid(b.H / oproj_sliced_rows<16>(), b.qd / 128); hipLaunchKernelGGL((oproj_sliced_kernel<DT_BF16, 64, 16>), grid, dim3(256), 0, b.st, a); }
   else if (b.qd % 512 == 0) { const dim3 grid(b.H / oproj_sliced_rows<64>(), b.qd / 512); hipLaunchKernelGGL((oproj_sliced_kernel<DT_BF16, 128, 64>), grid, dim3(256), 0, b.st, a); }
@@ -307,7 +310,124 @@ static void lab_oproj_shapes(Lab& b) {
   printf("o_proj sliced alone: 256-column slices (4 heads) %.2f us, 128-column slices (2 heads) %.2f; with the attention launch in front: %.2f / %.2f\n", t32, t16, p32, p16);
   CK(hipFree(acc));
 }
+// ---- round 6: the QKV product and the split-form attention as ONE launch (kernels/qkv_attn.h) -----------------------------------------------
+struct FuseBufs { unsigned long long *gq, *gkv; unsigned* epoch; float* part2; unsigned long long* stamps; };
+template <int DEPTH = 4, bool TIMING = false, bool COMMUTE = false>
+static void v_qkv_attn(Lab& b, int l, const FuseBufs& f, float* part, int n_prod) {
+  const LayerBuf& w = b.lb[(size_t)l];
+  QkvAttnArgs A{};
+  const int ks = b.H >= 2048 ? 4 : 1;
+  GemvArgs& k = A.g;
+  k.W = w.wqkv; k.x = b.x; k.norm_w = w.in_norm; k.eps = b.eps; k.N = b.NQ; k.K = b.H; k.ldw = b.H; k.units = b.NQ / 2; k.ks = ks;
+  k.k_cache = w.kc; k.v_cache = w.vc; k.rope_cos = b.rc; k.rope_sin = b.rs; k.pos = b.pos;
+  k.heads = b.g.heads; k.kv_heads = b.g.kv; k.hd = b.g.hd; k.max_ctx = b.max_ctx;
+  A.a = attn_args(b, l); A.a.part = part;
+  A.gran_q = f.gq; A.gran_kv = f.gkv; A.epoch = f.epoch; A.n_prod = n_prod; A.stamps = f.stamps;
+  const int grid = n_prod + b.g.heads * b.nsplit;
+  switch (b.nx_of(b.H, ks)) {
+    case 1: hipLaunchKernelGGL((qkv_attn_kernel<DT_BF16, 64, 1, DEPTH, TIMING, COMMUTE>), dim3(grid), dim3(256), 0, b.st, A); break;
+    case 2: hipLaunchKernelGGL((qkv_attn_kernel<DT_BF16, 64, 2, DEPTH, TIMING, COMMUTE>), dim3(grid), dim3(256), 0, b.st, A); break;
+    default: printf("lab: qkv_attn nx not instantiated\n");
+  }
+}
+static void lab_qkv_attn(Lab& b) {
+  if (b.g.hd != 64) { printf("qkv || attention: head_dim 64 only\n"); return; }
+  FuseBufs f{};
+  CK(hipMalloc(&f.stamps, (size_t)4096 * 64)); CK(hipMemsetAsync(f.stamps, 0, (size_t)4096 * 64, b.st));
+  CK(hipMalloc(&f.gq, (size_t)b.qd * 8)); CK(hipMalloc(&f.gkv, (size_t)2 * b.kvd * 8)); CK(hipMalloc(&f.epoch, 4)); CK(hipMalloc(&f.part2, b.part_row * 4));
+  CK(hipMemsetAsync(f.gq, 0, (size_t)b.qd * 8, b.st)); CK(hipMemsetAsync(f.gkv, 0, (size_t)2 * b.kvd * 8, b.st)); CK(hipMemsetAsync(f.part2, 0, b.part_row * 4, b.st));
+  const unsigned one = 1; CK(hipMemcpyAsync(f.epoch, &one, 4, hipMemcpyHostToDevice, b.st));
+  long long* acc; CK(hipMalloc(&acc, (size_t)b.H * 8)); CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
+  // ---- values: the two product launches vs the fused launch, records compared bit for bit (layer 3)
+  const int cache_row = b.g.kv * b.g.hd;   // one position of every kv head is rewritten by either path with the same values
+  (void)cache_row;
+  p_qkv(b, 3, nullptr); v_attn<1, 4, 4>(b, 3);
+  CK(hipStreamSynchronize(b.st));
+  std::vector<float> ra(b.part_row), rb(b.part_row);
+  CK(hipMemcpy(ra.data(), b.part, b.part_row * 4, hipMemcpyDeviceToHost));
+  for (int np : {256, 512, 768}) {
+    CK(hipMemsetAsync(f.part2, 0, b.part_row * 4, b.st));
+    v_qkv_attn(b, 3, f, f.part2, np);
+    hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(64), 0, b.st, f.epoch);
+    CK(hipStreamSynchronize(b.st));
+    CK(hipMemcpy(rb.data(), f.part2, b.part_row * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0; const int active = (b.pos_h + 1 + 127) / 128;
+    for (int h = 0; h < b.g.heads; h++) for (int s = 0; s < b.nsplit; s++) {
+      const float* x = &ra[((size_t)h * b.nsplit + s) * 68]; const float* y = &rb[((size_t)h * b.nsplit + s) * 68];
+      if (s >= active) { if (!(y[64] == -INFINITY)) bad++; continue; }
+      for (int d = 0; d < 66; d++) if (memcmp(&x[d], &y[d], 4)) bad++;
+    }
+    printf("qkv || attention, %d producer workgroups: %zu record words differ from {qkv, attention} (0 = bit-identical)\n", np, bad);
+  }
+  // ---- timeline of one fused launch in the middle of a chain of layers (100 MHz stamps; us from the first workgroup's start)
+  {   // the norm scale commuted into the epilogue: same records within rounding
+    CK(hipMemsetAsync(f.part2, 0, b.part_row * 4, b.st));
+    v_qkv_attn<3, false, true>(b, 3, f, f.part2, 512);
+    hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(64), 0, b.st, f.epoch);
+    CK(hipStreamSynchronize(b.st));
+    CK(hipMemcpy(rb.data(), f.part2, b.part_row * 4, hipMemcpyDeviceToHost));
+    double mx = 0, ref = 0; const int active = (b.pos_h + 1 + 127) / 128;
+    for (int h = 0; h < b.g.heads; h++) for (int s = 0; s < active; s++) for (int d = 0; d < 64; d++) {
+      const size_t i = ((size_t)h * b.nsplit + s) * 68 + d;
+      mx = std::max(mx, (double)fabsf(ra[i] - rb[i])); ref = std::max(ref, (double)fabsf(ra[i]));
+    }
+    printf("qkv || attention with the RMSNorm scale commuted into the epilogue: records differ by %.3g of max |o| %.3g\n", mx / ref, ref);
+  }
+  auto timeline = [&](int np, int depth) {
+    for (int l = 0; l < 8; l++) {
+      if (l == 6) { switch (depth) { case 2: v_qkv_attn<2, true>(b, l, f, f.part2, np); break; case 3: v_qkv_attn<3, true>(b, l, f, f.part2, np); break; default: v_qkv_attn<4, true>(b, l, f, f.part2, np); } }
+      else v_qkv_attn<2>(b, l, f, f.part2, np);
+      g_epoch = f.epoch; v_oproj_sliced(b, l, acc, b.x); g_epoch = nullptr;
+      v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x);
+    }
+    CK(hipStreamSynchronize(b.st));
+    const int nwg = np + b.g.heads * b.nsplit;
+    std::vector<unsigned long long> st((size_t)nwg * 8);
+    CK(hipMemcpy(st.data(), f.stamps, st.size() * 8, hipMemcpyDeviceToHost));
+    CK(hipMemset(f.stamps, 0, (size_t)4096 * 64));
+    unsigned long long t0 = ~0ull; for (int w = 0; w < nwg; w++) t0 = std::min(t0, st[(size_t)w * 8]);
+    auto stat = [&](int lo, int hi, int idx, const char* what) {
+      std::vector<double> v; for (int w = lo; w < hi; w++) if (st[(size_t)w * 8 + idx]) v.push_back((double)(st[(size_t)w * 8 + idx] - t0) / 100.0);
+      if (v.empty()) return; std::sort(v.begin(), v.end());
+      printf("    %-34s n %4zu  min %5.2f  median %5.2f  p90 %5.2f  max %5.2f us\n", what, v.size(), v[0], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+    };
+    const int active = ((b.pos_h + 1 + 127) / 128) * b.g.heads;
+    printf("  timeline, %d producers (depth %d), %d consumers holding keys:\n", np, depth, active);
+    stat(0, np, 0, "producer start"); stat(0, np, 1, "producer x normalised"); stat(0, np, 2, "producer dots done (last batch)"); stat(0, np, 3, "producer published (last batch)"); stat(0, np, 7, "producer end");
+    stat(np, np + active, 0, "consumer start"); stat(np, np + active, 1, "consumer position read"); stat(np, np + active, 2, "consumer q arrived"); stat(np, np + active, 3, "consumer keys done"); stat(np, np + active, 7, "consumer end");
+    stat(np + active, nwg, 7, "empty-split consumer end");
+  };
+  timeline(512, 3);
+  // ---- time: the pair, and the layer of five / four launches
+  const float t_q = time_graph(b, [&] { for (int l = 0; l < b.L; l++) p_qkv(b, l, nullptr); }, b.L);
+  const float t_a = time_graph(b, [&] { for (int l = 0; l < b.L; l++) v_attn<1, 4, 4>(b, l); }, b.L);
+  const float t_pair = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); v_attn<1, 4, 4>(b, l); } }, b.L);
+  printf("product: qkv %.2f us, attention (1 head per workgroup) %.2f us, the pair back to back %.2f us\n", t_q, t_a, t_pair);
+  const float t_bump = time_graph(b, [&] { for (int l = 0; l < b.L; l++) hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(64), 0, b.st, f.epoch); }, b.L);
+  for (int np : {256, 384, 448, 512, 768, 1024}) {
+    const float t2 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { v_qkv_attn<2>(b, l, f, f.part2, np); hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(64), 0, b.st, f.epoch); } }, b.L);
+    const float t4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { v_qkv_attn<4>(b, l, f, f.part2, np); hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(64), 0, b.st, f.epoch); } }, b.L);
+    const float t6 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { v_qkv_attn<6>(b, l, f, f.part2, np); hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(64), 0, b.st, f.epoch); } }, b.L);
+    printf("  fused launch (minus the %.2f us epoch-bump launch behind it), %4d producers: depth 2 %.2f us, depth 4 %.2f, depth 6 %.2f\n", t_bump, np, t2 - t_bump, t4 - t_bump, t6 - t_bump);
+  }
+  g_epoch = nullptr;
+  CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
+  const float l5 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { p_qkv(b, l, nullptr); v_attn<1, 4, 4>(b, l); v_oproj_sliced(b, l, acc, b.x); v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x); } }, b.L);
+  g_epoch = f.epoch;
+  for (int np : {384, 448, 512, 640}) {
+    CK(hipMemsetAsync(acc, 0, (size_t)b.H * 8, b.st));
+    const float l3 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { v_qkv_attn<3>(b, l, f, b.part, np); v_oproj_sliced(b, l, acc, b.x); v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x); } }, b.L);
+    const float l4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { v_qkv_attn<4>(b, l, f, b.part, np); v_oproj_sliced(b, l, acc, b.x); v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x); } }, b.L);
+    const float c3 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { v_qkv_attn<3, false, true>(b, l, f, b.part, np); v_oproj_sliced(b, l, acc, b.x); v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x); } }, b.L);
+    const float c4 = time_graph(b, [&] { for (int l = 0; l < b.L; l++) { v_qkv_attn<4, false, true>(b, l, f, b.part, np); v_oproj_sliced(b, l, acc, b.x); v_gateup_acc(b, l, acc); v_down_acc(b, l, acc, b.scratch_x); } }, b.L);
+    printf("layer: {qkv, attention, o_proj sliced, gate_up, down} %.2f us   {qkv || attention (%d producers), o_proj sliced, gate_up, down} depth 3 %.2f, depth 4 %.2f; norm scale commuted: %.2f, %.2f us\n", l5, np, l3, l4, c3, c4);
+  }
+  g_epoch = nullptr;
+  CK(hipFree(f.gq)); CK(hipFree(f.gkv)); CK(hipFree(f.epoch)); CK(hipFree(f.part2)); CK(hipFree(acc));
+}
+
 static void lab_variants_main(Lab& b) {
+  if (getenv("LAB_FUSE")) { lab_qkv_attn(b); return; }
   if (getenv("LAB_MLP")) { lab_mlp_fused(b); return; }
   if (getenv("LAB_OPROJ")) { lab_oproj_shapes(b); return; }
   if (b.pos_h < 1024 || getenv("LAB_SHORT_ONLY")) { lab_fused_short(b); if (getenv("LAB_SHORT_ONLY")) return; }

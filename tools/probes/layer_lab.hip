@@ -2,7 +2,7 @@
 // {qkv, attention, combine, o_proj, gate_up, down} over L layers of distinct weights and caches, as one hipGraph (the product's structure) and class by
 // class (one class back-to-back over all layers, what tgx_profile_decode measures).  Compiles in seconds — the place where kernel variants are tried
 // against the product kernels on identical data before they enter csrc/decode.hip.
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -I../../tinygpt_amd/csrc layer_lab.hip -o build/layer_lab
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -DLAB_VARIANTS -DLAB_EPOCH -I../../tinygpt_amd/csrc layer_lab.hip -o build/layer_lab
 // Run:   layer_lab [geom=1b|0.5b|3b|7b] [pos=2064] [layers=16] [nsplit=CUs / kv heads, <= 32]
 #include <hip/hip_runtime.h>
 #include <cmath>
