@@ -132,6 +132,8 @@ struct tgx_ctx {
   unsigned long long seed_on_dev = 0;         // value last copied to seed_dev: an unchanged seed costs no copy and no stream sync
   bool seed_valid = false;
   tgx::SampScratch* samp_scratch = nullptr;   // [max_batch] histograms / thresholds / partial sums of the staged sampler
+  unsigned long long* samp_list_comp = nullptr;   // [max_batch][vocab] compacted threshold-bin entries of a filter (kernels/sampler.h): composite keys ...
+  float* samp_list_v = nullptr;                   // ... and logit / T
   bool have_probs = false;
   bool use_graph = true;
 

@@ -21,9 +21,9 @@
 //                                                              is unpinnable): per-workgroup sums, then one workgroup
 //                                                              walks the selected 1024 entries
 // The pick kernel also performs the duties of finalize_greedy_kernel (token publish, pastLength+1, token rings, next
-// embedding row).  Launches per sampled step: 5 per active top-k/top-p filter + 2 (+1 with min-p) + 1 pick per row;
-// T = 0.8 / top-p 0.9 (the CLI defaults): 8 launches, +50 us per decode step for V = 128 256 (the one-workgroup version of
-// this round added 600 us; profiles/r01_sampler_cost.txt).
+// embedding row).  Launches per sampled step: 3 per active top-k/top-p filter (first digit, compaction, tail) + 1 (+2 with
+// min-p) + 1 pick per row; T = 0.8 / top-p 0.9 (the CLI defaults): 5 launches (rounds 1-5: 8, +48 us per decode step at
+// V = 128 256; the one-workgroup version of round 1 added 600 us; profiles/r06_sampler_cost.txt).
 #pragma once
 #include "common.h"
 #include "gemv.h"
@@ -45,14 +45,18 @@ struct SampLevelState {
 };
 
 struct SampScratch {                  // one per batch row; zero at allocation, re-zeroed by the pick kernel
-  unsigned int cnt[SAMP_LEVELS][SAMP_BINS];
-  unsigned long long mass[SAMP_LEVELS][SAMP_BINS];
+  unsigned int cnt[1][SAMP_BINS];               // first-digit histograms (the later digits live in the tail's LDS)
+  unsigned long long mass[1][SAMP_BINS];
   SampLevelState st_k[SAMP_LEVELS], st_p[SAMP_LEVELS];
   unsigned long long thr_k, thr_p;    // kept <=> composite key >= thr
   double wg_z[SAMP_MAX_WG];           // per-workgroup sums of exp(v - max): the set min-p looks at.  The softmax normaliser is
   double wg_z2[SAMP_MAX_WG];          // ... the final kept set.       accumulated in double and rounded once (as the oracle
                                       //                                does): independent of the summation order
   double wg_p[SAMP_MAX_WG];           // per-workgroup sums of the final probabilities
+  double wg_above[SAMP_MAX_WG];       // per-workgroup sums of exp(v - max) over the entries ABOVE the threshold's first-digit bin (kept for sure)
+  unsigned int list_n;                // entries of the compacted list (the threshold's first-digit bin); zeroed by the tail
+  float zk;                           // normaliser of the final kept set, derived by the last filter's tail (no min-p)
+  float mx;                           // max(logits / T) of this step, left by the first sampler launch (SampArgs.mx_ready tells the later ones)
 };
 
 struct SampArgs {
@@ -63,7 +67,10 @@ struct SampArgs {
   float* probs_out; long long probs_stride;           // [rows][V] final probabilities (tgx_read_probs)
   int V, idx_bits, level;
   float temperature; long long top_k; float top_p; float min_p;
-  int k_from_hist, p_from_hist;       // 1: this launch is the first after the filter's last level and derives the threshold
+  int mx_ready;                       // 1: sc->mx holds the row maximum (an earlier launch of this step reduced the lm_head partials)
+  int z_from_tail;                    // 1: the kept set's normaliser is sc->zk (the last filter's tail summed it); 0: the ordered sum of wg_z2
+  unsigned long long* list_comp;      // [rows][V] compacted entries of the threshold's first-digit bin: composite keys ...
+  float* list_v;                      // ... and logit / T
 };
 
 __device__ __forceinline__ unsigned int float_key(float f) {   // ascending order-preserving key
@@ -169,11 +176,14 @@ __device__ __forceinline__ void samp_load(const SampArgs& a, int row, int wg, Sa
 
 // max over the row of logit / T: the maximum of the lm_head epilogue's per-workgroup maxima, scaled (x -> x / T is monotone)
 __device__ __forceinline__ float samp_row_max(const SampArgs& a, int row, float* sh4) {
+  if (a.mx_ready) return a.sc[row].mx;                       // (kernel-uniform)
   const float* pv = a.part_val + (size_t)row * a.part_stride;
   float m = -INFINITY;
   for (int i = threadIdx.x; i < a.n_part; i += SAMP_WG) m = fmaxf(m, pv[i]);
   m = samp_block_max(m, sh4);
-  return a.temperature > 0.f ? m / a.temperature : m;
+  m = a.temperature > 0.f ? m / a.temperature : m;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.sc[row].mx = m;
+  return m;
 }
 
 __device__ __forceinline__ unsigned long long samp_mass(float v, float mx) {
@@ -235,62 +245,21 @@ __device__ SampLevelState samp_select_mass(const unsigned long long* hist, int n
   return st;
 }
 
-// composite-key threshold of a finished descent (kept <=> comp >= thr)
-__device__ unsigned long long samp_threshold_k(const SampArgs& a, SampScratch* sc, unsigned long long* sh4, unsigned long long* sh_res) {
-  const int L = SAMP_LEVELS - 1, w = samp_width(L, a.idx_bits);
-  const SampLevelState st = samp_select_count(sc->cnt[L], 1 << w, w, sc->st_k[L], sh4, sh_res);
-  return st.prefix;                       // the k-th entry itself is kept
-}
-__device__ unsigned long long samp_threshold_p(const SampArgs& a, SampScratch* sc, unsigned long long* sh4, unsigned long long* sh_res) {
-  const int L = SAMP_LEVELS - 1, w = samp_width(L, a.idx_bits);
-  const SampLevelState st = samp_select_mass(sc->mass[L], 1 << w, w, sc->st_p[L], false, a.top_p, sh4, sh_res);
-  if (st.done) return 0ull;               // cumulative mass never exceeds top_p: nothing is cut
-  // st.prefix is the first entry whose inclusive cumulative mass exceeds top_p: it is cut, unless it is the very first entry
-  return st.acc == 0 ? st.prefix : st.prefix + 1ull;
+// thresholds as seen by the stages behind the filters' tails
+__device__ __forceinline__ void samp_thresholds(const SampArgs& a, const SampScratch* sc, unsigned long long& thr_k, unsigned long long& thr_p) {
+  thr_k = a.top_k > 0 ? sc->thr_k : 0ull;
+  thr_p = a.top_p < 1.f ? sc->thr_p : 0ull;
 }
 
-// thresholds as seen by a stage: derived here (first stage after the filter's last level) or read back
-__device__ __forceinline__ void samp_thresholds(const SampArgs& a, SampScratch* sc, unsigned long long& thr_k, unsigned long long& thr_p,
-                                                unsigned long long* sh4, unsigned long long* sh_res) {
-  thr_k = 0; thr_p = 0;
-  if (a.top_k > 0) {
-    if (a.k_from_hist) { thr_k = samp_threshold_k(a, sc, sh4, sh_res); if (blockIdx.x == 0 && threadIdx.x == 0) sc->thr_k = thr_k; }
-    else thr_k = sc->thr_k;
-  }
-  if (a.top_p < 1.f) {
-    if (a.p_from_hist) { thr_p = samp_threshold_p(a, sc, sh4, sh_res); if (blockIdx.x == 0 && threadIdx.x == 0) sc->thr_p = thr_p; }
-    else thr_p = sc->thr_p;
-  }
-}
-
-// ---- one digit level of a radix descent.  MODE 0: top-k (counts), MODE 1: top-p (masses over the top-k survivors) --------
+// ---- first digit of a radix descent: the whole chip over the vocabulary.  MODE 0: top-k (counts), MODE 1: top-p (masses over the top-k survivors) ----
 template <int MODE>
-__global__ __launch_bounds__(SAMP_WG) void samp_level_kernel(const SampArgs a) {
-  __shared__ unsigned long long sh4[4], sh_res[2];
+__global__ __launch_bounds__(SAMP_WG) void samp_level0_kernel(const SampArgs a) {
   __shared__ float shf[4];
   __shared__ unsigned long long lds_hist[SAMP_BINS];       // counts use the low word
-  const int row = blockIdx.y, L = a.level, tid = threadIdx.x;
+  const int row = blockIdx.y, tid = threadIdx.x;
   SampScratch* sc = a.sc + row;
-
-  unsigned long long thr_k = 0;
-  SampLevelState st;
-  if (L == 0) {
-    st.prefix = 0; st.acc = 0; st.done = 0; st.pad = 0;
-    st.need = MODE == 0 ? (unsigned long long)(a.top_k < (long long)a.V ? a.top_k : (long long)a.V) : 0ull;
-    if (MODE == 1 && a.top_k > 0) {       // the first top-p level runs right after the last top-k level
-      thr_k = samp_threshold_k(a, sc, sh4, sh_res);
-      if (blockIdx.x == 0 && tid == 0) sc->thr_k = thr_k;
-    }
-  } else {
-    const int wprev = samp_width(L - 1, a.idx_bits);
-    if (MODE == 0) st = samp_select_count(sc->cnt[L - 1], 1 << wprev, wprev, sc->st_k[L - 1], sh4, sh_res);
-    else st = samp_select_mass(sc->mass[L - 1], 1 << wprev, wprev, sc->st_p[L - 1], L == 1, a.top_p, sh4, sh_res);
-    if (MODE == 1 && a.top_k > 0) thr_k = sc->thr_k;
-  }
-  if (blockIdx.x == 0 && tid == 0) { if (MODE == 0) sc->st_k[L] = st; else sc->st_p[L] = st; }
-  if (st.done) return;                     // block-uniform
-
-  const int w = samp_width(L, a.idx_bits), shift = samp_shift(L, a.idx_bits), nbins = 1 << w;
+  const unsigned long long thr_k = (MODE == 1 && a.top_k > 0) ? sc->thr_k : 0ull;       // the top-k tail ran before
+  const int w = samp_width(0, a.idx_bits), shift = samp_shift(0, a.idx_bits), nbins = 1 << w;
   for (int b = tid; b < nbins; b += SAMP_WG) lds_hist[b] = 0ull;
   float mx = 0.f;
   if (MODE == 1) mx = samp_row_max(a, row, shf);
@@ -301,7 +270,7 @@ __global__ __launch_bounds__(SAMP_WG) void samp_level_kernel(const SampArgs a) {
   int cur = -1; unsigned long long sum = 0;
 #pragma unroll
   for (int j = 0; j < SAMP_EPT; j++) {
-    const bool take = e.in[j] && (e.comp[j] >> (shift + w)) == st.prefix && (MODE == 0 || e.comp[j] >= thr_k);
+    const bool take = e.in[j] && (MODE == 0 || e.comp[j] >= thr_k);
     if (!take) continue;
     const int d = (int)((e.comp[j] >> shift) & (unsigned long long)(nbins - 1));
     const unsigned long long val = MODE == 0 ? 1ull : samp_mass(e.v[j], mx);
@@ -313,9 +282,154 @@ __global__ __launch_bounds__(SAMP_WG) void samp_level_kernel(const SampArgs a) {
   for (int b = tid; b < nbins; b += SAMP_WG) {
     const unsigned long long hv = lds_hist[b];
     if (!hv) continue;
-    if (MODE == 0) atomicAdd(&sc->cnt[L][b], (unsigned int)hv);
-    else atomicAdd(&sc->mass[L][b], hv);
+    if (MODE == 0) atomicAdd(&sc->cnt[0][b], (unsigned int)hv);
+    else atomicAdd(&sc->mass[0][b], hv);
   }
+}
+
+// ---- second pass of the chip: every workgroup derives the threshold's first-digit bin from the global histogram; entries above it are kept for sure
+// (their exp sums per workgroup: the normaliser's bulk), entries inside it go to the compacted list the tail finishes
+template <int MODE>
+__global__ __launch_bounds__(SAMP_WG) void samp_compact_kernel(const SampArgs a) {
+  __shared__ unsigned long long sh4[4], sh_res[2];
+  __shared__ float shf[4];
+  __shared__ double shd[4];
+  const int row = blockIdx.y, tid = threadIdx.x;
+  SampScratch* sc = a.sc + row;
+  const unsigned long long thr_k = (MODE == 1 && a.top_k > 0) ? sc->thr_k : 0ull;
+  const int w = samp_width(0, a.idx_bits), shift = samp_shift(0, a.idx_bits);
+  SampLevelState st0;
+  st0.prefix = 0; st0.acc = 0; st0.done = 0; st0.pad = 0;
+  st0.need = MODE == 0 ? (unsigned long long)(a.top_k < (long long)a.V ? a.top_k : (long long)a.V) : 0ull;
+  SampLevelState st;
+  if (MODE == 0) st = samp_select_count(sc->cnt[0], 1 << w, w, st0, sh4, sh_res);
+  else st = samp_select_mass(sc->mass[0], 1 << w, w, st0, true, a.top_p, sh4, sh_res);
+  if (blockIdx.x == 0 && tid == 0) { if (MODE == 0) sc->st_k[1] = st; else sc->st_p[1] = st; }
+  const float mx = samp_row_max(a, row, shf);
+  SampElems e;
+  samp_load(a, row, blockIdx.x, e);
+  unsigned long long* lc = a.list_comp + (size_t)row * a.V;
+  float* lv = a.list_v + (size_t)row * a.V;
+  double above = 0.0;
+  bool mine[SAMP_EPT];
+  int n_mine = 0;
+#pragma unroll
+  for (int j = 0; j < SAMP_EPT; j++) {
+    mine[j] = false;
+    const bool take = e.in[j] && (MODE == 0 || e.comp[j] >= thr_k);
+    if (!take) continue;
+    const unsigned long long d = e.comp[j] >> shift;           // the first digit (nothing above it)
+    if (st.done || d > st.prefix) above += (double)expf(e.v[j] - mx);
+    else if (d == st.prefix) { mine[j] = true; n_mine++; }
+  }
+  // one reservation per workgroup on the list's counter (list order = arrival order of the workgroups: every use of the list is order-independent)
+  unsigned long long wg_total;
+  const unsigned long long after = samp_suffix_excl((unsigned long long)n_mine, sh4, wg_total);
+  if (tid == 0) sh_res[0] = wg_total ? (unsigned long long)atomicAdd(&sc->list_n, (unsigned int)wg_total) : 0ull;
+  __syncthreads();
+  unsigned int slot = (unsigned int)(sh_res[0] + wg_total - after - (unsigned long long)n_mine);
+#pragma unroll
+  for (int j = 0; j < SAMP_EPT; j++)
+    if (mine[j]) { lc[slot] = e.comp[j]; lv[slot] = e.v[j]; slot++; }
+  above = samp_block_sum_d(above, shd);
+  if (tid == 0) sc->wg_above[blockIdx.x] = above;
+}
+
+// ---- the tail: ONE workgroup per row takes the remaining four digits over the compacted list, derives the filter's threshold and — when it is the
+// last filter and min-p is off — the normaliser of the kept set (bulk sums of the compaction pass + the list's kept entries, double, rounded once)
+template <int MODE>
+__global__ __launch_bounds__(SAMP_WG) void samp_tail_kernel(const SampArgs a, int nwg, int last_filter) {
+  __shared__ unsigned long long sh4[4], sh_res[2];
+  __shared__ float shf[4];
+  __shared__ double shd[4];
+  __shared__ unsigned long long lds_hist[SAMP_BINS];
+  __shared__ unsigned int lds_cnt[SAMP_BINS];
+  const int row = blockIdx.y, tid = threadIdx.x;
+  SampScratch* sc = a.sc + row;
+  const unsigned long long* lc = a.list_comp + (size_t)row * a.V;
+  const float* lv = a.list_v + (size_t)row * a.V;
+  const int n = (int)sc->list_n;
+  const float mx = samp_row_max(a, row, shf);
+  SampLevelState st = MODE == 0 ? sc->st_k[1] : sc->st_p[1];
+  double above_w = 0.0;                   // this thread's share of the compaction pass's bulk sums (in flight beside the list)
+  if (last_filter) for (int i = tid; i < nwg; i += SAMP_WG) above_w += sc->wg_above[i];
+  // the list is read ONCE: up to TAIL_CACHE entries per thread stay in registers (keys, and for top-p their masses) for the digits, the lone-entry
+  // search and the normaliser; a longer list (every logit in one first-digit bin) streams from memory at each use instead
+  constexpr int TAIL_CACHE = 16;
+  const bool cached = n <= SAMP_WG * TAIL_CACHE;           // (block-uniform)
+  unsigned long long ck[TAIL_CACHE], cm[TAIL_CACHE];
+  float cv[TAIL_CACHE];
+#pragma unroll
+  for (int q = 0; q < TAIL_CACHE; q++) {
+    const int i = tid + q * SAMP_WG;
+    const bool in = cached && i < n;
+    ck[q] = in ? lc[i] : 0ull;                             // key 0 matches no prefix below the first digit of a real entry
+    cv[q] = in ? lv[i] : 0.f;
+  }
+  if (MODE == 1) {
+#pragma unroll
+    for (int q = 0; q < TAIL_CACHE; q++) cm[q] = samp_mass(cv[q], mx);
+  }
+  __shared__ unsigned long long s_only;
+  bool unique = false;                    // the chosen bin holds ONE entry: it is the threshold entry, the remaining digits have nothing to decide
+  for (int L = 1; L < SAMP_LEVELS && !st.done && !unique; L++) {
+    const int w = samp_width(L, a.idx_bits), shift = samp_shift(L, a.idx_bits), nbins = 1 << w;
+    __syncthreads();
+    for (int b = tid; b < nbins; b += SAMP_WG) { lds_cnt[b] = 0u; if (MODE == 1) lds_hist[b] = 0ull; }
+    __syncthreads();
+    if (cached) {
+#pragma unroll
+      for (int q = 0; q < TAIL_CACHE; q++) {
+        if (tid + q * SAMP_WG >= n || (ck[q] >> (shift + w)) != st.prefix) continue;
+        const int d = (int)((ck[q] >> shift) & (unsigned long long)(nbins - 1));
+        atomicAdd(&lds_cnt[d], 1u);
+        if (MODE == 1) atomicAdd(&lds_hist[d], cm[q]);
+      }
+    } else {
+      for (int i = tid; i < n; i += SAMP_WG) {
+        const unsigned long long cmp = lc[i];
+        if ((cmp >> (shift + w)) != st.prefix) continue;
+        const int d = (int)((cmp >> shift) & (unsigned long long)(nbins - 1));
+        atomicAdd(&lds_cnt[d], 1u);
+        if (MODE == 1) atomicAdd(&lds_hist[d], samp_mass(lv[i], mx));
+      }
+    }
+    __syncthreads();
+    if (MODE == 0) st = samp_select_count(lds_cnt, nbins, w, st, sh4, sh_res);
+    else st = samp_select_mass(lds_hist, nbins, w, st, false, a.top_p, sh4, sh_res);
+    if (!st.done && L + 1 < SAMP_LEVELS && lds_cnt[(int)(st.prefix & (unsigned long long)(nbins - 1))] == 1u) {     // (block-uniform)
+      if (cached) {
+#pragma unroll
+        for (int q = 0; q < TAIL_CACHE; q++) if (tid + q * SAMP_WG < n && (ck[q] >> shift) == st.prefix) s_only = ck[q];
+      } else {
+        for (int i = tid; i < n; i += SAMP_WG) if ((lc[i] >> shift) == st.prefix) s_only = lc[i];
+      }
+      __syncthreads();
+      st.prefix = s_only;                 // the full composite key, as the last digit would have left it
+      unique = true;
+    }
+  }
+  // kept <=> composite key >= thr.  top-k: the k-th entry itself is kept; top-p: st.prefix is the first entry whose inclusive cumulative mass exceeds
+  // top_p — it is cut, unless it is the very first entry; a cumulative mass that never exceeds top_p cuts nothing
+  unsigned long long thr;
+  if (MODE == 0) thr = st.prefix;
+  else thr = st.done ? 0ull : (st.acc == 0 ? st.prefix : st.prefix + 1ull);
+  if (tid == 0) { if (MODE == 0) sc->thr_k = thr; else sc->thr_p = thr; }
+  if (last_filter) {
+    double s = above_w;
+    if (cached) {
+#pragma unroll
+      for (int q = 0; q < TAIL_CACHE; q++) if (tid + q * SAMP_WG < n && ck[q] >= thr) s += (double)expf(cv[q] - mx);
+    } else {
+      for (int i = tid; i < n; i += SAMP_WG) if (lc[i] >= thr) s += (double)expf(lv[i] - mx);
+    }
+    s = samp_block_sum_d(s, shd);
+    if (tid == 0) sc->zk = (float)s;
+  }
+  __syncthreads();
+  // the first-digit histogram and the list of this filter are spent
+  for (int b = tid; b < SAMP_BINS; b += SAMP_WG) { if (MODE == 0) sc->cnt[0][b] = 0u; else sc->mass[0][b] = 0ull; }
+  if (tid == 0) sc->list_n = 0u;
 }
 
 // ---- partial sums over the kept set.  STAGE 0: Z of the set min-p looks at; 1: Z of the final set; 2: final probabilities ----
@@ -328,13 +442,12 @@ __device__ __forceinline__ float samp_ordered_sum(const double* part, int n, dou
 
 template <int STAGE>
 __global__ __launch_bounds__(SAMP_WG) void samp_sum_kernel(const SampArgs a) {
-  __shared__ unsigned long long sh4[4], sh_res[2];
   __shared__ float shf[4];
   __shared__ double shd[4];
   const int row = blockIdx.y, tid = threadIdx.x, nwg = gridDim.x;
   SampScratch* sc = a.sc + row;
   unsigned long long thr_k, thr_p;
-  samp_thresholds(a, sc, thr_k, thr_p, sh4, sh_res);
+  samp_thresholds(a, sc, thr_k, thr_p);
   const float mx = samp_row_max(a, row, shf);
   SampElems e;
   samp_load(a, row, blockIdx.x, e);
@@ -359,7 +472,7 @@ __global__ __launch_bounds__(SAMP_WG) void samp_sum_kernel(const SampArgs a) {
     if (tid == 0) (STAGE == 0 ? sc->wg_z : sc->wg_z2)[blockIdx.x] = s;
     return;
   }
-  const float z = samp_ordered_sum(sc->wg_z2, nwg, shd);
+  const float z = a.z_from_tail ? sc->zk : samp_ordered_sum(sc->wg_z2, nwg, shd);
   const float inv = 1.0f / z;
   double mine = 0.0;
   float p[SAMP_EPT];
@@ -392,24 +505,57 @@ __global__ __launch_bounds__(SAMP_WG) void samp_pick_kernel(const SampPickArgs p
   const SampArgs& a = pa.s;
   const int row = pa.fin.row, tid = threadIdx.x, nwg = pa.nwg;
   SampScratch* sc = a.sc + row;
+  // every independent load of the launch leaves first (one workgroup on an idle chip: each dependent round trip costs ~1 us)
+  double pw[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { const int w = tid * 4 + j; pw[j] = sc->wg_p[min(w, nwg - 1)]; }
+  const unsigned long long seed_w = *pa.seed;
+  const int pos_w = *pa.fin.pos;
+  const unsigned long long thr_k = a.top_k > 0 ? sc->thr_k : 0ull, thr_p = a.top_p < 1.f ? sc->thr_p : 0ull;
+  const float zk_w = sc->zk;
+  const int step_w = pa.fin.log ? *pa.fin.step : 0;
   const float mx = samp_row_max(a, row, shf);
-  // u, and the workgroup whose index range holds the draw (sequential scan of <= 1024 partial sums by one thread)
+  // u, and the workgroup whose index range holds the draw: a block-wide prefix sum over the <= 1024 per-workgroup sums (thread t owns workgroups
+  // 4t .. 4t+3; rounds 1-5 walked them with one thread — ~60 dependent loads on average, the longest single item of a sampled step)
   if (tid == 0) {
-    unsigned long long s = (*pa.seed) * 0x9E3779B97F4A7C15ull + (unsigned long long)(*pa.fin.pos + pa.fin.advance_pos) * 0xD1342543DE82EF95ull +
+    unsigned long long s = seed_w * 0x9E3779B97F4A7C15ull + (unsigned long long)(pos_w + pa.fin.advance_pos) * 0xD1342543DE82EF95ull +
                            (unsigned long long)pa.fin.row;
-    const double u = (double)(splitmix64(s) >> 11) * (1.0 / 9007199254740992.0);
-    double run = 0.0; int w = 0, last = 0;
-    for (; w < nwg; w++) { const double pw = sc->wg_p[w]; if (pw > 0.0) last = w; if (u < run + pw) break; run += pw; }
-    if (w >= nwg) { w = last; run = -1.0; }          // rounding left u above the total: the last kept entry (as the oracle's loop)
-    s_wg = w; s_run = run; s_pick = 0x7fffffff; s_last = -1;
-    shd[0] = u;
+    shd[0] = (double)(splitmix64(s) >> 11) * (1.0 / 9007199254740992.0);
+    s_wg = 0x7fffffff; s_pick = 0x7fffffff; s_last = -1;
   }
   __syncthreads();
   const double u = shd[0];
+  {
+    double mine_w = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int w = tid * 4 + j; if (w >= nwg) pw[j] = 0.0; mine_w += pw[j]; }
+    __syncthreads();                                   // shd[0] was read by everyone
+    double run = samp_prefix_excl_d(mine_w, shd);      // sum of the workgroups below this thread's four
+    int lastw = -1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int w = tid * 4 + j;
+      if (w < nwg && pw[j] > 0.0) lastw = w;
+      // the inclusive sums ascend, so the workgroups with u < inclusive sum form a suffix: the smallest of them is the walk's stopping point
+      if (w < nwg && u < run + pw[j]) atomicMin(&s_wg, w);
+      run += pw[j];
+    }
+    if (lastw >= 0) atomicMax(&s_last, lastw);
+    __syncthreads();
+    const int w0 = s_wg;
+    if (w0 != 0x7fffffff && (w0 >> 2) == tid) {        // its owner publishes the sum of the workgroups below it
+      double r = run - mine_w;
+      for (int j = 0; j < (w0 & 3); j++) r += pw[j];
+      s_run = r;
+    }
+    if (w0 == 0x7fffffff && tid == 0) { s_wg = s_last < 0 ? 0 : s_last; s_run = -1.0; }     // rounding left u above the total: the last kept entry (as the oracle's loop)
+    __syncthreads();
+  }
   const int wsel = s_wg;
   const double run0 = s_run;
   __syncthreads();
-  unsigned long long thr_k = a.top_k > 0 ? sc->thr_k : 0ull, thr_p = a.top_p < 1.f ? sc->thr_p : 0ull;
+  if (tid == 0) s_last = -1;                           // reused below for the last kept ENTRY of the selected range
+  __syncthreads();
   SampElems e;
   samp_load(a, row, wsel, e);
   bool kept[SAMP_EPT];
@@ -427,7 +573,7 @@ __global__ __launch_bounds__(SAMP_WG) void samp_pick_kernel(const SampPickArgs p
     for (int j = 0; j < SAMP_EPT; j++)
       if (kept[j] && ex[j] * inv0 < thr) { kept[j] = false; ex[j] = 0.f; }
   }
-  const float z = samp_ordered_sum(sc->wg_z2, nwg, shd);
+  const float z = a.z_from_tail ? zk_w : samp_ordered_sum(sc->wg_z2, nwg, shd);
   const float inv = 1.0f / z;
   double mine = 0.0;
   float p[SAMP_EPT];
@@ -445,20 +591,17 @@ __global__ __launch_bounds__(SAMP_WG) void samp_pick_kernel(const SampPickArgs p
   }
   if (hit != 0x7fffffff) atomicMin(&s_pick, hit);
   if (last >= 0) atomicMax(&s_last, last);
-  // the histograms of this step are spent: zero them for the next one (only the filters that ran touched them)
-  if (a.top_k > 0) for (int i = tid; i < SAMP_LEVELS * SAMP_BINS; i += SAMP_WG) (&sc->cnt[0][0])[i] = 0u;
-  if (a.top_p < 1.f) for (int i = tid; i < SAMP_LEVELS * SAMP_BINS; i += SAMP_WG) (&sc->mass[0][0])[i] = 0ull;
-  __syncthreads();
+  __syncthreads();       // (the filters' tails left their histograms and the list at zero)
   if (tid == 0) {
     int pick = s_pick != 0x7fffffff ? s_pick : s_last;   // no hit inside the selected range: its last kept entry
     if ((unsigned)pick >= (unsigned)a.V) pick = 0;       // all-NaN logits: stay inside the embedding table
     s_pick = pick;
     *pa.fin.tok = pick;
-    const int np = *pa.fin.pos + (pa.fin.advance_pos ? 1 : 0);
+    const int np = pos_w + (pa.fin.advance_pos ? 1 : 0);
     if (pa.fin.advance_pos) *pa.fin.pos = np;
     s_pos = np < pa.fin.n_pos ? np : pa.fin.n_pos - 1;
     if (pa.fin.log) {
-      const int st = *pa.fin.step;
+      const int st = step_w;
       pa.fin.tok_log[(st % pa.fin.log_cap) * pa.fin.rows + pa.fin.row] = pick;
       if (pa.fin.host_ring) pa.fin.host_ring[(st % pa.fin.ring_cap) * pa.fin.rows + pa.fin.row] = pick;
       if (pa.fin.bump_step) *pa.fin.step = st + 1;

@@ -183,8 +183,8 @@ class Model:
         self._check(st)
         return True
 
-    def load_synthetic(self, seed: int = 1234, std: float = 0.02):
-        for name, bits in synth.synth_checkpoint(self.desc, seed, std):
+    def load_synthetic(self, seed: int = 1234, std: float = 0.02, peaked: bool = False):
+        for name, bits in synth.synth_checkpoint(self.desc, seed, std, peaked):
             self.upload(name, bits)
         return self
 

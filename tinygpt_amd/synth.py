@@ -108,10 +108,41 @@ def synth_tensor_bf16(seed: int, name: str, shape, std: float, force_numpy: bool
     return out.reshape(shape)
 
 
-def synth_checkpoint(desc: ModelDesc, seed: int = 1234, std: float = 0.02):
-    """Yield (hf_name, uint16 bf16-bits ndarray) for every tensor of `desc`, in checkpoint order."""
-    for name, shape in desc.tensor_shapes().items():
-        yield name, synth_tensor_bf16(seed, name, shape, std)
+PEAK_ROWS, PEAK_SCALE = 4, 256.0
+
+
+def peaked_rows(seed: int, vocab: int):
+    """(loud, mirror): PEAK_ROWS + PEAK_ROWS distinct vocabulary rows of a *peaked* synthetic checkpoint, hashed from the seed"""
+    base = np.uint64((seed * 0xC2B2AE3D27D4EB4F + 0x165667B19E3779F9) & 0xFFFFFFFFFFFFFFFF)
+    picked, k = [], 0
+    while len(picked) < 2 * PEAK_ROWS:
+        with np.errstate(over="ignore"):
+            z = _splitmix64(np.array([(int(base) + k * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0]
+        r = int(z % np.uint64(vocab)); k += 1
+        if r not in picked:
+            picked.append(r)
+    return picked[:PEAK_ROWS], picked[PEAK_ROWS:]
+
+
+def synth_checkpoint(desc: ModelDesc, seed: int = 1234, std: float = 0.02, peaked: bool = False):
+    """Yield (hf_name, uint16 bf16-bits ndarray) for every tensor of `desc`, in checkpoint order.
+
+    peaked=True (tests/test_hip_parity_bar.py, tools/verify_checkpoint.py --synthetic-peaked; never the bench; untied heads only): PEAK_ROWS rows of
+    lm_head are scaled by PEAK_SCALE (a power of two: exact in bf16) and PEAK_ROWS other rows hold their NEGATION.  Every step's winner is then the loud
+    row with the largest |row . h| (or its mirror, by sign): the logits of 128 256 random rows have a top-2 gap under 2e-3 of the maximum at one step in
+    twenty, these 2 x 4 at one step in four hundred — which is what lets "greedy tokens identical" be tested free-running over a whole decode
+    (a prompt seed whose 257 gaps all clear the bar is found in a few tries; the test asserts the bar on the oracle's own logits)."""
+    shapes = desc.tensor_shapes()
+    if peaked and "lm_head.weight" not in shapes:
+        raise ValueError("peaked synthetic checkpoints need an untied lm_head (a loud tied embedding row dominates its own residual stream)")
+    for name, shape in shapes.items():
+        bits = synth_tensor_bf16(seed, name, shape, std)
+        if peaked and name == "lm_head.weight":
+            loud, mirror = peaked_rows(seed, shape[0])
+            for lo, mi in zip(loud, mirror):
+                bits[lo] = f32_to_bf16_bits(bf16_bits_to_f32(bits[lo]) * np.float32(PEAK_SCALE))
+                bits[mi] = bits[lo] ^ np.uint16(0x8000)
+        yield name, bits
 
 
 def synth_prompt(vocab: int, length: int, seed: int = 1234) -> np.ndarray:
