@@ -120,7 +120,7 @@ class HostEngine:
             self.h = None
 
 
-def write_model_dir(path, cfg, seed, std, shards=1, dtype="bf16", eos=None):
+def write_model_dir(path, cfg, seed, std, shards=1, dtype="bf16", eos=None, peaked=False):
     """HF-layout directory with deterministic weights: config.json, generation_config.json, model.safetensors
     (or 2 shards + model.safetensors.index.json).  Written with the `safetensors` package (an independent writer)."""
     import torch
@@ -132,7 +132,7 @@ def write_model_dir(path, cfg, seed, std, shards=1, dtype="bf16", eos=None):
     with open(os.path.join(path, "generation_config.json"), "w") as f:
         json.dump({"bos_token_id": 1, "eos_token_id": eos if eos is not None else cfg.get("eos_token_id", 2)}, f)
     tensors = {}
-    for name, bits in synth.synth_checkpoint(d, seed, std):
+    for name, bits in synth.synth_checkpoint(d, seed, std, peaked):
         if dtype == "bf16":      # reinterpret the bit patterns: no float round trip (matters at full model size)
             tensors[name] = torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(torch.bfloat16)
         elif dtype == "fp16":

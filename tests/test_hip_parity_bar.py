@@ -144,3 +144,70 @@ def test_full_depth_flip_floor_oracle_vs_reordered_oracle(name, tol, oracle_lib)
     3e-3 / 4e-3 are ~2x that floor, not slack."""
     from test_oracle_reorder import flip_floor
     flip_floor(name, tol, oracle_lib, 320, 6)
+
+
+PEAK_PROMPT_SEED = 8      # found with the CPU path alone (tools/verify_checkpoint.py --synthetic-peaked --find-seed): every one of the 257 top-2 gaps >= 9e-3
+
+
+def test_greedy_tokens_identical_free_running_at_the_bench_operating_point(oracle_lib, tmp_path):
+    """north_star: "greedy tokens identical" — literally, at bench.py's operating point: Llama-3.2-1B geometry, 2048-token prompt, then 256 decode steps
+    FREE-RUNNING on both sides (== generateSync, GPTEngine.cpp:154-174: prefill, sample, maxNewTokens - 1 steps), no teacher forcing and no tie band.
+    With N(0, 0.02^2) weights the top-2 logit gap is under the HIP-vs-CPU distance at one step in twenty, so an id comparison would mostly test the
+    tie-break; the *peaked* synthetic checkpoint (tinygpt_amd.synth: four loud lm_head rows and their negations, untied head — the only change against
+    the bench model, whose tied head a loud row would turn into a fixed point) makes every step's winner clear.  Held to:
+      * at EVERY step the CPU path's top-2 gap exceeds 4x the HIP-vs-CPU logit distance measured at that step (asserted, not assumed).  The distance
+        itself is normalised by the largest |logit|, here the largest of 8 loud rows rather than of 128 256 — ~3x smaller than on the bench checkpoint
+        for the same hidden-state error — so it reads 2-3e-3 where the bench checkpoint reads 5e-4 (held to 1e-3 by the test above); held to 4e-3;
+      * tgx_decode(256) in ONE call (the bench's call: multi-step graph replays) returns the CPU path's 256 ids; a second context stepping one token
+        at a time (where the distance is measured at every step) returns them too; so does the C++ engine behind tgx_cli from a checkpoint directory."""
+    import copy
+    import subprocess
+    from host_util import write_model_dir
+    from oracle.oracle_ffi import OracleModel
+    from tinygpt_amd import build, known_desc
+    from tinygpt_amd.desc import KNOWN_CONFIGS
+    S, STEPS = BENCH_S, 256
+    d = copy.deepcopy(known_desc("llama-3.2-1b"))
+    d.tied, d.max_ctx, d.max_batch = False, S + STEPS + 8, 1
+    prompt = synth.synth_prompt(d.vocab, S, PEAK_PROMPT_SEED)[None, :]
+    one_call, stepwise = Model(d, product_backend()), Model(d, product_backend())
+    oracle_lib.set_threads(min(32, __import__("os").cpu_count() or 8))
+    ref = OracleModel(d)
+    for name, bits in synth.synth_checkpoint(d, 1234, 0.02, peaked=True):
+        for m in (one_call, stepwise, ref):
+            m.upload(name, bits)
+    for m in (one_call, stepwise, ref):
+        m.finalize()
+        m.forward(prompt)
+    first = one_call.sample(GREEDY).copy()
+    ids_one_call = np.concatenate([first, one_call.decode(STEPS, GREEDY)[:, 0]])          # the bench's call shape
+    ids_ref, ids_step, gaps, dist = [], [], [], []
+    for step in range(STEPS + 1):
+        lr, lg = ref.logits(rounded=False), stepwise.logits(rounded=False)
+        top2 = np.partition(lr[0], -2)[-2:]
+        gaps.append(float((top2[1] - top2[0]) / np.abs(lr).max()))
+        dist.append(rel_err(lg, lr))
+        tr, tg = ref.sample(GREEDY), stepwise.sample(GREEDY)
+        ids_ref.append(int(tr[0])); ids_step.append(int(tg[0]))
+        assert ids_step[-1] == ids_ref[-1], (step, gaps[-1], dist[-1])          # from here on the two contexts would differ
+        if step < STEPS:
+            ref.forward(tr[None, :]); stepwise.decode(1, GREEDY)
+    ref.close(); oracle_lib.set_threads(8)
+    print("free-running: min top-2 gap %.2e, max HIP-vs-CPU distance %.2e, %d distinct ids" % (min(gaps), max(dist), len(set(ids_ref))))
+    margin = min(g / max(e, 1e-12) for g, e in zip(gaps, dist))
+    print("smallest gap / distance ratio of a step: %.1f" % margin)
+    assert max(dist) < 4e-3
+    assert margin > 4.0, (margin, min(gaps), max(dist))                         # the margin that makes the id comparison meaningful, step by step
+    assert len(set(ids_ref)) >= 4                                               # not a fixed point
+    np.testing.assert_array_equal(ids_one_call, np.array(ids_ref))              # zero skips
+    np.testing.assert_array_equal(np.array(ids_step), np.array(ids_ref))
+    one_call.close(); stepwise.close()
+    # ---- the same through the C++ engine and its CLI, from a checkpoint directory (3 shards, untied lm_head tensor)
+    cfg = dict(KNOWN_CONFIGS["llama-3.2-1b"]); cfg["tie_word_embeddings"] = False
+    write_model_dir(str(tmp_path), cfg, 1234, 0.02, shards=3, eos=[128001, 128009], peaked=True)
+    _, cli = build.build_host()
+    out = subprocess.run([cli, "--model", str(tmp_path), "--device", "mi355x", "--dtype", "bf16", "--max-tokens", str(STEPS + 1), "--temperature", "0", "--top-p", "1",
+                          "--prompt-ids", ",".join(str(int(t)) for t in prompt[0])], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("Output ids:")][0]
+    np.testing.assert_array_equal(np.array([int(t) for t in line.split(":")[1].split()]), np.array(ids_ref))
