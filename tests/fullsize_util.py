@@ -18,8 +18,8 @@ WIDE = min(32, os.cpu_count() or 8)      # oracle team for full-size passes (tes
 
 
 class Trajectory:
-    def __init__(self, desc, prompt, logits, toks, kv):
-        self.desc, self.prompt, self.logits, self.toks, self.kv = desc, prompt, logits, toks, kv
+    def __init__(self, desc, prompt, logits, toks, kv, key=None):
+        self.desc, self.prompt, self.logits, self.toks, self.kv, self.key = desc, prompt, logits, toks, kv, key
 
     def kv_prefix(self, layer, n_rows):
         k, v = self.kv[layer]
@@ -36,7 +36,10 @@ def oracle_trajectory(oracle_lib, name, prompt_len, seed, steps, dtype="bf16", r
     """`forced`: another Trajectory whose tokens drive this one (the reordered schedule is teacher-forced with the forward schedule's tokens);
     `keep_logits(step) -> bool` drops the logits of steps nobody reads (a 272-step run of a 128k vocabulary); `kv_layers`: layers whose cache is kept."""
     from oracle.oracle_ffi import OracleModel
-    key = (name, dtype, prompt_len, seed, steps, reorder, act16, id(forced) if forced is not None else None, max_ctx)
+    # everything that shapes what is stored is part of the key (ADVICE r5): which steps keep their logits (by the filter's name), which layers keep their
+    # cache, and the forcing trajectory by ITS key (an id() can be reused after garbage collection)
+    key = (name, dtype, prompt_len, seed, steps, reorder, act16, forced.key if forced is not None else None, max_ctx,
+           getattr(keep_logits, "__name__", None) if keep_logits is not None else None, tuple(kv_layers) if kv_layers is not None else None)
     if key in _CACHE:
         return _CACHE[key]
     d = full_desc(name, max_ctx)
@@ -60,7 +63,7 @@ def oracle_trajectory(oracle_lib, name, prompt_len, seed, steps, dtype="bf16", r
         m.close()
     finally:
         oracle_lib.set_threads(8)
-    t = Trajectory(d, prompt, logits, toks, kv)
+    t = Trajectory(d, prompt, logits, toks, kv, key)
     _CACHE[key] = t
     return t
 

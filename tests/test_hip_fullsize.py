@@ -47,8 +47,9 @@ def test_llama_3_2_1b_at_the_bench_operating_point_vs_oracle(oracle_lib):
     """bench.py's own workload against the oracle: full-size Llama-3.2-1B (16 layers, 32q/8kv heads, V = 128 256),
     bench.py's 2048-token prompt through the MFMA prefill, then 8 teacher-forced decode steps at context 2048..2055 on the SPLIT
     attention form + combine — 4 as single-position tgx_forward passes, 4 as replays of the captured decode graph (what the bench
-    times).  fp32 logits within 2e-3 of the oracle's at every step (the bf16 KV-rounding floor, see the 48-token test above), greedy
-    id equal unless the oracle's own top-2 gap is inside that tolerance, KV rows of layers 0 and 15 within one bf16 ulp.
+    times).  fp32 logits within north_star's 1e-3 of the oracle's at every step (measured 3.4-5.4e-4; the same bound tests/test_hip_parity_bar.py holds
+    over the whole bench range on this trajectory), greedy id equal unless the oracle's own top-2 gap is inside twice that tolerance, KV rows of
+    layers 0 and 15 within one bf16 ulp.
     Reference: Attention.h:71-112, GPTModel.h:51-58."""
     from fullsize_util import bench_range_trajectory
     S, STEPS = 2048, 8
@@ -62,11 +63,11 @@ def test_llama_3_2_1b_at_the_bench_operating_point_vs_oracle(oracle_lib):
     def check(step):
         lg, lr = gpu.logits(rounded=False), traj.logits[step]
         errs.append(rel_err(lg, lr))
-        assert errs[-1] < 2e-3, (step, errs)
+        assert errs[-1] < 1e-3, (step, errs)
         top2 = np.sort(lr[0])[-2:]
         tok_ref = traj.toks[step]
         tok_gpu = gpu.sample(GREEDY)          # also leaves the GPU's current token / embedding row set (overwritten below when forced)
-        if (top2[1] - top2[0]) > 4e-3 * np.abs(lr).max():
+        if (top2[1] - top2[0]) > 2e-3 * np.abs(lr).max():
             np.testing.assert_array_equal(tok_gpu, tok_ref)
         return tok_ref
 

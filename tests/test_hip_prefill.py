@@ -60,11 +60,19 @@ def test_fixture_prefill_matches_steps_and_oracle(fam, dtype, oracle_lib):
                                           ("llama-3.2-1b", 300, "fp16"), ("mistral-7b-v0.3", 130, "fp16"),
                                           ("qwen2.5-3b", 200, "bf16"), ("qwen3-1.7b", 150, "bf16"),   # the README's other checkpoints: 8 query heads per kv head; q/k norm
                                           ("gpt2", 300, "bf16"), ("gpt2", 300, "fp16"), ("gpt2", 300, "fp32"),           # BASELINE configs[0]'s model
-                                          ("llama-3.2-1b", 300, "fp32"), ("mistral-7b-v0.3", 130, "fp32"), ("qwen2.5-0.5b", 257, "fp32"), ("qwen3-1.7b", 90, "fp32")])
+                                          ("llama-3.2-1b", 300, "fp32"), ("mistral-7b-v0.3", 130, "fp32"), ("qwen2.5-0.5b", 257, "fp32"), ("qwen3-1.7b", 90, "fp32"),
+                                          # the long-prompt forms of round 5 at the shapes their A / B tests used (those compared new against old bit for bit through option
+                                          # switches that are gone: VERDICT r5 item 6): gate_up on whole 128-byte lines, the QKV product on shared activation lines with RoPE /
+                                          # cache append / q split in its epilogue (also with a QKV bias, ADVICE r5, and a ragged last row block), `down` as one slab
+                                          ("llama-3.2-1b", 1024, "bf16"), ("llama-3.2-1b", 1900, "bf16"), ("llama-3.2-1b", 2048, "fp16"), ("mistral-7b-v0.3", 1100, "bf16"),
+                                          ("llama-3.2-1b+qkv_bias", 1000, "bf16"), ("llama-3.2-1b", 2048, "bf16")])
 def test_real_layer_shapes_prefill_equals_steps(name, S, dtype):
-    """Real hidden/intermediate/head geometry (2 layers, 4096-entry vocabulary to keep the upload small)."""
-    d = copy.deepcopy(known_desc(name, dtype))
-    d.layers, d.vocab, d.max_ctx = 2, 4096, 512
+    """Real hidden/intermediate/head geometry (2 layers, 4096-entry vocabulary to keep the upload small): the batched matrix-core prefill against the same
+    prompt through the decode kernels (other kernels, the same math)."""
+    d = copy.deepcopy(known_desc(name.split("+")[0], dtype))
+    d.layers, d.vocab, d.max_ctx = 2, 4096, max(512, S + 16)
+    if name.endswith("+qkv_bias"):
+        d.qkv_bias = True
     m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
     prompt = synth.synth_prompt(d.vocab, S, 77)[None, :]
     l1, f1, r1, kv1 = run(m, prompt, mfma=True, n_decode=3)
@@ -199,47 +207,8 @@ def test_prefill_attention_forms_agree(name, S, dtype):
 
 
 @pytest.mark.parametrize("name,S,dtype", [("llama-3.2-1b", 1024, "bf16"), ("llama-3.2-1b", 1900, "bf16"), ("llama-3.2-1b", 2048, "fp16"), ("mistral-7b-v0.3", 1100, "bf16")])
-def test_gate_up_on_full_lines_is_bit_identical(name, S, dtype):
-    """Round 5 (option prefill.full_lines, on by default): where the gate_up product fills the chip with 256 x 256 tiles its activation terms arrive interleaved per k32
-    block (rmsnorm_split_kernel `inter`: one 128-byte line per row and stage) and the weights per k64 block (kernels/gemm_dma.h gemm_dma8i_kernel) — the same matrix
-    instructions on the same operands in the same order as the half-line kernel, the same siluMul epilogue: logits BIT-identical, also with a ragged last row tile."""
-    d = copy.deepcopy(known_desc(name, dtype))
-    d.layers, d.vocab, d.max_ctx = 2, 4096, S + 16
-    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
-    prompt = synth.synth_prompt(d.vocab, S, 82)[None, :]
-    outs = []
-    for on in (0, 1):
-        m.set_option("prefill.full_lines", on)
-        m.reset_cache(); m.forward(prompt)
-        outs.append((m.logits(rounded=False).copy(), m.read_kv(0, 1)))
-    np.testing.assert_array_equal(outs[1][0], outs[0][0])
-    np.testing.assert_array_equal(outs[1][1][0], outs[0][1][0])
-    np.testing.assert_array_equal(outs[1][1][1], outs[0][1][1])
-
-
-@pytest.mark.parametrize("name,S", [("llama-3.2-1b", 1024), ("llama-3.2-1b", 1900), ("mistral-7b-v0.3", 1100)])
-def test_qkv_on_shared_activation_lines_is_bit_identical(name, S):
-    """Round 5 (option prefill.qkv_shared, on by default): where q_dim = 4 kv_dim the QKV product of a bf16 prompt runs as eight-wave workgroups that own the Q tile AND the
-    K | V tile of a 128-row block and stage the three activation term tiles once for both (kernels/gemm_dma.h gemm_dma_qkv8_kernel) — per accumulator the same matrix
-    instructions in the same order as the balanced two-kind launch: logits and cache rows BIT-identical, also with a ragged last row block."""
-    d = copy.deepcopy(known_desc(name, "bf16"))
-    d.layers, d.vocab, d.max_ctx = 2, 4096, S + 16
-    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
-    prompt = synth.synth_prompt(d.vocab, S, 83)[None, :]
-    outs = []
-    for on in (0, 1):
-        m.set_option("prefill.qkv_shared", on)
-        m.reset_cache(); m.forward(prompt)
-        outs.append((m.logits(rounded=False).copy(), m.read_kv(0, 0), m.read_kv(0, 1)))
-    np.testing.assert_array_equal(outs[1][0], outs[0][0])
-    for l in (1, 2):
-        np.testing.assert_array_equal(outs[1][l][0], outs[0][l][0])
-        np.testing.assert_array_equal(outs[1][l][1], outs[0][l][1])
-
-
-@pytest.mark.parametrize("name,S,dtype", [("llama-3.2-1b", 1024, "bf16"), ("llama-3.2-1b", 1900, "bf16"), ("llama-3.2-1b", 2048, "fp16"), ("mistral-7b-v0.3", 1100, "bf16")])
 def test_down_on_wide_tiles_matches_the_square_tiles(name, S, dtype):
-    """Round 5 (option prefill.wide_n, on by default): the K >> N product (`down`) of a chip-filling prompt runs on 128 x 256 tiles x 2 K slabs (kernels/gemm_dma.h
+    """Round 5: the K >> N product (`down`) of a prompt worth two chips of its workgroups (regime knob prefill.wide_n_min) runs on 128 x 256 tiles x 2 K slabs (kernels/gemm_dma.h
     gemm_dma8n_kernel: a third fewer operand lines per output; the slabs are summed in z order by the next norm launch) instead of one slab of 128 x 128 tiles — the same
     products in another fp32 summation order: TWO layers (the second layer's norm consumes the slabs), logits within 2e-5, the same first token; bit-identical on a rerun."""
     d = copy.deepcopy(known_desc(name, dtype))
@@ -247,9 +216,8 @@ def test_down_on_wide_tiles_matches_the_square_tiles(name, S, dtype):
     m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
     prompt = synth.synth_prompt(d.vocab, S, 84)[None, :]
     outs = []
-    m.set_option("prefill.wide_n_min", 1)             # (the default takes the form from two chips' worth of workgroups)
-    for on in (0, 1, 1):
-        m.set_option("prefill.wide_n", on)
+    for chips in (1 << 20, 1, 1):                     # never / from one chip's worth of workgroups on (the default: two)
+        m.set_option("prefill.wide_n_min", chips)
         m.reset_cache(); m.forward(prompt)
         outs.append((m.logits(rounded=False).copy(), m.sample(GREEDY).copy()))
     assert rel_err(outs[1][0], outs[0][0]) < 2e-5, rel_err(outs[1][0], outs[0][0])
@@ -257,28 +225,3 @@ def test_down_on_wide_tiles_matches_the_square_tiles(name, S, dtype):
     np.testing.assert_array_equal(outs[1][0], outs[2][0])
 
 
-@pytest.mark.parametrize("name,S,dtype", [("llama-3.2-1b", 1024, "bf16"), ("llama-3.2-1b", 1900, "bf16")])
-def test_qkv_epilogue_with_rope_and_cache_append_is_bit_identical(name, S, dtype):
-    """Round 5 (option prefill.qkv_rope, on by default; head_dim 64, one sequence): the shared-line QKV launch also adds the bias, rotates q and k at the row's
-    position, splits q into its two 16-bit terms and rounds k / v into the cache in its epilogue — the arithmetic of rope_kv_split_kernel on the same accumulators:
-    logits and cache rows BIT-identical to the two-launch form, also with a ragged last row block; a second prompt behind a reset as well (the cache rows are rewritten)."""
-    d = copy.deepcopy(known_desc(name, dtype))
-    d.layers, d.vocab, d.max_ctx = 2, 4096, S + 16
-    m = Model(d, product_backend()).load_synthetic(1234, 0.02).finalize()
-    outs = []
-    for on in (0, 1):
-        m.set_option("prefill.qkv_rope", on)
-        res = []
-        for seed in (85, 86):
-            prompt = synth.synth_prompt(d.vocab, S - (seed - 85) * 100, seed)[None, :]
-            m.reset_cache(); m.forward(prompt)
-            lg, kv0, kv1 = m.logits(rounded=False).copy(), m.read_kv(0, 0), m.read_kv(0, 1)
-            m.sample(GREEDY)
-            res.append((lg, kv0, kv1, m.decode(3, GREEDY).copy()))
-        outs.append(res)
-    for a, b in zip(outs[0], outs[1]):
-        np.testing.assert_array_equal(a[0], b[0])
-        for l in (1, 2):
-            np.testing.assert_array_equal(a[l][0], b[l][0])
-            np.testing.assert_array_equal(a[l][1], b[l][1])
-        np.testing.assert_array_equal(a[3], b[3])

@@ -686,7 +686,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
       if (rc) return rc;
       if (f32_path && (rc = ensure_f32_part(c, nb * seq))) return rc;
       if (f32_path) launch_prefill_f32(c, row0, nb, seq);
-      else if (skinny) launch_prefill_skinny(c, row0, nb, seq); else launch_prefill(c, row0, nb, seq);
+      else if (skinny) launch_prefill_skinny(c, row0, nb, seq); else launch_prefill(c, row0, nb, seq, (int)c->past);   // tgx_forward: every row at the batch's pastLength
       for (int b = row0; b < row0 + nb;) {
         const int rem = row0 + nb - b, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
         launch_lm_head(c, b, R);
@@ -901,7 +901,7 @@ int tgx_forward_row(tgx_ctx* c, int row, const int64_t* ids, int seq) {
     if (!rc && f32_path) rc = ensure_f32_part(c, seq);
     if (!rc) {
       if (f32_path) launch_prefill_f32(c, row, 1, seq);
-      else if (skinny) launch_prefill_skinny(c, row, 1, seq); else launch_prefill(c, row, 1, seq);
+      else if (skinny) launch_prefill_skinny(c, row, 1, seq); else launch_prefill(c, row, 1, seq, /*past=*/0);
       launch_lm_head(c, row, 1);
       launch_add_pos(c, r.pos, seq);
     }
@@ -1151,10 +1151,6 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "prefill.splitk_dma")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "prefill.splitk_dma is 0, 1 (<= 64 rows) or 2 (always)"); c->splitk_dma = value; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_mirror")) { c->attn_mirror = value; return TGX_OK; }
   if (!strcmp(key, "prefill.wide_n_min")) { c->wide_n_min = value; return TGX_OK; }
-  if (!strcmp(key, "prefill.wide_n")) { c->wide_n = value != 0; return TGX_OK; }
-  if (!strcmp(key, "prefill.qkv_rope")) { c->qkv_rope = value != 0; return TGX_OK; }
-  if (!strcmp(key, "prefill.qkv_shared")) { c->qkv_shared = value != 0; return TGX_OK; }
-  if (!strcmp(key, "prefill.full_lines")) { c->full_lines = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_dma")) { c->attn_dma = value; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_ksplit")) { c->attn_ksplit = value; return TGX_OK; }
   if (!strcmp(key, "attn.qk_fuse")) { c->qk_fuse = value; return TGX_OK; }

@@ -71,7 +71,7 @@ struct Profiler {
 };
 
 // where the QKV product of a one-sequence prefill may finish its rows (prefill.hip launch_prefill -> launch_gemm)
-struct QkvEpi { bf16_t *q_hi = nullptr, *q_lo = nullptr, *k = nullptr, *v = nullptr; };
+struct QkvEpi { bf16_t *q_hi = nullptr, *q_lo = nullptr, *k = nullptr, *v = nullptr; int past = 0; };     // past: the position of the pass's first row (RoPE, cache append)
 
 struct tgx_ctx {
   tgx_model_desc d{};
@@ -157,11 +157,7 @@ struct tgx_ctx {
   int qkv_balanced = 1;      // option prefill.qkv_balanced: the bf16 QKV product as one launch of equal-work tiles (round 3)
   int attn_mirror = 1;       // experiment: prefill attention block order
   int wide_n_min = 2;        // ... from this many chips' worth of its workgroups (option prefill.wide_n_min)
-  int wide_n = 1;            // option prefill.wide_n: K >> N products (`down`) of a chip-filling prompt on 128 x 256 tiles x 2 K slabs (gemm_dma8n_kernel)
   QkvEpi qkv_epi;
-  int qkv_rope = 1;          // option prefill.qkv_rope: ... with RoPE, the cache append and the q split in that launch's epilogue (head_dim 64, one sequence)
-  int qkv_shared = 1;        // option prefill.qkv_shared: the QKV product of a bf16 prompt as eight-wave workgroups that stage the activation lines once for their Q and K | V tiles
-  int full_lines = 1;        // option prefill.full_lines: gate_up of a chip-filling prompt stages whole 128-byte lines (interleaved activation terms; gemm_dma8i_kernel)
   int attn_dma = 1;          // option prefill.attn_dma: head_dim 64 prompts of three or more workgroups per CU take kernels/attn_prefill_dma.h (0 never, 2 always)
   int attn_ksplit = 1;       // option prefill.attn_ksplit: key split inside the prefill attention workgroup (0 never, 1 auto: head_dim 128, and head_dim 64 below three workgroups per CU, 2 always)
   int qk_fuse = 1;           // experiment: 0 keeps Qwen3's separate q/k norm launch
@@ -314,7 +310,7 @@ int sampler_alloc(tgx_ctx* c);
 // ---- prefill.hip (kernels/prefill.h, gemm_dma.h)
 bool prefill_shapes_ok(const tgx_model_desc& d);
 int ensure_prefill_ws(tgx_ctx* c, int S);
-void launch_prefill(tgx_ctx* c, int row0, int NB, int S);
+void launch_prefill(tgx_ctx* c, int row0, int NB, int S, int past);      // past: the rows' common pastLength (their positions are past .. past + S - 1) — explicit, not read from the context
 int prefill_set_attrs(tgx_ctx* c);
 void launch_attn_prefill(tgx_ctx* c, const tgx::AttnPrefillArgs& a, bool allow_lean);
 void launch_rope_kv_split(tgx_ctx* c, const tgx::RopeKvArgs& a, int S);

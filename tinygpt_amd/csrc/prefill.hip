@@ -54,11 +54,11 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
 // -1 (round 5, option prefill.defer_store): the UNSPLIT eight-wave N = hidden product stored its result as ONE slab instead of adding it to the residual
 // stream in its epilogue — a read-modify-write of M x N floats by four waves per CU at the end of a launch that has one tile per CU (nothing left to overlap
 // it: 18-19 of o_proj's 52 us, tools/probes/gemm_lab.hip); the row-wise norm kernel that reads the stream next adds the slab while it streams.
-// The gate_up product on full 128-byte lines (kernels/gemm_dma.h gemm_dma8i_kernel; option prefill.full_lines): taken where the 256 x 256 kernel would be, on the
+// The gate_up product on full 128-byte lines (kernels/gemm_dma.h gemm_dma8i_kernel): taken where the 256 x 256 kernel would be, on the
 // default contract; the producing norm launch then writes the two terms interleaved per k32 block (rmsnorm_split_kernel `inter`) into ws_out, which is idle
 // between the RoPE / cache-append launch and the next layer's QKV product.
 static bool gemm_full_lines(const tgx_ctx* c, int epi, int M, int N, int K) {
-  if (!c->full_lines || epi != tgx::GEMM_SILU || c->gpt2 || (c->act16 && c->ws_zero) || !(c->gemm_dma & 4) || K % 64 != 0 || N % 256 != 0) return false;
+  if (epi != tgx::GEMM_SILU || c->gpt2 || (c->act16 && c->ws_zero) || !(c->gemm_dma & 4) || K % 64 != 0 || N % 256 != 0) return false;
   const tgx_model_desc& d = c->d;
   if ((size_t)d.heads * d.head_dim + 2 * (size_t)d.kv_heads * d.head_dim < (size_t)K) return false;      // ws_out holds [M][2 K] 16-bit terms
   const int t256 = ((N + 255) / 256) * ((M + 255) / 256), r256 = (t256 + c->num_cus - 1) / c->num_cus;
@@ -118,9 +118,9 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
     if (z >= 2) { part_8k = true; nsplit = z; }
   }
   // K >> N (`down`) on 128 x 256 tiles x 2 K slabs: a third fewer operand lines per output than the 128 x 128 kernel, which waits for them (kernels/gemm_dma.h
-  // gemm_dma8n_kernel; option prefill.wide_n).  Needs a consumer that sums pending slabs (`defer`) and two rounds of workgroups (prefill.wide_n_min, in chips): at one
+  // gemm_dma8n_kernel).  Needs a consumer that sums pending slabs (`defer`) and two rounds of workgroups (prefill.wide_n_min, in chips): at one
   // round (Llama-3.2-1B S = 2048: 256 workgroups) it ties with the one-slab 128 x 128 launch (141 vs 140-146 us) and costs a second slab; Mistral-7B S = 2048 56.1 -> 54.1 ms
-  if (nsplit == 1 && defer && c->wide_n && c->defer_reduce && epi == tgx::GEMM_RESIDUAL && (c->gemm_dma & 8) && !three_terms && !one && K >= 2 * N && K % 128 == 0 && N % 256 == 0 &&
+  if (nsplit == 1 && defer && c->defer_reduce && epi == tgx::GEMM_RESIDUAL && (c->gemm_dma & 8) && !three_terms && !one && K >= 2 * N && K % 128 == 0 && N % 256 == 0 &&
       2 * (N / 256) * ((M + 127) / 128) >= c->wide_n_min * c->num_cus) {
     const size_t need = (size_t)2 * M * N * 4;
     if (need > c->ws_part_bytes) {
@@ -245,15 +245,15 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
       return;
     }
   }
-  if ((c->gemm_dma & 3) && c->qkv_balanced && c->qkv_shared && three_terms && epi == tgx::GEMM_STORE && three_from > 0 && three_from % tgx::GBN == 0 && N > three_from && K % 64 == 0 &&
+  if ((c->gemm_dma & 3) && c->qkv_balanced && three_terms && epi == tgx::GEMM_STORE && three_from > 0 && three_from % tgx::GBN == 0 && N > three_from && K % 64 == 0 &&
       (N - three_from) % 64 == 0 && three_from / tgx::GBN == (N - three_from) / 64 && 2 * (three_from / tgx::GBN) * ((M + 127) / 128) >= c->num_cus) {
     // ... with as many 128-column Q tiles as 64-column K | V tiles (q_dim = 4 kv_dim) and at least half a chip of workgroups: eight waves per workgroup, the Q tile and the
-    // K | V tile of a row block on ONE staging of the activation lines (kernels/gemm_dma.h gemm_dma_qkv8_kernel; option prefill.qkv_shared)
+    // K | V tile of a row block on ONE staging of the activation lines (kernels/gemm_dma.h gemm_dma_qkv8_kernel)
     const int nwg = (three_from / tgx::GBN) * ((M + 127) / 128);
-    if (c->qkv_epi.q_hi && c->qkv_rope && c->d.head_dim == 64 && !c->d.qk_norm && defer) {
-      // ... and RoPE + cache append + the q split in its epilogue (one sequence, head_dim 64; option prefill.qkv_rope): no fp32 QKV matrix, no rope_kv_split launch
+    if (c->qkv_epi.q_hi && c->d.head_dim == 64 && !c->d.qk_norm && defer) {
+      // ... and RoPE + cache append + the q split in its epilogue (one sequence, head_dim 64): no fp32 QKV matrix, no rope_kv_split launch
       g.rope_q_hi = c->qkv_epi.q_hi; g.rope_q_lo = c->qkv_epi.q_lo; g.rope_k = c->qkv_epi.k; g.rope_v = c->qkv_epi.v;
-      g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.rope_past = (int)c->past; g.rope_max_ctx = c->d.max_ctx; g.rope_kv_heads = c->d.kv_heads;
+      g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.rope_past = c->qkv_epi.past; g.rope_max_ctx = c->d.max_ctx; g.rope_kv_heads = c->d.kv_heads;
       TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma_qkv8_kernel<DT, true>), dim3(nwg), dim3(512), (size_t)2 * (3 * 128 + 128 + 64) * 64 * 2, c->stream, g))
       *defer = 0;         // the rows are finished: the caller skips its RoPE / cache-append launch
       return;
@@ -361,7 +361,7 @@ void launch_embed_rows(tgx_ctx* c, const long long* ids, float* X, int M, int S)
 // == CausalLM::forward on [1,S] ids with an empty cache (GPTModel.h:51-56)
 // NB batch rows [row0, row0 + NB) are stacked into ONE [NB*S] row block for the row-wise kernels and the GEMMs (the weights stream
 // once for all of them); RoPE / cache append and attention run per batch row on its slice and its own cache.
-void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
+void launch_prefill(tgx_ctx* c, int row0, int NB, int S, int past) {
   const tgx_model_desc& d = c->d;
   const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
   const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd;
@@ -369,7 +369,7 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
   const size_t wout = (size_t)qd + 2 * kvd;
   // GPT-2 (ModelGPT2.h:23-208): wte + wpe rows, LayerNorm with bias ahead of both products, a bias on every Conv1D, c_fc -> gelu_new;
   // its rotation tables are the identity, so the RoPE / cache-append kernel and the attention are the Llama family's
-  TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_rows_any_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const long long*)c->rows[(size_t)row0].prompt, (const void*)c->embed, (const void*)(c->gpt2 ? c->wpe : nullptr), c->ws_x, H, S, (long long)d.max_ctx, (int)c->past))
+  TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::embed_rows_any_kernel<DT>, dim3(M), dim3(256), 0, c->stream, (const long long*)c->rows[(size_t)row0].prompt, (const void*)c->embed, (const void*)(c->gpt2 ? c->wpe : nullptr), c->ws_x, H, S, (long long)d.max_ctx, past))
   int pend = 1;                     // slabs of the previous layer's down product still to be added to ws_x (1: none; -1: one whole-K slab, see launch_gemm)
   const bf16_t* pend_bias = nullptr;
   for (int l = 0; l < d.layers; l++) {
@@ -385,7 +385,7 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
     c->qkv_epi = QkvEpi{};
     if (NB == 1) {      // one sequence: the QKV product may finish its rows itself (launch_gemm: gemm_dma_qkv8_kernel<.., ROPE>)
       RowState& r0 = c->rows[(size_t)row0];
-      c->qkv_epi.q_hi = c->ws_qh; c->qkv_epi.q_lo = c->ws_ql;
+      c->qkv_epi.q_hi = c->ws_qh; c->qkv_epi.q_lo = c->ws_ql; c->qkv_epi.past = past;
       c->qkv_epi.k = reinterpret_cast<bf16_t*>(r0.kcache) + (size_t)l * kv_layer; c->qkv_epi.v = reinterpret_cast<bf16_t*>(r0.vcache) + (size_t)l * kv_layer;
     }
     launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, M, qd + 2 * kvd, H, qd + 2 * kvd, /*three_terms=*/three, nullptr, nullptr, /*three_from=*/qd, &qsl);   // Q columns: two terms
@@ -400,7 +400,7 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
       if (qsl > 1) { a.QKV = nullptr; a.part = c->ws_part + ro * wout; a.nsplit = qsl; a.slab = (long long)M * (long long)wout; a.bias = reinterpret_cast<const bf16_t*>(w.bqkv); }
       a.k_cache = kc + (size_t)l * kv_layer; a.v_cache = vc + (size_t)l * kv_layer;
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
-      a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = (int)c->past;
+      a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = past;
       a.q_norm_w = d.qk_norm ? (const bf16_t*)w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? (const bf16_t*)w.k_norm : nullptr; a.eps = d.norm_eps;
       launch_rope_kv_split(c, a, S);
     }
@@ -411,7 +411,7 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S) {
       const size_t ro = (size_t)b * S;
       tgx::AttnPrefillArgs a{};
       a.q_hi = c->ws_qh + ro * qd; a.q_lo = c->ws_ql + ro * qd; a.k_cache = kc + (size_t)l * kv_layer; a.v_cache = vc + (size_t)l * kv_layer;
-      a.o_hi = c->ws_ah + ro * qd; a.o_lo = c->ws_al + ro * qd; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
+      a.o_hi = c->ws_ah + ro * qd; a.o_lo = c->ws_al + ro * qd; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = past;
       a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = c->attn_mirror;
       launch_attn_prefill(c, a, /*allow_lean=*/true);
     }
