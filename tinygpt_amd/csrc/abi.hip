@@ -646,7 +646,7 @@ void tgx_destroy(tgx_ctx* c) {
   fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->wpe); fr(c->final_norm_b); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch); fr(c->samp_list_comp); fr(c->samp_list_v);
   fr(c->slab_acc);
   fr(c->ch_x); fr(c->ch_q); fr(c->ch_kraw); fr(c->ch_attn); fr(c->ch_h); fr(c->ch_part); fr(c->ch_pos);
-  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl); fr(c->ws_part); fr(c->ws_ssq); fr(c->ws_pos); fr(c->ws_attn_part);
+  fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl); fr(c->ws_part); fr(c->ws_ssq); fr(c->ws_pos);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); fr(w.in_norm_b); fr(w.post_norm_b); fr(w.bo); fr(w.bfc); fr(w.bdown); }
   fr(c->slab_x); fr(c->slab_q); fr(c->slab_kraw); fr(c->slab_attn); fr(c->slab_h); fr(c->slab_logits); fr(c->slab_probs);
   fr(c->slab_part_val); fr(c->slab_part_idx); fr(c->slab_attn_part); fr(c->slab_tok); fr(c->slab_pos); fr(c->slab_prompt); fr(c->slab_k); fr(c->slab_v);
@@ -1122,7 +1122,6 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "attn.mfma_min")) { c->attn_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "prefill.defer_min_rows")) { c->defer_min_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.defer_reduce")) { c->defer_reduce = value != 0; return TGX_OK; }
-  if (!strcmp(key, "prefill.defer_store")) { c->defer_store = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.dma")) { drop_step_graphs(c); c->skinny_dma = value != 0; return TGX_OK; }
   if (!strcmp(key, "skinny.dma_oproj")) { drop_step_graphs(c); c->skinny_dma_oproj = value; return TGX_OK; }
   if (!strcmp(key, "skinny.dma_qkv")) { drop_step_graphs(c); c->skinny_dma_qkv = value; return TGX_OK; }
@@ -1135,21 +1134,14 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "debug.gemv")) { c->debug_gemv = value; return TGX_OK; }
   if (!strcmp(key, "prefill.mfma")) { c->prefill_mfma = value != 0; return TGX_OK; }
   if (!strcmp(key, "prefill.min_rows")) { c->prefill_min_rows = value; return TGX_OK; }
-  if (!strcmp(key, "prefill.f32_flash")) { c->f32_flash = value; return TGX_OK; }
   if (!strcmp(key, "prefill.f32_min_rows")) { c->prefill_f32_min_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.splitk")) { c->gemm_splitk = value; return TGX_OK; }
-  if (!strcmp(key, "prefill.qkv_balanced")) { c->qkv_balanced = value != 0; return TGX_OK; }
   if (!strcmp(key, "decode.step_rows")) { if (value != 32 && value != 64 && value != 128) return set_err(c, TGX_ERR_INVALID, "decode.step_rows is 32, 64 or 128"); drop_step_graphs(c); c->decode_step_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.skinny_hidden_max_wide")) { c->prefill_skinny_hidden_max_wide = value; return TGX_OK; }
   if (!strcmp(key, "prefill.skinny_hidden_max")) { c->prefill_skinny_hidden_max = value; return TGX_OK; }
   if (!strcmp(key, "prefill.skinny_rows")) { if (value < 0 || value > 128) return set_err(c, TGX_ERR_INVALID, "prefill.skinny_rows is 0..128"); c->prefill_skinny_rows = value; return TGX_OK; }
   if (!strcmp(key, "prefill.wide_8k_eff")) { c->wide_8k_eff = value; return TGX_OK; }
   if (!strcmp(key, "prefill.wide_8k_max")) { c->wide_8k_max = value; return TGX_OK; }
-  if (!strcmp(key, "prefill.xcd_tiles")) { c->xcd_tiles = value != 0; return TGX_OK; }
-  if (!strcmp(key, "prefill.wide_8k")) { c->wide_8k = value != 0; return TGX_OK; }
-  if (!strcmp(key, "prefill.hidden_256")) { c->hidden_256 = value != 0; return TGX_OK; }
-  if (!strcmp(key, "prefill.splitk_dma")) { if (value < 0 || value > 2) return set_err(c, TGX_ERR_INVALID, "prefill.splitk_dma is 0, 1 (<= 64 rows) or 2 (always)"); c->splitk_dma = value; return TGX_OK; }
-  if (!strcmp(key, "prefill.attn_mirror")) { c->attn_mirror = value; return TGX_OK; }
   if (!strcmp(key, "prefill.wide_n_min")) { c->wide_n_min = value; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_dma")) { c->attn_dma = value; return TGX_OK; }
   if (!strcmp(key, "prefill.attn_ksplit")) { c->attn_ksplit = value; return TGX_OK; }

@@ -28,7 +28,6 @@ typedef unsigned char ebyte;   // parameter / KV-cache storage in the compute dt
 namespace tgx { struct SampScratch; }
 
 constexpr int MAX_TICKET_EVENTS = 64;
-constexpr int F32_ATTN_ROWS = 64;      // prompt rows per attention launch of the fp32 prefill (bounds the split-partials workspace)
 constexpr int HOST_RING = 256;
 
 struct LayerW {
@@ -150,12 +149,8 @@ struct tgx_ctx {
   bool poisoned = false;                                // a pass failed after some of its kernels were issued (device-side position / cache / counters may have moved): every entry point refuses until tgx_reset_cache
   const char* launch_fault = nullptr;                   // a launcher could not issue a kernel (a combination that is not instantiated): the issuing entry point fails with it
   int* ws_pos = nullptr;                                // fp32 prefill: [rows] positions of the prompt rows
-  float* ws_attn_part = nullptr;                        // fp32 prefill: split-attention partials of one block of rows
   float* ws_ssq = nullptr;                              // [32][SK_NCB] partial sums of squares of the batched step's rows
   int gemm_splitk = 1;       // experiment: 0 disables split-K
-  int splitk_dma = 1;        // option prefill.splitk_dma: the split-K slabs of a short prompt through the LDS-DMA GEMM (round 3)
-  int qkv_balanced = 1;      // option prefill.qkv_balanced: the bf16 QKV product as one launch of equal-work tiles (round 3)
-  int attn_mirror = 1;       // experiment: prefill attention block order
   int wide_n_min = 2;        // ... from this many chips' worth of its workgroups (option prefill.wide_n_min)
   QkvEpi qkv_epi;
   int attn_dma = 1;          // option prefill.attn_dma: head_dim 64 prompts of three or more workgroups per CU take kernels/attn_prefill_dma.h (0 never, 2 always)
@@ -189,7 +184,6 @@ struct tgx_ctx {
   int decode_mfma_min = 3;
   bool prefill_mfma = true;
   int prefill_min_rows = 4;  // prompts shorter than this go through the decode kernels, 4 positions per pass (set in tgx_create)
-  int f32_flash = 1;               // option prefill.f32_flash: 0 = attention of the fp32 prefill through the decode attention kernel
   int prefill_f32_min_rows = 16;   // fp32 storage: prompts from this length on take the f32-input MFMA GEMMs (64-row tiles; option prefill.f32_min_rows)
   int gemm_tm = 0;           // experiment: force the GEMM row tile (64 / 128); 0 = by the number of tiles
   // option prefill.gemm_dma: bit 0 / 1 = unsplit prefill GEMMs take their tiles by LDS-DMA (kernels/gemm_dma.h), bit 2 = the wide product (gate_up / c_fc)
@@ -199,9 +193,6 @@ struct tgx_ctx {
   int gemm_dma = 15 | (1 << 4) | (2 << 8);
   int wide_8k_max = 8;       // option prefill.wide_8k_max: ... while its tiles number at most this many half-chips (8 = 4 tiles per CU: everything below the 256 x 256 kernel's range;
                              // 3 / 8: Llama-3.2-1B S = 512 3.62 / 3.44 ms, 768 5.06 / 4.94; Mistral-7B S = 256 11.16 / 10.81, 512 22.5 / 21.4)
-  int xcd_tiles = 1;         // option prefill.xcd_tiles: the eight-wave GEMMs hand every XCD a 2 x 4 cut of the tile grid (gemm_dma.h xcd_tile)
-  int wide_8k = 1;           // option prefill.wide_8k: gate_up of 129-384-row prompts on the eight-wave 128 x 128 kernel
-  int hidden_256 = 1;        // option prefill.hidden_256: o_proj / down on the 256 x 256 eight-wave kernel when their tiles fill the chip
   int debug_attn = 0;        // experiment: AttnArgs.dbg
   int attn_gmax = 0;         // experiment: query heads per attention workgroup (default 2)
   int attn_direct_nw4 = 0;   // option attn.direct_nw4: contexts up to this many keys run the direct attention form with four waves per head (set in tgx_create)
@@ -218,7 +209,6 @@ struct tgx_ctx {
   int skinny_terms = 1;            // option skinny.terms: batches of 17-32 rows take gate_up's activations as terms prepared once per layer (round 3)
   int skinny_ksplit = 1;           // wide products (gate_up, lm_head) of the batched step on the barrier-free K-split kernel (option skinny.ksplit)
   int defer_min_rows = 129;        // option prefill.defer_min_rows (192 until the row-wise norm launch loaded its slabs eight at a time: Llama-3.2-1B S = 160 2.51 -> 2.41 ms, 191 2.54 -> 2.46; Mistral-7B S = 160 9.90 -> 9.65)
-  int defer_store = 1;             // option prefill.defer_store (round 5): the unsplit eight-wave N = hidden products store ONE slab that the next row-wise norm launch adds to the residual stream, instead of a read-modify-write epilogue
   int defer_reduce = 1;            // split-K slabs of the prefill's N = hidden / QKV products are summed by the next row-wise kernel (option prefill.defer_reduce)
   int attn_mfma_min = -1;          // -1: the measured crossover of the geometry (attn_mfma_threshold); option attn.mfma_min overrides
   bool attn_mfma = false;

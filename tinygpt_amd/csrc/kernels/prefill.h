@@ -304,7 +304,6 @@ struct GemmArgs {
   // gemm_x2_kernel with A_lo2: tile columns below three_from take two terms only.  The third term exists for results that are rounded
   // to 16 bits again — the K / V columns of the QKV product; its Q columns (the first heads*head_dim) stay fp32.
   int three_from;
-  int xcd_tiles;          // 1: gemm_dma8 / gemm_dma8k map workgroups to tiles per XCD (gemm_dma.h xcd_tile; option prefill.xcd_tiles)
   // gemm_dma_qkv8_kernel<DT, ROPE = true> (head_dim 64, one sequence): split + RoPE(q), RoPE(k) + cache append + q as two 16-bit terms run in the product's epilogue
   // (== rope_kv_split_kernel on the finished rows, same arithmetic: Attention.h:96-106); row m sits at position rope_past + m
   bf16_t *rope_q_hi, *rope_q_lo;     // [M][three_from]

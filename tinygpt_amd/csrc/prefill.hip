@@ -43,7 +43,6 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
     if (c->ws_pos) (void)hipFree(c->ws_pos);
     c->ws_pos = nullptr;
     HIP_OK(c, hipMalloc((void**)&c->ws_pos, rows * 4));
-    if (!c->ws_attn_part) HIP_OK(c, hipMalloc((void**)&c->ws_attn_part, (size_t)F32_ATTN_ROWS * c->attn_part_row * 4));
   }
   c->ws_rows = S;
   return TGX_OK;
@@ -51,7 +50,7 @@ int ensure_prefill_ws(tgx_ctx* c, int S) {
 
 // defer (optional, RESIDUAL / STORE products): when the product is split over K, leave the slabs in ws_part for the consumer kernel to sum
 // (rmsnorm_split_kernel / rope_kv_split_kernel: same z order, one launch and one pass over the rows less) and report the slab count; 1 = done here.
-// -1 (round 5, option prefill.defer_store): the UNSPLIT eight-wave N = hidden product stored its result as ONE slab instead of adding it to the residual
+// -1 (round 5): the UNSPLIT eight-wave N = hidden product stored its result as ONE slab instead of adding it to the residual
 // stream in its epilogue — a read-modify-write of M x N floats by four waves per CU at the end of a launch that has one tile per CU (nothing left to overlap
 // it: 18-19 of o_proj's 52 us, tools/probes/gemm_lab.hip); the row-wise norm kernel that reads the stream next adds the slab while it streams.
 // The gate_up product on full 128-byte lines (kernels/gemm_dma.h gemm_dma8i_kernel): taken where the 256 x 256 kernel would be, on the
@@ -62,7 +61,7 @@ static bool gemm_full_lines(const tgx_ctx* c, int epi, int M, int N, int K) {
   const tgx_model_desc& d = c->d;
   if ((size_t)d.heads * d.head_dim + 2 * (size_t)d.kv_heads * d.head_dim < (size_t)K) return false;      // ws_out holds [M][2 K] 16-bit terms
   const int t256 = ((N + 255) / 256) * ((M + 255) / 256), r256 = (t256 + c->num_cus - 1) / c->num_cus;
-  const bool ragged256 = c->wide_8k && c->wide_8k_eff > 0 && (c->gemm_dma & 8) && t256 >= c->num_cus && 100 * t256 < c->wide_8k_eff * r256 * c->num_cus;
+  const bool ragged256 = c->wide_8k_eff > 0 && (c->gemm_dma & 8) && t256 >= c->num_cus && 100 * t256 < c->wide_8k_eff * r256 * c->num_cus;
   return t256 >= c->num_cus && !ragged256;
 }
 
@@ -72,7 +71,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
   if (a_inter) {       // A arrives interleaved in a_hi (the caller asked gemm_full_lines first)
     tgx::GemmArgs g{};
     g.A_hi = a_hi; g.A_lo = nullptr; g.A_lo2 = nullptr; g.inter = N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
-    g.B = reinterpret_cast<const bf16_t*>(B_); g.bias = nullptr; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc; g.three_from = 1 << 30; g.xcd_tiles = c->xcd_tiles;
+    g.B = reinterpret_cast<const bf16_t*>(B_); g.bias = nullptr; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc; g.three_from = 1 << 30;
     const dim3 g8((N + 255) / 256, (M + 255) / 256), b8(512);
     TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma8i_kernel<DT, tgx::GEMM_SILU>), g8, b8, (size_t)5 * 256 * 128, c->stream, g))
     return;
@@ -85,7 +84,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
   tgx::GemmArgs g{};
   g.A_hi = a_hi ? a_hi : c->ws_ah; g.A_lo = one ? c->ws_zero : (a_lo ? a_lo : c->ws_al); g.A_lo2 = three_terms ? c->ws_al2 : nullptr;
   g.inter = N / 2; g.out_hi = c->ws_hh; g.out_lo = c->ws_hl;
-  g.B = B; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc; g.three_from = three_from; g.xcd_tiles = c->xcd_tiles;
+  g.B = B; g.bias = bias; g.C = C; g.M = M; g.N = N; g.K = K; g.ldc = ldc; g.three_from = three_from;
   // few column tiles (N = hidden) -> 64-row tiles, so that at least two workgroups share a CU
   const bool few = ((N + tgx::GBN - 1) / tgx::GBN) * ((M + tgx::GBM - 1) / tgx::GBM) < 2 * c->num_cus;
   // measured (tools/prefill_bench.py --gemm-tm, Llama-3.2-1B, S = 2048): this policy 15.0 ms, 64-row tiles also for the three-term
@@ -99,7 +98,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
   const int ntiles = (int)(grid.x * grid.y), ktiles = K / tgx::GBK;
   int nsplit = 1;
   // (the balanced QKV launch below fills the chip by itself from 1024 rows on at hidden 2048: 128 + 128 workgroups of equal work; Llama-3.2-1B S = 1024 5.16 -> 5.06 ms — no slabs then; option prefill.qkv_nosplit)
-  const bool qkv_bal = (c->gemm_dma & 3) && c->qkv_balanced && three_terms && epi == tgx::GEMM_STORE && three_from > 0 && three_from % tgx::GBN == 0 && N > three_from && K % 64 == 0 && M >= 128;
+  const bool qkv_bal = (c->gemm_dma & 3) && three_terms && epi == tgx::GEMM_STORE && three_from > 0 && three_from % tgx::GBN == 0 && N > three_from && K % 64 == 0 && M >= 128;
   const int qkv_wgs = qkv_bal ? (three_from / tgx::GBN) * ((M + 127) / 128) + ((N - three_from + tgx::GBN - 1) / tgx::GBN) * ((M + 63) / 64) : 0;
   const bool qkv_nosplit = qkv_bal && c->qkv_nosplit && qkv_wgs >= c->num_cus;
   if (c->gemm_splitk && ntiles < c->num_cus && K % tgx::GBK == 0 && !qkv_nosplit) nsplit = std::min(std::min(16, ktiles), (2 * c->num_cus + ntiles - 1) / ntiles);
@@ -140,9 +139,9 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
   }
   // one tile per CU on the eight-wave 128 x 128 kernel, a consumer that can take a pending slab: store the product, let the consumer add it (see `defer` above)
   const int t128u = ((N + 127) / 128) * ((M + 127) / 128);
-  const bool store_slab = nsplit == 1 && defer && c->defer_store && c->defer_reduce && epi == tgx::GEMM_RESIDUAL && (c->gemm_dma & 8) && K % 64 == 0 && !three_terms &&
+  const bool store_slab = nsplit == 1 && defer && c->defer_reduce && epi == tgx::GEMM_RESIDUAL && (c->gemm_dma & 8) && K % 64 == 0 && !three_terms &&
                           2 * t128u >= c->num_cus && 2 * t128u <= 3 * c->num_cus &&
-                          !((c->gemm_dma & 4) && c->hidden_256 && ((N + 255) / 256) * ((M + 255) / 256) >= c->num_cus);
+                          !((c->gemm_dma & 4) && ((N + 255) / 256) * ((M + 255) / 256) >= c->num_cus);
   if (nsplit > 1 || store_slab) {
     const size_t need = (size_t)nsplit * M * N * 4;
     if (need > c->ws_part_bytes) {
@@ -167,7 +166,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
     const dim3 gz(grid.x, grid.y, nsplit);
     const size_t nout = (size_t)M * (epi == tgx::GEMM_SILU ? N / 2 : N);
     const dim3 rg((unsigned)((nout + 255) / 256));
-    // the slabs' GEMM: operand tiles by LDS-DMA (round 3; option prefill.splitk_dma) — the register-staged kernel streamed a short prompt's weights at
+    // the slabs' GEMM: operand tiles by LDS-DMA (round 3) — the register-staged kernel streamed a short prompt's weights at
     // 1-2 TB/s (S = 48: gate_up 32 us for 67 MB); 64-row tiles whenever the prompt fits them, k = 64 per stage (32 for the 128-row three-term tile)
     // measured (Llama-3.2-1B, ms per prompt, DMA vs register-staged slabs): S = 40 1.61 / 1.79, 48 1.65 / 1.76, 64 1.71 / 1.87; 96 2.08 / 1.99, 128 2.12 / 2.09,
     // 256 2.65 / 2.68; Mistral-7B S = 48 5.40 / 6.23 — the 64-row tile wins, the 128-row one does not: prompts of <= 64 rows only (value 2 = always)
@@ -176,7 +175,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
       const size_t lds8 = (size_t)3 * 3 * 128 * 64 * 2;
       TGX_DT16_SWITCH(c->dt, if (one_k) hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_PARTIAL, false>), g8, b8, lds8, c->stream, g); else hipLaunchKernelGGL((tgx::gemm_dma8k_kernel<DT, tgx::GEMM_PARTIAL>), g8, b8, lds8, c->stream, g);)
     }
-    const bool dma_part = !part_8k && c->splitk_dma && (M <= 64 || c->splitk_dma == 2) && (c->gemm_dma & 3) && g.k_per % 64 == 0 && K % 64 == 0;
+    const bool dma_part = !part_8k && M <= 64 && (c->gemm_dma & 3) && g.k_per % 64 == 0 && K % 64 == 0;
     if (dma_part) {
       const int mi = (small || M <= 64) ? 1 : 2;
       const int dbk = (mi == 2 && three_terms) ? 32 : 64;
@@ -201,7 +200,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
   // (a prompt whose 256 x 256 tiles leave the last round of workgroups mostly empty — 1152 rows at intermediate 8192: 320 tiles = 1.25 rounds, the time of 2048 rows — takes the
   //  128 x 128 kernel below instead: 1152 tiles = 4.5 rounds; option prefill.wide_8k_eff = per cent of the last round's fill below which that happens)
   const int t256 = ((N + 255) / 256) * ((M + 255) / 256), r256 = (t256 + c->num_cus - 1) / c->num_cus;
-  const bool ragged256 = c->wide_8k && c->wide_8k_eff > 0 && epi == tgx::GEMM_SILU && (c->gemm_dma & 8) && t256 >= c->num_cus && 100 * t256 < c->wide_8k_eff * r256 * c->num_cus;
+  const bool ragged256 = c->wide_8k_eff > 0 && epi == tgx::GEMM_SILU && (c->gemm_dma & 8) && t256 >= c->num_cus && 100 * t256 < c->wide_8k_eff * r256 * c->num_cus;
   if ((c->gemm_dma & 4) && K % 64 == 0 && !three_terms && (epi == tgx::GEMM_SILU || epi == tgx::GEMM_GELU) && t256 >= c->num_cus && !ragged256) {
     // the wide product (gate_up / c_fc) with enough 256 x 256 tiles to fill the chip: 8 waves, three-stage LDS-DMA ring
     const dim3 g8((N + 255) / 256, (M + 255) / 256), b8(512);
@@ -211,10 +210,10 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
       else hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_GELU>), g8, b8, lds8, c->stream, g);)
     return;
   }
-  if ((c->gemm_dma & 4) && c->hidden_256 && K % 64 == 0 && !three_terms && (epi == tgx::GEMM_RESIDUAL || epi == tgx::GEMM_STORE) &&
+  if ((c->gemm_dma & 4) && K % 64 == 0 && !three_terms && (epi == tgx::GEMM_RESIDUAL || epi == tgx::GEMM_STORE) &&
       ((N + 255) / 256) * ((M + 255) / 256) >= c->num_cus) {
     // the N = hidden products of a prompt long enough to give every CU a 256 x 256 tile (Llama-3.2-1B from 8192 rows, Mistral-7B from 4096): the wide
-    // product's kernel with the plain fp32 epilogue (option prefill.hidden_256)
+    // product's kernel with the plain fp32 epilogue 
     const dim3 g8((N + 255) / 256, (M + 255) / 256), b8(512);
     const size_t lds8 = (size_t)3 * 3 * 256 * 32 * 2;
     TGX_DT16_SWITCH(c->dt,
@@ -222,7 +221,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
       else { if (one_k) hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_STORE, false>), g8, b8, lds8, c->stream, g); else hipLaunchKernelGGL((tgx::gemm_dma8_kernel<DT, tgx::GEMM_STORE>), g8, b8, lds8, c->stream, g); })
     return;
   }
-  if ((c->gemm_dma & 8) && c->wide_8k && K % 64 == 0 && !three_terms && epi == tgx::GEMM_SILU) {
+  if ((c->gemm_dma & 8) && K % 64 == 0 && !three_terms && epi == tgx::GEMM_SILU) {
     // the wide product of a prompt too short for 256 x 256 tiles (129-384 rows: 128-384 tiles of 128 x 128): the eight-wave kernel with the K step split between
     // wave pairs instead of the four-wave one (option prefill.wide_8k: Llama-3.2-1B S = 256 gate_up 61 us per layer)
     const int t128 = ((N + 127) / 128) * ((M + 127) / 128);
@@ -245,7 +244,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
       return;
     }
   }
-  if ((c->gemm_dma & 3) && c->qkv_balanced && three_terms && epi == tgx::GEMM_STORE && three_from > 0 && three_from % tgx::GBN == 0 && N > three_from && K % 64 == 0 &&
+  if ((c->gemm_dma & 3) && three_terms && epi == tgx::GEMM_STORE && three_from > 0 && three_from % tgx::GBN == 0 && N > three_from && K % 64 == 0 &&
       (N - three_from) % 64 == 0 && three_from / tgx::GBN == (N - three_from) / 64 && 2 * (three_from / tgx::GBN) * ((M + 127) / 128) >= c->num_cus) {
     // ... with as many 128-column Q tiles as 64-column K | V tiles (q_dim = 4 kv_dim) and at least half a chip of workgroups: eight waves per workgroup, the Q tile and the
     // K | V tile of a row block on ONE staging of the activation lines (kernels/gemm_dma.h gemm_dma_qkv8_kernel)
@@ -261,7 +260,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
     TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma_qkv8_kernel<DT>), dim3(nwg), dim3(512), (size_t)2 * (3 * 128 + 128 + 64) * 64 * 2, c->stream, g))
     return;
   }
-  if ((c->gemm_dma & 3) && c->qkv_balanced && three_terms && epi == tgx::GEMM_STORE && three_from > 0 && three_from % tgx::GBN == 0 && N > three_from && K % 64 == 0 && M >= 128) {
+  if ((c->gemm_dma & 3) && three_terms && epi == tgx::GEMM_STORE && three_from > 0 && three_from % tgx::GBN == 0 && N > three_from && K % 64 == 0 && M >= 128) {
     // the QKV product of a bf16 prompt: Q columns as two-term 128-row tiles, K / V columns as three-term 64-row tiles, ONE launch with
     // equal work per workgroup pair (kernels/gemm_dma.h gemm_dma_qkv_kernel)
     const int nq = (three_from / tgx::GBN) * ((M + 127) / 128), nkv = ((N - three_from + tgx::GBN - 1) / tgx::GBN) * ((M + 63) / 64);
@@ -269,17 +268,12 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
     TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma_qkv_kernel<DT, 32, 2>), dim3(nq + nkv), blk, ldsq, c->stream, g))
     return;
   }
-  if ((c->gemm_dma & 3) && K % 64 == 0) {     // operand tiles by LDS-DMA into a ring of stages (kernels/gemm_dma.h): one barrier per K step
-    // geometry per tile height (option prefill.gemm_dma bits 4-7 / 8-11 override: value = BK/32 + 4*(stages-2)): 128-row tiles k = 32 x 3 stages,
-    // 64-row tiles k = 64 x 2 stages
-    int sel = small ? ((c->gemm_dma >> 8) & 15) : ((c->gemm_dma >> 4) & 15);
-    if (!sel) sel = small ? 2 : 5;
-    const int dbk = (sel & 3) == 1 ? 32 : 64, ns = 2 + (sel >> 2);
-    const size_t lds = tgx::gemm_dma_lds_bytes(small ? 1 : 2, three_terms, dbk, ns);
-#define TGX_DMA2(EPI_, MI_, BK_) do { if (ns == 2) hipLaunchKernelGGL((tgx::gemm_dma_kernel<DT, EPI_, MI_, BK_, 2>), grid, blk, lds, c->stream, g); \
-                                      else if (ns == 3) hipLaunchKernelGGL((tgx::gemm_dma_kernel<DT, EPI_, MI_, BK_, 3>), grid, blk, lds, c->stream, g); \
-                                      else hipLaunchKernelGGL((tgx::gemm_dma_kernel<DT, EPI_, MI_, BK_, 4>), grid, blk, lds, c->stream, g); } while (0)
-#define TGX_DMA(EPI_, MI_) do { if (dbk == 32) TGX_DMA2(EPI_, MI_, 32); else TGX_DMA2(EPI_, MI_, 64); } while (0)
+  if ((c->gemm_dma & 3) && K % 64 == 0) {     // operand tiles by LDS-DMA into a two-stage ring (kernels/gemm_dma.h): one barrier per K step
+    // geometry per tile height: 128-row tiles k = 32, 64-row tiles k = 64 (round 2's sweep, profiles/r02_prefill_dma_sweep.txt: deeper rings lose 4-20 % to occupancy
+    // here — the eight-wave kernels are where they pay; the other geometries went with the option bits that selected them in round 6)
+    const size_t lds = small ? tgx::gemm_dma_lds_bytes(1, three_terms, 64, 2) : tgx::gemm_dma_lds_bytes(2, three_terms, 32, 2);
+#define TGX_DMA(EPI_, MI_) do { if ((MI_) == 1) hipLaunchKernelGGL((tgx::gemm_dma_kernel<DT, EPI_, 1, 64, 2>), grid, blk, lds, c->stream, g); \
+                                else hipLaunchKernelGGL((tgx::gemm_dma_kernel<DT, EPI_, 2, 32, 2>), grid, blk, lds, c->stream, g); } while (0)
     if (lds <= 160 * 1024) {
       TGX_DT16_SWITCH(c->dt,
         if (epi == tgx::GEMM_SILU) TGX_DMA(tgx::GEMM_SILU, 2);
@@ -289,7 +283,6 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
       return;
     }
 #undef TGX_DMA
-#undef TGX_DMA2
   }
   TGX_DT16_SWITCH(c->dt,
     if (epi == tgx::GEMM_SILU) hipLaunchKernelGGL((tgx::gemm_x2_kernel<DT, tgx::GEMM_SILU, 2>), grid, blk, dyn, c->stream, g);
@@ -412,7 +405,7 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S, int past) {
       tgx::AttnPrefillArgs a{};
       a.q_hi = c->ws_qh + ro * qd; a.q_lo = c->ws_ql + ro * qd; a.k_cache = kc + (size_t)l * kv_layer; a.v_cache = vc + (size_t)l * kv_layer;
       a.o_hi = c->ws_ah + ro * qd; a.o_lo = c->ws_al + ro * qd; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = past;
-      a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = c->attn_mirror;
+      a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = 1;
       launch_attn_prefill(c, a, /*allow_lean=*/true);
     }
     int osl = 1;
@@ -446,7 +439,7 @@ int prefill_set_attrs(tgx_ctx* c) {
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_BF16, tgx::GEMM_PARTIAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_x2_kernel<tgx::DT_F16, tgx::GEMM_PARTIAL, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, tgx::GBM * tgx::GLD * 2));
 #define TGX_DMA_ATTR1(DT_, EPI_, MI_, BK_, NS_) HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma_kernel<DT_, EPI_, MI_, BK_, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(160 * 1024, tgx::gemm_dma_lds_bytes(MI_, true, BK_, NS_))));
-#define TGX_DMA_ATTR(DT_, EPI_, MI_) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 64, 4) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 2) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 3) TGX_DMA_ATTR1(DT_, EPI_, MI_, 32, 4)
+#define TGX_DMA_ATTR(DT_, EPI_, MI_) TGX_DMA_ATTR1(DT_, EPI_, MI_, ((MI_) == 1 ? 64 : 32), 2)
 #define TGX_DMA_ATTR_D(DT_) TGX_DMA_ATTR(DT_, tgx::GEMM_SILU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_GELU, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_RESIDUAL, 2) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 1) TGX_DMA_ATTR(DT_, tgx::GEMM_STORE, 2)
   TGX_DMA_ATTR_D(tgx::DT_BF16) TGX_DMA_ATTR_D(tgx::DT_F16)
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8n_kernel<tgx::DT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 128 + 256) * 64 * 2));

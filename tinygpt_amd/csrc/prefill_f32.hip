@@ -94,25 +94,14 @@ void launch_prefill_f32(tgx_ctx* c, int row0, int NB, int S) {
     for (int b = 0; b < NB; b++) {
       RowState& r = c->rows[(size_t)(row0 + b)];
       const size_t ro = (size_t)b * S;
-      if (c->f32_flash) {        // causal flash attention on the f32-input MFMA (K / V tiles shared by 128 queries)
+      {                          // causal flash attention on the f32-input MFMA (K / V tiles shared by 128 queries)
         tgx::AttnPrefillF32Args a{};
         a.q = qrows + ro * qd; a.k_cache = reinterpret_cast<const float*>(r.kcache + (size_t)l * kv_layer); a.v_cache = reinterpret_cast<const float*>(r.vcache + (size_t)l * kv_layer);
         a.out = xn + ro * qd; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
-        a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = c->attn_mirror;
+        a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = 1;
         const dim3 grid((S + 127) / 128, d.heads), blk(256);
         if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_f32_kernel<64>), grid, blk, 0, c->stream, a);
         else hipLaunchKernelGGL((tgx::attn_prefill_f32_kernel<128>), grid, blk, 0, c->stream, a);
-        continue;
-      }
-      for (int s0 = 0; s0 < S; s0 += F32_ATTN_ROWS) {       // option prefill.f32_flash = 0: the decode attention kernel, blocks of rows
-        const int R = std::min(F32_ATTN_ROWS, S - s0);
-        tgx::AttnArgs a{};
-        a.q = qrows + (ro + s0) * qd; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
-        a.pos = c->ws_pos + s0; a.part = c->ws_attn_part; a.out = xn + (ro + s0) * qd;
-        a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
-        a.scale = 1.0f / sqrtf((float)hd);
-        a.q_stride = qd; a.kv_stride = 0; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
-        launch_attn(c, a, R);
       }
     }
     launch_gemm_f32(c, tgx::F32_RESIDUAL, w.wo, w.bo, xn, c->ws_x, M, H, qd, H);

@@ -383,7 +383,7 @@ void launch_prefill_skinny(tgx_ctx* c, int row0, int NB, int S) {
       a.q_hi = c->ws_qh + ro * qd; a.q_lo = c->ws_ql + ro * qd;
       a.k_cache = reinterpret_cast<bf16_t*>(r.kcache) + (size_t)l * kv_layer; a.v_cache = reinterpret_cast<bf16_t*>(r.vcache) + (size_t)l * kv_layer;
       a.o_hi = c->ws_ah + ro * qd; a.o_lo = c->ws_al + ro * qd; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
-      a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = c->attn_mirror;
+      a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = 1;
       launch_attn_prefill(c, a, /*allow_lean=*/false);
     }
     SkinnyCall o;

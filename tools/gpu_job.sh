@@ -39,17 +39,6 @@ job_sweep() {
   done > $O/sweep.log 2>&1; cat $O/sweep.log
 }
 
-# prefill GEMMs: FETCH_SIZE (x2 on gfx950) and duration with / without the XCD-aware tile order (option prefill.xcd_tiles)
-job_prefill_xcd() {
-  cd /tmp
-  for o in 0 1; do
-    rm -rf /tmp/px$o; rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/px$o -o p -- python $R/tools/prefill_bench.py --reps 3 --opts "prefill.xcd_tiles=$o" > $O/prefill_xcd$o.log 2>&1
-    echo "== prefill.xcd_tiles=$o  FETCH_SIZE (KiB, x2 for bytes on gfx950)"; python $R/tools/rocpd_pmc.py $(find /tmp/px$o -name "*.db" | head -1) 2>&1 | head -12
-    rm -rf /tmp/pm$o; rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm$o -o p -- python $R/tools/prefill_bench.py --reps 3 --opts "prefill.xcd_tiles=$o" >> $O/prefill_xcd$o.log 2>&1
-    echo "== prefill.xcd_tiles=$o  MFMA busy"; python $R/tools/rocpd_pmc.py $(find /tmp/pm$o -name "*.db" | head -1) 2>&1 | head -16
-  done > $O/prefill_xcd.txt 2>&1; cat $O/prefill_xcd.txt; cd $R
-}
-
 # per-kernel durations of the batched prefill (rocprofv3 --kernel-trace; PREFILL_ARGS e.g. "--seq 2048")
 job_prefill_trace() {
   cd /tmp; rm -rf /tmp/pt

@@ -12,7 +12,7 @@
 #pragma once
 #include <type_traits>
 
-#include "prefill.h"
+#include "kernels/prefill.h"
 
 namespace tgx {
 
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(512) void gemm_dma_qkv8_kernel(const GemmArgs a) {
   int rb = (int)blockIdx.x / ncg, cg = (int)blockIdx.x - rb * ncg;
   {
     const int nrb = (int)gridDim.x / ncg;
-    if ((nrb & 7) == 0) {
+    if (a.xcd_tiles && (nrb & 7) == 0) {
       const int xcd = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
       rb = xcd * (nrb >> 3) + l / ncg; cg = l % ncg;
     }
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(512) void gemm_dma_qkv8_kernel(const GemmArgs a) {
 __device__ __forceinline__ void xcd_tile(const GemmArgs& a, int& tm, int& tn) {
   const int gn = (int)gridDim.x, gm = (int)gridDim.y;
   tm = (int)blockIdx.y; tn = (int)blockIdx.x;
-  if ((gm & 1) || (gn & 3)) return;
+  if (!a.xcd_tiles || (gm & 1) || (gn & 3)) return;
   const int id = tn + gn * tm, xcd = id & 7, l = id >> 3;
   const int sm = gm >> 1, sn = gn >> 2;          // the XCD's rectangle: sm x sn tiles
   const int xm = xcd >> 2, xn = xcd & 3;
@@ -495,15 +495,17 @@ __device__ __forceinline__ void silu_epilogue_transposed(const f32x16 (&acc)[2][
 // (bit-identical; tools/probes/gemm_lab.hip, profiles/r05_prefill.txt).
 // LO = false (option act.round16: the Linear's input is rounded to the storage dtype, so A_hi IS the activation): the A_lo tile is neither staged nor
 // multiplied — 4 DMA pieces per stage instead of 6, half the MFMAs (gate_up at S = 2048: 232 -> 130 us, profiles/r04_act16_cost.txt)
-// (Round 5's lab-only template switches of this kernel — parts compiled out, the ping-pong schedule, the free-running operand stream — live in
-// tools/probes/archive/gemm_dma_r05_lab.h, the copy tools/probes/gemm_lab.hip builds against; measured, not adopted: profiles/r05_prefill.txt section 5.)
-// The siluMul epilogue goes through LDS.  In the MFMA C layout a lane ends up with ONE (gate, up) result per row pair, so the
+// DIS (lab only): 1 = no MFMAs, 2 = no DMA after the prologue, 4 = no fragment reads, 8 = no epilogue stores; 17 = the operand stream free-running (no ring discipline), 18 = the same through buffer_load ... lds.
+// PP (lab only, tools/probes/gemm_lab.hip): 1 = the two waves of a SIMD half a stage apart (ping-pong), + 2 s_setprio around the matrix phase, + 4 static s_setprio for
+// waves 4-7, + 8 DMA issue ahead of the fragment reads — measured, not adopted (profiles/r05_prefill.txt section 5).  GEMM_PARTIAL (blockIdx.z = K slab) likewise serves the lab's
+// `down` experiment only; the product's slab forms live in gemm_dma8k_kernel / gemm_dma8n_kernel.
+// TEPI (round 5, GEMM_SILU with WJ = 4): the siluMul epilogue goes through LDS.  In the MFMA C layout a lane ends up with ONE (gate, up) result per row pair, so the
 // direct epilogue stores 2 bytes per lane, 32 contiguous bytes per row and instruction — 128 store instructions per wave and term, a quarter of a line each.  Here every wave
 // writes its 64 x 64 results (hi and lo) into its own 18-KB slice of the idle ring ([64 rows][72]: 144-byte rows keep the 16-byte reads aligned and the row pairs off each
 // other's banks), reads them back eight outputs per lane and stores whole 128-byte rows: 16 store instructions per wave.  Same values, same rounding.
-template <int DT, int EPI, bool LO = true>
+template <int DT, int EPI, bool LO = true, int WJ = 4, int DIS = 0, bool TEPI = true, int PP = 0>
 __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
-  constexpr int DBK = 32, CPR = 4, RPP = 16, TMN = 256, NS = 3, WJ = 4;      // a wave owns 64 x 128 of the tile: WI x WJ = 2 x 4 blocks of 32 x 32
+  constexpr int DBK = 32, CPR = 4, RPP = 16, TMN = 256, NS = 3;
   constexpr int WI = 8 / WJ, NWN = TMN / (32 * WJ);      // 32 x 32 blocks per wave along M / N, waves along N
   constexpr int STAGE = 3 * TMN * DBK;                    // 16-bit elements per stage
   extern __shared__ __attribute__((aligned(1024))) bf16_t dma_lds[];
@@ -524,7 +526,9 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int prow = lane / CPR, pslot = lane % CPR;
-  const int k_begin = 0, k_end = a.K;
+  // GEMM_PARTIAL: blockIdx.z covers k_per elements of K and stores its fp32 tile to slab z (the N = hidden products with K >> N: `down` as 64 tiles x 4 slabs)
+  const int k_begin = EPI == GEMM_PARTIAL ? (int)blockIdx.z * a.k_per : 0;
+  const int k_end = EPI == GEMM_PARTIAL ? min(a.K, k_begin + a.k_per) : a.K;
   const bf16_t* gsrc[6];
   unsigned ldst[6];
 #pragma unroll
@@ -541,11 +545,13 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
   const int klast = (nk - 1) * DBK;
   auto issue_piece = [&](int q, int s) {
     if (!LO && q % 3 == 1) return;
+    if ((DIS & 2) && s > ((PP & 1) ? 1 : 2)) return;
     dma_1k(gsrc[q] + min(s * DBK, klast), lds_base + (unsigned)((s % NS) * STAGE * 2) + ldst[q]);
   };
   const int swz = ((lane & 31) >> 2) & 3;
   const int arow = (wm * 32 * WI + (lane & 31)) * DBK, brow_l = (wn * 32 * WJ + (lane & 31)) * DBK;
   auto read_frags = [&](int s, int kk, bf16x8* fa, bf16x8* fb) {
+    if (DIS & 4) return;
     const bf16_t* st = dma_lds + (size_t)(s % NS) * STAGE;
     const int ko = ((kk * 2 + (lane >> 5)) ^ swz) << 3;
 #pragma unroll
@@ -563,14 +569,112 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
 #pragma unroll
       for (int p = 0; p < 2; p++) {
         const int idx = 2 * g + p, i = idx / WJ, j = idx % WJ;
-        if (LO) acc[i][j] = mfma16<DT>(fa[2 * i + 1], fb[j], acc[i][j]);   // small term first
-        acc[i][j] = mfma16<DT>(fa[2 * i], fb[j], acc[i][j]);
+        if (!(DIS & 1)) {
+          if (LO) acc[i][j] = mfma16<DT>(fa[2 * i + 1], fb[j], acc[i][j]);   // small term first
+          acc[i][j] = mfma16<DT>(fa[2 * i], fb[j], acc[i][j]);
+        }
       }
       if (g < 3) issue_piece(q0 + g, s);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
+  if constexpr (DIS == 17) {
+    // lab: the tile's whole operand stream issued back to back, no ring discipline (slots overwritten unsynchronised: values are garbage), ONE wait at the end —
+    // what the CU's memory pipeline delivers when nothing limits the bytes in flight
+    for (int s = 0; s < nk; s++) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) dma_1k(gsrc[q] + s * DBK, lds_base + (unsigned)((s % NS) * STAGE * 2) + ldst[q]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nk == 12345) a.C[0] = 1.f;
+    return;
+  }
+  if constexpr (DIS == 18) {
+    // lab: DIS 17 with buffer_load_dwordx4 ... lds (buffer resource + 32-bit offsets) instead of global_load_lds_dwordx4 (64-bit addresses)
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A_hi, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc((void*)a.A_lo, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, 0x7fffffff, 0x00020000);
+    int voff[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) voff[q] = (int)((const char*)gsrc[q] - (const char*)(q % 3 == 0 ? a.A_hi : (q % 3 == 1 ? a.A_lo : a.B)));
+    for (int s = 0; s < nk; s++) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)((char*)dma_lds + (s % NS) * STAGE * 2 + ldst[q]);
+        if (q % 3 == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, dst, 16, voff[q] + s * DBK * 2, 0, 0, 0);
+        else if (q % 3 == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rL, dst, 16, voff[q] + s * DBK * 2, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, dst, 16, voff[q] + s * DBK * 2, 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nk == 12345) a.C[0] = 1.f;
+    return;
+  }
+  if constexpr (PP & 1) {
+    // ---- ping-pong form (round 5): the two waves of a SIMD (w and w + 4: a workgroup's waves are dealt to the SIMDs cyclically) work half a stage apart —
+    // while one runs the 32 MFMAs of its k32 stage back to back, the other issues its six DMA pieces of stage s + 2 and reads its sixteen fragments of the next stage.
+    // A phase ends with one workgroup barrier; group 1 (waves 4-7) enters one phase late.  Stage s is read in phases 2s (group 0) and 2s + 1 (group 1); its buffer
+    // is refilled (stage s + 3) from phase 2s + 2 on.  Same MFMAs per accumulator in the same order: bit-identical to the lock-step loop below.
+    const int grp = wv >> 2;
+#pragma unroll
+    for (int q = 0; q < 6; q++) issue_piece(q, 0);
+#pragma unroll
+    for (int q = 0; q < 6; q++) issue_piece(q, 1);
+    bf16x8 fa[2][2 * WI], fb[2][WJ];
+    if (DIS & 4) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int i = 0; i < 2 * WI; i++) fa[h][i] = bf16x8{};
+#pragma unroll
+        for (int j = 0; j < WJ; j++) fb[h][j] = bf16x8{};
+      }
+    }
+    if (LO) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // stage 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    if (PP & 4) { if (grp) __builtin_amdgcn_s_setprio(1); }
+    if (grp) __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < nk; s++) {
+      // memory phase
+      if (PP & 8) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) issue_piece(q, s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      read_frags(s, 0, fa[0], fb[0]);
+      read_frags(s, 1, fa[1], fb[1]);
+      if (!(PP & 8)) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) issue_piece(q, s + 2);
+      }
+      // stage s + 1 landed = only the pieces just issued may fly; this wave's fragment reads are complete (the buffer is refilled two phases on)
+      if (DIS & 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      else if (LO) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // matrix phase
+      if (PP & 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int i = 0; i < WI; i++)
+#pragma unroll
+          for (int j = 0; j < WJ; j++) {
+            if (!(DIS & 1)) {
+              if (LO) acc[i][j] = mfma16<DT>(fa[h][2 * i + 1], fb[h][j], acc[i][j]);   // small term first
+              acc[i][j] = mfma16<DT>(fa[h][2 * i], fb[h][j], acc[i][j]);
+            }
+          }
+      if (PP & 2) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!grp) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
 #pragma unroll
   for (int q = 0; q < 6; q++) issue_piece(q, 0);
 #pragma unroll
@@ -578,6 +682,12 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
 #pragma unroll
   for (int q = 0; q < 3; q++) issue_piece(q, 2);
   bf16x8 fa0[2 * WI], fb0[WJ], fa1[2 * WI], fb1[WJ];
+  if (DIS & 4) {
+#pragma unroll
+    for (int i = 0; i < 2 * WI; i++) { fa0[i] = bf16x8{}; fa1[i] = bf16x8{}; }
+#pragma unroll
+    for (int j = 0; j < WJ; j++) { fb0[j] = bf16x8{}; fb1[j] = bf16x8{}; }
+  }
   if (LO) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // stage 0 landed (this wave's pieces); stage 1 and half of stage 2 may fly
   else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -587,7 +697,8 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     mfma_step(fa0, fb0, 3, k + 2);
     // stage k+1 landed = only what was issued after its last piece may fly (three pieces of the previous half step, three of this one); this wave's reads of stage k are complete
-    if (LO) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    if (DIS & 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else if (LO) asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_frags(k + 1, 0, fa0, fb0);
@@ -596,7 +707,20 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  if constexpr (EPI == GEMM_SILU) {
+  }
+
+  if (DIS & 8) {            // lab: no epilogue — every accumulator still feeds one value, so no MFMA chain is dead code
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < WI; i++)
+#pragma unroll
+      for (int j = 0; j < WJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) t += acc[i][j][r];
+    if (t == 12345.678f) a.C[0] = t;
+    return;
+  }
+  if constexpr (EPI == GEMM_SILU && TEPI && WJ == 4) {
     silu_epilogue_transposed<DT>(acc, dma_lds, a, wv, lane, m0, n0, wm, wn);
     return;
   }
@@ -610,6 +734,14 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
         continue;
       }
       if (col >= a.N) continue;
+      if (EPI == GEMM_PARTIAL) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + wm * 32 * WI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < a.M) a.part[((size_t)blockIdx.z * a.M + row) * a.N + col] = acc[i][j][r];
+        }
+        continue;
+      }
       const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
@@ -638,7 +770,7 @@ __global__ __launch_bounds__(512) void gemm_dma8_kernel(const GemmArgs a) {
 // two are consumed, as before (96 KB).  Same MFMAs in the same order as gemm_dma8_kernel: bit-identical results.  Wave = 64 x 128 of the output; the siluMul
 // epilogue goes through LDS (silu_epilogue_transposed).  In the product for gate_up of prompts that fill the chip with 256 x 256 tiles (prefill.hip, option
 // prefill.full_lines): 226 -> 213-216 us per launch in the lab (profiles/r05_prefill.txt).
-template <int DT, int EPI>
+template <int DT, int EPI, int DIS = 0>
 __global__ __launch_bounds__(512) void gemm_dma8i_kernel(const GemmArgs a) {
   constexpr int TMN = 256, NSLOT = 5, UNIT = TMN * 64;     // 16-bit elements per unit: 256 rows x 128 bytes
   constexpr int WI = 2, WJ = 4;
@@ -659,8 +791,10 @@ __global__ __launch_bounds__(512) void gemm_dma8i_kernel(const GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+  // GEMM_PARTIAL: blockIdx.z covers k_per elements of K and stores its fp32 tile to slab z (`down` as 64 tiles x 4 slabs: a 256-row tile asks half the operand lines per
   // output of the 128 x 128 kernel's)
-  const int k_begin = 0, k_end = a.K;
+  const int k_begin = EPI == GEMM_PARTIAL ? (int)blockIdx.z * a.k_per : 0;
+  const int k_end = EPI == GEMM_PARTIAL ? min(a.K, k_begin + a.k_per) : a.K;
   // DMA map: a unit = 32 pieces of 1 KiB = 8 rows x 128 bytes each; wave w takes pieces w, w + 8, w + 16, w + 24; chunk c of row r sits in slot c ^ ((r >> 1) & 7)
   const int prow = lane >> 3, pslot = lane & 7;
   const bf16_t *srcA[4], *srcB[4];
@@ -676,6 +810,7 @@ __global__ __launch_bounds__(512) void gemm_dma8i_kernel(const GemmArgs a) {
   const int nblk = (k_end - k_begin) / 64;
   // unit u = 3 b + j: j = 0 the A lines of step 2b, 1 the B lines of block b, 2 the A lines of step 2b + 1 (units past the end reload the last block)
   auto issue = [&](int b, int j, int p) {
+    if ((DIS & 2) && b > 0) return;
     const int bb = min(b, nblk - 1);
     const unsigned dst = lds_base + (unsigned)(((3 * b + j) % NSLOT) * UNIT * 2) + (unsigned)((wv + 8 * p) * 1024);
     if (j == 1) dma_1k(srcB[p] + (size_t)bb * 64, dst);
@@ -685,6 +820,7 @@ __global__ __launch_bounds__(512) void gemm_dma8i_kernel(const GemmArgs a) {
   const int arow = (wm * 64 + (lane & 31)) * 64, brow_l = (wn * 128 + (lane & 31)) * 64;
   // fragments of k16 step kk of k32 step s: A chunks (term * 4 + kk * 2 + half), B chunks ((s & 1) * 4 + kk * 2 + half) of the block's lines
   auto read_frags = [&](int s, int kk, bf16x8* fa, bf16x8* fb) {
+    if (DIS & 4) return;
     const int b = s >> 1;
     const bf16_t* ua = dma_lds + (size_t)((3 * b + ((s & 1) << 1)) % NSLOT) * UNIT;
     const bf16_t* ub = dma_lds + (size_t)((3 * b + 1) % NSLOT) * UNIT;
@@ -704,8 +840,10 @@ __global__ __launch_bounds__(512) void gemm_dma8i_kernel(const GemmArgs a) {
 #pragma unroll
       for (int p = 0; p < 2; p++) {
         const int idx = 2 * g + p, i = idx / WJ, jj = idx % WJ;
-        acc[i][jj] = mfma16<DT>(fa[2 * i + 1], fb[jj], acc[i][jj]);   // small term first
-        acc[i][jj] = mfma16<DT>(fa[2 * i], fb[jj], acc[i][jj]);
+        if (!(DIS & 1)) {
+          acc[i][jj] = mfma16<DT>(fa[2 * i + 1], fb[jj], acc[i][jj]);   // small term first
+          acc[i][jj] = mfma16<DT>(fa[2 * i], fb[jj], acc[i][jj]);
+        }
       }
       if (g < np) issue(b, j, p0 + g);
       __builtin_amdgcn_sched_barrier(0);
@@ -717,6 +855,12 @@ __global__ __launch_bounds__(512) void gemm_dma8i_kernel(const GemmArgs a) {
 #pragma unroll
     for (int p = 0; p < 4; p++) issue(u / 3, u % 3, p);
   bf16x8 fa0[2 * WI], fb0[WJ], fa1[2 * WI], fb1[WJ];
+  if (DIS & 4) {
+#pragma unroll
+    for (int i = 0; i < 2 * WI; i++) { fa0[i] = bf16x8{}; fa1[i] = bf16x8{}; }
+#pragma unroll
+    for (int j = 0; j < WJ; j++) { fb0[j] = bf16x8{}; fb1[j] = bf16x8{}; }
+  }
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // units 0, 1 landed (this wave's pieces); units 2, 3, 4 may fly
   __builtin_amdgcn_s_barrier();
   read_frags(0, 0, fa0, fb0);
@@ -727,7 +871,8 @@ __global__ __launch_bounds__(512) void gemm_dma8i_kernel(const GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     mfma_step(fa0, fb0, b + 1, 1, 0, b > 0 ? 4 : 0);             // unit 3b+4 = B of block b+1 (the prologue issued block 1's)
     // step 2b+1 needs unit 3b+2: behind its last piece only units 3b+3, 3b+4 were issued (8 pieces)
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    if (DIS & 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                               // every wave has read the A lines of step 2b: unit 3b is free
     read_frags(s + 1, 0, fa0, fb0);
     __builtin_amdgcn_sched_barrier(0);
@@ -737,7 +882,8 @@ __global__ __launch_bounds__(512) void gemm_dma8i_kernel(const GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     mfma_step(fa0, fb0, b + 1, 2, 3, 1);                         // ... piece 3
     // step 2b+2 needs units 3b+3, 3b+4: behind them only unit 3b+5 (4 pieces)
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    if (DIS & 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                               // units 3b+1 (B) and 3b+2 are free
     read_frags(s + 2, 0, fa0, fb0);                             // (after the last block: a harmless read of a reloaded unit)
     __builtin_amdgcn_sched_barrier(0);
@@ -745,8 +891,54 @@ __global__ __launch_bounds__(512) void gemm_dma8i_kernel(const GemmArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  static_assert(EPI == GEMM_SILU, "the whole-line kernel serves the gate_up product (its activation terms arrive interleaved from the norm launch)");
-  silu_epilogue_transposed<DT>(acc, dma_lds, a, wv, lane, m0, n0, wm, wn);
+  if (DIS & 8) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < WI; i++)
+#pragma unroll
+      for (int j = 0; j < WJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) t += acc[i][j][r];
+    if (t == 12345.678f) a.C[0] = t;
+    return;
+  }
+  if constexpr (EPI == GEMM_SILU) {
+    silu_epilogue_transposed<DT>(acc, dma_lds, a, wv, lane, m0, n0, wm, wn);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < WI; i++)
+#pragma unroll
+    for (int j = 0; j < WJ; j++) {
+      const int col = n0 + wn * 128 + j * 32 + (lane & 31);
+      if (EPI == GEMM_SILU) {
+        silu_block_store<DT>(acc[i][j], lane, col, m0 + wm * 64 + i * 32, a);
+        continue;
+      }
+      if (col >= a.N) continue;
+      if (EPI == GEMM_PARTIAL) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < a.M) a.part[((size_t)blockIdx.z * a.M + row) * a.N + col] = acc[i][j][r];
+        }
+        continue;
+      }
+      const float bv = a.bias ? elem_to_f32<DT>(a.bias[col]) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= a.M) continue;
+        const float v = acc[i][j][r] + bv;
+        if (EPI == GEMM_GELU) {
+          const size_t o = (size_t)row * a.N + col;
+          split16<DT>(gelu_new_fast(v), a.out_hi[o], a.out_lo[o]);
+          continue;
+        }
+        float* dst = a.C + (size_t)row * a.ldc + col;
+        *dst = (EPI == GEMM_RESIDUAL) ? (*dst + v) : v;
+      }
+    }
 }
 
 // ---- 128 x 256 tile, 8 waves = 2 row halves x 2 column halves x 2 k halves, split-K slabs (the N = hidden products with K >> N: `down`; round 5) -----------------
@@ -871,7 +1063,7 @@ __global__ __launch_bounds__(512) void gemm_dma8n_kernel(const GemmArgs a) {
 // stages in the ring, and the four partial accumulators meet through LDS after the K loop in a fixed order, (q0 + q2) + (q1 + q3); the last
 // exchange hands each of the two surviving wave pairs one column half, so four waves run the epilogue as before.  down at S = 2048 (K = 8192): 161 -> 140 us;
 // o_proj (K = 2048) 52 -> 52 (tools/probes/gemm_lab.hip, profiles/r05_prefill.txt).  Another fp32 summation order than the 4-wave kernel: results differ by ~1e-6.
-template <int DT, int EPI, bool LO = true>
+template <int DT, int EPI, bool LO = true, int DIS = 0>
 __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
   constexpr int DBK = 64, CPR = 8, RPP = 8, TMN = 128, NS = 3;
   constexpr int STAGE = 3 * TMN * DBK;
@@ -919,30 +1111,40 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
     for (int q = 0; q < 6; q++) issue_piece(q, DBK, 1);
   }
   bf16x8 fah[2], fal[2], fb[4];
+  if (DIS & 4) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) { fah[i] = bf16x8{}; fal[i] = bf16x8{}; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) fb[j] = bf16x8{};
+  }
   for (int k = 0; k < nk; k++) {
     // stage k landed = only this wave's pieces of stage k+1 may fly
-    if (k + 1 < nk) { if (LO) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    if (k + 1 < nk && !(DIS & 2)) { if (LO) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const bool more = k + 2 < nk;
+    const bool more = k + 2 < nk && !(DIS & 2);
     const int nk0 = (k + 2) * DBK, nst = (k + 2) % NS;
     const bf16_t* st = dma_lds + (size_t)(k % NS) * STAGE;
     const bf16_t *tAh = st, *tAl = st + TMN * DBK, *tB = st + 2 * TMN * DBK;
     const int kchunk = kq * 2 + (lane >> 5);               // this wave's k16 step of the stage
+    if (!(DIS & 4)) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) fb[j] = frag(tB, j * 32 + (lane & 31), kchunk);
+      for (int j = 0; j < 4; j++) fb[j] = frag(tB, j * 32 + (lane & 31), kchunk);
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int row = wm * 64 + i * 32 + (lane & 31);
-      fah[i] = frag(tAh, row, kchunk);
-      if (LO) fal[i] = frag(tAl, row, kchunk);
+      for (int i = 0; i < 2; i++) {
+        const int row = wm * 64 + i * 32 + (lane & 31);
+        fah[i] = frag(tAh, row, kchunk);
+        if (LO) fal[i] = frag(tAl, row, kchunk);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        if (LO) acc[i][j] = mfma16<DT>(fal[i], fb[j], acc[i][j]);   // small term first
-        acc[i][j] = mfma16<DT>(fah[i], fb[j], acc[i][j]);
+        if (!(DIS & 1)) {
+          if (LO) acc[i][j] = mfma16<DT>(fal[i], fb[j], acc[i][j]);   // small term first
+          acc[i][j] = mfma16<DT>(fah[i], fb[j], acc[i][j]);
+        }
         if (more && (i * 4 + j) < 6) issue_piece(i * 4 + j, nk0, nst);     // one DMA per two MFMAs
       }
   }
@@ -996,6 +1198,17 @@ __global__ __launch_bounds__(512) void gemm_dma8k_kernel(const GemmArgs a) {
         const float o = other[((i * 2 + jj) * 16 + r) * 64 + lane];
         fin[i][jj][r] = kq == 0 ? acc[i][jj][r] + o : o + acc[i][2 + jj][r];      // (q0 + q2) + (q1 + q3) on both sides
       }
+  if (DIS & 8) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) t += fin[i][jj][r];
+    if (t == 12345.678f) a.C[0] = t;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll

@@ -11,7 +11,7 @@
 #include <cstring>
 #include <vector>
 
-#include "kernels/gemm_dma.h"
+#include "archive/gemm_dma_r05_lab.h"      // round 5's header with its lab-only template switches (DIS / PP / TEPI / WJ); the product header dropped them in round 6
 #include "gemm_lab_variants.h"
 
 using namespace tgx;

@@ -2,7 +2,7 @@
 // (gemm_dma8i_kernel, the full-line form, moved to kernels/gemm_dma.h.)
 // Included after kernels/gemm_dma.h (uses its helpers).  Numbers: profiles/r05_prefill.txt.
 #pragma once
-#include "kernels/gemm_dma.h"
+#include "archive/gemm_dma_r05_lab.h"      // round 5's header with its lab-only template switches (DIS / PP / TEPI / WJ); the product header dropped them in round 6
 
 namespace tgx {
 
