@@ -416,7 +416,7 @@ def main():
                 # where `achieved` comes from: no per-kernel clock exists inside a hipGraph replay, so the class is launched back to back over all
                 # layers between two HIP events on the launch stream right after the timed region (tgx_profile_decode); the in-situ figure is rocprofv3's
                 "achieved_source": "HIP events around the kernel class launched back-to-back over all layers on the launch stream, right after the timed graph replay "
-                                   "(tgx_profile_decode); rocprofv3 --kernel-trace of the headline command with eager launches: profiles/r05_bench_kernel_stats.txt (12.57 us avg for the gate_up kernel against 12.9 here)",
+                                   "(tgx_profile_decode); rocprofv3 --kernel-trace of the headline command with eager launches: profiles/r06_bench_kernel_stats.txt (12.53 us avg for the gate_up kernel against 12.8-13.1 here)",
                 "kernel_classes_avg_us": classes,
                 "step_bytes_per_token": bytes_tok, "step_achieved": round(bytes_tok * tok_s / world / 1e9, 1),
                 "step_frac": round(bytes_tok * tok_s / world / 1e9 / HBM_PEAK_GBS, 4)}
