@@ -250,6 +250,13 @@ TGX_API int tgx_set_logits(tgx_ctx* ctx, const float* logits, int batch);
  *                  product — what a module constructed in config.torch_dtype sees (ModelLlama.h:62) — instead of entering in fp32.  The matrix-core
  *                  products of the prefill and of batched steps then take one 16-bit term per activation instead of two or three;
  *                  fp32 storage: no effect.  Set it before the first tgx_forward of a sequence: the cache of a sequence must be filled under one contract
+ *   "kv.budget_tokens"  (default 0; set BEFORE tgx_finalize, which sizes the caches; 16-bit storage dtypes) PAGED KV — the kernel contract of the reference's
+ *                  "Paged Attention" TODO (README.md:32-34).  0: every row owns a max_ctx slab ([layer][kv_head][max_ctx][hd], max_batch x max_ctx tokens of
+ *                  cache whatever the rows hold).  N > 0: the caches are pools of 128-token blocks worth N tokens in all, shared by the rows; a row's blocks are
+ *                  assigned as its sequence grows (a device-resident block table per row, read by the attention and cache-append kernels) and returned by
+ *                  tgx_reset_row / tgx_reset_cache; max_ctx stays the per-row limit.  A call that would need a block when none is free returns TGX_ERR_CONTEXT and
+ *                  changes nothing (retire a row, retry).  Results are those of the unpaged cache, bit for bit on the same kernels (tests/test_hip_paged.py);
+ *                  tgx_get_option "kv.free_tokens" = the unassigned blocks' worth of tokens (-1 when unpaged)
  *   "debug.*"      experiment switches (tools/gemv_dissect.py, tools/attn_dissect.py; live only in a -DTGX_DISSECT=1 build) */
 TGX_API int tgx_set_option(tgx_ctx* ctx, const char* key, int value);
 

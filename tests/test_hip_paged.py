@@ -1,0 +1,150 @@
+"""Paged KV cache (round 6; option kv.budget_tokens before tgx_finalize; include/tgx.h) — the kernel-contract half of the reference's "Paged Attention" TODO
+(README.md:32-34).  The reference's KVCacheManager grows every row's cache by concat (src/engine/CacheManager.h:24-51); the unpaged layout gives every row a
+max_ctx slab.  Paged: per-layer pools of 128-token blocks shared by the rows, a block table per row on the device, blocks assigned as a sequence grows and
+returned when it is retired.  Held to:
+  * the SAME results as the unpaged cache — bit for bit where the two run the same kernels (the paged attention is the unpaged kernel with another address
+    computation): prompts through the decode-kernel passes, decode steps on the direct and on the split attention form, across block boundaries, four
+    families / both head sizes / a QKV bias / Qwen3's q-k norm;
+  * rows of very different lengths whose summed length exceeds max_ctx — impossible with one slab of the same total size — decode together and each equals
+    its run in an unpaged batch;
+  * the budget: a row that needs a block when none is free is refused (TGX_ERR_CONTEXT), retiring another row frees its blocks, and the refused row then
+    proceeds; kv.free_tokens accounts for every block; tgx_read_kv / tgx_write_kv go through the table."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from tinygpt_amd.desc import desc_from_hf_config
+from tinygpt_amd.ffi import GREEDY, Model, TgxError
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from tinygpt_amd.ffi import product_backend
+    return product_backend()
+
+
+def make(fam, hip, dtype="bf16", max_batch=1, max_ctx=512, budget=0, opts=()):
+    cfg, g = load_golden(fam)
+    d = desc_from_hf_config(cfg, dtype, max_batch=max_batch)
+    d.max_ctx = max_ctx
+    m = Model(d, hip)
+    if budget:
+        m.set_option("kv.budget_tokens", budget)
+    m.load_synthetic(int(g["seed"]), float(g["std"])).finalize()
+    # the unpaged reference on the kernels a paged context runs: prompts through the decode kernels, no o_proj strip in the direct attention launch, the GEMV step for batches
+    for k, v in (("prefill.mfma", 0), ("oproj.fused", 0), ("decode.mfma_min_batch", 1 << 20)) + tuple(opts):
+        m.set_option(k, v)
+    return m, g
+
+
+@pytest.mark.parametrize("direct_max", [100000, 0])
+@pytest.mark.parametrize("fam,dtype", [("llama_tiny", "bf16"), ("qwen2_tiny", "bf16"), ("mistral_tiny", "fp16"), ("qwen3_tiny", "bf16")])
+def test_paged_equals_unpaged_bit_for_bit(fam, dtype, direct_max, hip):
+    opts = (("attn.direct_max", direct_max),)
+    paged, g = make(fam, hip, dtype, max_ctx=512, budget=512, opts=opts)
+    plain, _ = make(fam, hip, dtype, max_ctx=512, opts=opts)
+    assert paged.get_option("kv.free_tokens") == 512 and plain.get_option("kv.free_tokens") == -1
+    V = paged.desc.vocab
+    p = g["prompt"][0]
+    prompt = np.concatenate([(p * (3 + i) + i) % V for i in range(14)])[:121].astype(np.int64)      # 121 tokens: the decode crosses the first block boundary (128)
+    for m in (paged, plain):
+        m.forward(prompt[None, :])
+    np.testing.assert_array_equal(paged.logits(rounded=False), plain.logits(rounded=False))
+    assert paged.get_option("kv.free_tokens") == 512 - 128
+    ta, tb = paged.sample(GREEDY), plain.sample(GREEDY)
+    np.testing.assert_array_equal(ta, tb)
+    da, db = paged.decode(150, GREEDY), plain.decode(150, GREEDY)              # 16-step graphs, two more blocks on the way
+    np.testing.assert_array_equal(da, db)
+    np.testing.assert_array_equal(paged.logits(rounded=False), plain.logits(rounded=False))
+    assert paged.past_length == 271 and paged.get_option("kv.free_tokens") == 512 - 3 * 128
+    for layer in (0, paged.desc.layers - 1):
+        for a, b in zip(paged.read_kv(0, layer), plain.read_kv(0, layer)):
+            np.testing.assert_array_equal(a, b)
+    # write_kv through the table: a round trip of perturbed rows reads back, and the next step sees them on both sides alike
+    k, v = plain.read_kv(0, 0)
+    k2 = (k * 0.5).astype(np.float32)
+    for m in (paged, plain):
+        m.write_kv(0, 0, k2, v)
+    np.testing.assert_array_equal(paged.read_kv(0, 0)[0], plain.read_kv(0, 0)[0])
+    np.testing.assert_array_equal(paged.decode(3, GREEDY), plain.decode(3, GREEDY))
+    np.testing.assert_array_equal(paged.logits(rounded=False), plain.logits(rounded=False))
+    # reset returns every block
+    paged.reset_cache()
+    assert paged.get_option("kv.free_tokens") == 512
+    paged.forward(prompt[None, :5]); plain.reset_cache(); plain.forward(prompt[None, :5])
+    np.testing.assert_array_equal(paged.logits(rounded=False), plain.logits(rounded=False))
+
+
+@pytest.mark.parametrize("fam", ["llama_tiny", "mistral_tiny"])
+def test_rows_of_very_different_lengths_share_a_budget_smaller_than_their_slabs(fam, hip):
+    """max_ctx 384, four rows: unpaged that is 4 x 384 = 1536 tokens of cache; the paged context gets 896 (seven blocks).  Rows of 300 + 200 + 60 + 20 prompt tokens (580 > max_ctx)
+    decode 25 steps together; each row equals the same row of an unpaged batch run on the same kernels, bit for bit."""
+    lens = [300, 200, 60, 20]
+    paged, g = make(fam, hip, max_batch=4, max_ctx=384, budget=896)
+    plain, _ = make(fam, hip, max_batch=4, max_ctx=384)
+    V = paged.desc.vocab
+    p = g["prompt"][0]
+    prompts = [np.concatenate([(p * (5 + r + i) + i) % V for i in range(40)])[:n].astype(np.int64) for r, n in enumerate(lens)]
+    for m in (paged, plain):
+        for r, pr in enumerate(prompts):
+            m.forward_row(r, pr)
+            m.sample_row(r, GREEDY)
+    used = sum((n + 127) // 128 for n in lens) * 128
+    assert paged.get_option("kv.free_tokens") == 896 - used == 0
+    da, db = paged.decode(25, GREEDY), plain.decode(25, GREEDY)
+    np.testing.assert_array_equal(da, db)
+    np.testing.assert_array_equal(paged.logits(rounded=False), plain.logits(rounded=False))
+    for r, n in enumerate(lens):
+        assert paged.past_length_row(r) == n + 25
+        for a, b in zip(paged.read_kv(r, 1), plain.read_kv(r, 1)):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_the_budget_is_enforced_and_retired_rows_return_their_blocks(hip):
+    paged, g = make("llama_tiny", hip, max_batch=3, max_ctx=512, budget=512)       # four blocks
+    solo, _ = make("llama_tiny", hip, max_batch=1, max_ctx=512)
+    V = paged.desc.vocab
+    p = g["prompt"][0]
+    long_p = np.concatenate([(p * (2 + i) + i) % V for i in range(40)])[:250].astype(np.int64)     # two blocks
+    mid_p = long_p[:130][::-1].copy()                                                               # two blocks
+    paged.forward_row(0, long_p); paged.sample_row(0, GREEDY)
+    paged.forward_row(1, mid_p); paged.sample_row(1, GREEDY)
+    assert paged.get_option("kv.free_tokens") == 0
+    with pytest.raises(TgxError) as ei:                        # a third sequence finds no block
+        paged.forward_row(2, long_p[:10])
+    assert ei.value.status == 8 and "budget" in str(ei.value)
+    assert paged.past_length_row(2) == 0
+    paged.decode(5, GREEDY)                                    # rows 0 and 1 still fit their blocks (255, 135)
+    with pytest.raises(TgxError) as ei:                        # row 0 would cross into a third block: refused, nothing was stepped
+        paged.decode(2, GREEDY)
+    assert ei.value.status == 8
+    assert paged.past_length_row(0) == 255 and paged.past_length_row(1) == 135
+    paged.reset_row(1)                                         # retire the shorter sequence: two blocks come back
+    assert paged.get_option("kv.free_tokens") == 256
+    ids = paged.decode(6, GREEDY)[:, 0]                        # row 0 crosses the boundary now; the retired row rides along on the scratch block
+    paged.forward_row(1, long_p[:10]); first = paged.sample_row(1, GREEDY)
+    tail = paged.decode(4, GREEDY)
+    # row 0 throughout == the same sequence alone in an unpaged context (the batch invariance bound of tests/test_hip_rows.py: other kernel paths)
+    solo.forward(long_p[None, :]); solo.sample(GREEDY)
+    want = solo.decode(15, GREEDY)[:, 0]
+    np.testing.assert_array_equal(np.concatenate([ids, tail[:, 0]]), want[5:15])
+    solo.reset_cache(); solo.forward(long_p[None, :10])
+    assert int(solo.sample(GREEDY)[0]) == int(first)
+    np.testing.assert_array_equal(solo.decode(4, GREEDY)[:, 0], tail[:, 1])
+
+
+def test_paged_needs_16_bit_storage_and_is_set_before_finalize(hip):
+    cfg, g = load_golden("llama_tiny")
+    d = desc_from_hf_config(cfg, "fp32")
+    m = Model(d, hip)
+    m.set_option("kv.budget_tokens", 256)
+    m.load_synthetic(int(g["seed"]), float(g["std"]))
+    with pytest.raises(TgxError) as ei:
+        m.finalize()
+    assert ei.value.status == 2
+    m2, _ = make("llama_tiny", hip)
+    with pytest.raises(TgxError) as ei:
+        m2.set_option("kv.budget_tokens", 256)
+    assert ei.value.status == 4

@@ -206,7 +206,7 @@ static void update_attn_modes(tgx_ctx* c, int n_positions, int rows_per_launch =
   const long long direct_lim = direct_limit(c, rpl, step), nw4_lim = nw4_limit(c, rpl, step);
   c->attn_direct = c->past + n_positions <= direct_lim;
   c->attn_nw4 = c->attn_direct && nw4_lim > 0 && c->past + n_positions <= nw4_lim;
-  c->attn_mfma = !c->attn_direct && c->past >= attn_mfma_threshold(c) && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
+  c->attn_mfma = !c->attn_direct && c->past >= attn_mfma_threshold(c) && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse) && !c->kv_paged;
 }
 
 static void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {
@@ -295,7 +295,48 @@ static int ensure_step_graph(tgx_ctx* c, const tgx_sampler_cfg& cfg, bool want_m
   return TGX_OK;
 }
 
+// ---- paged KV: block assignment (include/tgx.h "kv.budget_tokens").  Host-side free list; the device tables are updated by a small launch that carries the
+// new entries BY VALUE (stream-ordered behind the launches that still read the old ones; no host buffer has to outlive the call).
+struct KvTblUpdate { int n; int idx[16]; int val[16]; };
+static __global__ void kv_tbl_set_kernel(int* tbl, KvTblUpdate u) { if ((int)threadIdx.x < u.n) tbl[u.idx[threadIdx.x]] = u.val[threadIdx.x]; }
+
+static void kv_tbl_push(tgx_ctx* c, const std::vector<std::pair<int, int>>& changes) {      // (flat table index, value)
+  for (size_t i = 0; i < changes.size(); i += 16) {
+    KvTblUpdate u{};
+    u.n = (int)std::min<size_t>(16, changes.size() - i);
+    for (int k = 0; k < u.n; k++) { u.idx[k] = changes[i + (size_t)k].first; u.val[k] = changes[i + (size_t)k].second; c->kv_tbl_host[(size_t)u.idx[k]] = u.val[k]; }
+    hipLaunchKernelGGL(kv_tbl_set_kernel, dim3(1), dim3(64), 0, c->stream, c->kv_tbl, u);
+  }
+}
+
+int kv_ensure_blocks(tgx_ctx* c, int row, long long tokens) {
+  if (!c->kv_paged) return TGX_OK;
+  const int need = (int)((tokens + tgx::KV_BLOCK - 1) / tgx::KV_BLOCK);
+  int& have = c->kv_row_nblk[(size_t)row];
+  if (need <= have) return TGX_OK;
+  if (need > c->kv_tbl_stride) return set_err(c, TGX_ERR_CONTEXT, "context size exceeded: row %d wants %lld tokens (contextSize %d)", row, tokens, c->d.max_ctx);
+  if ((size_t)(need - have) > c->kv_free.size())
+    return set_err(c, TGX_ERR_CONTEXT, "KV budget exhausted: row %d needs %d more blocks of %d tokens, %zu free of %d (option kv.budget_tokens = %d)", row, need - have,
+                   tgx::KV_BLOCK, c->kv_free.size(), c->kv_nblocks - 1, c->kv_budget_tokens);
+  std::vector<std::pair<int, int>> ch;
+  for (; have < need; have++) { ch.emplace_back(row * c->kv_tbl_stride + have, c->kv_free.back()); c->kv_free.pop_back(); }
+  kv_tbl_push(c, ch);
+  return TGX_OK;
+}
+
+static void kv_release_row(tgx_ctx* c, int row) {       // the row's blocks back to the free list; its table entries back to the scratch block
+  if (!c->kv_paged) return;
+  int& have = c->kv_row_nblk[(size_t)row];
+  std::vector<std::pair<int, int>> ch;
+  for (int b = 0; b < have; b++) { const int i = row * c->kv_tbl_stride + b; c->kv_free.push_back(c->kv_tbl_host[(size_t)i]); ch.emplace_back(i, 0); }
+  have = 0;
+  kv_tbl_push(c, ch);
+}
+
 static int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int n) {
+  if (c->kv_paged)       // every live row's next n positions have a block before the steps that write them are enqueued
+    for (int b = 0; b < c->batch; b++)
+      if (!c->row_idle[(size_t)b]) { int rc = kv_ensure_blocks(c, b, c->row_past[(size_t)b] + n); if (rc) return rc; }
   if (!is_greedy(&cfg)) {
     // the engine passes one seed for a whole generation (the draw mixes in position and row): only a CHANGED seed is copied — and that
     // copy must drain the stream, because steps already enqueued still read the old word.  With an unchanged seed tgx_step_async returns
@@ -570,8 +611,23 @@ int tgx_finalize(tgx_ctx* c) {
 
   c->rows.resize((size_t)d.max_batch);
   const size_t B = (size_t)d.max_batch;
-  const size_t kv_elems = (size_t)d.layers * d.kv_heads * d.max_ctx * hd;
+  size_t kv_elems = (size_t)d.layers * d.kv_heads * d.max_ctx * hd;
   c->kv_row_elems = kv_elems;
+  size_t kv_total = B * kv_elems;                     // elements of the K cache (and of the V cache)
+  if (c->kv_budget_tokens > 0) {                      // paged KV: pools of KV_BLOCK-token blocks shared by the rows (kernels/common.h)
+    if (c->dt == tgx::DT_F32) return set_err(c, TGX_ERR_UNSUPPORTED, "kv.budget_tokens: paged KV serves the 16-bit storage dtypes");
+    c->kv_paged = true;
+    c->kv_nblocks = (c->kv_budget_tokens + tgx::KV_BLOCK - 1) / tgx::KV_BLOCK + 1;       // + the scratch block 0
+    c->kv_tbl_stride = (d.max_ctx + tgx::KV_BLOCK - 1) / tgx::KV_BLOCK;
+    kv_total = (size_t)d.layers * c->kv_nblocks * d.kv_heads * tgx::KV_BLOCK * hd;
+    c->kv_row_elems = 1;                              // "the rows are separate sequences" wherever a row stride is tested against 0; never used as a stride (decode.hip kvs)
+    if ((rc = dev_alloc(c, &c->kv_tbl, B * (size_t)c->kv_tbl_stride))) return rc;
+    HIP_OK(c, hipMemset(c->kv_tbl, 0, B * (size_t)c->kv_tbl_stride * 4));
+    c->kv_tbl_host.assign(B * (size_t)c->kv_tbl_stride, 0);
+    c->kv_row_nblk.assign(B, 0);
+    c->kv_free.clear();
+    for (int b = c->kv_nblocks - 1; b >= 1; b--) c->kv_free.push_back(b);
+  }
   c->attn_part_row = (size_t)d.heads * c->attn_nsplit * (hd + 4);
   if ((rc = dev_alloc(c, &c->slab_x, B * H))) return rc;
   if ((rc = dev_alloc(c, &c->slab_q, B * qd))) return rc;
@@ -586,12 +642,12 @@ int tgx_finalize(tgx_ctx* c) {
   if ((rc = dev_alloc(c, &c->slab_tok, B))) return rc;
   if ((rc = dev_alloc(c, &c->slab_pos, B))) return rc;
   if ((rc = dev_alloc(c, &c->slab_prompt, B * d.max_ctx))) return rc;
-  if ((rc = dev_alloc(c, &c->slab_k, B * kv_elems * c->esz))) return rc;
-  if ((rc = dev_alloc(c, &c->slab_v, B * kv_elems * c->esz))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_k, kv_total * c->esz))) return rc;
+  if ((rc = dev_alloc(c, &c->slab_v, kv_total * c->esz))) return rc;
   HIP_OK(c, hipMemset(c->slab_tok, 0, B * 4));
   HIP_OK(c, hipMemset(c->slab_pos, 0, B * 4));
-  HIP_OK(c, hipMemset(c->slab_k, 0, B * kv_elems * c->esz));
-  HIP_OK(c, hipMemset(c->slab_v, 0, B * kv_elems * c->esz));
+  HIP_OK(c, hipMemset(c->slab_k, 0, kv_total * c->esz));
+  HIP_OK(c, hipMemset(c->slab_v, 0, kv_total * c->esz));
   for (size_t b = 0; b < B; b++) {
     RowState& r = c->rows[b];
     r.x = c->slab_x + b * H; r.q = c->slab_q + b * qd; r.k_raw = c->slab_kraw + b * kvd; r.attn = c->slab_attn + b * qd;
@@ -600,6 +656,7 @@ int tgx_finalize(tgx_ctx* c) {
     r.attn_part = c->slab_attn_part + b * c->attn_part_row;
     r.tok = c->slab_tok + b; r.pos = c->slab_pos + b; r.prompt = c->slab_prompt + b * d.max_ctx;
     r.kcache = c->slab_k + b * kv_elems * c->esz; r.vcache = c->slab_v + b * kv_elems * c->esz;
+    if (c->kv_paged) { r.kcache = c->slab_k; r.vcache = c->slab_v; r.tbl = c->kv_tbl + b * (size_t)c->kv_tbl_stride; }
   }
   if ((rc = dev_alloc(c, &c->ch_x, 4 * (size_t)H))) return rc;
   if ((rc = dev_alloc(c, &c->ch_q, 4 * (size_t)qd))) return rc;
@@ -644,7 +701,7 @@ void tgx_destroy(tgx_ctx* c) {
   drop_step_graphs(c);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
   fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->wpe); fr(c->final_norm_b); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch); fr(c->samp_list_comp); fr(c->samp_list_v);
-  fr(c->slab_acc);
+  fr(c->slab_acc); fr(c->kv_tbl);
   fr(c->ch_x); fr(c->ch_q); fr(c->ch_kraw); fr(c->ch_attn); fr(c->ch_h); fr(c->ch_part); fr(c->ch_pos);
   fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl); fr(c->ws_part); fr(c->ws_ssq); fr(c->ws_pos);
   for (auto& w : c->L) { fr(w.in_norm); fr(w.post_norm); fr(w.wqkv); fr(w.bqkv); fr(w.wo); fr(w.q_norm); fr(w.k_norm); fr(w.wgu); fr(w.wdown); fr(w.in_norm_b); fr(w.post_norm_b); fr(w.bo); fr(w.bfc); fr(w.bdown); }
@@ -672,7 +729,9 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
   c->batch = batch;
   // matrix-core prefill: 16-bit storage through the split-term GEMMs (every family incl. GPT-2), fp32 storage through the f32-input MFMA
   const bool f32_path = c->dt == tgx::DT_F32 && seq >= c->prefill_f32_min_rows && c->prefill_mfma;
-  const bool mfma_path = f32_path || (seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && prefill_shapes_ok(c->d));
+  // (paged KV: prompts go through the decode kernels, four positions per pass — the matrix-core prefill's cache kernels are unpaged)
+  const bool mfma_path = !c->kv_paged && (f32_path || (seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && prefill_shapes_ok(c->d)));
+  for (int b = 0; b < batch; b++) { int rc = kv_ensure_blocks(c, b, c->past + seq); if (rc) return rc; }
   for (int b = 0; b < batch; b++) HIP_OK(c, hipMemcpyAsync(c->rows[(size_t)b].prompt, ids + (size_t)b * seq, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream));
   if (mfma_path) {
     // batched prefill on the matrix cores; logits for the last position only (== forward + narrow, GPTEngine.cpp:96-97).  Batch rows are
@@ -704,7 +763,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
     for (int s0 = 0; s0 < seq;) {
       const int rem = seq - s0, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
       launch_embed_chunk(c, r.prompt + s0, R, (int)c->past + s0);
-      for (int k = 0; k < R; k++) { c->chunk[k].kcache = r.kcache; c->chunk[k].vcache = r.vcache; }
+      for (int k = 0; k < R; k++) { c->chunk[k].kcache = r.kcache; c->chunk[k].vcache = r.vcache; c->chunk[k].tbl = r.tbl; }
       launch_layers(c, c->chunk, R, 0);
       s0 += R;
       if (s0 == seq) {                                   // the last position's hidden state feeds lm_head; publish token and length
@@ -821,6 +880,7 @@ int tgx_reset_cache(tgx_ctx* c) {
   if (!c->finalized) return set_err(c, TGX_ERR_STATE, "reset before finalize");
   HIP_OK(c, hipSetDevice(c->device));
   for (auto& r : c->rows) HIP_OK(c, hipMemsetAsync(r.pos, 0, 4, c->stream));
+  for (int b = 0; b < c->d.max_batch; b++) kv_release_row(c, b);
   if (c->slab_acc) HIP_OK(c, hipMemsetAsync(c->slab_acc, 0, (size_t)c->d.max_batch * c->d.hidden * 8, c->stream));
   HIP_OK(c, hipStreamSynchronize(c->stream));
   c->past = 0;
@@ -864,6 +924,7 @@ int tgx_reset_row(tgx_ctx* c, int row) {
   if (c->poisoned) return set_err(c, TGX_ERR_STATE, "an earlier pass failed half-way: call tgx_reset_cache first");
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipMemsetAsync(c->rows[(size_t)row].pos, 0, 4, c->stream));     // stream-ordered behind the steps already enqueued
+  kv_release_row(c, row);                                                     // paged KV: its blocks go back to the pool (a retired row rides along on the scratch block)
   c->row_past[(size_t)row] = 0;
   c->row_tok[(size_t)row] = 0;
   c->row_idle[(size_t)row] = row < c->batch;                                  // a live slot becomes a retired one: the batch keeps stepping without it
@@ -886,7 +947,8 @@ int tgx_forward_row(tgx_ctx* c, int row, const int64_t* ids, int seq) {
   const int batch_before = c->batch;
   c->past = 0;
   const bool f32_path = c->dt == tgx::DT_F32 && seq >= c->prefill_f32_min_rows && c->prefill_mfma;
-  const bool mfma_path = f32_path || (seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && prefill_shapes_ok(c->d));
+  const bool mfma_path = !c->kv_paged && (f32_path || (seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && prefill_shapes_ok(c->d)));
+  if (c->kv_paged) { kv_release_row(c, row); int rc0 = kv_ensure_blocks(c, row, seq); if (rc0) { c->past = longest; return rc0; } }
   RowState& r = c->rows[(size_t)row];
   int rc = TGX_OK;
   hipError_t e = hipMemcpyAsync(r.prompt, ids, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream);
@@ -910,7 +972,7 @@ int tgx_forward_row(tgx_ctx* c, int row, const int64_t* ids, int seq) {
     for (int s0 = 0; s0 < seq;) {
       const int rem = seq - s0, R = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
       launch_embed_chunk(c, r.prompt + s0, R, s0);
-      for (int k = 0; k < R; k++) { c->chunk[k].kcache = r.kcache; c->chunk[k].vcache = r.vcache; }
+      for (int k = 0; k < R; k++) { c->chunk[k].kcache = r.kcache; c->chunk[k].vcache = r.vcache; c->chunk[k].tbl = r.tbl; }
       launch_layers(c, c->chunk, R, 0);
       s0 += R;
       if (s0 == seq) {
@@ -982,7 +1044,15 @@ int tgx_read_kv(tgx_ctx* c, int row, int layer, float* k_out, float* v_out) {
     float* out = which ? v_out : k_out;
     if (!out) continue;
     const ebyte* base = (which ? c->rows[(size_t)row].vcache : c->rows[(size_t)row].kcache) + (size_t)layer * d.kv_heads * per_head * c->esz;
+    if (c->kv_paged) base = (which ? c->slab_v : c->slab_k) + (size_t)layer * c->kv_nblocks * d.kv_heads * tgx::KV_BLOCK * hd * c->esz;
     for (int h = 0; h < d.kv_heads; h++) {
+      if (c->kv_paged) {      // the row's tokens block by block through its table
+        for (size_t t0 = 0; t0 < T; t0 += tgx::KV_BLOCK) {
+          const size_t n = std::min<size_t>(tgx::KV_BLOCK, T - t0);
+          const size_t blk = (size_t)c->kv_tbl_host[(size_t)row * c->kv_tbl_stride + t0 / tgx::KV_BLOCK];
+          HIP_OK(c, hipMemcpy(tmp.data() + t0 * hd * c->esz, base + ((blk * d.kv_heads + h) * tgx::KV_BLOCK) * hd * c->esz, n * hd * c->esz, hipMemcpyDeviceToHost));
+        }
+      } else
       HIP_OK(c, hipMemcpy(tmp.data(), base + (size_t)h * per_head * c->esz, T * hd * c->esz, hipMemcpyDeviceToHost));
       for (size_t t = 0; t < T; t++)
         for (size_t k = 0; k < hd; k++) {   // BSHD view
@@ -1008,6 +1078,7 @@ int tgx_write_kv(tgx_ctx* c, int row, int layer, const float* k_in, const float*
     const float* in = which ? v_in : k_in;
     if (!in || !T) continue;
     ebyte* base = (which ? c->rows[(size_t)row].vcache : c->rows[(size_t)row].kcache) + (size_t)layer * d.kv_heads * per_head * c->esz;
+    if (c->kv_paged) base = (which ? c->slab_v : c->slab_k) + (size_t)layer * c->kv_nblocks * d.kv_heads * tgx::KV_BLOCK * hd * c->esz;
     for (int h = 0; h < d.kv_heads; h++) {
       for (size_t t = 0; t < T; t++)
         for (size_t k = 0; k < hd; k++) {   // BSHD view in, head-major cache out; one round-to-nearest-even into the storage dtype
@@ -1016,6 +1087,13 @@ int tgx_write_kv(tgx_ctx* c, int row, int layer, const float* k_in, const float*
           if (c->dt == tgx::DT_F32) memcpy(tmp.data() + 4 * i, &v, 4);
           else { const uint16_t u = c->dt == tgx::DT_BF16 ? host_f32_to_bf16(v) : host_f32_to_half(v); memcpy(tmp.data() + 2 * i, &u, 2); }
         }
+      if (c->kv_paged) {
+        for (size_t t0 = 0; t0 < T; t0 += tgx::KV_BLOCK) {
+          const size_t n = std::min<size_t>(tgx::KV_BLOCK, T - t0);
+          const size_t blk = (size_t)c->kv_tbl_host[(size_t)row * c->kv_tbl_stride + t0 / tgx::KV_BLOCK];
+          HIP_OK(c, hipMemcpy(base + ((blk * d.kv_heads + h) * tgx::KV_BLOCK) * hd * c->esz, tmp.data() + t0 * hd * c->esz, n * hd * c->esz, hipMemcpyHostToDevice));
+        }
+      } else
       HIP_OK(c, hipMemcpy(base + (size_t)h * per_head * c->esz, tmp.data(), T * hd * c->esz, hipMemcpyHostToDevice));
     }
   }
@@ -1088,6 +1166,8 @@ int tgx_get_option(const tgx_ctx* c, const char* key, int* out_value) {
   if (!strcmp(key, "attn.nw4_limit")) { *out_value = (int)nw4_limit(c, c->batch, true); return TGX_OK; }
   if (!strcmp(key, "graph.steps")) { *out_value = c->graph_steps; return TGX_OK; }
   if (!strcmp(key, "act.round16")) { *out_value = c->act16; return TGX_OK; }
+  if (!strcmp(key, "kv.budget_tokens")) { *out_value = c->kv_budget_tokens; return TGX_OK; }
+  if (!strcmp(key, "kv.free_tokens")) { *out_value = c->kv_paged ? (int)c->kv_free.size() * tgx::KV_BLOCK : -1; return TGX_OK; }      // paged KV: tokens' worth of unassigned blocks
   return TGX_ERR_INVALID;
 }
 
@@ -1154,6 +1234,11 @@ int tgx_set_option(tgx_ctx* c, const char* key, int value) {
   if (!strcmp(key, "decode.mfma_min_batch")) { if (value < 1) return set_err(c, TGX_ERR_INVALID, "decode.mfma_min_batch must be >= 1"); c->decode_mfma_min = value; return TGX_OK; }
   if (!strcmp(key, "debug.profile_same_layer")) { c->prof_same_layer = value; return TGX_OK; }
   if (!strcmp(key, "oproj.sliced")) { drop_step_graphs(c); c->oproj_sliced = value != 0; return TGX_OK; }
+  if (!strcmp(key, "kv.budget_tokens")) {
+    if (c->finalized) return set_err(c, TGX_ERR_STATE, "kv.budget_tokens is set before tgx_finalize (it sizes the caches)");
+    if (value < 0) return set_err(c, TGX_ERR_INVALID, "kv.budget_tokens >= 0 (0 = one max_ctx slab per row)");
+    c->kv_budget_tokens = value; return TGX_OK;
+  }
   if (!strcmp(key, "attn.nsplit")) {
     if (c->finalized) return set_err(c, TGX_ERR_STATE, "attn.nsplit must be set before tgx_finalize");
     if (value < 1 || value > 32) return set_err(c, TGX_ERR_INVALID, "attn.nsplit out of range");

@@ -146,7 +146,36 @@ static void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R, bool combine) {
   launch_combine();
 }
 
+// Paged KV (option kv.budget_tokens; kernels/common.h kv_paged_off): the VALU forms through the rows' block tables — the direct form (one workgroup per query
+// head, four or sixteen waves) and the split form (+ combine, or the K-sliced o_proj's merge).  The matrix-core forms, the QKV finish in the attention prologue
+// and the o_proj strip in the direct launch are unpaged-only: a paged context never selects them (abi.hip kv_paged_restrict).
+template <int DT, int HD, bool QKN>
+static void launch_attn_paged(tgx_ctx* c, tgx::AttnArgs a, int R, bool combine) {
+  const int gfull = a.heads / a.kv_heads;
+  a.gfull = gfull;
+  a.direct = c->attn_direct ? 1 : 0;
+  if (a.direct) {
+    const dim3 grid(a.kv_heads, R, gfull);
+    if (c->attn_nw4) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, QKN, false, 4, false, true>), grid, dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 16, QKN, false, 4, false, true>), grid, dim3(1024), 0, c->stream, a);
+    return;
+  }
+  const int gmax = R == 1 ? 1 : 2, ngroups = gfull > gmax ? (gfull + gmax - 1) / gmax : 1, G = (gfull + ngroups - 1) / ngroups;
+  const dim3 grid(a.kv_heads * a.nsplit, R, ngroups), blk(256);
+  if (G == 1) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, QKN, false, 4, false, true>), grid, blk, 0, c->stream, a);
+  else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 4, QKN, false, 4, false, true>), grid, blk, 0, c->stream, a);
+  if (combine) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
+}
+
 void launch_attn(tgx_ctx* c, const tgx::AttnArgs& a, int R, bool combine) {
+  if (a.blk_tbl) {
+    const bool qkn = a.k_raw && c->d.head_dim == 128;
+    TGX_DT16_SWITCH(c->dt,
+      if (c->d.head_dim == 64) launch_attn_paged<DT, 64, false>(c, a, R, combine);
+      else if (qkn) launch_attn_paged<DT, 128, true>(c, a, R, combine);
+      else launch_attn_paged<DT, 128, false>(c, a, R, combine);)
+    return;
+  }
   // k_raw set: Qwen3's q/k norm + RoPE + cache append happen inside the attention launch (head_dim 128: every released Qwen3 size)
   if (a.k_raw && c->d.head_dim == 128) { TGX_DT_SWITCH(c->dt, (launch_attn_g<DT, 128, true>(c, a, R, combine))) return; }
   TGX_DT_SWITCH(c->dt, if (c->d.head_dim == 64) launch_attn_g<DT, 64>(c, a, R, combine); else launch_attn_g<DT, 128>(c, a, R, combine))

@@ -54,7 +54,8 @@ struct RowState {       // independent KV/sequence state of one batch row
   float* attn_part = nullptr;
   int *tok = nullptr, *pos = nullptr;
   long long* prompt = nullptr;
-  ebyte *kcache = nullptr, *vcache = nullptr;   // [layers][kv_heads][max_ctx][hd] in the compute dtype
+  ebyte *kcache = nullptr, *vcache = nullptr;   // [layers][kv_heads][max_ctx][hd] in the compute dtype; paged KV: the pools [layers][blocks][kv_heads][KV_BLOCK][hd], shared by the rows
+  const int* tbl = nullptr;                     // paged KV: this row's block table on the device
 };
 
 struct Tune {
@@ -231,6 +232,16 @@ struct tgx_ctx {
   // batch-1 steps on the direct attention form (short contexts, head_dim 64): the o_proj product runs in the attention launch's epilogue (attn_decode_kernel
   // template OPJ) — 4 launches per layer; the direct form then serves contexts up to attn_fused_max keys, with four wave-loads per softmax block up to attn_fused_nw4 keys and eight beyond (four waves per head either way); was: four / eight waves up to attn_fused_nw4
   int oproj_fused = 1, attn_fused_max = 640, attn_fused_nw4 = 384;
+  // ---- paged KV (round 6; option kv.budget_tokens before tgx_finalize; include/tgx.h).  The caches become pools of KV_BLOCK-token blocks shared by the rows; a row's
+  // blocks are assigned on the host as its sequence grows (before the launch that writes them) and returned by tgx_reset_row / tgx_reset_cache.  Block 0 is scratch.
+  int kv_budget_tokens = 0;        // > 0: paged
+  bool kv_paged = false;
+  int kv_nblocks = 0;              // physical blocks incl. the scratch block
+  int kv_tbl_stride = 0;           // table entries per row = ceil(max_ctx / KV_BLOCK)
+  int* kv_tbl = nullptr;           // device [max_batch][kv_tbl_stride]
+  std::vector<int> kv_tbl_host;    // its host mirror
+  std::vector<int> kv_free;        // free physical blocks
+  std::vector<int> kv_row_nblk;    // blocks assigned to each row
   long long* slab_acc = nullptr;   // [max_batch][hidden], resting at zero between layers
   float* scratch_x = nullptr;   // [hidden] residual sink for tgx_profile_decode
   Profiler prof;
@@ -274,6 +285,7 @@ namespace tgx { struct AttnArgs; struct FinalizeArgs; struct AttnPrefillArgs; st
 
 // ---- abi.hip
 void drop_step_graphs(tgx_ctx* c);
+int kv_ensure_blocks(tgx_ctx* c, int row, long long tokens);       // paged KV: row `row` may hold `tokens` tokens after this (assigns blocks, updates the device table, stream-ordered)
 bool is_greedy(const tgx_sampler_cfg* s);   // Sampler.cpp:15-21
 // ---- decode.hip (kernels/gemv.h, kernels/oproj_sliced.h)
 int gemv_grid(const tgx_ctx* c, int units, int ks, int bpc);

@@ -32,6 +32,7 @@ static tgx::GemvArgs gemv_row(const tgx_ctx* c, tgx::GemvArgs a, int r) {
   if (a.k_cache) a.k_cache = (ebyte*)a.k_cache + (size_t)r * a.kv_stride * c->esz;
   if (a.v_cache) a.v_cache = (ebyte*)a.v_cache + (size_t)r * a.kv_stride * c->esz;
   if (a.pos) a.pos += r;
+  if (a.blk_tbl) a.blk_tbl += (size_t)r * a.tbl_stride;
   if (a.logits) a.logits += (size_t)r * a.logits_stride;
   if (a.part_val) a.part_val += (size_t)r * a.part_stride;
   if (a.part_idx) a.part_idx += (size_t)r * a.part_stride;
@@ -119,6 +120,7 @@ bool oproj_sliced_ok(const tgx_ctx* c, int R, long long kv_stride) {
 // 600 20.2 / 21.0 / 21.8 -> 18.8 / 19.9 / 21.4 us, Llama-3.2-1B 33.3 / 34.2 / 35.5 -> 30.9 / 32.9 / 34.3; the split form is ahead from ~700 / ~900 keys.
 bool oproj_fused_capable(const tgx_ctx* c) {
   const tgx_model_desc& d = c->d;
+  if (c->kv_paged) return false;                     // (the o_proj strip rides in an unpaged-only attention form)
   if (!c->oproj_fused || c->gpt2 || c->dt == tgx::DT_F32 || !c->slab_acc) return false;
   return d.head_dim == 64 && !d.qk_norm && d.inter <= 16384 && d.hidden % 8 == 0 && d.hidden <= tgx::XACC_HIDDEN_MAX;
 }
@@ -134,7 +136,10 @@ int launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float* 
   const tgx_model_desc& d = c->d;
   RowState& r = rv[0];   // R consecutive row views with the slabs' row strides; kv_stride = 0 when the rows are positions of ONE sequence
   const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
-  const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd * c->esz;   // bytes (ebyte pointers)
+  // bytes between a layer's caches (ebyte pointers): a row's slab [kv_heads][max_ctx][hd], or — paged KV — the layer's pool of KV_BLOCK-token blocks
+  const size_t kv_layer = (c->kv_paged ? (size_t)c->kv_nblocks * d.kv_heads * tgx::KV_BLOCK : (size_t)d.kv_heads * d.max_ctx) * hd * c->esz;
+  // paged: the rows share the pools (no row stride) and differ by their block tables; rows that are positions of ONE sequence (kv_stride 0) share one table
+  const long long kvs = c->kv_paged ? 0 : kv_stride, tbs = (c->kv_paged && kv_stride != 0) ? c->kv_tbl_stride : 0;
   const LayerW& w = c->L[(size_t)l];
   switch (cls) {
     case TGX_KERNEL_QKV: {   // input_layernorm -> qkv_proj -> RoPE -> cache append   (DecoderLayer.h:40, Attention.h:94-106)
@@ -142,7 +147,8 @@ int launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float* 
       fill_strides(c, a);
       a.W = w.wqkv; a.bias = w.bqkv; a.x = r.x; a.x_stride = H; a.norm_w = w.in_norm; a.eps = d.norm_eps;
       a.N = qd + 2 * kvd; a.K = H; a.units = a.N / 2;
-      a.q_out = r.q; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer; a.kv_stride = kv_stride;
+      a.q_out = r.q; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer; a.kv_stride = kvs;
+      a.blk_tbl = r.tbl; a.tbl_stride = tbs;
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos = r.pos;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx;
       a.raw_qk = d.qk_norm ? 1 : 0; a.k_raw = r.k_raw;
@@ -157,7 +163,7 @@ int launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float* 
         n.q = r.q; n.k_raw = r.k_raw; n.k_cache = r.kcache + (size_t)l * kv_layer; n.q_norm_w = w.q_norm; n.k_norm_w = w.k_norm;
         n.rope_cos = c->rope_cos; n.rope_sin = c->rope_sin; n.pos = r.pos;
         n.heads = d.heads; n.kv_heads = d.kv_heads; n.hd = hd; n.max_ctx = d.max_ctx; n.eps = d.norm_eps;
-        n.q_stride = qd; n.kraw_stride = kvd; n.kv_stride = kv_stride;
+        n.q_stride = qd; n.kraw_stride = kvd; n.kv_stride = kvs; n.blk_tbl = r.tbl; n.tbl_stride = tbs;
         TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::qk_norm_rope_kernel<DT>, dim3(d.heads + d.kv_heads, R), dim3(64), 0, c->stream, n))
       }
       break;
@@ -168,7 +174,8 @@ int launch_layer_kernel(tgx_ctx* c, RowState* rv, int R, int l, int cls, float* 
       a.pos = r.pos; a.part = r.attn_part; a.out = r.attn;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
       a.scale = 1.0f / sqrtf((float)hd);
-      a.q_stride = qd; a.kv_stride = kv_stride; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
+      a.q_stride = qd; a.kv_stride = kvs; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
+      a.blk_tbl = r.tbl; a.tbl_stride = tbs;
       a.act16 = c->act16 ? (c->dt == tgx::DT_BF16 ? 1 : (c->dt == tgx::DT_F16 ? 2 : 0)) : 0;
       if (qk_fused(c, kv_stride)) {
         a.k_raw = r.k_raw; a.kraw_stride = kvd; a.q_norm_w = w.q_norm; a.k_norm_w = w.k_norm;

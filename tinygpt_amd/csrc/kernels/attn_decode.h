@@ -61,6 +61,9 @@ struct AttnArgs {
   const float* oj_x;      // [H] residual input (added once, by head 0)
   long long* oj_acc;      // [H] fixed-point accumulators, zero on entry
   int oj_H, oj_ldw, oj_rsplit;
+  // paged KV (kernel template PAGED; common.h kv_paged_off): k_cache / v_cache = this layer's pools, row r's keys through blk_tbl + r * tbl_stride
+  const int* blk_tbl;
+  long long tbl_stride;
   int act16;              // option act.round16 (0 off, 1 bf16, 2 fp16): the normalised output — the o_proj input, in this launch (OPJ) or the next — is rounded to the
                           // storage dtype.  (ONE field for both uses: with a second one the split form's kernel, which executes neither, measured 5.02 -> 5.26 us)
 };
@@ -82,9 +85,12 @@ __device__ __forceinline__ float attn_out_value(float acc, float L, int round16)
 // RAW (direct forms of a batched step): the workgroup first finishes its own slice of the QKV product (AttnArgs.raw_*: slab sums + bias, q / k norm at
 // head_dim 128, RoPE, cache append by the kv head's first head group) — q, k and v of this position go through LDS, the row-wise rope_kv_rows launch
 // disappears; the same arithmetic in the same order (common.h rope_rotate_pair / head_rms_inv): bit-identical to it.  See attn_decode_mfma.h for the MFMA twin.
-template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool RAW = false, int UNR_ = 4, bool OPJ = false>
+// PAGED (round 6): the keys of a row are found through its block table — every wave-load (TPW consecutive tokens at a multiple of TPW) lies inside one
+// KV_BLOCK-token page, so the lookup is one table entry per wave-load; the arithmetic is the unpaged kernel's.
+template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool RAW = false, int UNR_ = 4, bool OPJ = false, bool PAGED = false>
 __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) {
   static_assert(!OPJ || (G == 1 && !QKN && !RAW && DT != DT_F32), "OPJ: one head per workgroup, 16-bit storage");
+  static_assert(!PAGED || (!RAW && !OPJ), "paged KV: the plain and the Qwen3 forms");
   typedef elem_t<DT> E;
   constexpr int LPT = HD / 8;         // lanes per token row
   constexpr int TPW = 64 / LPT;       // tokens per wave-load
@@ -110,15 +116,22 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
   // sp + nsplit, ...: the active splits are the first ceil(n_keys / STEP) of every kv head and each runs whole blocks;
   // the addresses of a split's first block do not depend on the context length.
   constexpr int STEP = NW * TPW * UNR;
-  const E* kbase = k_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
-  const E* vbase = v_row + (size_t)kvh * a.max_ctx * HD + part_i * 8;
+  const E* kbase = k_row + (PAGED ? (size_t)0 : (size_t)kvh * a.max_ctx * HD) + part_i * 8;
+  const E* vbase = v_row + (PAGED ? (size_t)0 : (size_t)kvh * a.max_ctx * HD) + part_i * 8;
+  const int* tbl = PAGED ? a.blk_tbl + blockIdx.y * a.tbl_stride : nullptr;
+  // element offset of token t's row from kbase / vbase
+  auto tok_off = [&](int t) -> size_t {
+    if constexpr (PAGED) return kv_paged_off(tbl, a.kv_heads, kvh, t, HD);
+    else return (size_t)t * HD;
+  };
   int t0 = sp * STEP + wv * TPW * UNR;
   Slice8<DT> kv[UNR], vv[UNR];
 #pragma unroll
   for (int r = 0; r < UNR; r++) {
     const int tc = min(t0 + r * TPW + slot, a.max_ctx - 1);
-    kv[r] = load_slice<DT>(kbase + (size_t)tc * HD, 0);
-    vv[r] = load_slice<DT>(vbase + (size_t)tc * HD, 0);
+    const size_t o = tok_off(tc);
+    kv[r] = load_slice<DT>(kbase + o, 0);
+    vv[r] = load_slice<DT>(vbase + o, 0);
   }
   const int n_keys = a.pos[blockIdx.y] + 1;
   if constexpr (RAW) {
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
         if (tok == n_keys - 1) {            // the key of this step: computed above, not yet in the cache
 #pragma unroll
           for (int j = 0; j < 8; j++) kf[r][j] = knew[j];
-          if (g_base == 0) store_slice<DT>(const_cast<E*>(kbase + (size_t)tok * HD), 0, knew);   // KVCacheManager::append, once per kv head
+          if (g_base == 0) store_slice<DT>(const_cast<E*>(kbase + tok_off(tok)), 0, knew);   // KVCacheManager::append, once per kv head
         }
       }
     }
@@ -336,8 +349,9 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
       const int tc = min(t0 + r * TPW + slot, n_keys - 1);
-      kv[r] = load_slice<DT>(kbase + (size_t)tc * HD, 0);
-      vv[r] = load_slice<DT>(vbase + (size_t)tc * HD, 0);
+      const size_t o = tok_off(tc);
+      kv[r] = load_slice<DT>(kbase + o, 0);
+      vv[r] = load_slice<DT>(vbase + o, 0);
     }
   };
   if constexpr (OPJ) {

@@ -154,6 +154,18 @@ __device__ __forceinline__ long long f32_to_fix(float v) { return __float2ll_rn(
 constexpr int XACC_HIDDEN_MAX = 8192;
 __device__ __forceinline__ float fix_to_f32(long long a) { return (float)a * (1.0f / 4294967296.0f); }
 
+// ---- paged KV cache (round 6; option kv.budget_tokens) --------------------------------------------------------------------------------------------
+// The reference's KVCacheManager grows a row's cache by concat (CacheManager.h:24-42); the unpaged layout here gives every row a max_ctx slab
+// [layer][kv_head][max_ctx][hd].  Paged: one pool per layer, [block][kv_head][KV_BLOCK tokens][hd], and a per-row block table on the device (entry b = the
+// physical block of tokens [b KV_BLOCK, (b + 1) KV_BLOCK); entry 0 of the pool is a scratch block that unassigned table entries point to, so a speculative or
+// clamped access is always legal).  KV_BLOCK = 128 = the key block of a decode-attention split at head_dim 64 (two of them at 128): a wave-load, a split's
+// block and a prefill attention tile never straddle two pages.
+constexpr int KV_BLOCK = 128, KV_BLOCK_SHIFT = 7;
+// element offset of token t of kv head kvh inside a layer's pool
+__device__ __forceinline__ size_t kv_paged_off(const int* tbl, int kv_heads, int kvh, int t, int hd) {
+  return (((size_t)tbl[t >> KV_BLOCK_SHIFT] * kv_heads + kvh) * KV_BLOCK + (t & (KV_BLOCK - 1))) * (size_t)hd;
+}
+
 // ---- cross-lane reductions ----------------------------------------------------------------------
 // 64-lane sum on the DPP crossbar (no LDS traffic): quad butterflies, half-row / row mirrors, then the two
 // row broadcasts of the GFX9 wave64 reduction; the total lands in lane 63 and is returned wave-uniform.

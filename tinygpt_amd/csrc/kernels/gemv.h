@@ -143,6 +143,8 @@ struct GemvArgs {
   const float* rope_sin;
   const int* pos;         // [R] device-resident pastLength of each row
   int heads, kv_heads, hd, max_ctx;
+  const int* blk_tbl;     // paged KV (common.h kv_paged_off): [R][tbl_stride] block tables of the rows, k_cache / v_cache = this layer's pools — or nullptr
+  long long tbl_stride;   // entries between batch rows (0: the rows are positions of ONE sequence)
   int raw_qk;             // Qwen3 (q/k RMSNorm before RoPE): emit un-rotated q and k, qk_norm_rope_kernel finishes them
   float* k_raw;           // [R][kv_heads*hd] fp32 staging for k when raw_qk
   // EPI_RESIDUAL: out[n] += acc;  EPI_SILU_MUL: out[i] = silu(g) * u;  EPI_GELU: out[n] = gelu_new(acc)      (fp32)
@@ -410,8 +412,9 @@ __global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void ge
     const bool writer = u < a.units && kpart == 0 && lane == 0 && !(TGX_DBG(a, 8));
     int ra = 0, rb = 0; bool rb_valid = false;
     float e0[R], e1[R];                // RESIDUAL: x[ra], x[rb];  QKV_ROPE: cos, sin
+    int eblk[R];                       // QKV_ROPE, paged KV: the physical block of this position (fetched with cos / sin, under the dot products)
 #pragma unroll
-    for (int r = 0; r < R; r++) { e0[r] = 0.f; e1[r] = 0.f; }
+    for (int r = 0; r < R; r++) { e0[r] = 0.f; e1[r] = 0.f; eblk[r] = 0; }
     if (writer) {
       unit_rows<EPI>(a, u, ra, rb, rb_valid);
 #pragma unroll
@@ -424,6 +427,7 @@ __global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void ge
           const int half = a.hd >> 1;
           const int p = u % half;
           e0[r] = a.rope_cos[(size_t)pos[r] * half + p]; e1[r] = a.rope_sin[(size_t)pos[r] * half + p];
+          if (a.blk_tbl) eblk[r] = a.blk_tbl[(size_t)r * a.tbl_stride + (pos[r] >> KV_BLOCK_SHIFT)];
         }
       }
     }
@@ -491,8 +495,10 @@ __global__ __launch_bounds__(256, (NX * R <= 4 && DT != DT_F32) ? 4 : 1) void ge
             float* q = a.q_out + (size_t)r * a.q_stride + hh * a.hd;
             q[p] = va; q[p + half] = vb;
           } else {   // KVCacheManager::append: this position's K / V row, rounded once into the storage dtype
-            E* dst = (is_k ? static_cast<E*>(a.k_cache) + ((size_t)(hh - a.heads) * a.max_ctx + pos[r]) * a.hd
-                           : static_cast<E*>(a.v_cache) + ((size_t)(hh - a.heads - a.kv_heads) * a.max_ctx + pos[r]) * a.hd) + (size_t)r * a.kv_stride;
+            const int kh = is_k ? hh - a.heads : hh - a.heads - a.kv_heads;
+            const size_t off = a.blk_tbl ? (((size_t)eblk[r] * a.kv_heads + kh) * KV_BLOCK + (pos[r] & (KV_BLOCK - 1))) * (size_t)a.hd
+                                         : ((size_t)kh * a.max_ctx + pos[r]) * a.hd + (size_t)r * a.kv_stride;
+            E* dst = (is_k ? static_cast<E*>(a.k_cache) : static_cast<E*>(a.v_cache)) + off;
             dst[p] = f32_to_elem<DT>(va);
             dst[p + half] = f32_to_elem<DT>(vb);
           }
@@ -549,13 +555,15 @@ struct QkNormArgs {
   int heads, kv_heads, hd, max_ctx;
   float eps;
   long long q_stride, kraw_stride, kv_stride;   // elements between batch rows (blockIdx.y); kv_stride 0 = the rows are positions of one sequence
+  const int* blk_tbl;     // paged KV: [rows][tbl_stride] block tables (k_cache = the layer's pool), or nullptr
+  long long tbl_stride;
 };
 template <int DT>
 __global__ __launch_bounds__(64) void qk_norm_rope_kernel(QkNormArgs a) {
   typedef elem_t<DT> E;
   const int hh = blockIdx.x, p = threadIdx.x, half = a.hd >> 1;
   a.q += blockIdx.y * a.q_stride; a.k_raw += blockIdx.y * a.kraw_stride; a.pos += blockIdx.y;
-  a.k_cache = static_cast<E*>(a.k_cache) + blockIdx.y * a.kv_stride;
+  a.k_cache = static_cast<E*>(a.k_cache) + blockIdx.y * a.kv_stride;       // (paged: kv_stride is 0, the rows differ by their tables)
   const bool is_q = hh < a.heads;
   const float* src = is_q ? a.q + hh * a.hd : a.k_raw + (hh - a.heads) * a.hd;
   const E* w = static_cast<const E*>(is_q ? a.q_norm_w : a.k_norm_w);
@@ -572,7 +580,8 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(QkNormArgs a) {
   rope_rotate_pair(r0, r1, cs, sn);
   if (is_q) { a.q[hh * a.hd + p] = r0; a.q[hh * a.hd + p + half] = r1; }
   else {
-    E* dst = static_cast<E*>(a.k_cache) + ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd;
+    E* dst = static_cast<E*>(a.k_cache) + (a.blk_tbl ? kv_paged_off(a.blk_tbl + blockIdx.y * a.tbl_stride, a.kv_heads, hh - a.heads, pos, a.hd)
+                                                     : ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd);
     dst[p] = f32_to_elem<DT>(r0); dst[p + half] = f32_to_elem<DT>(r1);
   }
 }

@@ -181,7 +181,7 @@ static void launch_reduce_rows(tgx_ctx* c, int epi, int nsplit, const ebyte* bia
 
 // rows beyond 4 of a decode batch take the matrix-core path when the model has 16-bit storage and tile-friendly shapes
 bool decode_mfma_ok(const tgx_ctx* c) {
-  return c->batch >= c->decode_mfma_min && c->dt != tgx::DT_F32 && !c->gpt2 && prefill_shapes_ok(c->d) && c->d.vocab >= 128;
+  return c->batch >= c->decode_mfma_min && c->dt != tgx::DT_F32 && !c->gpt2 && prefill_shapes_ok(c->d) && c->d.vocab >= 128 && !c->kv_paged;       // (paged KV: the GEMV step, rows in groups of four)
 }
 
 // workspace of the batched step, sized before the step is captured: qkv rows, siluMul terms, split-K slabs, sums of squares
