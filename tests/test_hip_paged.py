@@ -25,7 +25,7 @@ def hip():
     return product_backend()
 
 
-def make(fam, hip, dtype="bf16", max_batch=1, max_ctx=512, budget=0, opts=()):
+def make(fam, hip, dtype="bf16", max_batch=1, max_ctx=512, budget=0, opts=(), gemv_step=True):
     cfg, g = load_golden(fam)
     d = desc_from_hf_config(cfg, dtype, max_batch=max_batch)
     d.max_ctx = max_ctx
@@ -34,7 +34,10 @@ def make(fam, hip, dtype="bf16", max_batch=1, max_ctx=512, budget=0, opts=()):
         m.set_option("kv.budget_tokens", budget)
     m.load_synthetic(int(g["seed"]), float(g["std"])).finalize()
     # the unpaged reference on the kernels a paged context runs: prompts through the decode kernels, no o_proj strip in the direct attention launch, the GEMV step for batches
-    for k, v in (("prefill.mfma", 0), ("oproj.fused", 0), ("decode.mfma_min_batch", 1 << 20)) + tuple(opts):
+    base = (("prefill.mfma", 0), ("oproj.fused", 0))
+    # batches: the GEMV step (rows in groups of four), or the matrix-core step on the forms a paged context takes (the QKV finish as its own launch, VALU attention)
+    base += (("decode.mfma_min_batch", 1 << 20),) if gemv_step else (("attn.raw_fuse", 0), ("attn.batch_mfma", 0))
+    for k, v in base + tuple(opts):
         m.set_option(k, v)
     return m, g
 
@@ -77,13 +80,14 @@ def test_paged_equals_unpaged_bit_for_bit(fam, dtype, direct_max, hip):
     np.testing.assert_array_equal(paged.logits(rounded=False), plain.logits(rounded=False))
 
 
-@pytest.mark.parametrize("fam", ["llama_tiny", "mistral_tiny"])
-def test_rows_of_very_different_lengths_share_a_budget_smaller_than_their_slabs(fam, hip):
+@pytest.mark.parametrize("gemv_step", [True, False])
+@pytest.mark.parametrize("fam", ["llama_tiny", "mistral_tiny", "qwen3_tiny"])
+def test_rows_of_very_different_lengths_share_a_budget_smaller_than_their_slabs(fam, gemv_step, hip):
     """max_ctx 384, four rows: unpaged that is 4 x 384 = 1536 tokens of cache; the paged context gets 896 (seven blocks).  Rows of 300 + 200 + 60 + 20 prompt tokens (580 > max_ctx)
     decode 25 steps together; each row equals the same row of an unpaged batch run on the same kernels, bit for bit."""
     lens = [300, 200, 60, 20]
-    paged, g = make(fam, hip, max_batch=4, max_ctx=384, budget=896)
-    plain, _ = make(fam, hip, max_batch=4, max_ctx=384)
+    paged, g = make(fam, hip, max_batch=4, max_ctx=384, budget=896, gemv_step=gemv_step)
+    plain, _ = make(fam, hip, max_batch=4, max_ctx=384, gemv_step=gemv_step)
     V = paged.desc.vocab
     p = g["prompt"][0]
     prompts = [np.concatenate([(p * (5 + r + i) + i) % V for i in range(40)])[:n].astype(np.int64) for r, n in enumerate(lens)]

@@ -8,7 +8,7 @@
 // the direct-form attention of a batched step runs on the matrix cores from attn.batch_mfma rows (17) when a kv head serves 3+ query heads (the VALU form's
 // cost grows with the heads per workgroup, the MFMA form's does not: Qwen3-1.7B, 2 heads per kv head, B = 32 2.29 (VALU) vs 2.39 ms/step)
 bool attn_batch_on_mfma(const tgx_ctx* c, int R) {
-  return c->attn_batch_mfma > 0 && R >= c->attn_batch_mfma && (c->d.heads / c->d.kv_heads >= 3 || c->attn_batch_mfma == 1);
+  return !c->kv_paged && c->attn_batch_mfma > 0 && R >= c->attn_batch_mfma && (c->d.heads / c->d.kv_heads >= 3 || c->attn_batch_mfma == 1);      // (paged KV: the VALU forms)
 }
 
 template <int DT, int HD, bool QKN = false>

@@ -309,6 +309,8 @@ struct RopeRowsArgs {
   long long q_stride, kv_stride;
   const void *q_norm_w, *k_norm_w;
   float eps;
+  const int* blk_tbl;      // paged KV (common.h kv_paged_off): [rows][tbl_stride] block tables, k_cache / v_cache = the layer's pools (kv_stride 0) — or nullptr
+  long long tbl_stride;
 };
 template <int DT>
 __global__ __launch_bounds__(64) void rope_kv_rows_kernel(const RopeRowsArgs a) {      // grid (rows, heads + 2*kv_heads): one wave per head vector
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(64) void rope_kv_rows_kernel(const RopeRowsArgs a) 
   } else {
     E* base = static_cast<E*>(hh < a.heads + a.kv_heads ? a.k_cache : a.v_cache) + (size_t)r * a.kv_stride;
     const int kh = hh < a.heads + a.kv_heads ? hh - a.heads : hh - a.heads - a.kv_heads;
-    E* dst = base + ((size_t)kh * a.max_ctx + pos) * a.hd;
+    E* dst = base + (a.blk_tbl ? kv_paged_off(a.blk_tbl + (size_t)r * a.tbl_stride, a.kv_heads, kh, pos, a.hd) : ((size_t)kh * a.max_ctx + pos) * a.hd);
     dst[p] = f32_to_elem<DT>(x0);
     dst[p + half] = f32_to_elem<DT>(x1);
   }

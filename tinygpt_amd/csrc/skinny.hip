@@ -181,7 +181,7 @@ static void launch_reduce_rows(tgx_ctx* c, int epi, int nsplit, const ebyte* bia
 
 // rows beyond 4 of a decode batch take the matrix-core path when the model has 16-bit storage and tile-friendly shapes
 bool decode_mfma_ok(const tgx_ctx* c) {
-  return c->batch >= c->decode_mfma_min && c->dt != tgx::DT_F32 && !c->gpt2 && prefill_shapes_ok(c->d) && c->d.vocab >= 128 && !c->kv_paged;       // (paged KV: the GEMV step, rows in groups of four)
+  return c->batch >= c->decode_mfma_min && c->dt != tgx::DT_F32 && !c->gpt2 && prefill_shapes_ok(c->d) && c->d.vocab >= 128;
 }
 
 // workspace of the batched step, sized before the step is captured: qkv rows, siluMul terms, split-K slabs, sums of squares
@@ -233,7 +233,8 @@ static void launch_ksplit(tgx_ctx* c, int epi, const ebyte* W, float* C, int ldc
 void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg& cfg) {
   const tgx_model_desc& d = c->d;
   const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd, V = d.vocab;
-  const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd * c->esz;
+  const size_t kv_layer = (c->kv_paged ? (size_t)c->kv_nblocks * d.kv_heads * tgx::KV_BLOCK : (size_t)d.kv_heads * d.max_ctx) * hd * c->esz;      // paged KV: a layer's pool
+  const long long kvs = c->kv_paged ? 0 : (long long)c->kv_row_elems, tbs = c->kv_paged ? c->kv_tbl_stride : 0;
   RowState& r = c->rows[(size_t)row0];
   const int nt_qkv = c->dt == tgx::DT_BF16 ? 3 : 2;
   float* ssq = c->ws_ssq;
@@ -256,7 +257,7 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
     const int qs = launch_skinny(c, q);
     // the QKV product's finish (slab sums + bias, q / k norm, RoPE, cache append) inside the attention launch when that is the batched matrix-core form
     // (option attn.raw_fuse): one launch per layer less
-    const bool raw_fuse = c->attn_raw_fuse && c->attn_direct && !(c->debug_skip & 1) && !(d.qk_norm && hd != 128) &&
+    const bool raw_fuse = !c->kv_paged && c->attn_raw_fuse && c->attn_direct && !(c->debug_skip & 1) && !(d.qk_norm && hd != 128) &&      // (the prologue that finishes the QKV rows is unpaged-only)
                           (attn_batch_on_mfma(c, M) ? d.heads / d.kv_heads <= tgx::ATTN_RAW_GMAX : c->attn_raw_fuse >= 2);      // 2: the VALU direct forms as well
     // the direct-form attention of the step leaves its rows as 16-bit terms for the o_proj product (option skinny.dma_oproj: 1 = the matrix-core form only, 2 = every direct form)
     const bool attn_terms = c->skinny_dma && c->skinny_dma_oproj && c->attn_direct && (c->skinny_dma_oproj >= 2 || attn_batch_on_mfma(c, M)) && !(c->debug_skip & 1) &&
@@ -265,7 +266,7 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
       tgx::RopeRowsArgs a{};
       if (qs > 1) { a.part = c->ws_part; a.nsplit = qs; a.bias = w.bqkv; } else a.QKV = c->ws_out;
       a.rows = M; a.q_out = r.q; a.q_stride = qd; a.k_cache = r.kcache + (size_t)l * kv_layer; a.v_cache = r.vcache + (size_t)l * kv_layer;
-      a.kv_stride = (long long)c->kv_row_elems; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos = r.pos;
+      a.kv_stride = kvs; a.blk_tbl = r.tbl; a.tbl_stride = tbs; a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.pos = r.pos;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx;
       a.q_norm_w = d.qk_norm ? w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? w.k_norm : nullptr; a.eps = d.norm_eps;
       TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL(tgx::rope_kv_rows_kernel<DT>, dim3(M, d.heads + 2 * d.kv_heads), dim3(64), 0, c->stream, a))
@@ -276,7 +277,7 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
       a.pos = r.pos; a.part = r.attn_part; a.out = r.attn;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.nsplit = c->attn_nsplit;
       a.scale = 1.0f / sqrtf((float)hd);
-      a.q_stride = qd; a.kv_stride = (long long)c->kv_row_elems; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
+      a.q_stride = qd; a.kv_stride = kvs; a.blk_tbl = r.tbl; a.tbl_stride = tbs; a.part_stride = (long long)c->attn_part_row; a.dbg = c->debug_attn;
       a.act16 = c->act16 ? (c->dt == tgx::DT_BF16 ? 1 : (c->dt == tgx::DT_F16 ? 2 : 0)) : 0;
       if (raw_fuse) {
         if (qs > 1) { a.raw_part = c->ws_part; a.raw_nsplit = qs; a.raw_bias = w.bqkv; } else a.raw_qkv = c->ws_out;
