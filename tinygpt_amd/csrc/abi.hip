@@ -729,8 +729,7 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
   c->batch = batch;
   // matrix-core prefill: 16-bit storage through the split-term GEMMs (every family incl. GPT-2), fp32 storage through the f32-input MFMA
   const bool f32_path = c->dt == tgx::DT_F32 && seq >= c->prefill_f32_min_rows && c->prefill_mfma;
-  // (paged KV: prompts go through the decode kernels, four positions per pass — the matrix-core prefill's cache kernels are unpaged)
-  const bool mfma_path = !c->kv_paged && (f32_path || (seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && prefill_shapes_ok(c->d)));
+  const bool mfma_path = (f32_path || (seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && prefill_shapes_ok(c->d)));
   for (int b = 0; b < batch; b++) { int rc = kv_ensure_blocks(c, b, c->past + seq); if (rc) return rc; }
   for (int b = 0; b < batch; b++) HIP_OK(c, hipMemcpyAsync(c->rows[(size_t)b].prompt, ids + (size_t)b * seq, (size_t)seq * 8, hipMemcpyHostToDevice, c->stream));
   if (mfma_path) {
@@ -947,7 +946,7 @@ int tgx_forward_row(tgx_ctx* c, int row, const int64_t* ids, int seq) {
   const int batch_before = c->batch;
   c->past = 0;
   const bool f32_path = c->dt == tgx::DT_F32 && seq >= c->prefill_f32_min_rows && c->prefill_mfma;
-  const bool mfma_path = !c->kv_paged && (f32_path || (seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && prefill_shapes_ok(c->d)));
+  const bool mfma_path = (f32_path || (seq >= c->prefill_min_rows && seq >= 4 && c->prefill_mfma && c->dt != tgx::DT_F32 && prefill_shapes_ok(c->d)));
   if (c->kv_paged) { kv_release_row(c, row); int rc0 = kv_ensure_blocks(c, row, seq); if (rc0) { c->past = longest; return rc0; } }
   RowState& r = c->rows[(size_t)row];
   int rc = TGX_OK;

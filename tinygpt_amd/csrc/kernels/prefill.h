@@ -180,6 +180,7 @@ struct RopeKvArgs {
   float eps;
   // the QKV product left as split-K slabs (QKV == nullptr): row s = sum_z part[z][s][:] + bias, z order as gemm_splitk_reduce_kernel<GEMM_STORE>
   const float* part; int nsplit; long long slab; const bf16_t* bias;
+  const int* blk_tbl;      // paged KV (common.h kv_paged_off): this sequence's block table, k_cache / v_cache = the layer's pools — or nullptr
 };
 template <int DT>
 __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) {
@@ -258,8 +259,9 @@ __global__ __launch_bounds__(256) void rope_kv_split_kernel(const RopeKvArgs a) 
       *reinterpret_cast<u32x2*>(a.q_hi + o) = pack4(h0); *reinterpret_cast<u32x2*>(a.q_lo + o) = pack4(l0);
       *reinterpret_cast<u32x2*>(a.q_hi + o + half) = pack4(h1); *reinterpret_cast<u32x2*>(a.q_lo + o + half) = pack4(l1);
     } else {
-      bf16_t* dst = (hh < a.heads + a.kv_heads) ? a.k_cache + ((size_t)(hh - a.heads) * a.max_ctx + pos) * a.hd
-                                                : a.v_cache + ((size_t)(hh - a.heads - a.kv_heads) * a.max_ctx + pos) * a.hd;
+      const bool is_k = hh < a.heads + a.kv_heads;
+      const int kh = is_k ? hh - a.heads : hh - a.heads - a.kv_heads;
+      bf16_t* dst = (is_k ? a.k_cache : a.v_cache) + (a.blk_tbl ? kv_paged_off(a.blk_tbl, a.kv_heads, kh, pos, a.hd) : ((size_t)kh * a.max_ctx + pos) * a.hd);
       bf16_t e0[4], e1[4];
 #pragma unroll
       for (int t = 0; t < 4; t++) { e0[t] = f32_to_elem<DT>(x0[t]); e1[t] = f32_to_elem<DT>(x1[t]); }
@@ -501,6 +503,7 @@ struct AttnPrefillArgs {
   float scale;                   // hd^-1/2
   int qblk_mirror;               // 1: see the block order in the kernel
   int heavy_first;               // 1 (the key-split form): grid = (heads, query blocks), blockIdx.y = rank of the block from the heaviest down — see the kernel
+  const int* blk_tbl;            // paged KV (kernel template PAGED): this sequence's block table, k_cache / v_cache = the layer's pools
 };
 
 // Scores and probabilities never leave the registers (the first version of this round routed them through LDS with four
@@ -523,7 +526,9 @@ struct AttnPrefillArgs {
 // the query sub-blocks of waves 0-3 on the ODD tiles, 0-3 take the even ones; two tiles are staged per barrier pair; the two online-softmax streams of a
 // query meet once, through LDS, after the loop ((m, l, O) merged as flash-decoding does).  One workgroup per CU instead of two, the same matrix work per CU and
 // cycle, half the chain; blocks are dispatched heaviest first (AttnPrefillArgs.heavy_first) so that the second round fills the CUs as they free up.
-template <int DT, int HD, int LA = 2, int KP = 1>
+// PAGED (round 6): the workgroup copies the part of the sequence's block table it needs (<= 1024 entries) into LDS first; a K / V row's address then takes one LDS
+// read (it does not touch the counted vmcnt waits of the tile pipeline) — a 64-key tile never straddles a 128-token page.
+template <int DT, int HD, int LA = 2, int KP = 1, bool PAGED = false>
 __global__ __launch_bounds__(256 * KP, KP == 2 ? 2 : (LA == 1 ? (HD == 64 ? 3 : 2) : 1)) void attn_prefill_kernel(const AttnPrefillArgs a) {      // head_dim 128: LA = 1 fits two waves per SIMD (LA = 2 needs 292 registers: one)
   constexpr int DIS = TGX_ATTN_DIS;
   constexpr int LQ = HD + 8;                  // 16-bit row stride of the K tile (144 / 272 B: conflict-free 16-byte fragment reads)
@@ -569,9 +574,18 @@ __global__ __launch_bounds__(256 * KP, KP == 2 ? 2 : (LA == 1 ? (HD == 64 ? 3 : 
     for (int r = 0; r < 16; r++) oacc[b][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const bf16_t* kbase = a.k_cache + (size_t)kvh * a.max_ctx * HD;
-  const bf16_t* vbase = a.v_cache + (size_t)kvh * a.max_ctx * HD;
+  const bf16_t* kbase = a.k_cache + (PAGED ? (size_t)0 : (size_t)kvh * a.max_ctx * HD);
+  const bf16_t* vbase = a.v_cache + (PAGED ? (size_t)0 : (size_t)kvh * a.max_ctx * HD);
   const int wg_last_pos = a.past + min(qblk * 128 + 127, a.S - 1);   // keys beyond it are never attended by this workgroup
+  __shared__ int stbl[PAGED ? 1024 : 1];
+  if constexpr (PAGED) {
+    for (int i = tid; i <= (wg_last_pos >> KV_BLOCK_SHIFT); i += 256 * KP) stbl[i] = a.blk_tbl[i];
+    __syncthreads();
+  }
+  auto key_off = [&](int key) -> size_t {      // element offset of a key's row from kbase / vbase
+    if constexpr (PAGED) return (((size_t)stbl[key >> KV_BLOCK_SHIFT] * a.kv_heads + kvh) * KV_BLOCK + (key & (KV_BLOCK - 1))) * (size_t)HD;
+    else return (size_t)key * HD;
+  };
   const int n_kt = (wg_last_pos / 64 + 1 + KP - 1) / KP;      // steps of KP tiles
   const int wave_last_pos = a.past + min(q0 + 31, a.S - 1);
   const bool wave_live = q0 < a.S;
@@ -587,9 +601,10 @@ __global__ __launch_bounds__(256 * KP, KP == 2 ? 2 : (LA == 1 ? (HD == 64 ? 3 : 
     for (int i = 0; i < NCH; i++) {
       const int c = (tid & 255) + 256 * i, row = c / CH, kc = c - row * CH;
       const int key = min((KP * kt + kp) * 64 + row, wg_last_pos);
-      kr[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * HD + kc * 8);
+      const size_t ko = key_off(key) + kc * 8;
+      kr[i] = *reinterpret_cast<const u32x4*>(kbase + ko);
       __builtin_amdgcn_sched_barrier(0);       // the same issue order at every call site: the counted vmcnt waits rely on it
-      vr[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * HD + kc * 8);
+      vr[i] = *reinterpret_cast<const u32x4*>(vbase + ko);
       __builtin_amdgcn_sched_barrier(0);
     }
   };

@@ -302,6 +302,20 @@ void launch_attn_prefill(tgx_ctx* c, const tgx::AttnPrefillArgs& a_, bool allow_
   const int hd = c->d.head_dim;
   const int nqb = (a.S + 127) / 128, nwg = nqb * a.heads;
   const size_t lds1 = (size_t)(64 * (hd + 8) + 64 * (hd + 32)) * 2;      // one K tile | V tile pair (kernels/prefill.h)
+  if (a.blk_tbl) {      // paged KV: the key-split form from two query blocks on, else the plain one (the LDS-DMA form reads unpaged rows)
+    if (nqb >= 2) {
+      a.heavy_first = 1;
+      const dim3 grid(a.heads, nqb), blk(512);
+      TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64, 2, 2, true>), grid, blk, 2 * lds1, c->stream, a);
+                             else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128, 1, 2, true>), grid, blk, 2 * lds1, c->stream, a))
+    } else {
+      a.heavy_first = 0;
+      const dim3 grid(nqb, a.heads), blk(256);
+      TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64, 2, 1, true>), grid, blk, lds1, c->stream, a);
+                             else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128, 1, 1, true>), grid, blk, lds1, c->stream, a))
+    }
+    return;
+  }
   // head_dim 64, three or more workgroups per CU (prompts from ~3k tokens at 32 heads): K / V tiles by LDS-DMA, the next tile's scores under the current tile's
   // softmax (kernels/attn_prefill_dma.h; bit-identical to attn_prefill_kernel): S = 4096 203 -> 177 us per layer, 8192 730 -> 632; at S = 2048 (one round of 512
   // workgroups) the launch lasts as long as its heaviest workgroup's chain of tiles in either form (62-63 us).  Option prefill.attn_dma: 0 never, 1 auto, 2 always
@@ -357,7 +371,7 @@ void launch_embed_rows(tgx_ctx* c, const long long* ids, float* X, int M, int S)
 void launch_prefill(tgx_ctx* c, int row0, int NB, int S, int past) {
   const tgx_model_desc& d = c->d;
   const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
-  const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd;
+  const size_t kv_layer = c->kv_paged ? (size_t)c->kv_nblocks * d.kv_heads * tgx::KV_BLOCK * hd : (size_t)d.kv_heads * d.max_ctx * hd;      // elements (paged KV: a layer's pool)
   const int M = NB * S;
   const size_t wout = (size_t)qd + 2 * kvd;
   // GPT-2 (ModelGPT2.h:23-208): wte + wpe rows, LayerNorm with bias ahead of both products, a bias on every Conv1D, c_fc -> gelu_new;
@@ -376,7 +390,7 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S, int past) {
     pend = 1;
     int qsl = 1;
     c->qkv_epi = QkvEpi{};
-    if (NB == 1) {      // one sequence: the QKV product may finish its rows itself (launch_gemm: gemm_dma_qkv8_kernel<.., ROPE>)
+    if (NB == 1 && !c->kv_paged) {      // one sequence: the QKV product may finish its rows itself (its cache append is unpaged) (launch_gemm: gemm_dma_qkv8_kernel<.., ROPE>)
       RowState& r0 = c->rows[(size_t)row0];
       c->qkv_epi.q_hi = c->ws_qh; c->qkv_epi.q_lo = c->ws_ql; c->qkv_epi.past = past;
       c->qkv_epi.k = reinterpret_cast<bf16_t*>(r0.kcache) + (size_t)l * kv_layer; c->qkv_epi.v = reinterpret_cast<bf16_t*>(r0.vcache) + (size_t)l * kv_layer;
@@ -393,7 +407,7 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S, int past) {
       if (qsl > 1) { a.QKV = nullptr; a.part = c->ws_part + ro * wout; a.nsplit = qsl; a.slab = (long long)M * (long long)wout; a.bias = reinterpret_cast<const bf16_t*>(w.bqkv); }
       a.k_cache = kc + (size_t)l * kv_layer; a.v_cache = vc + (size_t)l * kv_layer;
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
-      a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = past;
+      a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = past; a.blk_tbl = r.tbl;
       a.q_norm_w = d.qk_norm ? (const bf16_t*)w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? (const bf16_t*)w.k_norm : nullptr; a.eps = d.norm_eps;
       launch_rope_kv_split(c, a, S);
     }
@@ -405,7 +419,7 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S, int past) {
       tgx::AttnPrefillArgs a{};
       a.q_hi = c->ws_qh + ro * qd; a.q_lo = c->ws_ql + ro * qd; a.k_cache = kc + (size_t)l * kv_layer; a.v_cache = vc + (size_t)l * kv_layer;
       a.o_hi = c->ws_ah + ro * qd; a.o_lo = c->ws_al + ro * qd; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = past;
-      a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = 1;
+      a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = 1; a.blk_tbl = r.tbl;
       launch_attn_prefill(c, a, /*allow_lean=*/true);
     }
     int osl = 1;
@@ -451,6 +465,8 @@ int prefill_set_attrs(tgx_ctx* c) {
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8i_kernel<tgx::DT_BF16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8i_kernel<tgx::DT_F16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_BF16, 128, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (64 * 136 + 64 * 160) * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_BF16, 128, 1, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (64 * 136 + 64 * 160) * 2));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_F16, 128, 1, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (64 * 136 + 64 * 160) * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_prefill_kernel<tgx::DT_F16, 128, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (64 * 136 + 64 * 160) * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_BF16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));
   HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::gemm_dma8k_kernel<tgx::DT_F16, tgx::GEMM_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * 128 * 64 * 2));

@@ -345,7 +345,7 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
 void launch_prefill_skinny(tgx_ctx* c, int row0, int NB, int S) {
   const tgx_model_desc& d = c->d;
   const int H = d.hidden, I = d.inter, hd = d.head_dim, qd = d.heads * hd, kvd = d.kv_heads * hd;
-  const size_t kv_layer = (size_t)d.kv_heads * d.max_ctx * hd;
+  const size_t kv_layer = c->kv_paged ? (size_t)c->kv_nblocks * d.kv_heads * tgx::KV_BLOCK * hd : (size_t)d.kv_heads * d.max_ctx * hd;      // elements (paged KV: a layer's pool)
   const int M = NB * S, nq = qd + 2 * kvd;
   const int nt_qkv = c->dt == tgx::DT_BF16 ? 3 : 2;
   float* ssq = c->ws_ssq;
@@ -373,7 +373,7 @@ void launch_prefill_skinny(tgx_ctx* c, int row0, int NB, int S) {
       a.QKV = c->ws_out + ro * nq; a.q_hi = c->ws_qh + ro * qd; a.q_lo = c->ws_ql + ro * qd;
       a.k_cache = reinterpret_cast<bf16_t*>(r.kcache) + (size_t)l * kv_layer; a.v_cache = reinterpret_cast<bf16_t*>(r.vcache) + (size_t)l * kv_layer;
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
-      a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = (int)c->past;
+      a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = (int)c->past; a.blk_tbl = r.tbl;
       a.q_norm_w = d.qk_norm ? (const bf16_t*)w.q_norm : nullptr; a.k_norm_w = d.qk_norm ? (const bf16_t*)w.k_norm : nullptr; a.eps = d.norm_eps;
       launch_rope_kv_split(c, a, S);
     }
@@ -384,7 +384,7 @@ void launch_prefill_skinny(tgx_ctx* c, int row0, int NB, int S) {
       a.q_hi = c->ws_qh + ro * qd; a.q_lo = c->ws_ql + ro * qd;
       a.k_cache = reinterpret_cast<bf16_t*>(r.kcache) + (size_t)l * kv_layer; a.v_cache = reinterpret_cast<bf16_t*>(r.vcache) + (size_t)l * kv_layer;
       a.o_hi = c->ws_ah + ro * qd; a.o_lo = c->ws_al + ro * qd; a.S = S; a.heads = d.heads; a.kv_heads = d.kv_heads; a.max_ctx = d.max_ctx; a.past = (int)c->past;
-      a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = 1;
+      a.scale = 1.0f / sqrtf((float)hd); a.qblk_mirror = 1; a.blk_tbl = r.tbl;
       launch_attn_prefill(c, a, /*allow_lean=*/false);
     }
     SkinnyCall o;
