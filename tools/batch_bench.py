@@ -16,10 +16,13 @@ ap.add_argument("--prompt", type=int, default=512)
 ap.add_argument("--steps", type=int, default=128)
 ap.add_argument("--batches", default="1,2,4,8")
 ap.add_argument("--opts", default="", help="tgx_set_option pairs applied after finalize, e.g. 'gateup.ks=4;oproj.ks=2'")
+ap.add_argument("--kv-budget", type=int, default=0, help="paged KV: option kv.budget_tokens (set before finalize); 0 = one max_ctx slab per row")
 args = ap.parse_args()
 batches = [int(b) for b in args.batches.split(",")]
 desc = dataclasses.replace(known_desc(args.model), max_batch=max(batches), max_ctx=args.prompt + 2 * args.steps + 64)
 m = Model(desc, product_backend())
+if args.kv_budget:
+    m.set_option("kv.budget_tokens", args.kv_budget)
 for name, bits in synth.synth_checkpoint(desc, 1234, 0.02):
     m.upload(name, bits)
 m.finalize()
@@ -31,4 +34,4 @@ for B in batches:
     m.forward(ids); m.sample(GREEDY)
     m.decode(16, GREEDY, fetch=False); m.synchronize()
     t0 = time.perf_counter(); m.decode(args.steps, GREEDY, fetch=False); m.synchronize(); dt = time.perf_counter() - t0
-    print(f"B={B}: {dt / args.steps * 1e3:.3f} ms/step, {B * args.steps / dt:.0f} tokens/s aggregate", flush=True)
+    print(f"{'paged ' if args.kv_budget else ''}B={B}: {dt / args.steps * 1e3:.3f} ms/step, {B * args.steps / dt:.0f} tokens/s aggregate", flush=True)
