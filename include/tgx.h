@@ -230,7 +230,10 @@ TGX_API int tgx_profile_decode(tgx_ctx* ctx, int n_reps, int64_t* launches /*[TG
                        double* total_ms /*[TGX_KERNEL_COUNT]*/);
 
 /* Final probability vector(s) [batch*vocab] of the last non-greedy tgx_sample / decode step: what the
- * reference passes to multinomial (Sampler.cpp:77) — zero where top-k/top-p/min-p removed a token. */
+ * reference passes to multinomial (Sampler.cpp:77) — zero where top-k/top-p/min-p removed a token.  A step
+ * does not materialise the vector (the draw needs per-tile sums only): this call evaluates it from what the
+ * step left on the device — valid until the next tgx_forward / tgx_forward_row / tgx_set_logits replaces the
+ * logits (TGX_ERR_STATE then); rows whose last step was greedy read as zeros. */
 TGX_API int tgx_read_probs(tgx_ctx* ctx, float* out);
 
 /* Injects logits [batch][vocab] as if a forward had produced them, so that Sampler::sample can be

@@ -333,6 +333,15 @@ static void kv_release_row(tgx_ctx* c, int row) {       // the row's blocks back
   kv_tbl_push(c, ch);
 }
 
+// tgx_read_probs evaluates a row's final probabilities on demand: remember what its last sampled step was configured with
+static void note_sampled(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg) {
+  if (c->row_probs_cfg.size() < (size_t)c->d.max_batch) { c->row_probs_cfg.resize((size_t)c->d.max_batch); c->row_probs_ok.assign((size_t)c->d.max_batch, 0); }
+  const bool sampled = !is_greedy(&cfg);
+  for (int b = row0; b < row0 + R; b++) { c->row_probs_cfg[(size_t)b] = cfg; c->row_probs_ok[(size_t)b] = sampled ? 1 : 0; }
+  c->have_probs = false;
+  for (int b = 0; b < c->batch; b++) c->have_probs = c->have_probs || c->row_probs_ok[(size_t)b];
+}
+
 static int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t seed, int n) {
   if (c->kv_paged)       // every live row's next n positions have a block before the steps that write them are enqueued
     for (int b = 0; b < c->batch; b++)
@@ -347,8 +356,8 @@ static int run_decode_steps(tgx_ctx* c, const tgx_sampler_cfg& cfg, uint64_t see
       HIP_OK(c, hipMemcpy(c->seed_dev, &s, 8, hipMemcpyHostToDevice));
       c->seed_on_dev = s; c->seed_valid = true;
     }
-    c->have_probs = true;
   }
+  note_sampled(c, 0, c->batch, cfg);
   if (decode_mfma_ok(c)) {   // the batched step's workspace must exist before the step is captured
     int rc = ensure_skinny_ws(c, std::min(c->decode_step_rows, c->batch));
     if (rc) return rc;
@@ -780,6 +789,8 @@ int tgx_forward(tgx_ctx* c, const int64_t* ids, int batch, int seq) {
   for (int b = 0; b < batch; b++) { c->row_past[(size_t)b] = c->past; c->row_tok[(size_t)b] = 0; c->row_idle[(size_t)b] = 0; }
   c->have_logits = true;
   c->have_token = false;
+  c->have_probs = false;                          // the logits are new: no sampled step belongs to them yet
+  std::fill(c->row_probs_ok.begin(), c->row_probs_ok.end(), 0);
   return TGX_OK;
 }
 
@@ -807,8 +818,8 @@ int tgx_sample(tgx_ctx* c, const tgx_sampler_cfg* cfg, uint64_t seed, int64_t* o
       HIP_OK(c, hipMemcpy(c->seed_dev, &s, 8, hipMemcpyHostToDevice));
       c->seed_on_dev = s; c->seed_valid = true;
     }
-    c->have_probs = true;
   }
+  note_sampled(c, 0, c->batch, *cfg);
   launch_sample(c, 0, c->batch, *cfg, /*advance_pos=*/false, /*log_step=*/false);
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipStreamSynchronize(c->stream));
@@ -994,6 +1005,7 @@ int tgx_forward_row(tgx_ctx* c, int row, const int64_t* ids, int seq) {
   c->row_idle[(size_t)row] = 0;
   refresh_longest(c);
   c->have_logits = true;
+  if ((size_t)row < c->row_probs_ok.size()) c->row_probs_ok[(size_t)row] = 0;
   return TGX_OK;
 }
 
@@ -1009,8 +1021,8 @@ int tgx_sample_row(tgx_ctx* c, int row, const tgx_sampler_cfg* cfg, uint64_t see
       HIP_OK(c, hipMemcpy(c->seed_dev, &s, 8, hipMemcpyHostToDevice));
       c->seed_on_dev = s; c->seed_valid = true;
     }
-    c->have_probs = true;
   }
+  note_sampled(c, row, 1, *cfg);
   launch_sample(c, row, 1, *cfg, /*advance_pos=*/false, /*log_step=*/false);
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipStreamSynchronize(c->stream));
@@ -1131,10 +1143,16 @@ int tgx_profile_decode(tgx_ctx* c, int n_reps, int64_t* launches, double* total_
 
 int tgx_read_probs(tgx_ctx* c, float* out) {
   if (!c || !out) return TGX_ERR_INVALID;
-  if (!c->have_probs) return set_err(c, TGX_ERR_STATE, "no probabilities: the last sample was greedy or none was taken");
+  if (!c->have_probs || !c->have_logits) return set_err(c, TGX_ERR_STATE, "no probabilities: the last sample was greedy or none was taken");
   HIP_OK(c, hipSetDevice(c->device));
-  HIP_OK(c, hipStreamSynchronize(c->stream));
+  // a sampled step leaves its logits, thresholds and normalisers on the device, not the vector: evaluate it now (rows whose last step was greedy read as zeros)
   const size_t V = (size_t)c->d.vocab;
+  for (int b = 0; b < c->batch; b++) {
+    if (c->row_probs_ok[(size_t)b]) launch_probs(c, b, c->row_probs_cfg[(size_t)b]);
+    else HIP_OK(c, hipMemsetAsync(c->rows[(size_t)b].probs, 0, V * 4, c->stream));
+  }
+  HIP_OK(c, hipGetLastError());
+  HIP_OK(c, hipStreamSynchronize(c->stream));
   for (int b = 0; b < c->batch; b++) HIP_OK(c, hipMemcpy(out + b * V, c->rows[(size_t)b].probs, V * 4, hipMemcpyDeviceToHost));
   return TGX_OK;
 }
@@ -1155,6 +1173,8 @@ int tgx_set_logits(tgx_ctx* c, const float* logits, int batch) {
   HIP_OK(c, hipGetLastError());
   HIP_OK(c, hipStreamSynchronize(c->stream));
   c->batch = batch;
+  c->have_probs = false;
+  std::fill(c->row_probs_ok.begin(), c->row_probs_ok.end(), 0);
   c->have_logits = true;
   return TGX_OK;
 }

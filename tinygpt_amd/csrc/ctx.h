@@ -135,6 +135,8 @@ struct tgx_ctx {
   unsigned long long* samp_list_comp = nullptr;   // [max_batch][vocab] compacted threshold-bin entries of a filter (kernels/sampler.h): composite keys ...
   float* samp_list_v = nullptr;                   // ... and logit / T
   bool have_probs = false;
+  std::vector<tgx_sampler_cfg> row_probs_cfg;   // per row: the sampler configuration of its last sampled step (tgx_read_probs evaluates the vector on demand) ...
+  std::vector<char> row_probs_ok;               // ... and whether that step was a non-greedy one
   bool use_graph = true;
 
   Tune tune[TGX_KERNEL_COUNT];   // per kernel class: K-split and workgroups per CU
@@ -308,6 +310,7 @@ void launch_attn(tgx_ctx* c, const tgx::AttnArgs& a, int R, bool combine = true)
 int attn_set_attrs(tgx_ctx* c);
 // ---- sampler.hip (kernels/sampler.h)
 void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool advance_pos, bool log_step);
+void launch_probs(tgx_ctx* c, int row, const tgx_sampler_cfg& cfg);
 int sampler_alloc(tgx_ctx* c);
 // ---- prefill.hip (kernels/prefill.h, gemm_dma.h)
 bool prefill_shapes_ok(const tgx_model_desc& d);

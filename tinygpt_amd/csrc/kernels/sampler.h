@@ -20,10 +20,13 @@
 //                                                              counter-based splitmix64 draw (the reference's RNG stream
 //                                                              is unpinnable): per-workgroup sums, then one workgroup
 //                                                              walks the selected 1024 entries
-// The pick kernel also performs the duties of finalize_greedy_kernel (token publish, pastLength+1, token rings, next
-// embedding row).  Launches per sampled step: 3 per active top-k/top-p filter (first digit, compaction, tail) + 1 (+2 with
-// min-p) + 1 pick per row; T = 0.8 / top-p 0.9 (the CLI defaults): 5 launches (rounds 1-5: 8, +48 us per decode step at
-// V = 128 256; the one-workgroup version of round 1 added 600 us; profiles/r06_sampler_cost.txt).
+// The draw also performs the duties of finalize_greedy_kernel (token publish, pastLength+1, token rings, next embedding
+// row).  It runs at the end of the last filter's tail launch; a chain that ends in min-p (its cut depends on the normaliser
+// of the set it looks at) or has no filter ends in one or two partial-sum stages and a pick launch instead.  Launches per
+// sampled step: 3 per active top-k / top-p filter (first digit, compaction, tail [+ draw]), or + 2..3 with min-p / without
+// filters; T = 0.8 / top-p 0.9 (the CLI defaults): 3 launches (rounds 1-5: 8, +48 us per decode step at V = 128 256; the
+// one-workgroup version of round 1 added 600 us; profiles/r06_sampler_cost.txt).  The final probability vector
+// (tgx_read_probs) is not part of a step: it is evaluated on demand from the thresholds and normalisers the step left.
 #pragma once
 #include "common.h"
 #include "gemv.h"
@@ -50,14 +53,24 @@ struct SampScratch {                  // one per batch row; zero at allocation, 
   SampLevelState st_k[SAMP_LEVELS], st_p[SAMP_LEVELS];
   unsigned long long thr_k, thr_p;    // kept <=> composite key >= thr
   double wg_z[SAMP_MAX_WG];           // per-workgroup sums of exp(v - max): the set min-p looks at.  The softmax normaliser is
-  double wg_z2[SAMP_MAX_WG];          // ... the final kept set.       accumulated in double and rounded once (as the oracle
-                                      //                                does): independent of the summation order
-  double wg_p[SAMP_MAX_WG];           // per-workgroup sums of the final probabilities
+  double wg_z2[SAMP_MAX_WG];          // ... the final kept set (the draw walks them as tile masses).  The normaliser is accumulated in double and
+                                      // rounded once (as the oracle does): independent of the summation order
   double wg_above[SAMP_MAX_WG];       // per-workgroup sums of exp(v - max) over the entries ABOVE the threshold's first-digit bin (kept for sure)
   unsigned int list_n;                // entries of the compacted list (the threshold's first-digit bin); zeroed by the tail
   float zk;                           // normaliser of the final kept set, derived by the last filter's tail (no min-p)
   float mx;                           // max(logits / T) of this step, left by the first sampler launch (SampArgs.mx_ready tells the later ones)
+#ifdef TGX_SAMP_TIMELINE              // experiment builds (tools/sampler_timeline.py): wall-clock stamps of the sampler's launches, one line per step
+  unsigned long long tl[64][10];
+  unsigned int tl_n;
+#endif
 };
+#ifdef TGX_SAMP_TIMELINE
+#define SAMP_STAMP(sc_, k_) do { if (blockIdx.x == 0 && threadIdx.x == 0) (sc_)->tl[(sc_)->tl_n & 63u][k_] = wall_clock64(); } while (0)
+#define SAMP_STAMP_NEXT(sc_) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned int n_ = (sc_)->tl_n + 1u; for (int k_ = 0; k_ < 10; k_++) (sc_)->tl[n_ & 63u][k_] = 0ull; (sc_)->tl_n = n_; } } while (0)
+#else
+#define SAMP_STAMP(sc_, k_) do {} while (0)
+#define SAMP_STAMP_NEXT(sc_) do {} while (0)
+#endif
 
 struct SampArgs {
   const float* logits; long long logits_stride;       // [rows][V]
@@ -258,14 +271,15 @@ __global__ __launch_bounds__(SAMP_WG) void samp_level0_kernel(const SampArgs a) 
   __shared__ unsigned long long lds_hist[SAMP_BINS];       // counts use the low word
   const int row = blockIdx.y, tid = threadIdx.x;
   SampScratch* sc = a.sc + row;
+  SAMP_STAMP(sc, 0);
   const unsigned long long thr_k = (MODE == 1 && a.top_k > 0) ? sc->thr_k : 0ull;       // the top-k tail ran before
   const int w = samp_width(0, a.idx_bits), shift = samp_shift(0, a.idx_bits), nbins = 1 << w;
+  SampElems e;
+  samp_load(a, row, blockIdx.x, e);             // (ahead of the barriers below: the logits travel while the maximum is reduced)
   for (int b = tid; b < nbins; b += SAMP_WG) lds_hist[b] = 0ull;
   float mx = 0.f;
   if (MODE == 1) mx = samp_row_max(a, row, shf);
   __syncthreads();
-  SampElems e;
-  samp_load(a, row, blockIdx.x, e);
   // runs of equal digits inside a thread are merged before they reach the LDS atomics
   int cur = -1; unsigned long long sum = 0;
 #pragma unroll
@@ -285,6 +299,7 @@ __global__ __launch_bounds__(SAMP_WG) void samp_level0_kernel(const SampArgs a) 
     if (MODE == 0) atomicAdd(&sc->cnt[0][b], (unsigned int)hv);
     else atomicAdd(&sc->mass[0][b], hv);
   }
+  SAMP_STAMP(sc, 1);
 }
 
 // ---- second pass of the chip: every workgroup derives the threshold's first-digit bin from the global histogram; entries above it are kept for sure
@@ -296,18 +311,19 @@ __global__ __launch_bounds__(SAMP_WG) void samp_compact_kernel(const SampArgs a)
   __shared__ double shd[4];
   const int row = blockIdx.y, tid = threadIdx.x;
   SampScratch* sc = a.sc + row;
+  SAMP_STAMP(sc, 2);
   const unsigned long long thr_k = (MODE == 1 && a.top_k > 0) ? sc->thr_k : 0ull;
   const int w = samp_width(0, a.idx_bits), shift = samp_shift(0, a.idx_bits);
   SampLevelState st0;
   st0.prefix = 0; st0.acc = 0; st0.done = 0; st0.pad = 0;
   st0.need = MODE == 0 ? (unsigned long long)(a.top_k < (long long)a.V ? a.top_k : (long long)a.V) : 0ull;
+  SampElems e;
+  samp_load(a, row, blockIdx.x, e);             // (ahead of the selection's barriers: the logits travel beside the histogram)
   SampLevelState st;
   if (MODE == 0) st = samp_select_count(sc->cnt[0], 1 << w, w, st0, sh4, sh_res);
   else st = samp_select_mass(sc->mass[0], 1 << w, w, st0, true, a.top_p, sh4, sh_res);
   if (blockIdx.x == 0 && tid == 0) { if (MODE == 0) sc->st_k[1] = st; else sc->st_p[1] = st; }
   const float mx = samp_row_max(a, row, shf);
-  SampElems e;
-  samp_load(a, row, blockIdx.x, e);
   unsigned long long* lc = a.list_comp + (size_t)row * a.V;
   float* lv = a.list_v + (size_t)row * a.V;
   double above = 0.0;
@@ -333,26 +349,164 @@ __global__ __launch_bounds__(SAMP_WG) void samp_compact_kernel(const SampArgs a)
     if (mine[j]) { lc[slot] = e.comp[j]; lv[slot] = e.v[j]; slot++; }
   above = samp_block_sum_d(above, shd);
   if (tid == 0) sc->wg_above[blockIdx.x] = above;
+  SAMP_STAMP(sc, 3);
 }
 
-// ---- the tail: ONE workgroup per row takes the remaining four digits over the compacted list, derives the filter's threshold and — when it is the
-// last filter and min-p is off — the normaliser of the kept set (bulk sums of the compaction pass + the list's kept entries, double, rounded once)
-template <int MODE>
-__global__ __launch_bounds__(SAMP_WG) void samp_tail_kernel(const SampArgs a, int nwg, int last_filter) {
+// ---- the draw: one workgroup per row ----------------------------------------------------------------------------------
+struct SampPickArgs {
+  SampArgs s;
+  int nwg;
+  const unsigned long long* seed;   // device word
+  FinalizeArgs fin;                 // token publish / rings / embedding (part_* unused)
+};
+
+// the words every draw needs; their loads leave at the top of the launch (one workgroup on an idle chip: each dependent round trip costs ~1 us)
+struct SampDrawWords {
+  unsigned long long seed;
+  int pos, step;
+};
+__device__ __forceinline__ SampDrawWords samp_draw_words(const SampPickArgs& pa) {
+  SampDrawWords w;
+  w.seed = *pa.seed;
+  w.pos = *pa.fin.pos;
+  w.step = pa.fin.log ? *pa.fin.step : 0;
+  return w;
+}
+
+// Inverse CDF in index order + the duties of finalize_greedy_kernel, run by the 256 threads of one workgroup.  pw[j] = the UNNORMALISED kept mass
+// (sum of exp(v - max) over the final kept set) of vocabulary tile 4 * tid + j; z = the kept set's normaliser; z0 = the normaliser of the set min-p
+// looks at (unused without min-p).  The tile that holds the draw comes from a block-wide prefix sum over the tile masses (x 1 / z in double); INSIDE
+// the tile the probabilities are the oracle's floats (e * inv) accumulated in double on top of the tiles below.  The two agree to ~1e-7 of the total:
+// a draw that close to a tile boundary takes the boundary's neighbour (the fallbacks below), every other draw is the oracle's.
+template <int DT>
+__device__ __forceinline__ void samp_draw_and_publish(const SampPickArgs& pa, int row, double (&pw)[4], const SampDrawWords& dw, float mx, float z, float z0,
+                                                      unsigned long long thr_k, unsigned long long thr_p, double* shd) {
+  __shared__ int s_wg, s_pick, s_last, s_pos;
+  __shared__ double s_run, s_u;
+  const SampArgs& a = pa.s;
+  const int tid = threadIdx.x, nwg = pa.nwg;
+  const float inv = 1.0f / z;
+  const double invd = (double)inv;
+  if (tid == 0) {
+    unsigned long long s = dw.seed * 0x9E3779B97F4A7C15ull + (unsigned long long)(dw.pos + pa.fin.advance_pos) * 0xD1342543DE82EF95ull +
+                           (unsigned long long)pa.fin.row;
+    s_u = (double)(splitmix64(s) >> 11) * (1.0 / 9007199254740992.0);
+    s_wg = 0x7fffffff; s_pick = 0x7fffffff; s_last = -1;
+  }
+  double mine_w = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { const int w = tid * 4 + j; if (w >= nwg) pw[j] = 0.0; mine_w += pw[j]; }
+  double run = samp_prefix_excl_d(mine_w, shd);        // sum of the tiles below this thread's four (its barriers publish s_u)
+  const double u = s_u;
+  int lastw = -1;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int w = tid * 4 + j;
+    if (w < nwg && pw[j] > 0.0) lastw = w;
+    // the inclusive sums ascend, so the tiles with u < inclusive sum form a suffix: the smallest of them is the walk's stopping point
+    if (w < nwg && u < (run + pw[j]) * invd) atomicMin(&s_wg, w);
+    run += pw[j];
+  }
+  if (lastw >= 0) atomicMax(&s_last, lastw);
+  __syncthreads();
+  const int w0 = s_wg;
+  if (w0 != 0x7fffffff && (w0 >> 2) == tid) {          // its owner publishes the mass of the tiles below it
+    double r = run - mine_w;
+    for (int j = 0; j < (w0 & 3); j++) r += pw[j];
+    s_run = r * invd;
+  }
+  if (w0 == 0x7fffffff && tid == 0) { s_wg = s_last < 0 ? 0 : s_last; s_run = -1.0; }     // rounding left u above the total: the last kept entry (as the oracle's loop)
+  __syncthreads();
+  const int wsel = s_wg;
+  const double run0 = s_run;
+  SAMP_STAMP(pa.s.sc + row, 6);
+  __syncthreads();
+  if (tid == 0) s_last = -1;                           // reused below for the last kept ENTRY of the selected tile
+  __syncthreads();
+  SampElems e;
+  samp_load(a, row, wsel, e);
+  bool kept[SAMP_EPT];
+  float ex[SAMP_EPT];
+#pragma unroll
+  for (int j = 0; j < SAMP_EPT; j++) {
+    kept[j] = e.in[j] && e.comp[j] >= thr_k && e.comp[j] >= thr_p;
+    ex[j] = kept[j] ? expf(e.v[j] - mx) : 0.f;
+  }
+  if (a.min_p > 0.f) {
+    const float inv0 = 1.0f / z0;
+    const float thr = (1.0f * inv0) * a.min_p;
+#pragma unroll
+    for (int j = 0; j < SAMP_EPT; j++)
+      if (kept[j] && ex[j] * inv0 < thr) { kept[j] = false; ex[j] = 0.f; }
+  }
+  double mine = 0.0;
+  float p[SAMP_EPT];
+#pragma unroll
+  for (int j = 0; j < SAMP_EPT; j++) { p[j] = kept[j] ? ex[j] * inv : 0.f; mine += (double)p[j]; }
+  double cum = (run0 < 0.0 ? 0.0 : run0) + samp_prefix_excl_d(mine, shd);
+  int hit = 0x7fffffff, last = -1;
+#pragma unroll
+  for (int j = 0; j < SAMP_EPT; j++) {
+    if (p[j] > 0.f) {
+      cum += (double)p[j];
+      last = e.base + j;
+      if (run0 >= 0.0 && u < cum && hit == 0x7fffffff) hit = e.base + j;
+    }
+  }
+  if (hit != 0x7fffffff) atomicMin(&s_pick, hit);
+  if (last >= 0) atomicMax(&s_last, last);
+  __syncthreads();
+  if (tid == 0) {
+    int pick = s_pick != 0x7fffffff ? s_pick : s_last;   // no hit inside the selected tile: its last kept entry
+    if ((unsigned)pick >= (unsigned)a.V) pick = 0;       // all-NaN logits: stay inside the embedding table
+    s_pick = pick;
+    *pa.fin.tok = pick;
+    const int np = dw.pos + (pa.fin.advance_pos ? 1 : 0);
+    if (pa.fin.advance_pos) *pa.fin.pos = np;
+    s_pos = np < pa.fin.n_pos ? np : pa.fin.n_pos - 1;
+    if (pa.fin.log) {
+      const int st = dw.step;
+      pa.fin.tok_log[(st % pa.fin.log_cap) * pa.fin.rows + pa.fin.row] = pick;
+      if (pa.fin.host_ring) pa.fin.host_ring[(st % pa.fin.ring_cap) * pa.fin.rows + pa.fin.row] = pick;
+      if (pa.fin.bump_step) *pa.fin.step = st + 1;
+    }
+  }
+  SAMP_STAMP(pa.s.sc + row, 7);
+  __syncthreads();
+  gather_embedding<DT>(pa.fin.embed, s_pick, pa.fin.x, pa.fin.H, pa.fin.wpe, pa.fin.wpe ? s_pos : 0);
+  __syncthreads();
+  SAMP_STAMP(pa.s.sc + row, 8);
+  SAMP_STAMP_NEXT(pa.s.sc + row);
+}
+
+// ---- the tail: ONE workgroup per row takes the remaining four digits over the compacted list and derives the filter's threshold.  PICK (the last
+// filter of a chain without min-p; one launch per row, pa.s pre-offset to the row): it also derives the kept set's normaliser and the kept mass of every
+// vocabulary tile (bulk sums of the compaction pass + the list's kept entries) and draws — the step's token leaves this launch
+template <int MODE, bool PICK, int DT>
+__global__ __launch_bounds__(SAMP_WG) void samp_tail_kernel(const SampPickArgs pa) {
   __shared__ unsigned long long sh4[4], sh_res[2];
   __shared__ float shf[4];
   __shared__ double shd[4];
   __shared__ unsigned long long lds_hist[SAMP_BINS];
   __shared__ unsigned int lds_cnt[SAMP_BINS];
-  const int row = blockIdx.y, tid = threadIdx.x;
+  const SampArgs& a = pa.s;
+  const int row = PICK ? 0 : blockIdx.y, tid = threadIdx.x, nwg = pa.nwg;
   SampScratch* sc = a.sc + row;
   const unsigned long long* lc = a.list_comp + (size_t)row * a.V;
   const float* lv = a.list_v + (size_t)row * a.V;
+  SAMP_STAMP(sc, 4);
   const int n = (int)sc->list_n;
+  SampDrawWords dw{};
+  double aw[4] = {0.0, 0.0, 0.0, 0.0};    // the compaction pass's bulk sums of this thread's four tiles (in flight beside the list)
+  unsigned long long thr_k_prev = 0ull;
+  if (PICK) {
+    dw = samp_draw_words(pa);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int w = tid * 4 + j; const double t = sc->wg_above[min(w, nwg - 1)]; aw[j] = w < nwg ? t : 0.0; }
+    if (MODE == 1 && a.top_k > 0) thr_k_prev = sc->thr_k;
+  }
   const float mx = samp_row_max(a, row, shf);
   SampLevelState st = MODE == 0 ? sc->st_k[1] : sc->st_p[1];
-  double above_w = 0.0;                   // this thread's share of the compaction pass's bulk sums (in flight beside the list)
-  if (last_filter) for (int i = tid; i < nwg; i += SAMP_WG) above_w += sc->wg_above[i];
   // the list is read ONCE: up to TAIL_CACHE entries per thread stay in registers (keys, and for top-p their masses) for the digits, the lone-entry
   // search and the normaliser; a longer list (every logit in one first-digit bin) streams from memory at each use instead
   constexpr int TAIL_CACHE = 16;
@@ -360,13 +514,15 @@ __global__ __launch_bounds__(SAMP_WG) void samp_tail_kernel(const SampArgs a, in
   unsigned long long ck[TAIL_CACHE], cm[TAIL_CACHE];
   float cv[TAIL_CACHE];
 #pragma unroll
-  for (int q = 0; q < TAIL_CACHE; q++) {
+  for (int q = 0; q < TAIL_CACHE; q++) {                   // the loads do not wait for n (the buffers hold V entries): one round trip less in front of the digits
     const int i = tid + q * SAMP_WG;
+    const unsigned long long k = i < a.V ? lc[i] : 0ull;
+    const float v = i < a.V ? lv[i] : 0.f;
     const bool in = cached && i < n;
-    ck[q] = in ? lc[i] : 0ull;                             // key 0 matches no prefix below the first digit of a real entry
-    cv[q] = in ? lv[i] : 0.f;
+    ck[q] = in ? k : 0ull;                                 // key 0 matches no prefix below the first digit of a real entry
+    cv[q] = in ? v : 0.f;
   }
-  if (MODE == 1) {
+  if (MODE == 1 || PICK) {
 #pragma unroll
     for (int q = 0; q < TAIL_CACHE; q++) cm[q] = samp_mass(cv[q], mx);
   }
@@ -415,24 +571,50 @@ __global__ __launch_bounds__(SAMP_WG) void samp_tail_kernel(const SampArgs a, in
   if (MODE == 0) thr = st.prefix;
   else thr = st.done ? 0ull : (st.acc == 0 ? st.prefix : st.prefix + 1ull);
   if (tid == 0) { if (MODE == 0) sc->thr_k = thr; else sc->thr_p = thr; }
-  if (last_filter) {
-    double s = above_w;
-    if (cached) {
-#pragma unroll
-      for (int q = 0; q < TAIL_CACHE; q++) if (tid + q * SAMP_WG < n && ck[q] >= thr) s += (double)expf(cv[q] - mx);
-    } else {
-      for (int i = tid; i < n; i += SAMP_WG) if (lc[i] >= thr) s += (double)expf(lv[i] - mx);
-    }
-    s = samp_block_sum_d(s, shd);
-    if (tid == 0) sc->zk = (float)s;
-  }
+  SAMP_STAMP(sc, 5);
   __syncthreads();
-  // the first-digit histogram and the list of this filter are spent
+  // the first-digit histogram and the list of this filter are spent (PICK: zeroed behind the draw — a barrier waits for the stores in flight)
+  if (!PICK) {
+    for (int b = tid; b < SAMP_BINS; b += SAMP_WG) { if (MODE == 0) sc->cnt[0][b] = 0u; else sc->mass[0][b] = 0ull; }
+    if (tid == 0) sc->list_n = 0u;
+    return;
+  }
+  // the list's kept entries: their exp sums join the normaliser (double, rounded once), their masses their tile's (2^-40 fixed point: integer LDS
+  // atomics are order-independent, so the draw is reproducible)
+  for (int b = tid; b < SAMP_MAX_WG; b += SAMP_WG) lds_hist[b] = 0ull;
+  __syncthreads();
+  const unsigned long long idx_mask = (1ull << a.idx_bits) - 1ull;
+  double s = ((aw[0] + aw[1]) + aw[2]) + aw[3];
+  if (cached) {
+#pragma unroll
+    for (int q = 0; q < TAIL_CACHE; q++)
+      if (tid + q * SAMP_WG < n && ck[q] >= thr) {
+        s += (double)expf(cv[q] - mx);
+        atomicAdd(&lds_hist[(int)((idx_mask - (ck[q] & idx_mask)) / SAMP_TILE)], cm[q]);
+      }
+  } else {
+    for (int i = tid; i < n; i += SAMP_WG) {
+      const unsigned long long cmp = lc[i];
+      if (cmp < thr) continue;
+      const float v = lv[i];
+      s += (double)expf(v - mx);
+      atomicAdd(&lds_hist[(int)((idx_mask - (cmp & idx_mask)) / SAMP_TILE)], samp_mass(v, mx));
+    }
+  }
+  s = samp_block_sum_d(s, shd);           // (its barriers also order the LDS atomics before the reads below)
+  const float z = (float)s;
+  if (tid == 0) sc->zk = z;               // tgx_read_probs evaluates the probabilities from it
+  double pw[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) pw[j] = aw[j] + (double)lds_hist[tid * 4 + j] * (1.0 / 1099511627776.0);
+  __syncthreads();                        // shd is reused by the draw
+  samp_draw_and_publish<DT>(pa, row, pw, dw, mx, z, 0.f, MODE == 0 ? thr : thr_k_prev, MODE == 1 ? thr : 0ull, shd);
   for (int b = tid; b < SAMP_BINS; b += SAMP_WG) { if (MODE == 0) sc->cnt[0][b] = 0u; else sc->mass[0][b] = 0ull; }
   if (tid == 0) sc->list_n = 0u;
 }
 
-// ---- partial sums over the kept set.  STAGE 0: Z of the set min-p looks at; 1: Z of the final set; 2: final probabilities ----
+// ---- partial sums over the kept set.  STAGE 0: Z of the set min-p looks at; 1: Z of the final set (and the tile masses the draw walks);
+// 2: the final probabilities — not part of a step: tgx_read_probs launches it on demand ----
 __device__ __forceinline__ float samp_ordered_sum(const double* part, int n, double* shd) {
   // the normaliser: double partial sums in a fixed association, rounded to fp32 once
   double s = 0.0;
@@ -446,11 +628,12 @@ __global__ __launch_bounds__(SAMP_WG) void samp_sum_kernel(const SampArgs a) {
   __shared__ double shd[4];
   const int row = blockIdx.y, tid = threadIdx.x, nwg = gridDim.x;
   SampScratch* sc = a.sc + row;
+  SAMP_STAMP(sc, STAGE == 0 ? 0 : 2);
+  SampElems e;
+  samp_load(a, row, blockIdx.x, e);
   unsigned long long thr_k, thr_p;
   samp_thresholds(a, sc, thr_k, thr_p);
   const float mx = samp_row_max(a, row, shf);
-  SampElems e;
-  samp_load(a, row, blockIdx.x, e);
   bool kept[SAMP_EPT];
   float ex[SAMP_EPT];
 #pragma unroll
@@ -470,145 +653,37 @@ __global__ __launch_bounds__(SAMP_WG) void samp_sum_kernel(const SampArgs a) {
     double s = (((double)ex[0] + (double)ex[1]) + (double)ex[2]) + (double)ex[3];
     s = samp_block_sum_d(s, shd);
     if (tid == 0) (STAGE == 0 ? sc->wg_z : sc->wg_z2)[blockIdx.x] = s;
+    SAMP_STAMP(sc, STAGE == 0 ? 1 : 3);
     return;
   }
   const float z = a.z_from_tail ? sc->zk : samp_ordered_sum(sc->wg_z2, nwg, shd);
   const float inv = 1.0f / z;
-  double mine = 0.0;
-  float p[SAMP_EPT];
+  float* po = a.probs_out + (size_t)row * a.probs_stride;
 #pragma unroll
-  for (int j = 0; j < SAMP_EPT; j++) { p[j] = kept[j] ? ex[j] * inv : 0.f; mine += (double)p[j]; }
-  if (a.probs_out) {
-    float* po = a.probs_out + (size_t)row * a.probs_stride;
-#pragma unroll
-    for (int j = 0; j < SAMP_EPT; j++) if (e.in[j]) po[e.base + j] = p[j];
-  }
-  // block total in thread order (double)
-  const double below = samp_prefix_excl_d(mine, shd);
-  if (tid == SAMP_WG - 1) sc->wg_p[blockIdx.x] = below + mine;
+  for (int j = 0; j < SAMP_EPT; j++) if (e.in[j]) po[e.base + j] = kept[j] ? ex[j] * inv : 0.f;
 }
 
-// ---- the draw: one workgroup per row ----------------------------------------------------------------------------------
-struct SampPickArgs {
-  SampArgs s;
-  int nwg;
-  const unsigned long long* seed;   // device word
-  FinalizeArgs fin;                 // token publish / rings / embedding (part_* unused)
-};
-
+// the draw of a chain that ends in partial-sum stages (min-p, or no filter at all): the tile masses are stage 1's sums
 template <int DT>
 __global__ __launch_bounds__(SAMP_WG) void samp_pick_kernel(const SampPickArgs pa) {
   __shared__ float shf[4];
   __shared__ double shd[4];
-  __shared__ int s_wg, s_pick, s_last, s_pos;
-  __shared__ double s_run;
   const SampArgs& a = pa.s;
-  const int row = pa.fin.row, tid = threadIdx.x, nwg = pa.nwg;
-  SampScratch* sc = a.sc + row;
-  // every independent load of the launch leaves first (one workgroup on an idle chip: each dependent round trip costs ~1 us)
+  const int tid = threadIdx.x, nwg = pa.nwg;
+  SampScratch* sc = a.sc;
+  SAMP_STAMP(sc, 4);
   double pw[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) { const int w = tid * 4 + j; pw[j] = sc->wg_p[min(w, nwg - 1)]; }
-  const unsigned long long seed_w = *pa.seed;
-  const int pos_w = *pa.fin.pos;
+  for (int j = 0; j < 4; j++) { const int w = tid * 4 + j; pw[j] = sc->wg_z2[min(w, nwg - 1)]; }
+  const SampDrawWords dw = samp_draw_words(pa);
   const unsigned long long thr_k = a.top_k > 0 ? sc->thr_k : 0ull, thr_p = a.top_p < 1.f ? sc->thr_p : 0ull;
-  const float zk_w = sc->zk;
-  const int step_w = pa.fin.log ? *pa.fin.step : 0;
-  const float mx = samp_row_max(a, row, shf);
-  // u, and the workgroup whose index range holds the draw: a block-wide prefix sum over the <= 1024 per-workgroup sums (thread t owns workgroups
-  // 4t .. 4t+3; rounds 1-5 walked them with one thread — ~60 dependent loads on average, the longest single item of a sampled step)
-  if (tid == 0) {
-    unsigned long long s = seed_w * 0x9E3779B97F4A7C15ull + (unsigned long long)(pos_w + pa.fin.advance_pos) * 0xD1342543DE82EF95ull +
-                           (unsigned long long)pa.fin.row;
-    shd[0] = (double)(splitmix64(s) >> 11) * (1.0 / 9007199254740992.0);
-    s_wg = 0x7fffffff; s_pick = 0x7fffffff; s_last = -1;
-  }
+  const float mx = samp_row_max(a, 0, shf);
+  const float z0 = a.min_p > 0.f ? samp_ordered_sum(sc->wg_z, nwg, shd) : 0.f;
   __syncthreads();
-  const double u = shd[0];
-  {
-    double mine_w = 0.0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) { const int w = tid * 4 + j; if (w >= nwg) pw[j] = 0.0; mine_w += pw[j]; }
-    __syncthreads();                                   // shd[0] was read by everyone
-    double run = samp_prefix_excl_d(mine_w, shd);      // sum of the workgroups below this thread's four
-    int lastw = -1;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int w = tid * 4 + j;
-      if (w < nwg && pw[j] > 0.0) lastw = w;
-      // the inclusive sums ascend, so the workgroups with u < inclusive sum form a suffix: the smallest of them is the walk's stopping point
-      if (w < nwg && u < run + pw[j]) atomicMin(&s_wg, w);
-      run += pw[j];
-    }
-    if (lastw >= 0) atomicMax(&s_last, lastw);
-    __syncthreads();
-    const int w0 = s_wg;
-    if (w0 != 0x7fffffff && (w0 >> 2) == tid) {        // its owner publishes the sum of the workgroups below it
-      double r = run - mine_w;
-      for (int j = 0; j < (w0 & 3); j++) r += pw[j];
-      s_run = r;
-    }
-    if (w0 == 0x7fffffff && tid == 0) { s_wg = s_last < 0 ? 0 : s_last; s_run = -1.0; }     // rounding left u above the total: the last kept entry (as the oracle's loop)
-    __syncthreads();
-  }
-  const int wsel = s_wg;
-  const double run0 = s_run;
+  const float z = samp_ordered_sum(sc->wg_z2, nwg, shd);
   __syncthreads();
-  if (tid == 0) s_last = -1;                           // reused below for the last kept ENTRY of the selected range
-  __syncthreads();
-  SampElems e;
-  samp_load(a, row, wsel, e);
-  bool kept[SAMP_EPT];
-  float ex[SAMP_EPT];
-#pragma unroll
-  for (int j = 0; j < SAMP_EPT; j++) {
-    kept[j] = e.in[j] && e.comp[j] >= thr_k && e.comp[j] >= thr_p;
-    ex[j] = kept[j] ? expf(e.v[j] - mx) : 0.f;
-  }
-  if (a.min_p > 0.f) {
-    const float z0 = samp_ordered_sum(sc->wg_z, nwg, shd);
-    const float inv0 = 1.0f / z0;
-    const float thr = (1.0f * inv0) * a.min_p;
-#pragma unroll
-    for (int j = 0; j < SAMP_EPT; j++)
-      if (kept[j] && ex[j] * inv0 < thr) { kept[j] = false; ex[j] = 0.f; }
-  }
-  const float z = a.z_from_tail ? zk_w : samp_ordered_sum(sc->wg_z2, nwg, shd);
-  const float inv = 1.0f / z;
-  double mine = 0.0;
-  float p[SAMP_EPT];
-#pragma unroll
-  for (int j = 0; j < SAMP_EPT; j++) { p[j] = kept[j] ? ex[j] * inv : 0.f; mine += (double)p[j]; }
-  double cum = (run0 < 0.0 ? 0.0 : run0) + samp_prefix_excl_d(mine, shd);
-  int hit = 0x7fffffff, last = -1;
-#pragma unroll
-  for (int j = 0; j < SAMP_EPT; j++) {
-    if (p[j] > 0.f) {
-      cum += (double)p[j];
-      last = e.base + j;
-      if (run0 >= 0.0 && u < cum && hit == 0x7fffffff) hit = e.base + j;
-    }
-  }
-  if (hit != 0x7fffffff) atomicMin(&s_pick, hit);
-  if (last >= 0) atomicMax(&s_last, last);
-  __syncthreads();       // (the filters' tails left their histograms and the list at zero)
-  if (tid == 0) {
-    int pick = s_pick != 0x7fffffff ? s_pick : s_last;   // no hit inside the selected range: its last kept entry
-    if ((unsigned)pick >= (unsigned)a.V) pick = 0;       // all-NaN logits: stay inside the embedding table
-    s_pick = pick;
-    *pa.fin.tok = pick;
-    const int np = pos_w + (pa.fin.advance_pos ? 1 : 0);
-    if (pa.fin.advance_pos) *pa.fin.pos = np;
-    s_pos = np < pa.fin.n_pos ? np : pa.fin.n_pos - 1;
-    if (pa.fin.log) {
-      const int st = step_w;
-      pa.fin.tok_log[(st % pa.fin.log_cap) * pa.fin.rows + pa.fin.row] = pick;
-      if (pa.fin.host_ring) pa.fin.host_ring[(st % pa.fin.ring_cap) * pa.fin.rows + pa.fin.row] = pick;
-      if (pa.fin.bump_step) *pa.fin.step = st + 1;
-    }
-  }
-  __syncthreads();
-  gather_embedding<DT>(pa.fin.embed, s_pick, pa.fin.x, pa.fin.H, pa.fin.wpe, pa.fin.wpe ? s_pos : 0);
+  SAMP_STAMP(sc, 5);
+  samp_draw_and_publish<DT>(pa, 0, pw, dw, mx, z, z0, thr_k, thr_p, shd);
 }
 
 }  // namespace tgx

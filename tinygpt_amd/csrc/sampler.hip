@@ -1,12 +1,12 @@
 // sampler.hip — Sampler::sample on the logits of a step (Sampler.cpp:23-79) + token publish / pastLength / next embedding.
 // Greedy: one finalize launch per row (decode.hip).  Otherwise the staged sampler of kernels/sampler.h: ceil(V/1024) workgroups per row
 // (rows on blockIdx.y) for the first digit of each active filter and for the compaction of its threshold bin, one workgroup per row for the
-// filter's tail, the probability stage, then one pick per row.
+// filter's tail — which also draws the token when the chain ends there.
 #include "ctx.h"
 #include "kernels/sampler.h"
+#include <type_traits>
 
-void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool advance_pos, bool log_step) {
-  if (is_greedy(&cfg)) { launch_finalize_greedy(c, row0, R, advance_pos, log_step); return; }
+static tgx::SampArgs samp_args(tgx_ctx* c, int row0, const tgx_sampler_cfg& cfg) {
   const int V = c->d.vocab;
   RowState& r = c->rows[(size_t)row0];
   tgx::SampArgs a{};
@@ -17,40 +17,73 @@ void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool
   a.V = V; a.idx_bits = 1;
   while ((1 << a.idx_bits) < V) a.idx_bits++;
   a.temperature = cfg.temperature; a.top_k = cfg.top_k; a.top_p = cfg.top_p; a.min_p = cfg.min_p;
-  const bool setK = cfg.top_k > 0, setP = cfg.top_p < 1.f, setM = cfg.min_p > 0.f;
-  const int nwg = (V + tgx::SAMP_TILE - 1) / tgx::SAMP_TILE;
-  const dim3 grid(nwg, R), blk(tgx::SAMP_WG);
   a.list_comp = c->samp_list_comp + (size_t)row0 * V; a.list_v = c->samp_list_v + (size_t)row0 * V;
-  const dim3 tail(1, R);
-  // a filter = first digit over the vocabulary, compaction of the threshold's bin, the tail (four digits, threshold[, normaliser]) in one workgroup
+  // the normaliser of the final kept set: left by the last filter's tail, or — with min-p, or without any filter — the ordered sum of stage 1's tile sums
+  a.z_from_tail = ((cfg.top_k > 0 || cfg.top_p < 1.f) && !(cfg.min_p > 0.f)) ? 1 : 0;
+  return a;
+}
+
+void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool advance_pos, bool log_step) {
+  if (is_greedy(&cfg)) { launch_finalize_greedy(c, row0, R, advance_pos, log_step); return; }
+  tgx::SampArgs a = samp_args(c, row0, cfg);
+  const bool setK = cfg.top_k > 0, setP = cfg.top_p < 1.f, setM = cfg.min_p > 0.f;
+  const int nwg = (a.V + tgx::SAMP_TILE - 1) / tgx::SAMP_TILE;
+  const dim3 grid(nwg, R), blk(tgx::SAMP_WG), one(1);
+  // per row: the draw's arguments (everything pre-offset to the row) — the last launch of the chain
+  auto pick_args = [&](int b, const tgx::SampArgs& now) {
+    tgx::SampPickArgs pa{};
+    pa.s = samp_args(c, b, cfg);
+    pa.s.mx_ready = now.mx_ready;
+    pa.nwg = nwg; pa.seed = c->seed_dev;
+    pa.fin = make_finalize_args(c, b, advance_pos, log_step);
+    return pa;
+  };
+  // a filter = first digit over the vocabulary, compaction of the threshold's bin, the tail (four digits, threshold) in one workgroup; the tail of the
+  // chain's LAST filter also draws when no min-p follows
   a.mx_ready = 0;                 // the first launch that needs max(logits / T) reduces the lm_head partials and leaves it in sc->mx for the others
+  auto tail = [&](auto mode, bool draws) {
+    constexpr int MODE = decltype(mode)::value;
+    if (!draws) {
+      tgx::SampPickArgs pa{};
+      pa.s = a; pa.nwg = nwg;
+      hipLaunchKernelGGL((tgx::samp_tail_kernel<MODE, false, 0>), dim3(1, R), blk, 0, c->stream, pa);
+      return;
+    }
+    for (int b = row0; b < row0 + R; b++) {
+      const tgx::SampPickArgs pa = pick_args(b, a);
+      TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL((tgx::samp_tail_kernel<MODE, true, DT>), one, blk, 0, c->stream, pa))
+    }
+  };
   if (setK) {
     hipLaunchKernelGGL(tgx::samp_level0_kernel<0>, grid, blk, 0, c->stream, a);       // (counts: no maximum needed)
     hipLaunchKernelGGL(tgx::samp_compact_kernel<0>, grid, blk, 0, c->stream, a);
     a.mx_ready = 1;
-    hipLaunchKernelGGL(tgx::samp_tail_kernel<0>, tail, blk, 0, c->stream, a, nwg, (!setP && !setM) ? 1 : 0);
+    tail(std::integral_constant<int, 0>{}, !setP && !setM);
   }
   if (setP) {
     hipLaunchKernelGGL(tgx::samp_level0_kernel<1>, grid, blk, 0, c->stream, a);
     a.mx_ready = 1;
     hipLaunchKernelGGL(tgx::samp_compact_kernel<1>, grid, blk, 0, c->stream, a);
-    hipLaunchKernelGGL(tgx::samp_tail_kernel<1>, tail, blk, 0, c->stream, a, nwg, !setM ? 1 : 0);
+    tail(std::integral_constant<int, 1>{}, !setM);
   }
-  // the normaliser: from the last filter's tail; with min-p (its cut depends on the normaliser of the set it looks at) or without any filter, two
-  // partial-sum stages over the vocabulary
-  a.z_from_tail = ((setK || setP) && !setM) ? 1 : 0;
+  if (a.z_from_tail) return;      // the last tail drew
+  // with min-p (its cut depends on the normaliser of the set it looks at) or without any filter: partial-sum stages over the vocabulary, then the pick
   if (setM) { hipLaunchKernelGGL(tgx::samp_sum_kernel<0>, grid, blk, 0, c->stream, a); a.mx_ready = 1; }
-  if (!a.z_from_tail) { hipLaunchKernelGGL(tgx::samp_sum_kernel<1>, grid, blk, 0, c->stream, a); a.mx_ready = 1; }
-  hipLaunchKernelGGL(tgx::samp_sum_kernel<2>, grid, blk, 0, c->stream, a);
+  hipLaunchKernelGGL(tgx::samp_sum_kernel<1>, grid, blk, 0, c->stream, a);
+  a.mx_ready = 1;
   for (int b = row0; b < row0 + R; b++) {
-    tgx::SampPickArgs pa{};
-    pa.s = a;
-    pa.s.logits = c->rows[(size_t)b].logits; pa.s.part_val = c->rows[(size_t)b].part_val; pa.s.sc = c->samp_scratch;   // the pick kernel indexes sc by fin.row
-    pa.s.logits_stride = 0; pa.s.part_stride = 0; pa.s.list_comp = nullptr; pa.s.list_v = nullptr;
-    pa.nwg = nwg; pa.seed = c->seed_dev;
-    pa.fin = make_finalize_args(c, b, advance_pos, log_step);
-    TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::samp_pick_kernel<DT>, dim3(1), dim3(tgx::SAMP_WG), 0, c->stream, pa))
+    const tgx::SampPickArgs pa = pick_args(b, a);
+    TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::samp_pick_kernel<DT>, one, blk, 0, c->stream, pa))
   }
+}
+
+// tgx_read_probs: the final probability vector of row `row`'s last sampled step, evaluated from what that step left on the device (its logits, the
+// filters' thresholds, the normalisers) — the step itself never needs the vector
+void launch_probs(tgx_ctx* c, int row, const tgx_sampler_cfg& cfg) {
+  tgx::SampArgs a = samp_args(c, row, cfg);
+  a.mx_ready = 0;
+  const int nwg = (a.V + tgx::SAMP_TILE - 1) / tgx::SAMP_TILE;
+  hipLaunchKernelGGL(tgx::samp_sum_kernel<2>, dim3(nwg, 1), dim3(tgx::SAMP_WG), 0, c->stream, a);
 }
 
 int sampler_alloc(tgx_ctx* c) {
@@ -63,3 +96,14 @@ int sampler_alloc(tgx_ctx* c) {
   if ((d.vocab + tgx::SAMP_TILE - 1) / tgx::SAMP_TILE > tgx::SAMP_MAX_WG) return set_err(c, TGX_ERR_UNSUPPORTED, "vocabulary %d exceeds the sampler's %d entries", d.vocab, tgx::SAMP_MAX_WG * tgx::SAMP_TILE);
   return TGX_OK;
 }
+
+#ifdef TGX_SAMP_TIMELINE
+// experiment builds only (tools/sampler_timeline.py): row 0's stamps, [64][10] ticks of the 100 MHz wall clock + the number of steps stamped
+extern "C" __attribute__((visibility("default"))) int tgx_debug_samp_timeline(tgx_ctx* c, unsigned long long* out, unsigned int* n) {
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return 1;
+  tgx::SampScratch h;
+  if (hipMemcpy(&h, c->samp_scratch, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  memcpy(out, h.tl, sizeof(h.tl)); *n = h.tl_n;
+  return 0;
+}
+#endif
