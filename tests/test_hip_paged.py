@@ -2,9 +2,10 @@
 (README.md:32-34).  The reference's KVCacheManager grows every row's cache by concat (src/engine/CacheManager.h:24-51); the unpaged layout gives every row a
 max_ctx slab.  Paged: per-layer pools of 128-token blocks shared by the rows, a block table per row on the device, blocks assigned as a sequence grows and
 returned when it is retired.  Held to:
-  * the SAME results as the unpaged cache — bit for bit where the two run the same kernels (the paged attention is the unpaged kernel with another address
-    computation): prompts through the decode-kernel passes, decode steps on the direct and on the split attention form, across block boundaries, four
-    families / both head sizes / a QKV bias / Qwen3's q-k norm;
+  * the SAME results as the unpaged cache — bit for bit on the same option set (every decode attention form has a paged instantiation: the unpaged kernel
+    with another address computation): prompts through the decode-kernel passes, decode steps on the direct (with and without the o_proj strip), split and
+    matrix-core attention forms, the batched step with VALU / matrix-core attention with and without the QKV finish in the prologue, across block boundaries,
+    four families / both head sizes / a QKV bias / Qwen3's q-k norm;
   * rows of very different lengths whose summed length exceeds max_ctx — impossible with one slab of the same total size — decode together and each equals
     its run in an unpaged batch;
   * the budget: a row that needs a block when none is free is refused (TGX_ERR_CONTEXT), retiring another row frees its blocks, and the refused row then
@@ -25,7 +26,7 @@ def hip():
     return product_backend()
 
 
-def make(fam, hip, dtype="bf16", max_batch=1, max_ctx=512, budget=0, opts=(), gemv_step=True):
+def make(fam, hip, dtype="bf16", max_batch=1, max_ctx=512, budget=0, opts=()):
     cfg, g = load_golden(fam)
     d = desc_from_hf_config(cfg, dtype, max_batch=max_batch)
     d.max_ctx = max_ctx
@@ -33,19 +34,27 @@ def make(fam, hip, dtype="bf16", max_batch=1, max_ctx=512, budget=0, opts=(), ge
     if budget:
         m.set_option("kv.budget_tokens", budget)
     m.load_synthetic(int(g["seed"]), float(g["std"])).finalize()
-    # the unpaged reference on the kernels a paged context runs: prompts through the decode kernels, no o_proj strip in the direct attention launch, the GEMV step for batches
-    base = (("prefill.mfma", 0), ("oproj.fused", 0))
-    # batches: the GEMV step (rows in groups of four), or the matrix-core step on the forms a paged context takes (the QKV finish as its own launch, VALU attention)
-    base += (("decode.mfma_min_batch", 1 << 20),) if gemv_step else (("attn.raw_fuse", 0), ("attn.batch_mfma", 0))
-    for k, v in base + tuple(opts):
+    for k, v in tuple(opts):
         m.set_option(k, v)
     return m, g
 
 
-@pytest.mark.parametrize("direct_max", [100000, 0])
+# Every decode attention form has a paged instantiation, so a paged context takes the forms an unpaged one takes: the comparisons below run both sides on the
+# SAME option set.  Prompts go through the decode-kernel passes here (prefill.mfma 0: the matrix-core prefill picks other — equivalent, not bit-identical —
+# forms for a paged cache; test_matrix_core_prefill_into_a_paged_cache holds that path).
+FORMS = {
+    "default": (("prefill.mfma", 0),),                                                     # direct attention with the o_proj strip in its launch
+    "split": (("prefill.mfma", 0), ("attn.direct_max", 0)),                                 # split attention, merged by the K-sliced o_proj
+    "plain_direct": (("prefill.mfma", 0), ("oproj.fused", 0)),                              # the plain direct form, o_proj as its own launch
+    "plain_split": (("prefill.mfma", 0), ("oproj.fused", 0), ("attn.direct_max", 0)),       # split + combine launch
+    "mfma_long": (("prefill.mfma", 0), ("attn.direct_max", 0), ("attn.mfma_min", 64)),      # the long-context matrix-core form (from 64 keys here)
+}
+
+
+@pytest.mark.parametrize("forms", list(FORMS))
 @pytest.mark.parametrize("fam,dtype", [("llama_tiny", "bf16"), ("qwen2_tiny", "bf16"), ("mistral_tiny", "fp16"), ("qwen3_tiny", "bf16")])
-def test_paged_equals_unpaged_bit_for_bit(fam, dtype, direct_max, hip):
-    opts = (("attn.direct_max", direct_max),)
+def test_paged_equals_unpaged_bit_for_bit(fam, dtype, forms, hip):
+    opts = FORMS[forms]
     paged, g = make(fam, hip, dtype, max_ctx=512, budget=512, opts=opts)
     plain, _ = make(fam, hip, dtype, max_ctx=512, opts=opts)
     assert paged.get_option("kv.free_tokens") == 512 and plain.get_option("kv.free_tokens") == -1
@@ -80,14 +89,24 @@ def test_paged_equals_unpaged_bit_for_bit(fam, dtype, direct_max, hip):
     np.testing.assert_array_equal(paged.logits(rounded=False), plain.logits(rounded=False))
 
 
-@pytest.mark.parametrize("gemv_step", [True, False])
+STEPS = {
+    "gemv": (("prefill.mfma", 0), ("decode.mfma_min_batch", 1 << 20)),                      # the GEMV step, rows in groups of four
+    "mfma_default": (("prefill.mfma", 0),),                                                 # the matrix-core step as four rows take it
+    "mfma_valu_plain": (("prefill.mfma", 0), ("attn.raw_fuse", 0), ("attn.batch_mfma", 0)),  # the QKV finish as its own launch, VALU attention
+    "mfma_valu_raw": (("prefill.mfma", 0), ("attn.raw_fuse", 2), ("attn.batch_mfma", 0)),   # VALU attention that finishes the QKV rows in its prologue
+    "mfma_attn": (("prefill.mfma", 0), ("attn.batch_mfma", 1)),                              # matrix-core attention (as from 17 rows) + the QKV finish in its prologue
+    "mfma_attn_plain": (("prefill.mfma", 0), ("attn.batch_mfma", 1), ("attn.raw_fuse", 0)),
+}
+
+
+@pytest.mark.parametrize("step", list(STEPS))
 @pytest.mark.parametrize("fam", ["llama_tiny", "mistral_tiny", "qwen3_tiny"])
-def test_rows_of_very_different_lengths_share_a_budget_smaller_than_their_slabs(fam, gemv_step, hip):
+def test_rows_of_very_different_lengths_share_a_budget_smaller_than_their_slabs(fam, step, hip):
     """max_ctx 384, four rows: unpaged that is 4 x 384 = 1536 tokens of cache; the paged context gets 896 (seven blocks).  Rows of 300 + 200 + 60 + 20 prompt tokens (580 > max_ctx)
     decode 25 steps together; each row equals the same row of an unpaged batch run on the same kernels, bit for bit."""
     lens = [300, 200, 60, 20]
-    paged, g = make(fam, hip, max_batch=4, max_ctx=384, budget=896, gemv_step=gemv_step)
-    plain, _ = make(fam, hip, max_batch=4, max_ctx=384, gemv_step=gemv_step)
+    paged, g = make(fam, hip, max_batch=4, max_ctx=384, budget=896, opts=STEPS[step])
+    plain, _ = make(fam, hip, max_batch=4, max_ctx=384, opts=STEPS[step])
     V = paged.desc.vocab
     p = g["prompt"][0]
     prompts = [np.concatenate([(p * (5 + r + i) + i) % V for i in range(40)])[:n].astype(np.int64) for r, n in enumerate(lens)]
@@ -107,8 +126,9 @@ def test_rows_of_very_different_lengths_share_a_budget_smaller_than_their_slabs(
 
 
 def test_the_budget_is_enforced_and_retired_rows_return_their_blocks(hip):
-    paged, g = make("llama_tiny", hip, max_batch=3, max_ctx=512, budget=512)       # four blocks
-    solo, _ = make("llama_tiny", hip, max_batch=1, max_ctx=512)
+    same = STEPS["gemv"] + (("oproj.fused", 0),)                                   # batch and solo on the same kernel path: their ids are compared below
+    paged, g = make("llama_tiny", hip, max_batch=3, max_ctx=512, budget=512, opts=same)       # four blocks
+    solo, _ = make("llama_tiny", hip, max_batch=1, max_ctx=512, opts=same)
     V = paged.desc.vocab
     p = g["prompt"][0]
     long_p = np.concatenate([(p * (2 + i) + i) % V for i in range(40)])[:250].astype(np.int64)     # two blocks

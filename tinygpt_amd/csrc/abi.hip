@@ -206,7 +206,7 @@ static void update_attn_modes(tgx_ctx* c, int n_positions, int rows_per_launch =
   const long long direct_lim = direct_limit(c, rpl, step), nw4_lim = nw4_limit(c, rpl, step);
   c->attn_direct = c->past + n_positions <= direct_lim;
   c->attn_nw4 = c->attn_direct && nw4_lim > 0 && c->past + n_positions <= nw4_lim;
-  c->attn_mfma = !c->attn_direct && c->past >= attn_mfma_threshold(c) && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse) && !c->kv_paged;
+  c->attn_mfma = !c->attn_direct && c->past >= attn_mfma_threshold(c) && c->dt != tgx::DT_F32 && !(c->d.qk_norm && c->d.head_dim == 128 && c->qk_fuse);
 }
 
 static void launch_decode_step(tgx_ctx* c, const tgx_sampler_cfg& cfg) {

@@ -8,10 +8,12 @@
 // the direct-form attention of a batched step runs on the matrix cores from attn.batch_mfma rows (17) when a kv head serves 3+ query heads (the VALU form's
 // cost grows with the heads per workgroup, the MFMA form's does not: Qwen3-1.7B, 2 heads per kv head, B = 32 2.29 (VALU) vs 2.39 ms/step)
 bool attn_batch_on_mfma(const tgx_ctx* c, int R) {
-  return !c->kv_paged && c->attn_batch_mfma > 0 && R >= c->attn_batch_mfma && (c->d.heads / c->d.kv_heads >= 3 || c->attn_batch_mfma == 1);      // (paged KV: the VALU forms)
+  return c->attn_batch_mfma > 0 && R >= c->attn_batch_mfma && (c->d.heads / c->d.kv_heads >= 3 || c->attn_batch_mfma == 1);
 }
 
-template <int DT, int HD, bool QKN = false>
+// P: paged KV (option kv.budget_tokens; kernels/common.h kv_paged_off) — every form exists in a paged instantiation (16-bit storage): same launch shapes, K / V
+// through the rows' block tables
+template <int DT, int HD, bool QKN = false, bool P = false>
 static void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R, bool combine) {
   // the query heads of a kv group go to workgroups two at a time (blockIdx.z): the per-head state (8 output registers, the
   // merges) is what a workgroup's time grows with, while the K/V tile the groups re-read is small and mostly L2-resident.
@@ -52,8 +54,8 @@ static void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R, bool combine) {
         a.oj_rsplit = rs;
         const dim3 grid(a.kv_heads, 1, gfull * rs);
         if (c->debug_skip & 1) return;
-        if (c->attn_nw4) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, false, false, 4, true>), grid, dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, false, false, 8, true>), grid, dim3(256), 0, c->stream, a);      // beyond: four waves x EIGHT wave-loads per block (layer_lab, 600 keys: 7.33 vs 7.57 us for eight waves x four on Llama-3.2-1B, 6.60 vs 6.85 on Qwen2.5-0.5B)
+        if (c->attn_nw4) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, false, false, 4, true, P>), grid, dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, false, false, 8, true, P>), grid, dim3(256), 0, c->stream, a);      // beyond: four waves x EIGHT wave-loads per block (layer_lab, 600 keys: 7.33 vs 7.57 us for eight waves x four on Llama-3.2-1B, 6.60 vs 6.85 on Qwen2.5-0.5B)
         return;
       }
     }
@@ -71,16 +73,16 @@ static void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R, bool combine) {
           if constexpr (HD == 64) {
             if ((a.raw_part || a.raw_qkv) && (c->attn_batch_nw8 >= 2 || (c->attn_batch_nw8 == 1 && (int)(gm.x * gm.y) <= c->num_cus))) {
               constexpr size_t lds8 = tgx::attn_mfma_raw_lds_bytes<HD, 8>();
-              hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 8, true, false>), gm, dim3(512), lds8, c->stream, a);
+              hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 8, true, false, P>), gm, dim3(512), lds8, c->stream, a);
               return;
             }
           }
           if (a.raw_part || a.raw_qkv) {     // + the QKV product's finish
-            if (la) hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, true>), gm, dim3(256), ldsr, c->stream, a);
-            else hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, true, false>), gm, dim3(256), ldsr, c->stream, a);
+            if (la) hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, true, true, P>), gm, dim3(256), ldsr, c->stream, a);
+            else hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, true, false, P>), gm, dim3(256), ldsr, c->stream, a);
           } else {
-            if (la) hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4>), gm, dim3(256), lds4, c->stream, a);
-            else hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, false, false>), gm, dim3(256), lds4, c->stream, a);
+            if (la) hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, false, true, P>), gm, dim3(256), lds4, c->stream, a);
+            else hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, false, false, P>), gm, dim3(256), lds4, c->stream, a);
           }
         }
         return;
@@ -97,22 +99,22 @@ static void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R, bool combine) {
       const dim3 gridg(a.kv_heads, R, gfull / dg), blkg(1024);
       if constexpr (!QKN && DT != tgx::DT_F32) {
         if (raw && !(c->debug_skip & 1)) {
-          if (dg == 2) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 16, false, true, 2>), gridg, blkg, 0, c->stream, a);
-          else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 16, false, true, 1>), gridg, blkg, 0, c->stream, a);
+          if (dg == 2) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 16, false, true, 2, false, P>), gridg, blkg, 0, c->stream, a);
+          else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 16, false, true, 1, false, P>), gridg, blkg, 0, c->stream, a);
           return;
         }
       }
       if constexpr (!QKN) {
         if (!(c->debug_skip & 1)) {
-          if (dg == 2) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 16, false, false, 2>), gridg, blkg, 0, c->stream, a);
-          else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 16, false, false, 1>), gridg, blkg, 0, c->stream, a);
+          if (dg == 2) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 16, false, false, 2, false, P>), gridg, blkg, 0, c->stream, a);
+          else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 16, false, false, 1, false, P>), gridg, blkg, 0, c->stream, a);
         }
       }
       return;
     }
     if constexpr (!QKN && DT != tgx::DT_F32) {
       if (raw && !(c->debug_skip & 1)) {          // (every remaining direct form of a batched step is one head per workgroup: also a group size dg does not divide)
-        hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 16, false, true>), dim3(a.kv_heads, R, gfull), dim3(1024), 0, c->stream, a);
+        hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 16, false, true, 4, false, P>), dim3(a.kv_heads, R, gfull), dim3(1024), 0, c->stream, a);
         return;
       }
     }
@@ -120,17 +122,17 @@ static void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R, bool combine) {
     // workgroup covers 128 keys at head_dim 64 (64 at 128), and four records merge faster than sixteen
     if (c->attn_nw4 && dg == 1) {
       const dim3 grid4(a.kv_heads, R, gfull), blk4(256);
-      if (!(c->debug_skip & 1)) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, QKN>), grid4, blk4, 0, c->stream, a);
+      if (!(c->debug_skip & 1)) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, QKN, false, 4, false, P>), grid4, blk4, 0, c->stream, a);
       return;
     }
     const dim3 grid(a.kv_heads, R, gfull), blk(1024);
-    if (!(c->debug_skip & 1)) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 16, QKN>), grid, blk, 0, c->stream, a);
+    if (!(c->debug_skip & 1)) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 16, QKN, false, 4, false, P>), grid, blk, 0, c->stream, a);
     return;
   }
   if (c->attn_mfma && !QKN && DT != tgx::DT_F32) {   // long context: QK^T and PV on the matrix cores, the kv group's query heads as the narrow operand
     if constexpr (!QKN && DT != tgx::DT_F32) {
       const dim3 gm(a.kv_heads * a.nsplit, R), bm(256);
-      hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD>), gm, bm, tgx::attn_mfma_lds_bytes<HD>(), c->stream, a);
+      hipLaunchKernelGGL((tgx::attn_decode_mfma_kernel<DT, HD, 4, false, true, P>), gm, bm, tgx::attn_mfma_lds_bytes<HD>(), c->stream, a);
     }
     launch_combine();
     return;
@@ -138,56 +140,39 @@ static void launch_attn_g(tgx_ctx* c, tgx::AttnArgs a, int R, bool combine) {
   const int gx = a.kv_heads * a.nsplit;
   const dim3 grid(gx, R, ngroups), blk(256);
   if (!(c->debug_skip & 1)) switch (G) {
-    case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, QKN>), grid, blk, 0, c->stream, a); break;
-    case 2: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 4, QKN>), grid, blk, 0, c->stream, a); break;
-    case 3: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 3, 4, QKN>), grid, blk, 0, c->stream, a); break;
-    default: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 4, QKN>), grid, blk, 0, c->stream, a); break;
+    case 1: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, QKN, false, 4, false, P>), grid, blk, 0, c->stream, a); break;
+    case 2: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 4, QKN, false, 4, false, P>), grid, blk, 0, c->stream, a); break;
+    case 3: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 3, 4, QKN, false, 4, false, P>), grid, blk, 0, c->stream, a); break;
+    default: hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 4, 4, QKN, false, 4, false, P>), grid, blk, 0, c->stream, a); break;
   }
   launch_combine();
 }
 
-// Paged KV (option kv.budget_tokens; kernels/common.h kv_paged_off): the VALU forms through the rows' block tables — the direct form (one workgroup per query
-// head, four or sixteen waves) and the split form (+ combine, or the K-sliced o_proj's merge).  The matrix-core forms, the QKV finish in the attention prologue
-// and the o_proj strip in the direct launch are unpaged-only: a paged context never selects them (abi.hip kv_paged_restrict).
-template <int DT, int HD, bool QKN>
-static void launch_attn_paged(tgx_ctx* c, tgx::AttnArgs a, int R, bool combine) {
-  const int gfull = a.heads / a.kv_heads;
-  a.gfull = gfull;
-  a.direct = c->attn_direct ? 1 : 0;
-  if (a.direct) {
-    const dim3 grid(a.kv_heads, R, gfull);
-    if (c->attn_nw4) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, QKN, false, 4, false, true>), grid, dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 16, QKN, false, 4, false, true>), grid, dim3(1024), 0, c->stream, a);
-    return;
-  }
-  const int gmax = R == 1 ? 1 : 2, ngroups = gfull > gmax ? (gfull + gmax - 1) / gmax : 1, G = (gfull + ngroups - 1) / ngroups;
-  const dim3 grid(a.kv_heads * a.nsplit, R, ngroups), blk(256);
-  if (G == 1) hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 1, 4, QKN, false, 4, false, true>), grid, blk, 0, c->stream, a);
-  else hipLaunchKernelGGL((tgx::attn_decode_kernel<DT, HD, 2, 4, QKN, false, 4, false, true>), grid, blk, 0, c->stream, a);
-  if (combine) hipLaunchKernelGGL((tgx::attn_combine_kernel<HD>), dim3(a.heads, R), dim3(256), 0, c->stream, a);
-}
-
 void launch_attn(tgx_ctx* c, const tgx::AttnArgs& a, int R, bool combine) {
+  const bool qkn = a.k_raw && c->d.head_dim == 128;       // Qwen3's q/k norm + RoPE + cache append inside the attention launch (head_dim 128: every released Qwen3 size)
   if (a.blk_tbl) {
-    const bool qkn = a.k_raw && c->d.head_dim == 128;
     TGX_DT16_SWITCH(c->dt,
-      if (c->d.head_dim == 64) launch_attn_paged<DT, 64, false>(c, a, R, combine);
-      else if (qkn) launch_attn_paged<DT, 128, true>(c, a, R, combine);
-      else launch_attn_paged<DT, 128, false>(c, a, R, combine);)
+      if (c->d.head_dim == 64) launch_attn_g<DT, 64, false, true>(c, a, R, combine);
+      else if (qkn) launch_attn_g<DT, 128, true, true>(c, a, R, combine);
+      else launch_attn_g<DT, 128, false, true>(c, a, R, combine);)
     return;
   }
-  // k_raw set: Qwen3's q/k norm + RoPE + cache append happen inside the attention launch (head_dim 128: every released Qwen3 size)
-  if (a.k_raw && c->d.head_dim == 128) { TGX_DT_SWITCH(c->dt, (launch_attn_g<DT, 128, true>(c, a, R, combine))) return; }
+  if (qkn) { TGX_DT_SWITCH(c->dt, (launch_attn_g<DT, 128, true>(c, a, R, combine))) return; }
   TGX_DT_SWITCH(c->dt, if (c->d.head_dim == 64) launch_attn_g<DT, 64>(c, a, R, combine); else launch_attn_g<DT, 128>(c, a, R, combine))
 }
 
 // dynamic LDS sizes of the matrix-core forms
-int attn_set_attrs(tgx_ctx* c) {
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 64, 8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<64, 8>()));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_F16, 64, 8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<64, 8>()));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 128, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<128>()));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_F16, 128, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<128>()));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_lds_bytes<128>()));
-  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_F16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_lds_bytes<128>()));
+template <bool P>
+static int attn_set_attrs_p(tgx_ctx* c) {
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 64, 8, true, false, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<64, 8>()));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_F16, 64, 8, true, false, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<64, 8>()));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 128, 4, true, true, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<128>()));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_F16, 128, 4, true, true, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_raw_lds_bytes<128>()));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_BF16, 128, 4, false, true, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_lds_bytes<128>()));
+  HIP_OK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&tgx::attn_decode_mfma_kernel<tgx::DT_F16, 128, 4, false, true, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tgx::attn_mfma_lds_bytes<128>()));
   return TGX_OK;
+}
+int attn_set_attrs(tgx_ctx* c) {
+  int rc = attn_set_attrs_p<false>(c);
+  return rc ? rc : attn_set_attrs_p<true>(c);
 }

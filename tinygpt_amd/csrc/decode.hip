@@ -120,7 +120,6 @@ bool oproj_sliced_ok(const tgx_ctx* c, int R, long long kv_stride) {
 // 600 20.2 / 21.0 / 21.8 -> 18.8 / 19.9 / 21.4 us, Llama-3.2-1B 33.3 / 34.2 / 35.5 -> 30.9 / 32.9 / 34.3; the split form is ahead from ~700 / ~900 keys.
 bool oproj_fused_capable(const tgx_ctx* c) {
   const tgx_model_desc& d = c->d;
-  if (c->kv_paged) return false;                     // (the o_proj strip rides in an unpaged-only attention form)
   if (!c->oproj_fused || c->gpt2 || c->dt == tgx::DT_F32 || !c->slab_acc) return false;
   return d.head_dim == 64 && !d.qk_norm && d.inter <= 16384 && d.hidden % 8 == 0 && d.hidden <= tgx::XACC_HIDDEN_MAX;
 }

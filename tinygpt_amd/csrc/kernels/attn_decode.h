@@ -90,7 +90,7 @@ __device__ __forceinline__ float attn_out_value(float acc, float L, int round16)
 template <int DT, int HD, int G, int NW = 4, bool QKN = false, bool RAW = false, int UNR_ = 4, bool OPJ = false, bool PAGED = false>
 __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) {
   static_assert(!OPJ || (G == 1 && !QKN && !RAW && DT != DT_F32), "OPJ: one head per workgroup, 16-bit storage");
-  static_assert(!PAGED || (!RAW && !OPJ), "paged KV: the plain and the Qwen3 forms");
+  static_assert(!PAGED || DT != DT_F32, "paged KV: 16-bit storage");
   typedef elem_t<DT> E;
   constexpr int LPT = HD / 8;         // lanes per token row
   constexpr int TPW = 64 / LPT;       // tokens per wave-load
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnArgs a) 
       else {
         const E e0 = f32_to_elem<DT>(x0), e1 = f32_to_elem<DT>(x1);
         if (g_base == 0) {                                                                // KVCacheManager::append, once per kv head
-          E* cache = const_cast<E*>(vec == G ? kbase : vbase) - part_i * 8 + (size_t)pos * HD;
+          E* cache = const_cast<E*>(vec == G ? kbase : vbase) - part_i * 8 + tok_off(pos);
           cache[p] = e0; cache[p + half] = e1;
         }
         raw_kv[vec - G][p] = elem_to_f32<DT>(e0); raw_kv[vec - G][p + half] = elem_to_f32<DT>(e1);

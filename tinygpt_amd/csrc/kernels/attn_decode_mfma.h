@@ -39,7 +39,9 @@ __host__ __device__ constexpr size_t attn_mfma_raw_lds_bytes() { return attn_mfm
 // same order, as rope_kv_rows_kernel (skinny.h): the two forms are bit-identical.
 // LOOKAHEAD: the next block's K / V loads are issued before the current block's arithmetic (a second register set: 309 registers at head_dim 64 = one
 // wave per SIMD).  Without it the RAW form fits 256: two workgroups per CU, for batches with more (row, kv head) workgroups than CUs.
-template <int DT, int HD, int NW = 4, bool RAW = false, bool LOOKAHEAD = true>
+// PAGED (round 6): K / V through the row's block table (common.h kv_paged_off) — a block of 64 keys lies inside one 128-token page, so a block's loads
+// share ONE table entry, read through the scalar cache (the block index is wave-uniform).
+template <int DT, int HD, int NW = 4, bool RAW = false, bool LOOKAHEAD = true, bool PAGED = false>
 __global__ __launch_bounds__(64 * NW) void attn_decode_mfma_kernel(const AttnArgs a) {
   typedef elem_t<DT> E;
   constexpr int LV = HD + 32;                 // 16-bit row stride of the wave's V tile ([key][d]; read with the transposing LDS read, as attn_prefill_kernel)
@@ -54,8 +56,14 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_mfma_kernel(const AttnArg
   const int kvh = blockIdx.x / nsp, sp = blockIdx.x - kvh * nsp;
   const int G = a.gfull;
   const float* q_row = a.q + blockIdx.y * a.q_stride;
-  const E* kbase = static_cast<const E*>(a.k_cache) + blockIdx.y * a.kv_stride + (size_t)kvh * a.max_ctx * HD;
-  const E* vbase = static_cast<const E*>(a.v_cache) + blockIdx.y * a.kv_stride + (size_t)kvh * a.max_ctx * HD;
+  const E* kbase = static_cast<const E*>(a.k_cache) + (PAGED ? (size_t)0 : blockIdx.y * a.kv_stride + (size_t)kvh * a.max_ctx * HD);
+  const E* vbase = static_cast<const E*>(a.v_cache) + (PAGED ? (size_t)0 : blockIdx.y * a.kv_stride + (size_t)kvh * a.max_ctx * HD);
+  const int* tbl = PAGED ? a.blk_tbl + blockIdx.y * a.tbl_stride : nullptr;
+  // element offset of key `t` (wave-uniform) from kbase / vbase
+  auto key_off = [&](int t) -> size_t {
+    if constexpr (PAGED) return kv_paged_off(tbl, a.kv_heads, kvh, __builtin_amdgcn_readfirstlane(t), HD);
+    else return (size_t)t * HD;
+  };
   float* part_row = a.part + blockIdx.y * a.part_stride;
   const int n_keys = a.pos[blockIdx.y] + 1;
   const bool qvalid = ql < G;
@@ -65,15 +73,16 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_mfma_kernel(const AttnArg
   constexpr bool PREF = HD == 64 && LOOKAHEAD;   // head_dim 128: a second register set spills (measured 40 -> 68 us per layer at 24k keys)
   u32x4 vvr[CH], kfr[2][KS], vnx[PREF ? CH : 1], knx[2][PREF ? KS : 1];
   auto load_block = [&](int blk, u32x4* vdst, u32x4 (*kdst)[KS]) {
-    const int key0 = blk * 64;
+    const int key0 = blk * 64, last = n_keys - 1 - key0;      // (>= 0: a block that is walked holds a key of the context)
+    const size_t o0 = key_off(key0);
 #pragma unroll
     for (int i = 0; i < CH; i++) {
       const int c = lane + 64 * i, row = c / CH, kc = c - row * CH;
-      vdst[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)min(key0 + row, n_keys - 1) * HD + kc * 8);     // clamped inside the context; masked by P = 0
+      vdst[i] = *reinterpret_cast<const u32x4*>(vbase + o0 + (size_t)min(row, last) * HD + kc * 8);     // clamped inside the context; masked by P = 0
     }
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
-      const E* krow = kbase + (size_t)min(key0 + 32 * sub + ql, n_keys - 1) * HD + 8 * hh;
+      const E* krow = kbase + o0 + (size_t)min(32 * sub + ql, last) * HD + 8 * hh;
 #pragma unroll
       for (int kk = 0; kk < KS; kk++) kdst[sub][kk] = *reinterpret_cast<const u32x4*>(krow + kk * 16);
     }
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_mfma_kernel(const AttnArg
       }
       if (vec < G) { sQ[vec * HD + p] = x0; sQ[vec * HD + p + half] = x1; }
       else {
-        E* cache = const_cast<E*>(vec == G ? kbase : vbase) + (size_t)pos * HD;     // KVCacheManager::append
+        E* cache = const_cast<E*>(vec == G ? kbase : vbase) + key_off(pos);         // KVCacheManager::append
         E* stage = reinterpret_cast<E*>(vec == G ? sKn : sVn);
         const E e0 = f32_to_elem<DT>(x0), e1 = f32_to_elem<DT>(x1);
         cache[p] = e0; cache[p + half] = e1;

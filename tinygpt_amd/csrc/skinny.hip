@@ -257,7 +257,7 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
     const int qs = launch_skinny(c, q);
     // the QKV product's finish (slab sums + bias, q / k norm, RoPE, cache append) inside the attention launch when that is the batched matrix-core form
     // (option attn.raw_fuse): one launch per layer less
-    const bool raw_fuse = !c->kv_paged && c->attn_raw_fuse && c->attn_direct && !(c->debug_skip & 1) && !(d.qk_norm && hd != 128) &&      // (the prologue that finishes the QKV rows is unpaged-only)
+    const bool raw_fuse = c->attn_raw_fuse && c->attn_direct && !(c->debug_skip & 1) && !(d.qk_norm && hd != 128) &&
                           (attn_batch_on_mfma(c, M) ? d.heads / d.kv_heads <= tgx::ATTN_RAW_GMAX : c->attn_raw_fuse >= 2);      // 2: the VALU direct forms as well
     // the direct-form attention of the step leaves its rows as 16-bit terms for the o_proj product (option skinny.dma_oproj: 1 = the matrix-core form only, 2 = every direct form)
     const bool attn_terms = c->skinny_dma && c->skinny_dma_oproj && c->attn_direct && (c->skinny_dma_oproj >= 2 || attn_batch_on_mfma(c, M)) && !(c->debug_skip & 1) &&
