@@ -71,7 +71,7 @@ struct Profiler {
 };
 
 // where the QKV product of a one-sequence prefill may finish its rows (prefill.hip launch_prefill -> launch_gemm)
-struct QkvEpi { bf16_t *q_hi = nullptr, *q_lo = nullptr, *k = nullptr, *v = nullptr; int past = 0; };     // past: the position of the pass's first row (RoPE, cache append)
+struct QkvEpi { bf16_t *q_hi = nullptr, *q_lo = nullptr, *k = nullptr, *v = nullptr; int past = 0; const int* tbl = nullptr; };     // past: the position of the pass's first row (RoPE, cache append)
 
 struct tgx_ctx {
   tgx_model_desc d{};

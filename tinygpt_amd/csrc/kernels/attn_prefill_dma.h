@@ -21,7 +21,9 @@
 
 namespace tgx {
 
-template <int DT>
+// PAGED (round 6): the workgroup's slice of the sequence's block table goes to LDS first; a DMA piece's source row then takes one LDS read (a tile of 64
+// keys lies inside one 128-token page, the clamped rows of the last tile in that page or an earlier one).
+template <int DT, bool PAGED = false>
 __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(const AttnPrefillArgs a) {
   constexpr int HD = 64, KS = HD / 16, NB = HD / 32, CH = HD / 8, NS = 3;
   constexpr int TILE = 64 * HD;                 // 16-bit elements of one K or V tile
@@ -60,9 +62,18 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(const AttnPref
     for (int r = 0; r < 16; r++) oacc[b][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const bf16_t* kbase = a.k_cache + (size_t)kvh * a.max_ctx * HD;
-  const bf16_t* vbase = a.v_cache + (size_t)kvh * a.max_ctx * HD;
+  const bf16_t* kbase = a.k_cache + (PAGED ? (size_t)0 : (size_t)kvh * a.max_ctx * HD);
+  const bf16_t* vbase = a.v_cache + (PAGED ? (size_t)0 : (size_t)kvh * a.max_ctx * HD);
   const int wg_last_pos = a.past + min(qblk * 128 + 127, a.S - 1);   // keys beyond it are never attended by this workgroup
+  __shared__ int stbl[PAGED ? 1024 : 1];
+  if constexpr (PAGED) {
+    for (int i = tid; i <= (wg_last_pos >> KV_BLOCK_SHIFT); i += 256) stbl[i] = a.blk_tbl[i];
+    __syncthreads();
+  }
+  auto key_off = [&](int key) -> size_t {      // element offset of a key's row from kbase / vbase
+    if constexpr (PAGED) return (((size_t)stbl[key >> KV_BLOCK_SHIFT] * a.kv_heads + kvh) * KV_BLOCK + (key & (KV_BLOCK - 1))) * (size_t)HD;
+    else return (size_t)key * HD;
+  };
   const int n_kt = wg_last_pos / 64 + 1;
   const bool wave_live = q0 < a.S;
   const int wave_last_pos = a.past + min(q0 + 31, a.S - 1);
@@ -83,12 +94,12 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_dma_kernel(const AttnPref
   auto issue_k = [&](int s, int slot) __attribute__((always_inline)) {
     const unsigned dst = lds_k + (unsigned)(slot * TILE * 2);
 #pragma unroll
-    for (int j = 0; j < 2; j++) dma_1k(kbase + (size_t)min(s * 64 + prw[j], wg_last_pos) * HD + kof[j], dst + (unsigned)((wv + 4 * j) * 1024));
+    for (int j = 0; j < 2; j++) dma_1k(kbase + key_off(min(s * 64 + prw[j], wg_last_pos)) + kof[j], dst + (unsigned)((wv + 4 * j) * 1024));
   };
   auto issue_v = [&](int s, int slot) __attribute__((always_inline)) {
     const unsigned dst = lds_v + (unsigned)(slot * TILE * 2);
 #pragma unroll
-    for (int j = 0; j < 2; j++) dma_1k(vbase + (size_t)min(s * 64 + prw[j], wg_last_pos) * HD + vof[j], dst + (unsigned)((wv + 4 * j) * 1024));
+    for (int j = 0; j < 2; j++) dma_1k(vbase + key_off(min(s * 64 + prw[j], wg_last_pos)) + vof[j], dst + (unsigned)((wv + 4 * j) * 1024));
   };
 
   f32x16 zero16;

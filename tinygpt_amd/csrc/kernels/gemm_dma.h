@@ -390,12 +390,15 @@ __global__ __launch_bounds__(512) void gemm_dma_qkv8_kernel(const GemmArgs a) {
         sh[rl * RS + p] = f32_to_elem<DT>(x0); sh[rl * RS + 32 + p] = f32_to_elem<DT>(x1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      bf16_t* const cache = (isk ? a.rope_k : a.rope_v) + (size_t)kvh * a.rope_max_ctx * 64;
+      // paged KV (rope_tbl set): rope_k / rope_v are the layer's pools and a row's page comes from the sequence's block table (common.h kv_paged_off)
+      bf16_t* const cache = (isk ? a.rope_k : a.rope_v) + (a.rope_tbl ? (size_t)0 : (size_t)kvh * a.rope_max_ctx * 64);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int rl = q * 8 + (lane >> 3), row = m0 + w4 * 32 + rl;
+        const int rl = q * 8 + (lane >> 3), row = m0 + w4 * 32 + rl, pos = a.rope_past + min(row, a.M - 1);
         const u32x4 v = *reinterpret_cast<const u32x4*>(sh + rl * RS + (lane & 7) * 8);
-        if (row < a.M) *reinterpret_cast<u32x4*>(cache + (size_t)(a.rope_past + row) * 64 + (lane & 7) * 8) = v;
+        const int page = a.rope_tbl ? a.rope_tbl[pos >> KV_BLOCK_SHIFT] : 0;
+        const size_t o = a.rope_tbl ? (((size_t)page * a.rope_kv_heads + kvh) * KV_BLOCK + (pos & (KV_BLOCK - 1))) * 64 : (size_t)pos * 64;
+        if (row < a.M) *reinterpret_cast<u32x4*>(cache + o + (lane & 7) * 8) = v;
       }
     }
     return;

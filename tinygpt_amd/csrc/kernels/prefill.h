@@ -312,6 +312,7 @@ struct GemmArgs {
   bf16_t *rope_k, *rope_v;           // this layer: [kv_heads][rope_max_ctx][64]
   const float *rope_cos, *rope_sin;  // [max_ctx][32]
   int rope_past, rope_max_ctx, rope_kv_heads;
+  const int* rope_tbl;           // paged KV: the sequence's block table (rope_k / rope_v = the layer's pools); nullptr = one slab per row
 };
 
 // GEMM_SILU epilogue of one 32 x 32 accumulator block (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)): even lanes hold

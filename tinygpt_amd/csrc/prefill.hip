@@ -1,6 +1,7 @@
 // prefill.hip — the batched prefill of the MI355X shim for 16-bit storage (kernels/prefill.h, gemm_dma.h): every product of S prompt positions on the
 // matrix cores, causal flash attention, RoPE + cache append.  == CausalLM::forward on [B,S] ids with an empty cache (GPTModel.h:51-56)
 #include "ctx.h"
+#include <type_traits>
 #include "kernels/prefill.h"
 #include "kernels/gemm_dma.h"
 #include "kernels/attn_prefill_dma.h"
@@ -252,7 +253,7 @@ static void launch_gemm(tgx_ctx* c, int epi, const ebyte* B_, const ebyte* bias_
     if (c->qkv_epi.q_hi && c->d.head_dim == 64 && !c->d.qk_norm && defer) {
       // ... and RoPE + cache append + the q split in its epilogue (one sequence, head_dim 64): no fp32 QKV matrix, no rope_kv_split launch
       g.rope_q_hi = c->qkv_epi.q_hi; g.rope_q_lo = c->qkv_epi.q_lo; g.rope_k = c->qkv_epi.k; g.rope_v = c->qkv_epi.v;
-      g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.rope_past = c->qkv_epi.past; g.rope_max_ctx = c->d.max_ctx; g.rope_kv_heads = c->d.kv_heads;
+      g.rope_cos = c->rope_cos; g.rope_sin = c->rope_sin; g.rope_past = c->qkv_epi.past; g.rope_max_ctx = c->d.max_ctx; g.rope_kv_heads = c->d.kv_heads; g.rope_tbl = c->qkv_epi.tbl;
       TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::gemm_dma_qkv8_kernel<DT, true>), dim3(nwg), dim3(512), (size_t)2 * (3 * 128 + 128 + 64) * 64 * 2, c->stream, g))
       *defer = 0;         // the rows are finished: the caller skips its RoPE / cache-append launch
       return;
@@ -302,47 +303,35 @@ void launch_attn_prefill(tgx_ctx* c, const tgx::AttnPrefillArgs& a_, bool allow_
   const int hd = c->d.head_dim;
   const int nqb = (a.S + 127) / 128, nwg = nqb * a.heads;
   const size_t lds1 = (size_t)(64 * (hd + 8) + 64 * (hd + 32)) * 2;      // one K tile | V tile pair (kernels/prefill.h)
-  if (a.blk_tbl) {      // paged KV: the key-split form from two query blocks on, else the plain one (the LDS-DMA form reads unpaged rows)
-    if (nqb >= 2) {
-      a.heavy_first = 1;
-      const dim3 grid(a.heads, nqb), blk(512);
-      TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64, 2, 2, true>), grid, blk, 2 * lds1, c->stream, a);
-                             else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128, 1, 2, true>), grid, blk, 2 * lds1, c->stream, a))
-    } else {
-      a.heavy_first = 0;
-      const dim3 grid(nqb, a.heads), blk(256);
-      TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64, 2, 1, true>), grid, blk, lds1, c->stream, a);
-                             else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128, 1, 1, true>), grid, blk, lds1, c->stream, a))
-    }
-    return;
-  }
   // head_dim 64, three or more workgroups per CU (prompts from ~3k tokens at 32 heads): K / V tiles by LDS-DMA, the next tile's scores under the current tile's
   // softmax (kernels/attn_prefill_dma.h; bit-identical to attn_prefill_kernel): S = 4096 203 -> 177 us per layer, 8192 730 -> 632; at S = 2048 (one round of 512
   // workgroups) the launch lasts as long as its heaviest workgroup's chain of tiles in either form (62-63 us).  Option prefill.attn_dma: 0 never, 1 auto, 2 always
   if (hd == 64 && (c->attn_dma == 2 || (c->attn_dma == 1 && allow_lean && nwg >= 3 * c->num_cus))) {
     a.heavy_first = 1;
     const dim3 grid(a.heads, nqb), blk(256);
-    TGX_DT16_SWITCH(c->dt, hipLaunchKernelGGL((tgx::attn_prefill_dma_kernel<DT>), grid, blk, (size_t)2 * 3 * 64 * 64 * 2, c->stream, a))
+    TGX_DT16_SWITCH(c->dt, if (a.blk_tbl) hipLaunchKernelGGL((tgx::attn_prefill_dma_kernel<DT, true>), grid, blk, (size_t)2 * 3 * 64 * 64 * 2, c->stream, a);
+                           else hipLaunchKernelGGL((tgx::attn_prefill_dma_kernel<DT, false>), grid, blk, (size_t)2 * 3 * 64 * 64 * 2, c->stream, a))
     return;
   }
   // key split inside the workgroup (attn_prefill_kernel KP = 2; option prefill.attn_ksplit: 0 never, 1 auto, 2 always): eight waves, the odd tiles on waves 4-7,
   // one merge at the end — half the chain of tiles per wave.  head_dim 128: S = 2048 94 -> 91 us per layer, 4096 401 -> 305, 8192 1284 -> 1086 (always);
   // head_dim 64 below three workgroups per CU: S = 2048 62 -> 55-56 us in isolation, 68.1 -> 61.3 in the model's trace (profiles/r05_prefill.txt section 5)
   const bool ksplit = nqb >= 2 && (c->attn_ksplit == 2 || (c->attn_ksplit == 1 && (hd == 128 || nwg < 3 * c->num_cus)));
-  if (ksplit) {
-    a.heavy_first = 1;
-    const dim3 grid(a.heads, nqb), blk(512);
-    TGX_DT16_SWITCH(c->dt, if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64, 2, 2>), grid, blk, 2 * lds1, c->stream, a);
-                           else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128, 1, 2>), grid, blk, 2 * lds1, c->stream, a))
-    return;
-  }
-  a.heavy_first = 0;
-  const dim3 grid(nqb, a.heads), blk(256);
   // head_dim 64 with three or more workgroups per CU: the one-tile look-ahead form at three waves per SIMD (prefill.h)
   const bool lean = allow_lean && hd == 64 && nwg >= 3 * c->num_cus;
-  TGX_DT16_SWITCH(c->dt, if (lean) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64, 1>), grid, blk, lds1, c->stream, a);
-                         else if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64>), grid, blk, lds1, c->stream, a);
-                         else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128, 1>), grid, blk, lds1, c->stream, a))     // head_dim 128: two waves per SIMD only in this form (95 vs 138 µs per layer at S = 2048)
+  a.heavy_first = ksplit ? 1 : 0;
+  const dim3 gridk(a.heads, nqb), blkk(512), grid(nqb, a.heads), blk(256);
+  auto go = [&](auto paged) {        // (paged KV: the same forms through the sequence's block table)
+    constexpr bool P = decltype(paged)::value;
+    TGX_DT16_SWITCH(c->dt,
+      if (ksplit) {
+        if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64, 2, 2, P>), gridk, blkk, 2 * lds1, c->stream, a);
+        else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128, 1, 2, P>), gridk, blkk, 2 * lds1, c->stream, a);
+      } else if (lean) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64, 1, 1, P>), grid, blk, lds1, c->stream, a);
+      else if (hd == 64) hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 64, 2, 1, P>), grid, blk, lds1, c->stream, a);
+      else hipLaunchKernelGGL((tgx::attn_prefill_kernel<DT, 128, 1, 1, P>), grid, blk, lds1, c->stream, a))     // head_dim 128: two waves per SIMD only in this form (95 vs 138 µs per layer at S = 2048)
+  };
+  if (a.blk_tbl) go(std::true_type{}); else go(std::false_type{});
 }
 // RoPE + cache append + q split of S prompt rows of one batch row
 void launch_rope_kv_split(tgx_ctx* c, const tgx::RopeKvArgs& a, int S) {
@@ -390,9 +379,9 @@ void launch_prefill(tgx_ctx* c, int row0, int NB, int S, int past) {
     pend = 1;
     int qsl = 1;
     c->qkv_epi = QkvEpi{};
-    if (NB == 1 && !c->kv_paged) {      // one sequence: the QKV product may finish its rows itself (its cache append is unpaged) (launch_gemm: gemm_dma_qkv8_kernel<.., ROPE>)
+    if (NB == 1) {      // one sequence: the QKV product may finish its rows itself (launch_gemm: gemm_dma_qkv8_kernel<.., ROPE>)
       RowState& r0 = c->rows[(size_t)row0];
-      c->qkv_epi.q_hi = c->ws_qh; c->qkv_epi.q_lo = c->ws_ql; c->qkv_epi.past = past;
+      c->qkv_epi.q_hi = c->ws_qh; c->qkv_epi.q_lo = c->ws_ql; c->qkv_epi.past = past; c->qkv_epi.tbl = r0.tbl;
       c->qkv_epi.k = reinterpret_cast<bf16_t*>(r0.kcache) + (size_t)l * kv_layer; c->qkv_epi.v = reinterpret_cast<bf16_t*>(r0.vcache) + (size_t)l * kv_layer;
     }
     launch_gemm(c, tgx::GEMM_STORE, w.wqkv, w.bqkv, c->ws_out, M, qd + 2 * kvd, H, qd + 2 * kvd, /*three_terms=*/three, nullptr, nullptr, /*three_from=*/qd, &qsl);   // Q columns: two terms
