@@ -205,3 +205,60 @@ def test_matrix_core_prefill_into_a_paged_cache(name, S, dtype, hip):
     np.testing.assert_array_equal(ta, tb)
     for x, y in zip(k0a + k1a, k0b + k1b):
         np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("fam,seed", [("llama_tiny", 1), ("llama_tiny", 2), ("mistral_tiny", 3), ("qwen3_tiny", 4)])
+def test_serving_churn_under_a_budget_equals_the_unpaged_batch(fam, seed, hip):
+    """A serving loop as a host would run it: six rows, sequences of random lengths admitted against a token budget (reserved up
+    front from kv.free_tokens' arithmetic), decoded together in calls of random length, retired and replaced — 60 ticks.  The paged context (1280 tokens for
+    rows that would own 6 x 384 = 2304 as slabs) and an unpaged one execute the same calls: every live row's tokens are equal call by call, the free-block
+    count follows ceil(length / 128) per live row exactly at every tick, and every block is back at the end."""
+    B, CTX, BUDGET = 6, 384, 1280
+    paged, g = make(fam, hip, max_batch=B, max_ctx=CTX, budget=BUDGET)
+    plain, _ = make(fam, hip, max_batch=B, max_ctx=CTX)
+    V = paged.desc.vocab
+    rng = np.random.default_rng(seed)
+    blocks = lambda n: (n + 127) // 128
+    length = [0] * B          # tokens in the row's cache; 0 = idle
+    target = [0] * B          # its final length
+    served = 0
+    # the batch is born by a whole-batch call (rows 1..5 retired at once, so that each starts idle)
+    first = rng.integers(0, V, size=(B, 3)).astype(np.int64)
+    for m in (paged, plain):
+        m.forward(first); m.sample(GREEDY)
+        for r in range(B):
+            m.reset_row(r)
+    for tick in range(60):
+        reserved = sum(blocks(t) for t in target) * 128
+        for r in range(B):
+            if length[r] == 0 and rng.random() < 0.6:
+                L, new = int(rng.integers(2, 180)), int(rng.integers(1, 120))
+                if L + new > CTX or reserved + blocks(L + new) * 128 > BUDGET:
+                    continue                                   # admission control: the sequence waits
+                prompt = rng.integers(0, V, size=L).astype(np.int64)
+                ta = []
+                for m in (paged, plain):
+                    m.forward_row(r, prompt); ta.append(int(m.sample_row(r, GREEDY)))
+                assert ta[0] == ta[1], (tick, r)
+                length[r], target[r] = L, L + new
+                reserved += blocks(L + new) * 128
+        live = [r for r in range(B) if length[r]]
+        if live:
+            n = int(min(rng.integers(1, 24), min(target[r] - length[r] for r in live)))
+            if n > 0:
+                da, db = paged.decode(n, GREEDY), plain.decode(n, GREEDY)
+                np.testing.assert_array_equal(da[:, live], db[:, live], err_msg=f"tick {tick}")
+                for r in live:
+                    length[r] += n
+        assert paged.get_option("kv.free_tokens") == BUDGET - sum(blocks(x) for x in length) * 128, tick
+        for r in live:
+            assert paged.past_length_row(r) == plain.past_length_row(r) == length[r]
+            if length[r] >= target[r]:
+                for m in (paged, plain):
+                    m.reset_row(r)
+                length[r] = target[r] = 0
+                served += 1
+    assert served >= 8                                         # the loop really turned sequences over
+    for r in range(B):
+        paged.reset_row(r)
+    assert paged.get_option("kv.free_tokens") == BUDGET
