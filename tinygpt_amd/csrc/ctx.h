@@ -311,6 +311,7 @@ int attn_set_attrs(tgx_ctx* c);
 // ---- sampler.hip (kernels/sampler.h)
 void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool advance_pos, bool log_step);
 void launch_probs(tgx_ctx* c, int row, const tgx_sampler_cfg& cfg);
+void launch_bump_step(tgx_ctx* c);
 int sampler_alloc(tgx_ctx* c);
 // ---- prefill.hip (kernels/prefill.h, gemm_dma.h)
 bool prefill_shapes_ok(const tgx_model_desc& d);

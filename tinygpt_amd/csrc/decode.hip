@@ -295,8 +295,9 @@ void launch_finalize_rows(tgx_ctx* c, int row0, int M) {
   fa.f = make_finalize_args(c, row0, /*advance_pos=*/true, /*log_step=*/true);
   fa.part_stride = c->lm_grid; fa.x_stride = c->d.hidden;
   TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::finalize_rows_kernel<DT>, dim3(M), dim3(256), 0, c->stream, fa))
-  if (row0 + M == c->batch) hipLaunchKernelGGL(tgx::bump_step_kernel, dim3(1), dim3(64), 0, c->stream, c->step);
+  if (row0 + M == c->batch) launch_bump_step(c);
 }
+void launch_bump_step(tgx_ctx* c) { hipLaunchKernelGGL(tgx::bump_step_kernel, dim3(1), dim3(64), 0, c->stream, c->step); }
 
 // prefill by steps: chunk row r <- embedding of prompt token r at position pos0 + r
 void launch_embed_chunk(tgx_ctx* c, const long long* ids, int R, int pos0) {

@@ -354,22 +354,30 @@ __global__ __launch_bounds__(SAMP_WG) void samp_compact_kernel(const SampArgs a)
 
 // ---- the draw: one workgroup per row ----------------------------------------------------------------------------------
 struct SampPickArgs {
-  SampArgs s;
+  SampArgs s;                       // the launch's first row (rows at the strides inside)
   int nwg;
   const unsigned long long* seed;   // device word
-  FinalizeArgs fin;                 // token publish / rings / embedding (part_* unused)
-};
+  FinalizeArgs fin;                 // token publish / rings / embedding of the launch's first row (part_* unused); row r of the launch = blockIdx.y:
+  long long x_stride;               // tok + r, pos + r, x + r * x_stride (the rows' state lives in slabs); a launch of several rows leaves the step
+};                                  // counter to bump_step_kernel (fin.bump_step = 0): its rows must all read the same step value
+
+// row r's view of the launch's finalize arguments
+__device__ __forceinline__ FinalizeArgs samp_row_fin(const SampPickArgs& pa, int r) {
+  FinalizeArgs f = pa.fin;
+  f.tok += r; f.pos += r; f.x += (size_t)r * pa.x_stride; f.row = pa.fin.row + r;
+  return f;
+}
 
 // the words every draw needs; their loads leave at the top of the launch (one workgroup on an idle chip: each dependent round trip costs ~1 us)
 struct SampDrawWords {
   unsigned long long seed;
   int pos, step;
 };
-__device__ __forceinline__ SampDrawWords samp_draw_words(const SampPickArgs& pa) {
+__device__ __forceinline__ SampDrawWords samp_draw_words(const unsigned long long* seed, const FinalizeArgs& fin) {
   SampDrawWords w;
-  w.seed = *pa.seed;
-  w.pos = *pa.fin.pos;
-  w.step = pa.fin.log ? *pa.fin.step : 0;
+  w.seed = *seed;
+  w.pos = *fin.pos;
+  w.step = fin.log ? *fin.step : 0;
   return w;
 }
 
@@ -379,17 +387,16 @@ __device__ __forceinline__ SampDrawWords samp_draw_words(const SampPickArgs& pa)
 // the tile the probabilities are the oracle's floats (e * inv) accumulated in double on top of the tiles below.  The two agree to ~1e-7 of the total:
 // a draw that close to a tile boundary takes the boundary's neighbour (the fallbacks below), every other draw is the oracle's.
 template <int DT>
-__device__ __forceinline__ void samp_draw_and_publish(const SampPickArgs& pa, int row, double (&pw)[4], const SampDrawWords& dw, float mx, float z, float z0,
-                                                      unsigned long long thr_k, unsigned long long thr_p, double* shd) {
+__device__ __forceinline__ void samp_draw_and_publish(const SampArgs& a, const FinalizeArgs& fin, int nwg, int row, double (&pw)[4], const SampDrawWords& dw, float mx,
+                                                      float z, float z0, unsigned long long thr_k, unsigned long long thr_p, double* shd) {
   __shared__ int s_wg, s_pick, s_last, s_pos;
   __shared__ double s_run, s_u;
-  const SampArgs& a = pa.s;
-  const int tid = threadIdx.x, nwg = pa.nwg;
+  const int tid = threadIdx.x;
   const float inv = 1.0f / z;
   const double invd = (double)inv;
   if (tid == 0) {
-    unsigned long long s = dw.seed * 0x9E3779B97F4A7C15ull + (unsigned long long)(dw.pos + pa.fin.advance_pos) * 0xD1342543DE82EF95ull +
-                           (unsigned long long)pa.fin.row;
+    unsigned long long s = dw.seed * 0x9E3779B97F4A7C15ull + (unsigned long long)(dw.pos + fin.advance_pos) * 0xD1342543DE82EF95ull +
+                           (unsigned long long)fin.row;
     s_u = (double)(splitmix64(s) >> 11) * (1.0 / 9007199254740992.0);
     s_wg = 0x7fffffff; s_pick = 0x7fffffff; s_last = -1;
   }
@@ -419,7 +426,7 @@ __device__ __forceinline__ void samp_draw_and_publish(const SampPickArgs& pa, in
   __syncthreads();
   const int wsel = s_wg;
   const double run0 = s_run;
-  SAMP_STAMP(pa.s.sc + row, 6);
+  SAMP_STAMP(a.sc + row, 6);
   __syncthreads();
   if (tid == 0) s_last = -1;                           // reused below for the last kept ENTRY of the selected tile
   __syncthreads();
@@ -460,27 +467,27 @@ __device__ __forceinline__ void samp_draw_and_publish(const SampPickArgs& pa, in
     int pick = s_pick != 0x7fffffff ? s_pick : s_last;   // no hit inside the selected tile: its last kept entry
     if ((unsigned)pick >= (unsigned)a.V) pick = 0;       // all-NaN logits: stay inside the embedding table
     s_pick = pick;
-    *pa.fin.tok = pick;
-    const int np = dw.pos + (pa.fin.advance_pos ? 1 : 0);
-    if (pa.fin.advance_pos) *pa.fin.pos = np;
-    s_pos = np < pa.fin.n_pos ? np : pa.fin.n_pos - 1;
-    if (pa.fin.log) {
+    *fin.tok = pick;
+    const int np = dw.pos + (fin.advance_pos ? 1 : 0);
+    if (fin.advance_pos) *fin.pos = np;
+    s_pos = np < fin.n_pos ? np : fin.n_pos - 1;
+    if (fin.log) {
       const int st = dw.step;
-      pa.fin.tok_log[(st % pa.fin.log_cap) * pa.fin.rows + pa.fin.row] = pick;
-      if (pa.fin.host_ring) pa.fin.host_ring[(st % pa.fin.ring_cap) * pa.fin.rows + pa.fin.row] = pick;
-      if (pa.fin.bump_step) *pa.fin.step = st + 1;
+      fin.tok_log[(st % fin.log_cap) * fin.rows + fin.row] = pick;
+      if (fin.host_ring) fin.host_ring[(st % fin.ring_cap) * fin.rows + fin.row] = pick;
+      if (fin.bump_step) *fin.step = st + 1;
     }
   }
-  SAMP_STAMP(pa.s.sc + row, 7);
+  SAMP_STAMP(a.sc + row, 7);
   __syncthreads();
-  gather_embedding<DT>(pa.fin.embed, s_pick, pa.fin.x, pa.fin.H, pa.fin.wpe, pa.fin.wpe ? s_pos : 0);
+  gather_embedding<DT>(fin.embed, s_pick, fin.x, fin.H, fin.wpe, fin.wpe ? s_pos : 0);
   __syncthreads();
-  SAMP_STAMP(pa.s.sc + row, 8);
-  SAMP_STAMP_NEXT(pa.s.sc + row);
+  SAMP_STAMP(a.sc + row, 8);
+  SAMP_STAMP_NEXT(a.sc + row);
 }
 
 // ---- the tail: ONE workgroup per row takes the remaining four digits over the compacted list and derives the filter's threshold.  PICK (the last
-// filter of a chain without min-p; one launch per row, pa.s pre-offset to the row): it also derives the kept set's normaliser and the kept mass of every
+// filter of a chain without min-p): it also derives the kept set's normaliser and the kept mass of every
 // vocabulary tile (bulk sums of the compaction pass + the list's kept entries) and draws — the step's token leaves this launch
 template <int MODE, bool PICK, int DT>
 __global__ __launch_bounds__(SAMP_WG) void samp_tail_kernel(const SampPickArgs pa) {
@@ -490,7 +497,8 @@ __global__ __launch_bounds__(SAMP_WG) void samp_tail_kernel(const SampPickArgs p
   __shared__ unsigned long long lds_hist[SAMP_BINS];
   __shared__ unsigned int lds_cnt[SAMP_BINS];
   const SampArgs& a = pa.s;
-  const int row = PICK ? 0 : blockIdx.y, tid = threadIdx.x, nwg = pa.nwg;
+  const int row = blockIdx.y, tid = threadIdx.x, nwg = pa.nwg;
+  const FinalizeArgs fin = samp_row_fin(pa, row);
   SampScratch* sc = a.sc + row;
   const unsigned long long* lc = a.list_comp + (size_t)row * a.V;
   const float* lv = a.list_v + (size_t)row * a.V;
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(SAMP_WG) void samp_tail_kernel(const SampPickArgs p
   double aw[4] = {0.0, 0.0, 0.0, 0.0};    // the compaction pass's bulk sums of this thread's four tiles (in flight beside the list)
   unsigned long long thr_k_prev = 0ull;
   if (PICK) {
-    dw = samp_draw_words(pa);
+    dw = samp_draw_words(pa.seed, fin);
 #pragma unroll
     for (int j = 0; j < 4; j++) { const int w = tid * 4 + j; const double t = sc->wg_above[min(w, nwg - 1)]; aw[j] = w < nwg ? t : 0.0; }
     if (MODE == 1 && a.top_k > 0) thr_k_prev = sc->thr_k;
@@ -608,7 +616,7 @@ __global__ __launch_bounds__(SAMP_WG) void samp_tail_kernel(const SampPickArgs p
 #pragma unroll
   for (int j = 0; j < 4; j++) pw[j] = aw[j] + (double)lds_hist[tid * 4 + j] * (1.0 / 1099511627776.0);
   __syncthreads();                        // shd is reused by the draw
-  samp_draw_and_publish<DT>(pa, row, pw, dw, mx, z, 0.f, MODE == 0 ? thr : thr_k_prev, MODE == 1 ? thr : 0ull, shd);
+  samp_draw_and_publish<DT>(a, fin, nwg, row, pw, dw, mx, z, 0.f, MODE == 0 ? thr : thr_k_prev, MODE == 1 ? thr : 0ull, shd);
   for (int b = tid; b < SAMP_BINS; b += SAMP_WG) { if (MODE == 0) sc->cnt[0][b] = 0u; else sc->mass[0][b] = 0ull; }
   if (tid == 0) sc->list_n = 0u;
 }
@@ -669,21 +677,22 @@ __global__ __launch_bounds__(SAMP_WG) void samp_pick_kernel(const SampPickArgs p
   __shared__ float shf[4];
   __shared__ double shd[4];
   const SampArgs& a = pa.s;
-  const int tid = threadIdx.x, nwg = pa.nwg;
-  SampScratch* sc = a.sc;
+  const int row = blockIdx.y, tid = threadIdx.x, nwg = pa.nwg;
+  const FinalizeArgs fin = samp_row_fin(pa, row);
+  SampScratch* sc = a.sc + row;
   SAMP_STAMP(sc, 4);
   double pw[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) { const int w = tid * 4 + j; pw[j] = sc->wg_z2[min(w, nwg - 1)]; }
-  const SampDrawWords dw = samp_draw_words(pa);
+  const SampDrawWords dw = samp_draw_words(pa.seed, fin);
   const unsigned long long thr_k = a.top_k > 0 ? sc->thr_k : 0ull, thr_p = a.top_p < 1.f ? sc->thr_p : 0ull;
-  const float mx = samp_row_max(a, 0, shf);
+  const float mx = samp_row_max(a, row, shf);
   const float z0 = a.min_p > 0.f ? samp_ordered_sum(sc->wg_z, nwg, shd) : 0.f;
   __syncthreads();
   const float z = samp_ordered_sum(sc->wg_z2, nwg, shd);
   __syncthreads();
   SAMP_STAMP(sc, 5);
-  samp_draw_and_publish<DT>(pa, 0, pw, dw, mx, z, z0, thr_k, thr_p, shd);
+  samp_draw_and_publish<DT>(a, fin, nwg, row, pw, dw, mx, z, z0, thr_k, thr_p, shd);
 }
 
 }  // namespace tgx

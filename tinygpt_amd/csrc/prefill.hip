@@ -4,6 +4,7 @@
 #include <type_traits>
 #include "kernels/prefill.h"
 #include "kernels/gemm_dma.h"
+#include "kernels/gemm_dma_qkv.h"
 #include "kernels/attn_prefill_dma.h"
 #include "kernels/gemm_f32.h"
 

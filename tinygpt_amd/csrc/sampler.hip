@@ -28,31 +28,28 @@ void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool
   tgx::SampArgs a = samp_args(c, row0, cfg);
   const bool setK = cfg.top_k > 0, setP = cfg.top_p < 1.f, setM = cfg.min_p > 0.f;
   const int nwg = (a.V + tgx::SAMP_TILE - 1) / tgx::SAMP_TILE;
-  const dim3 grid(nwg, R), blk(tgx::SAMP_WG), one(1);
-  // per row: the draw's arguments (everything pre-offset to the row) — the last launch of the chain
-  auto pick_args = [&](int b, const tgx::SampArgs& now) {
+  const dim3 grid(nwg, R), blk(tgx::SAMP_WG);
+  // the draw's arguments — the last launch of the chain, one workgroup per row (blockIdx.y).  Several rows: the step counter moves afterwards, once (as
+  // launch_finalize_rows: rows running concurrently must all read the same step value)
+  auto pick_args = [&](const tgx::SampArgs& now) {
     tgx::SampPickArgs pa{};
-    pa.s = samp_args(c, b, cfg);
-    pa.s.mx_ready = now.mx_ready;
+    pa.s = now;
     pa.nwg = nwg; pa.seed = c->seed_dev;
-    pa.fin = make_finalize_args(c, b, advance_pos, log_step);
+    pa.fin = make_finalize_args(c, row0, advance_pos, log_step);
+    pa.x_stride = c->d.hidden;
+    if (R > 1) pa.fin.bump_step = 0;
     return pa;
   };
+  auto bump = [&]() { if (R > 1 && log_step && row0 + R == c->batch) launch_bump_step(c); };
   // a filter = first digit over the vocabulary, compaction of the threshold's bin, the tail (four digits, threshold) in one workgroup; the tail of the
   // chain's LAST filter also draws when no min-p follows
   a.mx_ready = 0;                 // the first launch that needs max(logits / T) reduces the lm_head partials and leaves it in sc->mx for the others
   auto tail = [&](auto mode, bool draws) {
     constexpr int MODE = decltype(mode)::value;
-    if (!draws) {
-      tgx::SampPickArgs pa{};
-      pa.s = a; pa.nwg = nwg;
-      hipLaunchKernelGGL((tgx::samp_tail_kernel<MODE, false, 0>), dim3(1, R), blk, 0, c->stream, pa);
-      return;
-    }
-    for (int b = row0; b < row0 + R; b++) {
-      const tgx::SampPickArgs pa = pick_args(b, a);
-      TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL((tgx::samp_tail_kernel<MODE, true, DT>), one, blk, 0, c->stream, pa))
-    }
+    const tgx::SampPickArgs pa = pick_args(a);
+    if (!draws) { hipLaunchKernelGGL((tgx::samp_tail_kernel<MODE, false, 0>), dim3(1, R), blk, 0, c->stream, pa); return; }
+    TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL((tgx::samp_tail_kernel<MODE, true, DT>), dim3(1, R), blk, 0, c->stream, pa))
+    bump();
   };
   if (setK) {
     hipLaunchKernelGGL(tgx::samp_level0_kernel<0>, grid, blk, 0, c->stream, a);       // (counts: no maximum needed)
@@ -71,9 +68,10 @@ void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool
   if (setM) { hipLaunchKernelGGL(tgx::samp_sum_kernel<0>, grid, blk, 0, c->stream, a); a.mx_ready = 1; }
   hipLaunchKernelGGL(tgx::samp_sum_kernel<1>, grid, blk, 0, c->stream, a);
   a.mx_ready = 1;
-  for (int b = row0; b < row0 + R; b++) {
-    const tgx::SampPickArgs pa = pick_args(b, a);
-    TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::samp_pick_kernel<DT>, one, blk, 0, c->stream, pa))
+  {
+    const tgx::SampPickArgs pa = pick_args(a);
+    TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::samp_pick_kernel<DT>, dim3(1, R), blk, 0, c->stream, pa))
+    bump();
   }
 }
 
