@@ -116,42 +116,55 @@ __device__ __forceinline__ float samp_block_max(float v, float* sh4) {
   __syncthreads();
   return fmaxf(fmaxf(sh4[0], sh4[1]), fmaxf(sh4[2], sh4[3]));
 }
+// 64-lane inclusive prefix sums of 64-bit values on the DPP crossbar (no LDS traffic: a __shfl of a double is two ds_bpermute round trips per step, and the
+// single-workgroup tail of a sampled step is a chain of such scans): shifts by 1 / 2 / 4 / 8 inside the rows of 16 lanes, then the two row broadcasts of the
+// GFX9 wave64 scan.  A lane without a source receives 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_mov64(unsigned long long v) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)v, CTRL, ROW_MASK, 0xf, false);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_scan_incl(unsigned long long v) {
+  v += dpp_mov64<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_mov64<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_mov64<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_mov64<0x118, 0xf>(v);   // row_shr:8
+  v += dpp_mov64<0x142, 0xa>(v);   // row_bcast:15 -> rows 1, 3
+  v += dpp_mov64<0x143, 0xc>(v);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+__device__ __forceinline__ double wave_scan_incl(double v) {
+#define TGX_SCAN_STEP(CTRL, RM) v += __builtin_bit_cast(double, dpp_mov64<CTRL, RM>(__builtin_bit_cast(unsigned long long, v)))
+  TGX_SCAN_STEP(0x111, 0xf); TGX_SCAN_STEP(0x112, 0xf); TGX_SCAN_STEP(0x114, 0xf); TGX_SCAN_STEP(0x118, 0xf); TGX_SCAN_STEP(0x142, 0xa); TGX_SCAN_STEP(0x143, 0xc);
+#undef TGX_SCAN_STEP
+  return v;
+}
 __device__ __forceinline__ double samp_block_sum_d(double v, double* sh4) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const double inc = wave_scan_incl(v);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 63) sh4[threadIdx.x >> 6] = inc;
   __syncthreads();
   return ((sh4[0] + sh4[1]) + sh4[2]) + sh4[3];
 }
-// sum of the values held by threads with a HIGHER thread index (exclusive suffix sum) and the block total
+// sum of the values held by threads with a HIGHER thread index (exclusive suffix sum) and the block total (integers: total - inclusive prefix, exact)
 __device__ __forceinline__ unsigned long long samp_suffix_excl(unsigned long long v, unsigned long long* sh4, unsigned long long& total) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  unsigned long long inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const unsigned long long t = __shfl_down(inc, off, 64);
-    if (lane + off < 64) inc += t;
-  }
+  const int w = threadIdx.x >> 6;
+  const unsigned long long inc = wave_scan_incl(v);
   __syncthreads();
-  if (lane == 0) sh4[w] = inc;
+  if ((threadIdx.x & 63) == 63) sh4[w] = inc;
   __syncthreads();
-  unsigned long long above = 0;
-  for (int k = w + 1; k < 4; k++) above += sh4[k];
+  unsigned long long below = 0;
+  for (int k = 0; k < w; k++) below += sh4[k];
   total = sh4[0] + sh4[1] + sh4[2] + sh4[3];
-  return inc - v + above;
+  return total - (below + inc);
 }
 // sum of the values held by threads with a LOWER thread index (exclusive prefix sum), double
 __device__ __forceinline__ double samp_prefix_excl_d(double v, double* sh4) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  double inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const double t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
+  const int w = threadIdx.x >> 6;
+  const double inc = wave_scan_incl(v);
   __syncthreads();
-  if (lane == 63) sh4[w] = inc;
+  if ((threadIdx.x & 63) == 63) sh4[w] = inc;
   __syncthreads();
   double below = 0.0;
   for (int k = 0; k < w; k++) below += sh4[k];
