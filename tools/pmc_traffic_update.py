@@ -23,6 +23,6 @@ for f in ("gemv.h", "common.h"):          # == bench.py kernel_source_sha256(): 
 rec = json.load(open(path))
 rec.setdefault("by_config", {})[f"{model}:{dtype}"] = {
     "gateup_bytes_per_launch": int(round(kib * 1024 * 2)), "fetch_size_kib_avg": round(kib, 2), "calls": calls, "kernel": name[:100], "kernel_src_sha256": h.hexdigest(),
-    "source": "tools/bench_configs.sh (rocprofv3 --pmc FETCH_SIZE pass of bench.py --no-graph, x2 gfx950 correction), round 5"}
+    "source": "tools/bench_configs.sh (rocprofv3 --pmc FETCH_SIZE pass of bench.py --no-graph, x2 gfx950 correction), round 6"}
 json.dump(rec, open(path, "w"), indent=1)
 print(f"{model}:{dtype} gate_up FETCH_SIZE {kib:.1f} KiB x 2 = {kib * 2048 / 1e6:.2f} MB per launch ({calls} launches)")
