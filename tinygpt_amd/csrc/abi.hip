@@ -680,13 +680,14 @@ int tgx_finalize(tgx_ctx* c) {
     r.attn_part = c->ch_part + k * c->attn_part_row; r.pos = c->ch_pos + k;
   }
   c->log_cap = d.max_ctx > 1024 ? d.max_ctx : 1024;
-  if ((rc = dev_alloc(c, &c->step, 1))) return rc;
+  if ((rc = dev_alloc(c, &c->step, 1)) || (rc = dev_alloc(c, &c->step_done, 1))) return rc;
   if ((rc = dev_alloc(c, &c->seed_dev, 1))) return rc;
   if ((rc = sampler_alloc(c))) return rc;
   if ((rc = dev_alloc(c, &c->scratch_x, (size_t)H))) return rc;
   HIP_OK(c, hipMemset(c->scratch_x, 0, (size_t)H * 4));
   if ((rc = dev_alloc(c, &c->tok_log, (size_t)c->log_cap * d.max_batch))) return rc;
   HIP_OK(c, hipMemset(c->step, 0, 4));
+  HIP_OK(c, hipMemset(c->step_done, 0, 4));
   HIP_OK(c, hipHostMalloc((void**)&c->host_ring, (size_t)HOST_RING * d.max_batch * 4, hipHostMallocMapped));
   HIP_OK(c, hipHostGetDevicePointer((void**)&c->host_ring_dev, c->host_ring, 0));
   for (int i = 0; i < MAX_TICKET_EVENTS; i++) HIP_OK(c, hipEventCreateWithFlags(&c->ticket_ev[i], hipEventDisableTiming));
@@ -709,7 +710,7 @@ void tgx_destroy(tgx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   drop_step_graphs(c);
   auto fr = [](void* p) { if (p) (void)hipFree(p); };
-  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->wpe); fr(c->final_norm_b); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->tok_log); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch); fr(c->samp_list_comp); fr(c->samp_list_v);
+  fr(c->embed); fr(c->lm_head); fr(c->final_norm); fr(c->wpe); fr(c->final_norm_b); fr(c->rope_cos); fr(c->rope_sin); fr(c->step); fr(c->step_done); fr(c->tok_log); fr(c->scratch_x); fr(c->seed_dev); fr(c->samp_scratch); fr(c->samp_list_comp); fr(c->samp_list_v);
   fr(c->slab_acc); fr(c->kv_tbl);
   fr(c->ch_x); fr(c->ch_q); fr(c->ch_kraw); fr(c->ch_attn); fr(c->ch_h); fr(c->ch_part); fr(c->ch_pos);
   fr(c->ws_x); fr(c->ws_out); fr(c->ws_ah); fr(c->ws_al); fr(c->ws_al2); fr(c->ws_qh); fr(c->ws_ql); fr(c->ws_hh); fr(c->ws_hl); fr(c->ws_part); fr(c->ws_ssq); fr(c->ws_pos);

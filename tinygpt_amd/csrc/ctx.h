@@ -110,6 +110,7 @@ struct tgx_ctx {
   bool have_logits = false, have_token = false;
 
   int* step = nullptr;    // device: number of decode steps finalized (monotonic)
+  int* step_done = nullptr;   // device: rows of the current step that have read `step` (batches; 0 between steps)
   int* tok_log = nullptr; // device ring [log_cap][rows]
   int log_cap = 0;
   int* host_ring = nullptr;  // pinned host ring [HOST_RING][rows]
@@ -311,7 +312,6 @@ int attn_set_attrs(tgx_ctx* c);
 // ---- sampler.hip (kernels/sampler.h)
 void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool advance_pos, bool log_step);
 void launch_probs(tgx_ctx* c, int row, const tgx_sampler_cfg& cfg);
-void launch_bump_step(tgx_ctx* c);
 int sampler_alloc(tgx_ctx* c);
 // ---- prefill.hip (kernels/prefill.h, gemm_dma.h)
 bool prefill_shapes_ok(const tgx_model_desc& d);

@@ -276,6 +276,7 @@ tgx::FinalizeArgs make_finalize_args(tgx_ctx* c, int row, bool advance_pos, bool
   a.log_cap = c->log_cap; a.ring_cap = HOST_RING;
   a.row = row; a.rows = c->batch;
   a.log = log_step ? 1 : 0; a.bump_step = (row == c->batch - 1) ? 1 : 0;
+  if (log_step && c->batch > 1) { a.done = c->step_done; a.done_total = c->batch; a.bump_step = 0; }      // rows of a batch may be finalized concurrently: the last to count itself moves the step
   a.embed = c->embed; a.x = r.x; a.H = c->d.hidden; a.V = c->d.vocab; a.advance_pos = advance_pos ? 1 : 0;
   a.wpe = c->gpt2 ? c->wpe : nullptr; a.n_pos = c->d.n_positions > 0 ? c->d.n_positions : 1;
   return a;
@@ -289,15 +290,13 @@ void launch_finalize_greedy(tgx_ctx* c, int row0, int R, bool advance_pos, bool 
   }
 }
 
-// the batched step: rows are finalized concurrently; the step counter moves afterwards, once, when this group holds the batch's last row
+// the batched step: rows are finalized concurrently; the row that completes the batch's count moves the step counter (FinalizeArgs.done)
 void launch_finalize_rows(tgx_ctx* c, int row0, int M) {
   tgx::FinalizeRowsArgs fa{};
   fa.f = make_finalize_args(c, row0, /*advance_pos=*/true, /*log_step=*/true);
   fa.part_stride = c->lm_grid; fa.x_stride = c->d.hidden;
   TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::finalize_rows_kernel<DT>, dim3(M), dim3(256), 0, c->stream, fa))
-  if (row0 + M == c->batch) launch_bump_step(c);
 }
-void launch_bump_step(tgx_ctx* c) { hipLaunchKernelGGL(tgx::bump_step_kernel, dim3(1), dim3(64), 0, c->stream, c->step); }
 
 // prefill by steps: chunk row r <- embedding of prompt token r at position pos0 + r
 void launch_embed_chunk(tgx_ctx* c, const long long* ids, int R, int pos0) {

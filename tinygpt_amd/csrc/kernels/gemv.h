@@ -68,7 +68,9 @@ struct FinalizeArgs {
   int log_cap, ring_cap;
   int row, rows;
   int log;               // 1: record the token in the rings (decode steps); 0: tgx_sample after a prefill
-  int bump_step;         // 1 on the last row of a step
+  int bump_step;         // 1 on the last row of a step (batch 1, or rows finalized by consecutive launches)
+  int* done;             // batches: rows of a step run concurrently and must all read the same step value — each counts itself here after reading it, and the
+  int done_total;        // row that completes the count (of the whole batch) resets it and moves the step counter.  nullptr: bump_step decides
   const void* embed;     // [V][H], storage dtype
   float* x;              // [H] residual stream of this row (fp32)
   int H, V;
@@ -110,7 +112,8 @@ __device__ __forceinline__ void finalize_row(const FinalizeArgs& a) {
       const int st = *a.step;
       a.tok_log[(st % a.log_cap) * a.rows + a.row] = t;
       if (a.host_ring) a.host_ring[(st % a.ring_cap) * a.rows + a.row] = t;
-      if (a.bump_step) *a.step = st + 1;
+      if (a.done) { if (atomicAdd(a.done, 1) == a.done_total - 1) { *a.done = 0; *a.step = st + 1; } }
+      else if (a.bump_step) *a.step = st + 1;
     }
   }
   __syncthreads();
@@ -590,9 +593,9 @@ template <int DT>
 __global__ __launch_bounds__(256) void finalize_greedy_kernel(const FinalizeArgs a) { finalize_row<DT>(a); }
 
 // The greedy finalize of every row of a decode batch in ONE launch (blockIdx.x = row; the batched-MFMA decode step): the step counter is
-// advanced by bump_step_kernel afterwards, because rows running concurrently must all read the same step value.
+// advanced by the row that completes the batch's count (FinalizeArgs.done), because rows running concurrently must all read the same step value.
 struct FinalizeRowsArgs {
-  FinalizeArgs f;          // row 0's view; bump_step is ignored
+  FinalizeArgs f;          // row 0's view
   long long part_stride, x_stride;
 };
 template <int DT>
@@ -600,10 +603,9 @@ __global__ __launch_bounds__(256) void finalize_rows_kernel(const FinalizeRowsAr
   FinalizeArgs f = a.f;
   const int r = blockIdx.x;
   f.part_val += (size_t)r * a.part_stride; f.part_idx += (size_t)r * a.part_stride;
-  f.tok += r; f.pos += r; f.x += (size_t)r * a.x_stride; f.row = a.f.row + r; f.bump_step = 0;
+  f.tok += r; f.pos += r; f.x += (size_t)r * a.x_stride; f.row = a.f.row + r;
   finalize_row<DT>(f);
 }
-static __global__ void bump_step_kernel(int* step) { if (threadIdx.x == 0) *step = *step + 1; }
 
 // Prefill-by-steps: chunk row r <- embedding of prompt token r, position pos0 + r (one workgroup per chunk row).
 struct EmbedChunkArgs {

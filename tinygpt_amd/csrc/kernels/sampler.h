@@ -371,8 +371,8 @@ struct SampPickArgs {
   int nwg;
   const unsigned long long* seed;   // device word
   FinalizeArgs fin;                 // token publish / rings / embedding of the launch's first row (part_* unused); row r of the launch = blockIdx.y:
-  long long x_stride;               // tok + r, pos + r, x + r * x_stride (the rows' state lives in slabs); a launch of several rows leaves the step
-};                                  // counter to bump_step_kernel (fin.bump_step = 0): its rows must all read the same step value
+  long long x_stride;               // tok + r, pos + r, x + r * x_stride (the rows' state lives in slabs)
+};
 
 // row r's view of the launch's finalize arguments
 __device__ __forceinline__ FinalizeArgs samp_row_fin(const SampPickArgs& pa, int r) {
@@ -488,7 +488,8 @@ __device__ __forceinline__ void samp_draw_and_publish(const SampArgs& a, const F
       const int st = dw.step;
       fin.tok_log[(st % fin.log_cap) * fin.rows + fin.row] = pick;
       if (fin.host_ring) fin.host_ring[(st % fin.ring_cap) * fin.rows + fin.row] = pick;
-      if (fin.bump_step) *fin.step = st + 1;
+      if (fin.done) { if (atomicAdd(fin.done, 1) == fin.done_total - 1) { *fin.done = 0; *fin.step = st + 1; } }
+      else if (fin.bump_step) *fin.step = st + 1;
     }
   }
   SAMP_STAMP(a.sc + row, 7);

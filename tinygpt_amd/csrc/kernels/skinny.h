@@ -360,8 +360,10 @@ __global__ __launch_bounds__(64) void rope_kv_rows_kernel(const RopeRowsArgs a) 
   }
 }
 
-// per-workgroup argmax partials of every row's logits (what the GEMV lm_head's epilogue leaves for the greedy finalize / the sampler)
-static __global__ __launch_bounds__(256) void argmax_partials_rows_kernel(const float* logits, long long logits_stride, int V, float* part_val, int* part_idx, long long part_stride) {
+// per-workgroup argmax partials of every row's logits (what the GEMV lm_head's epilogue leaves for the greedy finalize / the sampler).  The row's `n_part`
+// slots (the GEMV lm_head's grid: ~2000) are filled by gridDim.x workgroups — as many as have a whole 16-byte load per thread to do (~125 at V = 128k; one
+// workgroup per slot was 64k nearly idle workgroups at 32 rows: 26 us) — slots from gridDim.x on are set to the reduction's identity.
+static __global__ __launch_bounds__(256) void argmax_partials_rows_kernel(const float* logits, long long logits_stride, int V, float* part_val, int* part_idx, long long part_stride, int n_part) {
   __shared__ float sv[256];
   __shared__ int si[256];
   const float* lg = logits + (size_t)blockIdx.y * logits_stride;
@@ -392,6 +394,9 @@ static __global__ __launch_bounds__(256) void argmax_partials_rows_kernel(const 
     __syncthreads();
   }
   if (threadIdx.x == 0) { part_val[(size_t)blockIdx.y * part_stride + blockIdx.x] = sv[0]; part_idx[(size_t)blockIdx.y * part_stride + blockIdx.x] = si[0]; }
+  for (int p = (int)gridDim.x + (int)blockIdx.x * 256 + (int)threadIdx.x; p < n_part; p += (int)gridDim.x * 256) {
+    part_val[(size_t)blockIdx.y * part_stride + p] = -INFINITY; part_idx[(size_t)blockIdx.y * part_stride + p] = 0x7fffffff;
+  }
 }
 
 }  // namespace tgx

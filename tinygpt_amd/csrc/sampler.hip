@@ -29,18 +29,15 @@ void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool
   const bool setK = cfg.top_k > 0, setP = cfg.top_p < 1.f, setM = cfg.min_p > 0.f;
   const int nwg = (a.V + tgx::SAMP_TILE - 1) / tgx::SAMP_TILE;
   const dim3 grid(nwg, R), blk(tgx::SAMP_WG);
-  // the draw's arguments — the last launch of the chain, one workgroup per row (blockIdx.y).  Several rows: the step counter moves afterwards, once (as
-  // launch_finalize_rows: rows running concurrently must all read the same step value)
+  // the draw's arguments — the last launch of the chain, one workgroup per row (blockIdx.y; the row that completes the batch's count moves the step counter)
   auto pick_args = [&](const tgx::SampArgs& now) {
     tgx::SampPickArgs pa{};
     pa.s = now;
     pa.nwg = nwg; pa.seed = c->seed_dev;
     pa.fin = make_finalize_args(c, row0, advance_pos, log_step);
     pa.x_stride = c->d.hidden;
-    if (R > 1) pa.fin.bump_step = 0;
     return pa;
   };
-  auto bump = [&]() { if (R > 1 && log_step && row0 + R == c->batch) launch_bump_step(c); };
   // a filter = first digit over the vocabulary, compaction of the threshold's bin, the tail (four digits, threshold) in one workgroup; the tail of the
   // chain's LAST filter also draws when no min-p follows
   a.mx_ready = 0;                 // the first launch that needs max(logits / T) reduces the lm_head partials and leaves it in sc->mx for the others
@@ -49,7 +46,6 @@ void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool
     const tgx::SampPickArgs pa = pick_args(a);
     if (!draws) { hipLaunchKernelGGL((tgx::samp_tail_kernel<MODE, false, 0>), dim3(1, R), blk, 0, c->stream, pa); return; }
     TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL((tgx::samp_tail_kernel<MODE, true, DT>), dim3(1, R), blk, 0, c->stream, pa))
-    bump();
   };
   if (setK) {
     hipLaunchKernelGGL(tgx::samp_level0_kernel<0>, grid, blk, 0, c->stream, a);       // (counts: no maximum needed)
@@ -71,7 +67,6 @@ void launch_sample(tgx_ctx* c, int row0, int R, const tgx_sampler_cfg& cfg, bool
   {
     const tgx::SampPickArgs pa = pick_args(a);
     TGX_DT_SWITCH(c->dt, hipLaunchKernelGGL(tgx::samp_pick_kernel<DT>, dim3(1, R), blk, 0, c->stream, pa))
-    bump();
   }
 }
 

@@ -331,7 +331,8 @@ void launch_decode_step_mfma(tgx_ctx* c, int row0, int M, const tgx_sampler_cfg&
   if (terms) { lm.asrc = 0; lm.a_hi = c->ws_ah; lm.a_lo = c->ws_al; lm.a_f32 = nullptr; lm.norm_w = nullptr; lm.ssq_in = nullptr; }
   launch_skinny(c, lm);
   }
-  hipLaunchKernelGGL(tgx::argmax_partials_rows_kernel, dim3(c->lm_grid, M), dim3(256), 0, c->stream, (const float*)r.logits, (long long)V, V, r.part_val, r.part_idx, (long long)c->lm_grid);
+  hipLaunchKernelGGL(tgx::argmax_partials_rows_kernel, dim3(std::min(c->lm_grid, std::max(1, (V / 4 + 255) / 256)), M), dim3(256), 0, c->stream, (const float*)r.logits, (long long)V, V, r.part_val, r.part_idx,
+                     (long long)c->lm_grid, c->lm_grid);
   if (is_greedy(&cfg)) {
     launch_finalize_rows(c, row0, M);
   } else {
