@@ -11,6 +11,8 @@ m = Model(desc, product_backend())
 for name, bits in synth.synth_checkpoint(desc, 1234, 0.02):
     m.upload(name, bits)
 m.finalize()
+for kv in filter(None, os.environ.get("TGX_OPTS", "").split(";")):      # e.g. TGX_OPTS="sampler.one_pass=0"
+    k, v = kv.split("="); m.set_option(k, int(v))
 prompt = synth.synth_prompt(desc.vocab, 256, 1)[None, :]
 CFGS = [("greedy", GREEDY), ("T=0.8 top-p 0.9 (CLI default)", SamplerCfg(temperature=0.8, top_p=0.9)),
         ("T=0.7 top-p 0.9 (server default)", SamplerCfg(temperature=0.7, top_p=0.9)),
