@@ -174,17 +174,18 @@ def test_paged_needs_16_bit_storage_and_is_set_before_finalize(hip):
     assert ei.value.status == 4
 
 
-@pytest.mark.parametrize("name,S,dtype", [("llama-3.2-1b", 40, "bf16"), ("llama-3.2-1b", 300, "bf16"), ("llama-3.2-1b", 1100, "bf16"), ("llama-3.2-1b", 3500, "bf16"),
+@pytest.mark.parametrize("name,S,dtype", [("llama-3.2-1b", 40, "bf16"), ("llama-3.2-1b", 300, "bf16"), ("llama-3.2-1b", 1100, "bf16"), ("llama-3.2-1b", 3500, "bf16"), ("llama-3.2-1b", 6500, "bf16"),
                                           ("mistral-7b-v0.3", 200, "fp16"), ("qwen2.5-0.5b", 700, "bf16"), ("qwen3-1.7b", 150, "bf16")])
 def test_matrix_core_prefill_into_a_paged_cache(name, S, dtype, hip):
-    """Prompts of 40 .. 3500 rows at real layer shapes (2 layers) through the skinny and the tiled matrix-core prefill of a paged context: RoPE + cache append
+    """Prompts of 40 .. 6500 rows (the last: the 20 decode steps run the long-context matrix-core attention) at real layer shapes (2 layers) through the skinny and the tiled matrix-core prefill of a paged context: RoPE + cache append
     (the QKV GEMM's epilogue at head_dim 64, else rope_kv_split_kernel) and the causal prompt attention (attn_prefill_kernel<.., PAGED> plain / key-split /
     lean, attn_prefill_dma_kernel<.., PAGED> from ~3k tokens: the table slice cached in LDS) through the block table.  Both contexts choose their forms by the
     same rules, so the paged one is held to the unpaged one bit for bit: logits, cache rows, greedy continuation."""
     import copy
     from tinygpt_amd import known_desc, synth
     out = []
-    for budget in (0, 4096):
+    BUDGET = ((S + 64 + 127) // 128 + 2) * 128
+    for budget in (0, BUDGET):
         d = copy.deepcopy(known_desc(name, dtype))
         d.layers, d.vocab, d.max_ctx = 2, 4096, S + 64
         m = Model(d, hip)
@@ -197,7 +198,7 @@ def test_matrix_core_prefill_into_a_paged_cache(name, S, dtype, hip):
         toks = m.decode(20, GREEDY).copy()
         out.append((lg, first, toks, m.read_kv(0, 0), m.read_kv(0, 1)))
         if budget:
-            assert m.get_option("kv.free_tokens") == 4096 - ((S + 20 + 127) // 128) * 128
+            assert m.get_option("kv.free_tokens") == BUDGET - ((S + 20 + 127) // 128) * 128
         m.close()
     (la, fa, ta, k0a, k1a), (lb, fb, tb, k0b, k1b) = out
     np.testing.assert_array_equal(la, lb)
