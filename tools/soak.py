@@ -10,7 +10,10 @@ import copy
 name = sys.argv[1] if len(sys.argv) > 1 else "llama-3.2-1b"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 d = copy.deepcopy(known_desc(name)); d.max_ctx = 4096; d.max_batch = 128
-m = Model(d).load_synthetic(1234, 0.02).finalize()
+m = Model(d)
+if os.environ.get("TGX_KV_BUDGET"):          # the same soak on a paged KV cache (option kv.budget_tokens)
+    m.set_option("kv.budget_tokens", int(os.environ["TGX_KV_BUDGET"]))
+m.load_synthetic(1234, 0.02).finalize()
 bad = 0
 for S in (2048, 3200, 1024, 1280, 700, 300, 40, 24, 12):      # (1024 / 1280 / 700: round 4's K slabs on the eight-wave kernel and 128 x 128 gate_up tiles)
     ids = synth.synth_prompt(d.vocab, S, 7)[None, :]
@@ -84,5 +87,16 @@ for opt in (0, 1):
     if not ok: bad += 1
     print(f"decode B=1 act.round16={opt}: 3 x 900 steps from context 200 (ids and final logits) equal: {ok}", flush=True)
 m.set_option("act.round16", 0)
+# round 6: sampled steps — the draws of a batch's rows in one launch, the step counter moved by the row that completes the batch's count, the tail that draws
+from tinygpt_amd.ffi import SamplerCfg
+for B, cfg in ((1, SamplerCfg(0.8, 0, 0.9, 0.0)), (2, SamplerCfg(0.8, 50, 0.9, 0.0)), (8, SamplerCfg(0.8, 0, 0.9, 0.0)), (8, SamplerCfg(1.0, 0, 1.0, 0.05)), (32, SamplerCfg(0.8, 50, 0.9, 0.05)), (32, SamplerCfg(0.7, 0, 0.9, 0.0))):
+    ids = np.stack([synth.synth_prompt(d.vocab, 200, 41 + b) for b in range(B)])
+    outs = []
+    for r in range(3):
+        m.reset_cache(); m.forward(ids); m.sample(cfg, seed=5)
+        outs.append(m.decode(300, cfg, seed=5).copy())
+    ok = all(np.array_equal(outs[0], o) for o in outs)
+    if not ok: bad += 1
+    print(f"sampled decode B={B} (T {cfg.temperature} top-k {cfg.top_k} top-p {cfg.top_p} min-p {cfg.min_p}): 3 x 300 steps equal: {ok}; distinct ids {len(np.unique(outs[0]))}", flush=True)
 print("SOAK", "FAILED" if bad else "OK", bad)
 sys.exit(1 if bad else 0)
