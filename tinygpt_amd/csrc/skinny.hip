@@ -366,12 +366,13 @@ void launch_prefill_skinny(tgx_ctx* c, int row0, int NB, int S) {
       q.asrc = 0; q.a_hi = c->ws_ah; q.a_lo = c->ws_al; q.a_lo2 = c->ws_al2; q.a_f32 = nullptr; q.norm_w = nullptr; q.ssq_in = nullptr;
     }
     const int qs = launch_skinny(c, q);
-    if (qs > 1) launch_reduce_rows(c, tgx::GEMM_STORE, qs, w.bqkv, c->ws_out, nq, M, nq, nullptr);
     for (int b = 0; b < NB; b++) {
       RowState& r = c->rows[(size_t)(row0 + b)];
       const size_t ro = (size_t)b * S;
       tgx::RopeKvArgs a{};
       a.QKV = c->ws_out + ro * nq; a.q_hi = c->ws_qh + ro * qd; a.q_lo = c->ws_ql + ro * qd;
+      // a K-split product: the RoPE launch sums the slabs itself (z order + bias: what reduce_rows_kernel<GEMM_STORE> did in its own launch until round 6)
+      if (qs > 1) { a.QKV = nullptr; a.part = c->ws_part + ro * nq; a.nsplit = qs; a.slab = (long long)M * nq; a.bias = reinterpret_cast<const bf16_t*>(w.bqkv); }
       a.k_cache = reinterpret_cast<bf16_t*>(r.kcache) + (size_t)l * kv_layer; a.v_cache = reinterpret_cast<bf16_t*>(r.vcache) + (size_t)l * kv_layer;
       a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin;
       a.heads = d.heads; a.kv_heads = d.kv_heads; a.hd = hd; a.max_ctx = d.max_ctx; a.past = (int)c->past; a.blk_tbl = r.tbl;
