@@ -263,3 +263,33 @@ def test_serving_churn_under_a_budget_equals_the_unpaged_batch(fam, seed, hip):
     for r in range(B):
         paged.reset_row(r)
     assert paged.get_option("kv.free_tokens") == BUDGET
+
+
+@pytest.mark.parametrize("name,dtype,B", [("llama-3.2-1b", "bf16", 20), ("mistral-7b-v0.3", "fp16", 18), ("qwen2.5-0.5b", "bf16", 24), ("qwen3-1.7b", "bf16", 6)])
+def test_batched_steps_at_real_layer_shapes_paged_equals_unpaged(name, dtype, B, hip):
+    """Real layer shapes (2 layers), batches that take the matrix-core step with its default forms (from 17 rows: matrix-core attention with the QKV finish in its
+    prologue; 6 rows: the VALU direct forms), ragged prompt lengths through the per-row lifecycle, 40 joint steps across a block boundary: token for token and
+    logit for logit the unpaged batch."""
+    import copy
+    from tinygpt_amd import known_desc, synth
+    out = []
+    lens = [40 + 37 * (r % 5) + r for r in range(B)]                    # 40 .. ~210 tokens: rows at different positions, some crossing 128 / 256 during the steps
+    for budget in (0, B * 384):
+        d = copy.deepcopy(known_desc(name, dtype))
+        d.layers, d.vocab, d.max_ctx, d.max_batch = 2, 4096, 512, B
+        m = Model(d, hip)
+        if budget:
+            m.set_option("kv.budget_tokens", budget)
+        m.load_synthetic(1234, 0.02).finalize()
+        m.forward(np.zeros((B, 1), dtype=np.int64)); m.sample(GREEDY)
+        for r in range(B):
+            m.reset_row(r)
+            m.forward_row(r, synth.synth_prompt(d.vocab, lens[r], 300 + r)); m.sample_row(r, GREEDY)
+        toks = m.decode(40, GREEDY).copy()
+        out.append((toks, m.logits(rounded=False).copy(), m.read_kv(B - 1, 1)))
+        m.close()
+    (ta, la, ka), (tb, lb, kb) = out
+    np.testing.assert_array_equal(ta, tb)
+    np.testing.assert_array_equal(la, lb)
+    for x, y in zip(ka, kb):
+        np.testing.assert_array_equal(x, y)
