@@ -9,7 +9,7 @@ serving loop would drive it, on the real kernels: a seeded stream of requests (p
 
 and reports generated tokens per second, the mean number of live rows per step and what the cache held.  The reference has neither (its server runs one request at
 a time, HttpServer.cpp:118-163; continuous batching and paged attention are README.md:32-34 TODOs): this is the measurement of the kernel half only — no queue, no
-HTTP, greedy, synthetic weights.
+HTTP, synthetic weights; greedy unless --sampler.
 
     python tools/serve_sim.py [--model llama-3.2-1b] [--rows 32] [--requests 200] [--prompt 16,512] [--new 16,256] [--kv-budget 16384] [--policy continuous|static|both]
 """
@@ -30,8 +30,13 @@ ap.add_argument("--max-ctx", type=int, default=1024)
 ap.add_argument("--kv-budget", type=int, default=0, help="paged KV: tokens of cache for all rows together (0 = one max_ctx slab per row)")
 ap.add_argument("--policy", default="both", choices=["continuous", "static", "both"])
 ap.add_argument("--seed", type=int, default=7)
+ap.add_argument("--sampler", default="", help="e.g. 'temperature=0.8,top_p=0.9' (default: greedy)")
 args = ap.parse_args()
 B = args.rows
+CFG = GREEDY
+if args.sampler:
+    from tinygpt_amd.ffi import SamplerCfg
+    CFG = SamplerCfg(**{k: (int(v) if k == "top_k" else float(v)) for k, v in (item.split("=") for item in args.sampler.split(","))})
 plo, phi = (int(x) for x in args.prompt.split(","))
 nlo, nhi = (int(x) for x in args.new.split(","))
 assert phi + nhi <= args.max_ctx
@@ -74,7 +79,7 @@ def serve(policy):
                 if reserved + blocks(L + new) > budget:
                     break                                    # the head of the queue waits for room (FIFO)
                 waiting.pop(0)
-                m.forward_row(r, prompts[i]); m.sample_row(r, GREEDY)
+                m.forward_row(r, prompts[i]); m.sample_row(r, CFG, seed=3)
                 length[r], target[r] = L, L + new
                 reserved += blocks(L + new)
                 produced += 1                                 # the first token came from the prefill's logits
@@ -83,7 +88,7 @@ def serve(policy):
             raise SystemExit("the budget admits no request")
         remaining = [target[r] - length[r] for r in live]
         n = min(16, min(remaining))
-        m.decode(n, GREEDY, fetch=False)
+        m.decode(n, CFG, seed=3, fetch=False)
         calls += 1; steps += n
         for r in live:
             length[r] += n; produced += n; live_steps += n
